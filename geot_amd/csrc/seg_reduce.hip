@@ -1,0 +1,964 @@
+// seg_reduce.hip -- MI355X (gfx950 / CDNA4) segment-reduction kernels behind include/geot_hip.h.
+//
+// One tile kernel serves index_scatter / gather_scatter / gather_weight_scatter / mh_spmm
+// (the reference has four copies of the same control flow:
+//  csrc/cuda/index_scatter_kernel.cuh:135-201, gather_scatter_kernel.cuh:118-186,
+//  gather_weight_scatter_kernel.cuh:118-185, mh_spmm_kernel.cuh:28-213).  It is NOT that
+// control flow: the reference flushes every run with atomicAdd into a zeroed dst; here the
+// sorted path has no global atomics, writes every dst row exactly once and is deterministic.
+//
+// Design (details in DESIGN.md):
+//   * edge-balanced tiles: block b owns edges [b*TE, (b+1)*TE) whatever the segment lengths are;
+//   * 256 threads = 4 wave64; a "lane group" of LPR lanes (LPR*VEC >= min(F, 64*VEC)) owns one
+//     row at a time, 16 B per lane (VEC=4 fp32) so a wave instruction moves 64/LPR whole rows;
+//   * each lane group walks CG consecutive edges of the tile keeping the running sum in
+//     registers with U row loads in flight; interior runs are stored straight to dst with plain
+//     coalesced stores; the group's first and last run go to LDS;
+//   * after one barrier the LDS partials of the tile are merged in edge order: runs that are
+//     complete inside the tile are stored; a run that continues from the previous tile goes to
+//     carry[tile]; a run that continues into the next tile is stored as the owner's partial;
+//   * seg_fixup_kernel (second launch = the only cross-workgroup ordering needed) adds the
+//     carries of follow-on tiles to the owner's row in tile order and zero-fills large gaps;
+//   * empty keys (gaps) are zero-filled by the lane group that sees the key jump: dst needs no
+//     memset pass (the reference's torch::zeros is 9 % of the traffic at the graded config).
+//   * unsorted mode: same walk, every run flushed with float atomics into a zeroed dst.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "geot_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kU = 8;          // row loads in flight per lane
+constexpr int kGapInline = 16; // gaps up to this many rows are zeroed by the lane group itself
+constexpr int kMinLprLog2 = 2; // lane groups are at least 4 lanes wide (<= 64 groups per block)
+constexpr int64_t kNoKey = -2; // key of the padding edges behind the end of the edge list (-1 = before edge 0)
+
+struct SegParams {
+  const int64_t *dst_index;
+  const int64_t *src_index;
+  const void *weight;
+  const void *src;
+  void *dst;
+  void *carry;              // [num_tiles, 2, F] slot 0: head partial (run continues from the
+                            //   previous tile); slot 1: tail partial (run starts here, continues)
+  int64_t *meta;            // [num_tiles]      first_key*4 + head_continues + 2*single_key_tile
+  unsigned long long *ctrl; // [0] large-gap count, [1] fix-up ticket; zero between calls
+  int64_t *gap_list;        // pairs (first_row, n_rows)
+  int64_t gap_cap;
+  int64_t nnz, F, K, src_rows;
+  int64_t H, Fh;            // mh_spmm: heads, features per head (F = H*Fh)
+  uint32_t rowbytes;        // F * sizeof(T)
+  int lpr_log2;             // lanes per row, log2
+  int cg;                   // edges per lane-group sub-chunk (multiple of 16)
+};
+
+template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
+template <typename T> struct VecOf<T, 1> { typedef T type; };
+
+template <typename T, int VEC, bool NT>
+__device__ __forceinline__ void load_vec(const void *p, T (&v)[VEC]) {
+  using V = typename VecOf<T, VEC>::type;
+  V x;
+  if constexpr (NT) x = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+  else x = *reinterpret_cast<const V *>(p);
+  if constexpr (VEC == 1) v[0] = x;
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = x[i];
+  }
+}
+
+template <typename T, int VEC, bool NT = false>
+__device__ __forceinline__ void store_vec(T *p, const T (&v)[VEC]) {
+  using V = typename VecOf<T, VEC>::type;
+  V x;
+  if constexpr (VEC == 1) x = v[0];
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) x[i] = v[i];
+  }
+  if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
+  else *reinterpret_cast<V *>(p) = x;
+}
+
+// LDS carve-up, shared by kernel and launcher.  te (edges per tile) is a multiple of 64.
+struct SmemLayout {
+  int te;
+  size_t off_keys; // int64 [te + 2] : [0] key of edge ts-1, [1+i] key of edge ts+i, [te+1] of ts+te
+  size_t off_off;  // int64 [te]     : byte offset of the gathered src row (gather modes)
+  size_t off_pk;   // int64 [2*ng]   : keys of the LDS partials
+  size_t off_mask; // u64   [te/64]  : bit i = "edge i starts a new run" (wave ballots)
+  size_t off_p;    // T     [2*ng][FB]
+  size_t off_w;    // T     [te*hw]  : edge weights, edge-major
+  size_t off_pv;   // int   [2*ng]   : valid flags of the partials
+  size_t bytes;
+};
+
+__host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec, int tsize,
+                                                  bool gather, int hw) {
+  SmemLayout L;
+  const int ng = kThreads >> lpr_log2;
+  L.te = ng * cg;
+  size_t o = 0;
+  L.off_keys = o; o += sizeof(int64_t) * (size_t)(L.te + 2);
+  L.off_off = o;  if (gather) o += sizeof(int64_t) * (size_t)L.te;
+  L.off_pk = o;   o += sizeof(int64_t) * (size_t)(2 * ng);
+  L.off_mask = o; o += sizeof(uint64_t) * (size_t)(L.te / 64);
+  o = (o + 15) & ~(size_t)15;
+  L.off_p = o;    o += (size_t)2 * kThreads * vec * tsize; // 2*ng*FB, FB = lpr*vec
+  L.off_w = o;    o += (size_t)tsize * L.te * hw;
+  o = (o + 7) & ~(size_t)7;
+  L.off_pv = o;   o += sizeof(int) * (size_t)(2 * ng);
+  L.bytes = (o + 15) & ~(size_t)15;
+  return L;
+}
+
+// WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
+// NT   : bit 0 non-temporal row loads, bit 1 non-temporal dst stores
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT>
+__global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
+  const int lpr = 1 << p.lpr_log2;
+  const int ng = kThreads >> p.lpr_log2;
+  const int cg = p.cg;
+  const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
+  const SmemLayout L = smem_layout(p.lpr_log2, cg, VEC, (int)sizeof(T), GATHER, hw);
+  const int te = L.te;
+  const int FB = lpr * VEC;
+
+  int64_t *keysL = reinterpret_cast<int64_t *>(smem + L.off_keys);
+  int64_t *offL = reinterpret_cast<int64_t *>(smem + L.off_off);
+  int64_t *pkL = reinterpret_cast<int64_t *>(smem + L.off_pk);
+  unsigned long long *maskL = reinterpret_cast<unsigned long long *>(smem + L.off_mask);
+  const unsigned char *mask8L = smem + L.off_mask;
+  T *pL = reinterpret_cast<T *>(smem + L.off_p);
+  T *wL = reinterpret_cast<T *>(smem + L.off_w);
+  int *pvL = reinterpret_cast<int *>(smem + L.off_pv);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int64_t tile = blockIdx.x;
+  const int64_t ts = tile * (int64_t)te;
+  const int64_t rem = p.nnz - ts;
+  const int n = rem < (int64_t)te ? (int)rem : te; // valid edges in this tile, >= 1
+
+  const T *__restrict__ weight = static_cast<const T *>(p.weight);
+  T *__restrict__ dst = static_cast<T *>(p.dst);
+  const int64_t F = p.F;
+  const int64_t K = p.K;
+  const uint32_t rb = p.rowbytes;
+
+  const int g = tid >> p.lpr_log2; // lane group in block
+  const int c = tid & (lpr - 1);   // lane in group
+  const int64_t f0 = (int64_t)blockIdx.y * FB + (int64_t)c * VEC;
+  const bool active = f0 < F;      // false only in the last feature block of a ragged F
+  const int64_t f0c = active ? f0 : 0; // loads of inactive lanes are clamped, never predicated
+  const int gs = g * cg;
+
+  // streamed operand: tile base is wave-uniform, the lane adds a 32-bit byte offset
+  const char *tbase = static_cast<const char *>(p.src) + (GATHER ? 0 : ts * (int64_t)rb);
+  const uint32_t fbytes = (uint32_t)(f0c * (int64_t)sizeof(T));
+  int hh = 0;
+  if constexpr (WMODE >= 2) {
+    hh = (int)(f0c / p.Fh);
+    if (hh >= (int)p.H) hh = (int)p.H - 1;
+  }
+
+  T v[kU][VEC];
+  auto load_batch = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      int r = gs + b + u;
+      r = r < n ? r : n - 1; // padding rows re-read the last valid row; their sum is discarded
+      if constexpr (GATHER) load_vec<T, VEC, NTL>(tbase + (offL[r] + fbytes), v[u]);
+      else load_vec<T, VEC, NTL>(tbase + ((uint32_t)r * rb + fbytes), v[u]);
+    }
+  };
+
+  if constexpr (!GATHER) load_batch(0); // rows do not depend on the keys: get them moving first
+
+  // ---- stage keys, run-start bitmasks (wave ballot), gather offsets, weights --------------------
+  for (int i0 = (tid >> 6) * 64; i0 < te; i0 += kThreads) {
+    const int i = i0 + lane;
+    const int64_t ge = ts + i;
+    const int64_t k = ge < p.nnz ? p.dst_index[ge] : kNoKey;
+    int64_t kp = __shfl_up(k, 1, 64);
+    if (lane == 0) kp = ge > 0 ? (ge - 1 < p.nnz ? p.dst_index[ge - 1] : kNoKey) : -1;
+    keysL[1 + i] = k;
+    if (i == 0) keysL[0] = kp;
+    const unsigned long long m = __ballot(k != kp);
+    if (lane == 0) maskL[i0 >> 6] = m;
+    if constexpr (GATHER) {
+      int64_t row = ge < p.nnz ? p.src_index[ge] : 0;
+      if ((uint64_t)row >= (uint64_t)p.src_rows) row = 0; // out-of-range gather index: memory-safe
+      offL[i] = row * (int64_t)rb;
+    }
+    if constexpr (WMODE == 1) wL[i] = ge < p.nnz ? weight[ge] : T(0);
+  }
+  if constexpr (WMODE == 2) {
+    const int64_t base = ts * p.H, lim = p.nnz * p.H;
+    for (int j = tid; j < te * hw; j += kThreads) wL[j] = base + j < lim ? weight[base + j] : T(0);
+  }
+  if constexpr (WMODE == 3) {
+    for (int j = tid; j < te * hw; j += kThreads) {
+      const int h = j / te, i = j - h * te;
+      wL[i * hw + h] = ts + i < p.nnz ? weight[(int64_t)h * p.nnz + ts + i] : T(0);
+    }
+  }
+  if (tid == 0) keysL[te + 1] = ts + te < p.nnz ? p.dst_index[ts + te] : kNoKey;
+  if constexpr (!ATOMIC) {
+    if (c == 0) {
+      pvL[2 * g] = 1;
+      pvL[2 * g + 1] = 0;
+    }
+  }
+  __syncthreads();
+
+  if constexpr (!ATOMIC) {
+    if (tid == 0 && blockIdx.y == 0) {
+      const int64_t kf = keysL[1], kl = keysL[n], kn = keysL[n + 1];
+      const int64_t head = kf == keysL[0];
+      const int64_t single = head && kl == kf && kn == kf;
+      p.meta[tile] = (uint64_t)kf < (uint64_t)K ? (kf * 4 + head + 2 * single) : 0;
+    }
+  }
+
+  T *dstf = dst + f0c;
+  auto gapfill = [&](int64_t lo, int64_t hi) {
+    if (hi <= lo || lo < 0 || hi > K) return; // also rejects the padding key and unsorted input
+    const int64_t cnt = hi - lo;
+    if (cnt <= kGapInline) {
+      if (active) {
+        T z[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) z[i] = T(0);
+        for (int64_t r = lo; r < hi; ++r) store_vec<T, VEC, NTS>(dstf + r * F, z);
+      }
+    } else if (c == 0 && blockIdx.y == 0) {
+      const unsigned long long slot = atomicAdd(&p.ctrl[0], 1ull);
+      if ((int64_t)slot < p.gap_cap) {
+        p.gap_list[2 * slot] = lo;
+        p.gap_list[2 * slot + 1] = cnt;
+      }
+    }
+  };
+
+  T acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = T(0);
+  int64_t cur = keysL[1 + gs];
+  bool first = true;
+  if constexpr (!ATOMIC) {
+    const int64_t kprev = keysL[gs];
+    if (cur > kprev + 1) gapfill(kprev + 1, cur);
+  }
+  if constexpr (GATHER) load_batch(0);
+
+  for (int b = 0;;) {
+    unsigned m8 = mask8L[(gs + b) >> 3];
+    if (b == 0) m8 &= 0xFEu; // the group's first edge opens its first run, it does not end one
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (m8 & (1u << u)) {
+        // the run of `cur` ends in front of local edge gs+b+u
+        const int64_t knew = keysL[1 + gs + b + u];
+        if constexpr (ATOMIC) {
+          if (active && (uint64_t)cur < (uint64_t)K) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+          }
+        } else {
+          if (first) {
+            store_vec<T, VEC>(pL + (size_t)(2 * g) * FB + c * VEC, acc);
+            if (c == 0) pkL[2 * g] = cur;
+            first = false;
+          } else if (active && (uint64_t)cur < (uint64_t)K) {
+            store_vec<T, VEC, NTS>(dstf + cur * F, acc);
+          }
+          if (knew > cur + 1) gapfill(cur + 1, knew);
+        }
+        cur = knew;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = T(0);
+      }
+      if constexpr (WMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+      } else {
+        const T w = WMODE == 1 ? wL[gs + b + u] : wL[(gs + b + u) * hw + hh];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i] * w;
+      }
+    }
+    b += kU;
+    if (b >= cg) break;
+    load_batch(b);
+  }
+
+  // the group's last run
+  if constexpr (ATOMIC) {
+    if (active && (uint64_t)cur < (uint64_t)K) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+    }
+    return;
+  } else {
+    const int slot = 2 * g + (first ? 0 : 1);
+    store_vec<T, VEC>(pL + (size_t)slot * FB + c * VEC, acc);
+    if (c == 0) {
+      pkL[slot] = cur;
+      pvL[slot] = 1;
+    }
+  }
+
+  // ---- merge the tile's LDS partials in edge order ---------------------------------------------
+  __syncthreads();
+  const int64_t kprev_tile = keysL[0];
+  const int64_t knext_tile = keysL[n + 1];
+  const int ne = 2 * ng;
+  for (int i = g; i < ne; i += ng) {
+    if (!pvL[i]) continue;
+    const int64_t k = pkL[i];
+    bool leader = true;
+    if (!(i & 1) && i > 0) {
+      const int pi = pvL[i - 1] ? i - 1 : i - 2; // previous valid partial
+      leader = pkL[pi] != k;
+    }
+    if (!leader) continue;
+    T sum[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) sum[q] = pL[(size_t)i * FB + c * VEC + q];
+    bool at_end = true; // the merged run reaches the last edge of the tile
+    for (int j = i + 1; j < ne; ++j) {
+      if (!pvL[j]) continue;
+      if (pkL[j] != k) { at_end = false; break; }
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) sum[q] += pL[(size_t)j * FB + c * VEC + q];
+    }
+    if (!active) continue;
+    T *cslot = static_cast<T *>(p.carry) + (tile * 2) * F + f0;
+    if (i == 0 && k == kprev_tile) {
+      // continues a run that started in an earlier tile: slot 0, added by seg_fixup_kernel
+      store_vec<T, VEC>(cslot, sum);
+    } else if (at_end && k == knext_tile) {
+      // starts here and continues into the next tile: slot 1; seg_fixup_kernel writes the row
+      store_vec<T, VEC>(cslot + F, sum);
+    } else if ((uint64_t)k < (uint64_t)K) {
+      store_vec<T, VEC, NTS>(dstf + k * F, sum);
+    }
+  }
+}
+
+// Second launch (= the only cross-workgroup ordering the sorted path needs):
+//  (a) one WAVE per tile: if the tile holds the FIRST carry of a chain (its head run continues
+//      from the previous tile, and that tile is where the run starts), add the chain's carries to
+//      the owner's row.  A hub run covers many whole tiles: their `single` bits are fetched 64 at
+//      a time (one meta word per lane + ballot) and the carry rows are summed by the wave's lane
+//      groups in parallel, then combined by xor-shuffles - a fixed order, so results are
+//      deterministic, and a 64-tile chain costs about as many memory round trips as a 1-tile one;
+//  (b) zero-fill the large gaps the tile kernel recorded;
+//  (c) the last block to finish re-zeroes the two control words for the next call.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_t num_tiles) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << p.lpr_log2;
+  const int R = 64 >> p.lpr_log2;  // carry rows a wave sums in parallel
+  const int gq = lane >> p.lpr_log2;
+  const int c = lane & (lpr - 1);
+  T *dst = static_cast<T *>(p.dst);
+  const T *carry = static_cast<const T *>(p.carry);
+  const int64_t F = p.F;
+  __shared__ unsigned long long s_ngap;
+  if (threadIdx.x == 0) s_ngap = p.ctrl[0];
+
+  const int64_t t = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (t >= 1 && t < num_tiles) { // wave-uniform from here on
+    // Every address below is known before any load returns: meta[t-1], meta[t..t+63], the
+    // owner's tail partial and this tile's head partial are all in flight together (one memory
+    // round trip); the row is then written with a plain store - no read-modify-write of dst.
+    const int64_t mp = p.meta[t - 1];
+    int64_t wt = t + lane;
+    const int64_t mw = p.meta[wt < num_tiles ? wt : num_tiles - 1]; // lane i <-> tile t+i
+    constexpr int J = 4;
+    T cv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t f = (int64_t)j * lpr + c;
+      // lane group 0: owner's tail partial (slot 1 of tile t-1); group 1 (or 0 again when the
+      // wave holds one row): this tile's head partial.  Summed in a fixed order below.
+      T a = T(0);
+      if (f < F) {
+        if (gq == 0) a = carry[((t - 1) * 2 + 1) * F + f];
+        if (R == 1) a += carry[(t * 2) * F + f];
+        else if (gq == 1) a = carry[(t * 2) * F + f];
+      }
+      cv[j] = a;
+    }
+    const int64_t m = __shfl(mw, 0, 64);
+    if ((m & 1) && !(mp & 2)) {
+      const int64_t k = m >> 2;
+      for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
+        if (fb > 0) { // wide rows: further feature chunks (first chunk was prefetched above)
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int64_t f = fb + (int64_t)j * lpr + c;
+            T a = T(0);
+            if (f < F) {
+              if (gq == 0) a = carry[((t - 1) * 2 + 1) * F + f];
+              if (R == 1) a += carry[(t * 2) * F + f];
+              else if (gq == 1) a = carry[(t * 2) * F + f];
+            }
+            cv[j] = a;
+          }
+        }
+        if (m & 2) {
+          // hub: tile x+1 joins the chain for as long as tile x is `single`; 64 tiles per window
+          int64_t wb = t;
+          int64_t mcur = mw;
+          for (;;) {
+            const unsigned long long S = __ballot((mcur & 2) && (wb + lane < num_tiles));
+            const int nn = ~S ? __builtin_ctzll(~S) : 64; // tiles wb+1 .. wb+nn join the chain
+            const int64_t hi = wb + nn;
+            for (int64_t i = wb + 1 + gq; i <= hi; i += (int64_t)R * 4) {
+              T cr[4][J];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int64_t tt = i + (int64_t)q * R;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                  const int64_t f = fb + (int64_t)j * lpr + c;
+                  cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : T(0);
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < J; ++j) cv[j] += cr[q][j];
+            }
+            if (nn < 64) break;
+            wb += 64;
+            wt = wb + lane;
+            mcur = p.meta[wt < num_tiles ? wt : num_tiles - 1];
+          }
+        }
+        for (int off = lpr; off < 64; off <<= 1) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) cv[j] += __shfl_xor(cv[j], off, 64);
+        }
+        if (gq == 0) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int64_t f = fb + (int64_t)j * lpr + c;
+            if (f < F) dst[k * F + f] = cv[j];
+          }
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  // Common case: no large gap was recorded -> nothing to fill and nothing to reset (no atomics).
+  if (s_ngap == 0) return;
+  const int64_t ngap = (int64_t)s_ngap < p.gap_cap ? (int64_t)s_ngap : p.gap_cap;
+  const int64_t gtid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t gsz = (int64_t)gridDim.x * kThreads;
+  for (int64_t gidx = 0; gidx < ngap; ++gidx) {
+    const int64_t lo = p.gap_list[2 * gidx];
+    const int64_t total = p.gap_list[2 * gidx + 1] * F;
+    T *base = dst + lo * F;
+    for (int64_t i = gtid; i < total; i += gsz) base[i] = T(0);
+  }
+  // every block has read ctrl[0] before it takes a ticket, so the last ticket may clear it
+  if (threadIdx.x == 0) {
+    const unsigned long long prev = atomicAdd(&p.ctrl[1], 1ull);
+    if (prev == (unsigned long long)gridDim.x - 1) {
+      atomicExch(&p.ctrl[0], 0ull);
+      atomicExch(&p.ctrl[1], 0ull);
+    }
+  }
+}
+
+// out[e] = <m1[d[e]], m2[s[e]]>; one lane group of LPR lanes per edge, xor-shuffle reduce.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_index,
+                                                             const int64_t *dst_index,
+                                                             const T *m1, const T *m2, T *out,
+                                                             int64_t nnz, int64_t F,
+                                                             int64_t rows1, int64_t rows2,
+                                                             int lpr_log2) {
+  const int lpr = 1 << lpr_log2;
+  const int ng = kThreads >> lpr_log2;
+  const int g = threadIdx.x >> lpr_log2;
+  const int c = threadIdx.x & (lpr - 1);
+  for (int64_t e = (int64_t)blockIdx.x * ng + g; e < nnz; e += (int64_t)gridDim.x * ng) {
+    const int64_t r1 = dst_index[e], r2 = src_index[e];
+    T s = T(0);
+    if ((uint64_t)r1 < (uint64_t)rows1 && (uint64_t)r2 < (uint64_t)rows2) {
+      const T *a = m1 + r1 * F, *b = m2 + r2 * F;
+      for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
+        T x[VEC], y[VEC];
+        load_vec<T, VEC, false>(a + f, x);
+        load_vec<T, VEC, false>(b + f, y);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s += x[i] * y[i];
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (c == 0) out[e] = s;
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const int64_t *index, const T *src,
+                                                               T *dst, int64_t nnz, int64_t F,
+                                                               int64_t src_rows, int lpr_log2) {
+  const int lpr = 1 << lpr_log2;
+  const int ng = kThreads >> lpr_log2;
+  const int g = threadIdx.x >> lpr_log2;
+  const int c = threadIdx.x & (lpr - 1);
+  for (int64_t e = (int64_t)blockIdx.x * ng + g; e < nnz; e += (int64_t)gridDim.x * ng) {
+    const int64_t r = index[e];
+    const bool ok = (uint64_t)r < (uint64_t)src_rows;
+    for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
+      T x[VEC];
+      if (ok) load_vec<T, VEC, false>(src + r * F + f, x);
+      else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) x[i] = T(0);
+      }
+      store_vec<T, VEC>(dst + e * F + f, x);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+struct Tune {
+  int cg = 0, vec = 0, nt = -1, lpr_log2 = -1;
+};
+Tune g_tune;
+
+struct Prof {
+  bool on = false;
+  std::mutex mu;
+  struct Rec { hipEvent_t e0, e1, e2, e3; bool has_fix; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  double main_ms = 0, fix_ms = 0, aux_ms = 0;
+  int64_t calls = 0;
+};
+Prof g_prof;
+
+hipEvent_t prof_event() {
+  if (!g_prof.pool.empty()) {
+    hipEvent_t e = g_prof.pool.back();
+    g_prof.pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(GEOT_ELAUNCH, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+  } while (0)
+
+struct Plan {
+  int vec, lpr_log2, cg, te;
+  int64_t num_tiles, nfb;
+  size_t meta_off, carry_off, list_off, total; // ctrl block sits at offset 0
+  int64_t gap_cap;
+};
+
+constexpr size_t kCtrlBytes = 256;
+
+inline int ceil_log2(int64_t x) {
+  int l = 0;
+  while (((int64_t)1 << l) < x) ++l;
+  return l;
+}
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// vec_unit: the feature granule that must stay inside one vector (F, or F per head for mh_spmm)
+// hw: weights staged in LDS per edge (0, 1 or H); gather: src offsets staged in LDS
+Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, bool aligned16,
+               bool gather, int hw) {
+  Plan P;
+  const int maxvec = 16 / tsize; // 16 B per lane
+  int vec = 1;
+  if (aligned16) {
+    if (vec_unit % maxvec == 0) vec = maxvec;
+    else if (maxvec >= 4 && vec_unit % 2 == 0) vec = 2;
+  }
+  if (g_tune.vec > 0 && g_tune.vec <= vec && vec_unit % g_tune.vec == 0) vec = g_tune.vec;
+  P.vec = vec;
+  const int64_t lanes = (F + vec - 1) / vec;
+  int l = ceil_log2(lanes);
+  if (l > 6) l = 6;
+  if (l < kMinLprLog2) l = kMinLprLog2;
+  if (g_tune.lpr_log2 >= 0 && g_tune.lpr_log2 <= 6 && g_tune.lpr_log2 >= l) l = g_tune.lpr_log2;
+  P.lpr_log2 = l;
+  const int ng = kThreads >> l;
+  int cg = g_tune.cg > 0 ? g_tune.cg : 32;
+  cg = (cg + 15) / 16 * 16;
+  if (cg > 256) cg = 256;
+  // bound the tile: <= 2048 edges, <= ~64 KB of LDS, and 32-bit byte offsets inside a tile
+  while (cg > 16 && ((int64_t)ng * cg > 2048 ||
+                     smem_layout(l, cg, vec, tsize, gather, hw).bytes > 64 * 1024 ||
+                     (int64_t)ng * cg * F * tsize >= ((int64_t)1 << 31)))
+    cg -= 16;
+  P.cg = cg;
+  P.te = ng * cg;
+  P.num_tiles = nnz > 0 ? (nnz + P.te - 1) / P.te : 0;
+  const int64_t fb = ((int64_t)1 << l) * vec;
+  P.nfb = (F + fb - 1) / fb;
+  if (P.nfb < 1) P.nfb = 1;
+  const size_t nt = (size_t)(P.num_tiles > 0 ? P.num_tiles : 1);
+  P.meta_off = kCtrlBytes;
+  P.carry_off = P.meta_off + up256(nt * sizeof(int64_t));
+  P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * tsize);
+  P.gap_cap = K / kGapInline + 2;
+  P.total = P.list_off + up256((size_t)P.gap_cap * 16);
+  return P;
+}
+
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT>
+void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
+  const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
+  const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(T), GATHER, hw);
+  dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+  hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT>), grid, dim3(kThreads),
+                     L.bytes, st, p);
+}
+
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC>
+void dispatch_nt(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
+  switch (nt & 3) {
+  case 0: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st); break;
+  case 1: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 1>(p, P, st); break;
+  case 2: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 2>(p, P, st); break;
+  default: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 3>(p, P, st); break;
+  }
+}
+
+template <typename T, bool GATHER, int WMODE, bool ATOMIC>
+int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
+  constexpr int MAXV = 16 / (int)sizeof(T);
+  if (P.vec == MAXV) dispatch_nt<T, MAXV, GATHER, WMODE, ATOMIC>(p, P, st, nt);
+  else if (MAXV >= 4 && P.vec == 2) dispatch_nt<T, 2, GATHER, WMODE, ATOMIC>(p, P, st, nt);
+  else if (P.vec == 1) dispatch_nt<T, 1, GATHER, WMODE, ATOMIC>(p, P, st, nt);
+  else return fail(GEOT_EINVAL, "internal: bad vector width");
+  return GEOT_OK;
+}
+
+inline bool is_aligned16(const void *a) { return ((uintptr_t)a & 15) == 0; }
+
+// mode: 0 index_scatter, 1 gather_scatter, 2 gather_weight_scatter, 3 mh edge-major, 4 mh head-major
+template <typename T>
+int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_t *dst_index,
+                   const void *weight, const void *src, void *dst, int64_t nnz, int64_t F,
+                   int64_t H, int64_t src_rows, int64_t K, void *ws, size_t ws_bytes,
+                   hipStream_t st) {
+  if (nnz < 0 || F < 0 || K < 0 || src_rows < 0 || H < 1) return fail(GEOT_EINVAL, "negative size");
+  if (K == 0 || F == 0) return GEOT_OK;
+  if (!dst || (nnz > 0 && (!dst_index || !src))) return fail(GEOT_EINVAL, "null pointer");
+  if (mode >= 1 && nnz > 0 && !src_index) return fail(GEOT_EINVAL, "null src_index");
+  if (mode >= 2 && nnz > 0 && !weight) return fail(GEOT_EINVAL, "null weight");
+  const int64_t Fh = F / H;
+  if (F * (int64_t)sizeof(T) >= ((int64_t)1 << 31)) return fail(GEOT_EUNSUPPORTED, "row too wide");
+  const bool al = is_aligned16(src) && is_aligned16(dst) && is_aligned16(ws);
+  const int hw = mode <= 1 ? 0 : (mode == 2 ? 1 : (int)H);
+  if (hw > 64) return fail(GEOT_EUNSUPPORTED, "more than 64 heads");
+  const Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw);
+  if (!ws || ws_bytes < P.total) return fail(GEOT_EWORKSPACE, "workspace too small");
+  if (((uintptr_t)ws & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
+
+  char *wsc = static_cast<char *>(ws);
+  SegParams p;
+  p.dst_index = dst_index;
+  p.src_index = src_index;
+  p.weight = weight;
+  p.src = src;
+  p.dst = dst;
+  p.ctrl = reinterpret_cast<unsigned long long *>(wsc);
+  p.meta = reinterpret_cast<int64_t *>(wsc + P.meta_off);
+  p.carry = wsc + P.carry_off;
+  p.gap_list = reinterpret_cast<int64_t *>(wsc + P.list_off);
+  p.gap_cap = P.gap_cap;
+  p.nnz = nnz;
+  p.F = F;
+  p.K = K;
+  p.src_rows = src_rows;
+  p.H = H;
+  p.Fh = Fh > 0 ? Fh : 1;
+  p.rowbytes = (uint32_t)(F * (int64_t)sizeof(T));
+  p.lpr_log2 = P.lpr_log2;
+  p.cg = P.cg;
+
+  // non-temporal policy: the streamed operand of index_scatter is read exactly once -> nt loads
+  // (measured: +13 % with the store mix of this op); gathered rows are re-used -> default policy.
+  int nt = g_tune.nt >= 0 ? g_tune.nt : (mode == 0 ? 1 : 0);
+
+  Prof::Rec rec{};
+  const bool prof = g_prof.on;
+  if (prof) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    rec.e0 = prof_event(); rec.e1 = prof_event(); rec.e2 = prof_event(); rec.e3 = prof_event();
+  }
+  if (prof) HIP_TRY(hipEventRecord(rec.e0, st));
+  if (nnz == 0 || !sorted) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)K * (size_t)F * sizeof(T), st));
+  if (prof) HIP_TRY(hipEventRecord(rec.e1, st));
+
+  int rc = GEOT_OK;
+  if (nnz > 0) {
+    if (!sorted) {
+      if (mode != 0) return fail(GEOT_EUNSUPPORTED, "unsorted is index_scatter only");
+      rc = dispatch_vec<T, false, 0, true>(p, P, st, nt);
+    } else {
+      switch (mode) {
+      case 0: rc = dispatch_vec<T, false, 0, false>(p, P, st, nt); break;
+      case 1: rc = dispatch_vec<T, true, 0, false>(p, P, st, nt); break;
+      case 2: rc = dispatch_vec<T, true, 1, false>(p, P, st, nt); break;
+      case 3: rc = dispatch_vec<T, true, 2, false>(p, P, st, nt); break;
+      case 4: rc = dispatch_vec<T, true, 3, false>(p, P, st, nt); break;
+      default: return fail(GEOT_EINVAL, "bad mode");
+      }
+    }
+    if (rc != GEOT_OK) return rc;
+    HIP_TRY(hipGetLastError());
+  }
+  if (prof) HIP_TRY(hipEventRecord(rec.e2, st));
+  rec.has_fix = false;
+  if (nnz > 0 && sorted) {
+    int64_t blocks = (P.num_tiles + kThreads / 64 - 1) / (kThreads / 64); // one wave per tile
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((seg_fixup_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p,
+                       P.num_tiles);
+    HIP_TRY(hipGetLastError());
+    rec.has_fix = true;
+  }
+  if (prof) {
+    HIP_TRY(hipEventRecord(rec.e3, st));
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.recs.push_back(rec);
+  }
+  return GEOT_OK;
+}
+
+int run_typed(int dtype, int mode, bool sorted, const int64_t *si, const int64_t *di,
+              const void *w, const void *src, void *dst, int64_t nnz, int64_t F, int64_t H,
+              int64_t src_rows, int64_t K, void *ws, size_t wsb, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == GEOT_F32)
+    return run_segment_op<float>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st);
+  if (dtype == GEOT_F64)
+    return run_segment_op<double>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st);
+  return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+}
+
+template <typename T> int pick_row_vec(int64_t F, const void *a, const void *b) {
+  const int maxvec = 16 / (int)sizeof(T);
+  if (is_aligned16(a) && is_aligned16(b)) {
+    if (F % maxvec == 0) return maxvec;
+    if (maxvec >= 4 && F % 2 == 0 ) return 2;
+  }
+  return 1;
+}
+
+template <typename T>
+int run_sddmm(const int64_t *si, const int64_t *di, const void *m1, const void *m2, void *out,
+              int64_t nnz, int64_t F, int64_t rows1, int64_t rows2, hipStream_t st) {
+  if (nnz < 0 || F < 0) return fail(GEOT_EINVAL, "negative size");
+  if (nnz == 0) return GEOT_OK;
+  if (!si || !di || !m1 || !m2 || !out) return fail(GEOT_EINVAL, "null pointer");
+  int vec = pick_row_vec<T>(F, m1, m2);
+  int l = ceil_log2((F + vec - 1) / vec);
+  if (l > 6) l = 6;
+  const int ng = kThreads >> l;
+  int64_t blocks = (nnz + ng - 1) / ng;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const T *a = static_cast<const T *>(m1), *b = static_cast<const T *>(m2);
+  T *o = static_cast<T *>(out);
+  constexpr int MAXV = 16 / (int)sizeof(T);
+  if (vec == MAXV)
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l);
+  else if (vec == 2 && MAXV >= 4)
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l);
+  else
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l);
+  HIP_TRY(hipGetLastError());
+  return GEOT_OK;
+}
+
+template <typename T>
+int run_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz, int64_t F,
+                    int64_t src_rows, hipStream_t st) {
+  if (nnz < 0 || F < 0) return fail(GEOT_EINVAL, "negative size");
+  if (nnz == 0 || F == 0) return GEOT_OK;
+  if (!index || !src || !dst) return fail(GEOT_EINVAL, "null pointer");
+  int vec = pick_row_vec<T>(F, src, dst);
+  int l = ceil_log2((F + vec - 1) / vec);
+  if (l > 6) l = 6;
+  const int ng = kThreads >> l;
+  int64_t blocks = (nnz + ng - 1) / ng;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const T *s = static_cast<const T *>(src);
+  T *d = static_cast<T *>(dst);
+  constexpr int MAXV = 16 / (int)sizeof(T);
+  if (vec == MAXV)
+    hipLaunchKernelGGL((gather_rows_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, index, s, d, nnz, F, src_rows, l);
+  else if (vec == 2 && MAXV >= 4)
+    hipLaunchKernelGGL((gather_rows_kernel<T, 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st, index, s, d, nnz, F, src_rows, l);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, index, s, d, nnz, F, src_rows, l);
+  HIP_TRY(hipGetLastError());
+  return GEOT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int geot_abi_version(void) { return GEOT_ABI_VERSION; }
+
+const char *geot_last_error(void) { return g_err.c_str(); }
+
+const char *geot_build_info(void) { return "libgeot_hip gfx950 (CDNA4) built " __DATE__ " " __TIME__; }
+
+size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype) {
+  const int tsize = dtype == GEOT_F64 ? 8 : 4;
+  if (nnz < 0) nnz = 0;
+  if (feat < 1) feat = 1;
+  if (out_rows < 0) out_rows = 0;
+  // upper bound over every plan the launcher can pick for these sizes: the smallest tile is
+  // 4 lane groups (64 lanes per row) x 16 edges
+  const size_t nt = (size_t)(nnz / 64 + 1);
+  return kCtrlBytes + up256(nt * sizeof(int64_t)) + up256(nt * 2 * (size_t)feat * tsize) +
+         up256((size_t)(out_rows / kGapInline + 2) * 16);
+}
+
+int geot_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+  if (!workspace || workspace_bytes < kCtrlBytes) return fail(GEOT_EWORKSPACE, "workspace too small");
+  HIP_TRY(hipMemsetAsync(workspace, 0, kCtrlBytes, static_cast<hipStream_t>(stream)));
+  return GEOT_OK;
+}
+
+int geot_index_scatter(const int64_t *index, const void *src, void *dst, int64_t nnz,
+                       int64_t feat, int64_t out_rows, int dtype, int sorted, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+  return run_typed(dtype, 0, sorted != 0, nullptr, index, nullptr, src, dst, nnz, feat, 1, nnz,
+                   out_rows, workspace, workspace_bytes, stream);
+}
+
+int geot_gather_scatter(const int64_t *src_index, const int64_t *dst_index, const void *src,
+                        void *dst, int64_t nnz, int64_t feat, int64_t src_rows,
+                        int64_t out_rows, int dtype, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+  return run_typed(dtype, 1, true, src_index, dst_index, nullptr, src, dst, nnz, feat, 1,
+                   src_rows, out_rows, workspace, workspace_bytes, stream);
+}
+
+int geot_gather_weight_scatter(const int64_t *src_index, const int64_t *dst_index,
+                               const void *weight, const void *src, void *dst, int64_t nnz,
+                               int64_t feat, int64_t src_rows, int64_t out_rows, int dtype,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+  return run_typed(dtype, 2, true, src_index, dst_index, weight, src, dst, nnz, feat, 1,
+                   src_rows, out_rows, workspace, workspace_bytes, stream);
+}
+
+int geot_mh_spmm(const int64_t *src_index, const int64_t *dst_index, const void *weight,
+                 const void *src, void *dst, int64_t nnz, int64_t heads, int64_t feat,
+                 int64_t src_rows, int64_t out_rows, int weight_layout, int dtype,
+                 void *workspace, size_t workspace_bytes, void *stream) {
+  if (heads < 1 || feat < 0) return fail(GEOT_EINVAL, "heads must be >= 1");
+  if (weight_layout != GEOT_W_EDGE_MAJOR && weight_layout != GEOT_W_HEAD_MAJOR)
+    return fail(GEOT_EINVAL, "Invalid weight size");
+  return run_typed(dtype, weight_layout == GEOT_W_EDGE_MAJOR ? 3 : 4, true, src_index, dst_index,
+                   weight, src, dst, nnz, heads * feat, heads, src_rows, out_rows, workspace,
+                   workspace_bytes, stream);
+}
+
+int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const void *mat_1,
+                   const void *mat_2, void *out, int64_t nnz, int64_t feat, int64_t rows_1,
+                   int64_t rows_2, int dtype, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == GEOT_F32) return run_sddmm<float>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
+  if (dtype == GEOT_F64) return run_sddmm<double>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
+  return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+}
+
+int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
+                     int64_t feat, int64_t src_rows, int dtype, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == GEOT_F32) return run_gather_rows<float>(index, src, dst, nnz, feat, src_rows, st);
+  if (dtype == GEOT_F64) return run_gather_rows<double>(index, src, dst, nnz, feat, src_rows, st);
+  return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+}
+
+void geot_profile_enable(int on) { g_prof.on = on != 0; }
+
+static void prof_drain_locked() {
+  for (auto &r : g_prof.recs) {
+    hipEventSynchronize(r.e3);
+    float a = 0, m = 0, f = 0;
+    hipEventElapsedTime(&a, r.e0, r.e1);
+    hipEventElapsedTime(&m, r.e1, r.e2);
+    hipEventElapsedTime(&f, r.e2, r.e3);
+    g_prof.aux_ms += a;
+    g_prof.main_ms += m;
+    g_prof.fix_ms += f;
+    g_prof.calls += 1;
+    g_prof.pool.push_back(r.e0);
+    g_prof.pool.push_back(r.e1);
+    g_prof.pool.push_back(r.e2);
+    g_prof.pool.push_back(r.e3);
+  }
+  g_prof.recs.clear();
+}
+
+void geot_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  prof_drain_locked();
+  g_prof.main_ms = g_prof.fix_ms = g_prof.aux_ms = 0;
+  g_prof.calls = 0;
+}
+
+int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  prof_drain_locked();
+  if (main_ms) *main_ms = g_prof.main_ms;
+  if (fixup_ms) *fixup_ms = g_prof.fix_ms;
+  if (aux_ms) *aux_ms = g_prof.aux_ms;
+  if (calls) *calls = g_prof.calls;
+  return GEOT_OK;
+}
+
+void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {
+  g_tune.cg = edges_per_group;
+  g_tune.vec = vec;
+  g_tune.nt = nontemporal;
+  g_tune.lpr_log2 = lpr_log2;
+}
+
+} // extern "C"

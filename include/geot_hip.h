@@ -1,0 +1,132 @@
+/*
+ * geot_hip.h -- C ABI of libgeot_hip.so, the MI355X (gfx950) segment-reduction engine.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one of the reference's
+ * device-side entry functions, which the reference's dispatcher shims call after they have
+ * computed the output row count and allocated the output (citations are relative to the
+ * reference tree):
+ *
+ *   geot_index_scatter            <- index_scatter_cuda          csrc/cuda/header_cuda.h:4-6
+ *                                    (impl csrc/cuda/index_scatter_cuda.cu:86-105)
+ *   geot_gather_scatter           <- gather_scatter_cuda         csrc/cuda/header_cuda.h:8-10
+ *                                    (impl csrc/cuda/gather_scatter_cuda.cu:15-28)
+ *   geot_gather_weight_scatter    <- gather_weight_scatter_cuda  csrc/cuda/header_cuda.h:12-17
+ *                                    (impl csrc/cuda/gather_weight_scatter_cuda.cu:22-39)
+ *   geot_mh_spmm                  <- mh_spmm_cuda                csrc/cuda/header_cuda.h:23-26
+ *                                    (impl csrc/cuda/mh_spmm_cuda.cu:20-38, layout pick
+ *                                     csrc/cuda/wrapper/mh_spmm_base.h:38-49)
+ *   geot_sddmm_coo                <- sddmm_coo_cuda              csrc/cuda/header_cuda.h:28-30
+ *                                    (impl csrc/cuda/gather_weight_scatter_cuda.cu:41-62)
+ *   geot_gather_rows              <- gather_eb_sorted_kernel     csrc/cuda/index_scatter_kernel.cuh:266-315
+ *                                    (backward of index_scatter; unwired in the reference)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless stated otherwise;
+ *   - indices are int64 (the reference's `Index`, csrc/util/utils.h:9); values are float32
+ *     (dtype GEOT_F32) or float64 (GEOT_F64), the AT_DISPATCH_FLOATING_TYPES set of the reference;
+ *   - `dst` is written in full by every sorted call: it does NOT need to be zeroed
+ *     (the reference requires torch::zeros, csrc/index_scatter.cpp:35, because it flushes with
+ *     atomicAdd); rows with no edge come out as 0 exactly as in the reference;
+ *   - `out_rows` is the reference's row rule, index[-1] + 1 (csrc/index_scatter.cpp:30-34),
+ *     computed by the caller; keys outside [0, out_rows) are ignored (never written);
+ *   - `workspace` is caller-owned scratch of at least geot_workspace_bytes(...) bytes, 256-B
+ *     aligned.  Its first 256 bytes are control words that must be ZERO before the first call
+ *     (geot_workspace_init, or any zeroing allocation); every call leaves them zero again, so a
+ *     workspace can be reused call after call - by one stream at a time - with no per-call
+ *     memset.  The rest is scratch whose content is irrelevant on entry;
+ *   - `stream` is a hipStream_t (NULL = default stream);
+ *   - all launches are asynchronous on `stream`; no host synchronisation, no allocation: the
+ *     calls are hipGraph-capturable;
+ *   - return value: GEOT_OK or a negative GEOT_E* code; geot_last_error() gives the message
+ *     (the reference's TORCH_CHECK texts are reproduced by the host layer above this ABI).
+ */
+#ifndef GEOT_HIP_H
+#define GEOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOT_ABI_VERSION 1
+
+enum {
+  GEOT_OK = 0,
+  GEOT_EINVAL = -1,     /* bad argument (negative size, null pointer, bad dtype ...)     */
+  GEOT_EWORKSPACE = -2, /* workspace too small or misaligned                              */
+  GEOT_ELAUNCH = -3,    /* HIP runtime reported an error (see geot_last_error)            */
+  GEOT_EUNSUPPORTED = -4
+};
+
+enum { GEOT_F32 = 0, GEOT_F64 = 1 };
+
+/* weight layouts of geot_mh_spmm (csrc/cuda/wrapper/mh_spmm_base.h:38-49) */
+enum { GEOT_W_EDGE_MAJOR = 0 /* [nnz, H] */, GEOT_W_HEAD_MAJOR = 1 /* [H, nnz] */ };
+
+int geot_abi_version(void);
+const char *geot_last_error(void);
+const char *geot_build_info(void); /* "gfx950 <date> ..." */
+
+/* Scratch needed by any of the segment-reduction calls below for an edge list of `nnz`
+ * edges, `feat` values per output row (H*F for mh_spmm) and `out_rows` output rows. */
+size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype);
+
+/* Zero the control words of a freshly allocated workspace (asynchronous on `stream`). */
+int geot_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+
+/* dst[index[e], :] += src[e, :]        src [nnz, feat], dst [out_rows, feat]
+ * sorted != 0: index ascending; atomic-free, deterministic, dst written exactly once.
+ * sorted == 0: any order; runs of equal keys are pre-reduced, then float atomics
+ *              (dst is zero-filled by the call). */
+int geot_index_scatter(const int64_t *index, const void *src, void *dst, int64_t nnz,
+                       int64_t feat, int64_t out_rows, int dtype, int sorted, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* dst[dst_index[e], :] += src[src_index[e], :]     dst_index ascending */
+int geot_gather_scatter(const int64_t *src_index, const int64_t *dst_index, const void *src,
+                        void *dst, int64_t nnz, int64_t feat, int64_t src_rows,
+                        int64_t out_rows, int dtype, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* dst[dst_index[e], :] += weight[e] * src[src_index[e], :]     dst_index ascending */
+int geot_gather_weight_scatter(const int64_t *src_index, const int64_t *dst_index,
+                               const void *weight, const void *src, void *dst, int64_t nnz,
+                               int64_t feat, int64_t src_rows, int64_t out_rows, int dtype,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
+/* dst[dst_index[e], h, :] += w(e, h) * src[src_index[e], h, :]   src [src_rows, heads, feat]
+ * w(e,h) = weight[e*heads + h] (GEOT_W_EDGE_MAJOR) or weight[h*nnz + e] (GEOT_W_HEAD_MAJOR) */
+int geot_mh_spmm(const int64_t *src_index, const int64_t *dst_index, const void *weight,
+                 const void *src, void *dst, int64_t nnz, int64_t heads, int64_t feat,
+                 int64_t src_rows, int64_t out_rows, int weight_layout, int dtype,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[e] = < mat_1[dst_index[e], :], mat_2[src_index[e], :] >      (float32) */
+int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const void *mat_1,
+                   const void *mat_2, void *out, int64_t nnz, int64_t feat, int64_t rows_1,
+                   int64_t rows_2, int dtype, void *stream);
+
+/* dst[e, :] = src[index[e], :] */
+int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
+                     int64_t feat, int64_t src_rows, int dtype, void *stream);
+
+/* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
+ * With profiling on, every segment-reduction call records hipEvents around its kernels on
+ * the call's stream; geot_profile_read waits for them and returns the accumulated device
+ * time per kernel class since the last reset. */
+void geot_profile_enable(int on);
+void geot_profile_reset(void);
+/* main = tile kernel, fixup = carry/gap kernel, aux = memsets; *_calls = launches counted */
+int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls);
+
+/* Tuning knobs for experiments: edges per lane-group sub-chunk (0 = auto), forced vector
+ * width in elements (0 = auto), non-temporal policy (-1 = auto; bit 0 = row loads, bit 1 = dst
+ * stores), lanes per row log2 (-1 = auto). */
+void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOT_HIP_H */

@@ -1,0 +1,169 @@
+// kexp.hip -- access-pattern probes (developer tool, not product).  Measures how close the tile
+// kernel's memory access shape can get to the streaming ceiling, one feature at a time:
+//   R0  grid-stride float4 read, 2048 blocks (reference point)
+//   R1  tile-shaped read: block b reads rows [b*TE,(b+1)*TE), lane group g walks CG consecutive rows
+//   R2  same tile, interleaved rows: a wave instruction reads 4 consecutive rows (1 KiB contiguous)
+//   R3  R1 made persistent: 256*BPC blocks loop over tiles
+//   W   tile read + one 256-B row store per `seglen` rows (the write mix of the real workload)
+// Build: hipcc -O3 --offload-arch=gfx950 tools/kexp.hip -o tools/kexp
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP %s @%d\n", hipGetErrorString(e_), __LINE__); exit(2);} } while (0)
+
+constexpr int F = 64;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ld(const float4 *p) {
+  if constexpr (NT) {
+    f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+    return float4{v[0], v[1], v[2], v[3]};
+  } else return *p;
+}
+
+__global__ void r0_kernel(const float4 *__restrict__ a, float *out, size_t n) {
+  float s = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = a[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  if (s == 123.456f) out[0] = s;
+}
+
+// MODE 0: blocked (group g owns CG consecutive rows); MODE 1: interleaved (row = 4*i + g within wave chunk)
+template <int U, int MODE, bool NT, bool PERSIST, int SEGLEN, int OUT = 0, bool NTS = false>
+__global__ __launch_bounds__(256) void tile_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                    float *sink, int64_t nrows, int cg, int64_t ntiles) {
+  const int tid = threadIdx.x;
+  const int g = tid >> 4, c = tid & 15;
+  const int te = 16 * cg;
+  float4 acc = {0, 0, 0, 0};
+  __shared__ float4 outL[OUT ? 64 * 16 : 1];
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += PERSIST ? gridDim.x : ntiles) {
+    const int64_t ts = tile * te;
+    const int64_t jfirst = SEGLEN > 0 ? ts / (SEGLEN > 0 ? SEGLEN : 1) : 0;
+    const int wave = tid >> 6, gw = g & 3;
+    for (int b = 0; b < cg; b += U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t row;
+        if (MODE == 0) row = ts + (int64_t)g * cg + b + u;
+        else row = ts + (int64_t)wave * 4 * cg + (int64_t)(b + u) * 4 + gw;
+        v[u] = row < nrows ? ld<NT>(reinterpret_cast<const float4 *>(src + row * F) + c) : float4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        if (SEGLEN > 0) {
+          const int64_t r = ts + (int64_t)g * cg + b + u;
+          if ((r % SEGLEN) == SEGLEN - 1 && r < nrows) {
+            if (OUT) outL[(r / SEGLEN - jfirst) * 16 + c] = acc;
+            else if (NTS) __builtin_nontemporal_store(f4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f4 *>(dst + (r / SEGLEN) * F) + c);
+            else reinterpret_cast<float4 *>(dst + (r / SEGLEN) * F)[c] = acc;
+            acc = float4{0, 0, 0, 0};
+          }
+        }
+      }
+    }
+    if (OUT) {
+      __syncthreads();
+      const int64_t tend = ts + te < nrows ? ts + te : nrows;
+      const int64_t jend = (tend - (SEGLEN > 0 ? SEGLEN : 1) + 1 + (SEGLEN > 0 ? SEGLEN : 1) - 1) / (SEGLEN > 0 ? SEGLEN : 1); // rows j with j*S+S-1 < tend
+      const int nout = (int)(jend - jfirst);
+      float4 *d4 = reinterpret_cast<float4 *>(dst + jfirst * F);
+      for (int i = tid; i < nout * 16; i += 256) {
+        if (NTS) __builtin_nontemporal_store(f4{outL[i].x, outL[i].y, outL[i].z, outL[i].w}, reinterpret_cast<f4 *>(d4 + i));
+        else d4[i] = outL[i];
+      }
+      __syncthreads();
+    }
+  }
+  if (acc.x == 123.456f) sink[0] = acc.x + acc.y + acc.z + acc.w;
+}
+
+__global__ void empty_kernel(float *sink) { if (sink == nullptr) sink[0] = 1.f; }
+// one dependent trip: every wave reads 256 B from a buffer the previous kernel wrote, writes 256 B
+__global__ void onetrip_kernel(const float *__restrict__ a, float *__restrict__ b, int64_t stride) {
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  b[w * stride + lane] = a[w * stride + lane] + 1.f;
+}
+
+static float ms_of(hipEvent_t a, hipEvent_t b) { float m; CK(hipEventElapsedTime(&m, a, b)); return m; }
+
+template <typename Fn> static double timeit(Fn fn, int iters = 10) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) fn();
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) fn();
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  return ms_of(e0, e1) / iters;
+}
+
+int main() {
+  const int64_t nrows = 10000000;
+  const size_t bytes = (size_t)nrows * F * 4;
+  float *src, *dst, *sink;
+  CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes / 4)); CK(hipMalloc(&sink, 256));
+  CK(hipMemset(src, 1, bytes));
+  {
+    double ms = timeit([&] { hipLaunchKernelGGL(r0_kernel, dim3(2048), dim3(256), 0, 0, (const float4 *)src, sink, bytes / 16); });
+    printf("R0 grid-stride read 2048 blocks            %.4f ms  %.2f TB/s\n", ms, bytes / ms / 1e9);
+  }
+#define RUN2(U, MODE, NT, PERSIST, SEGLEN, CG, BPC, OUT, NTS, LABEL)                                      \
+  {                                                                                                      \
+    const int cg = CG; const int64_t nt = (nrows + 16 * cg - 1) / (16 * cg);                            \
+    const unsigned grid = PERSIST ? 256 * BPC : (unsigned)nt;                                            \
+    double ms = timeit([&] { hipLaunchKernelGGL((tile_kernel<U, MODE, NT, PERSIST, SEGLEN, OUT, NTS>), dim3(grid), dim3(256), 0, 0, src, dst, sink, nrows, cg, nt); }); \
+    const double b = (double)bytes + (SEGLEN > 0 ? (double)bytes / SEGLEN : 0);                           \
+    printf("%-44s U=%-2d cg=%-3d grid=%-6u %.4f ms  %.2f TB/s\n", LABEL, U, cg, grid, ms, b / ms / 1e9);   \
+  }
+#define RUN(U, MODE, NT, PERSIST, SEGLEN, CG, BPC, LABEL)                                               \
+  {                                                                                                      \
+    const int cg = CG; const int64_t nt = (nrows + 16 * cg - 1) / (16 * cg);                            \
+    const unsigned grid = PERSIST ? 256 * BPC : (unsigned)nt;                                            \
+    double ms = timeit([&] { hipLaunchKernelGGL((tile_kernel<U, MODE, NT, PERSIST, SEGLEN>), dim3(grid), dim3(256), 0, 0, src, dst, sink, nrows, cg, nt); }); \
+    const double b = (double)bytes + (SEGLEN > 0 ? (double)bytes / SEGLEN : 0);                           \
+    printf("%-44s U=%-2d cg=%-3d grid=%-6u %.4f ms  %.2f TB/s\n", LABEL, U, cg, grid, ms, b / ms / 1e9);   \
+  }
+  RUN(8, 0, false, false, 0, 32, 0, "R1 tile blocked");
+  RUN(8, 0, true, false, 0, 32, 0, "R1 tile blocked nt");
+  RUN(8, 0, true, false, 0, 64, 0, "R1 tile blocked nt");
+  RUN(4, 0, true, false, 0, 32, 0, "R1 tile blocked nt");
+  RUN(16, 0, true, false, 0, 32, 0, "R1 tile blocked nt");
+  RUN(8, 1, false, false, 0, 32, 0, "R2 tile interleaved");
+  RUN(8, 1, true, false, 0, 32, 0, "R2 tile interleaved nt");
+  RUN(16, 1, true, false, 0, 32, 0, "R2 tile interleaved nt");
+  RUN(8, 0, true, true, 0, 32, 4, "R3 persistent blocked nt bpc=4");
+  RUN(8, 0, true, true, 0, 32, 8, "R3 persistent blocked nt bpc=8");
+  RUN(8, 1, true, true, 0, 32, 8, "R3 persistent interleaved nt bpc=8");
+  RUN(16, 1, true, true, 0, 32, 8, "R3 persistent interleaved nt bpc=8");
+  RUN(8, 0, true, false, 10, 32, 0, "W  tile blocked nt + store/10 rows");
+  RUN(8, 0, false, false, 10, 32, 0, "W  tile blocked + store/10 rows");
+  RUN(8, 0, true, true, 10, 32, 8, "W  persistent blocked nt + store/10 rows");
+  RUN(8, 0, true, false, 10, 64, 0, "W  tile blocked nt + store/10 rows");
+  RUN2(8, 0, true, false, 10, 32, 0, 0, true, "W  nt loads + nt stores");
+  RUN2(8, 0, true, false, 10, 64, 0, 0, true, "W  nt loads + nt stores");
+  RUN2(8, 0, true, false, 10, 32, 0, 1, false, "W2 LDS-staged burst");
+  RUN2(8, 0, true, false, 10, 32, 0, 1, true, "W2 LDS-staged burst + nt stores");
+  RUN2(8, 0, true, false, 10, 64, 0, 1, true, "W2 LDS-staged burst + nt stores");
+  RUN2(16, 0, true, false, 10, 32, 0, 1, true, "W2 LDS-staged burst + nt stores");
+  RUN2(8, 0, true, true, 10, 32, 8, 1, true, "W2 persistent LDS-staged burst + nt stores");
+  // boundary cost probes: W kernel followed by a small second kernel, timed as a pair
+  {
+    const int cg = 64; const int64_t nt = (nrows + 16 * cg - 1) / (16 * cg);
+    auto w = [&] { hipLaunchKernelGGL((tile_kernel<8, 0, true, false, 10, 0, true>), dim3((unsigned)nt), dim3(256), 0, 0, src, dst, sink, nrows, cg, nt); };
+    double base = timeit(w, 20);
+    double e1 = timeit([&] { w(); hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, 0, sink); }, 20);
+    double e2 = timeit([&] { w(); hipLaunchKernelGGL(empty_kernel, dim3(2442), dim3(256), 0, 0, sink); }, 20);
+    double e3 = timeit([&] { w(); hipLaunchKernelGGL(onetrip_kernel, dim3(2442), dim3(256), 0, 0, dst, dst + (size_t)128 * 1024 * 1024 / 4, (int64_t)6400); }, 20);
+    double e4 = timeit([&] { w(); hipLaunchKernelGGL(onetrip_kernel, dim3(610), dim3(256), 0, 0, dst, dst + (size_t)128 * 1024 * 1024 / 4, (int64_t)6400); }, 20);
+    printf("W alone %.4f | +empty(1 blk) %.4f | +empty(2442 blk) %.4f | +onetrip(2442 blk) %.4f | +onetrip(610 blk) %.4f ms\n", base, e1, e2, e3, e4);
+  }
+  return 0;
+}
