@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): aggregated edges/sec + HBM GB/s, index_scatter feat=64 sorted sum.
+Workload (BASELINE.json configs[1]): synthetic power-law 10M edges -> 1M nodes, feat=64, fp32,
+int64 index, generated on the device from fixed seeds (SURVEY.md section 8d generator).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one call of the drop-in operator ``geot.index_scatter(0, src, index, 'sum', True)`` on the
+resident inputs: the D2H read of index[-1] (the reference's row rule), the output allocation, the
+tile kernel and the fix-up kernel.  N > 1 = weak scaling: every rank reduces its own 10M-edge shard
+of a dst-sorted edge list whose neighbouring shards share their boundary key, and the partial
+boundary rows are exchanged with one small RCCL all_gather per step (geot_amd/sharding.py).
+
+One JSON line on rank 0.  `roofline` is the tile kernel alone (HIP events around it on its stream,
+over K extra steps); `cpu_baseline` is the reference's own CPU index_scatter (oracle/_ref, compiled
+from /root/reference in the build container) - or the oracle port when that library is absent -
+timed on this host on the same full-size inputs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NNZ, KEYS, FEAT = 10_000_000, 1_000_000, 64
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+METRIC = "aggregated edges/sec + HBM GB/s, index_scatter feat=64 sorted sum"
+
+
+def powerlaw_index(nnz, keys, seed, device):
+    """Sorted int64 keys, w_k ~ rank^(-1/1.5), ranks randomly permuted, index[-1] = keys-1."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    w = torch.arange(1, keys + 1, device=device, dtype=torch.float64) ** (-1.0 / 1.5)
+    cdf = torch.cumsum(w, 0)
+    perm = torch.randperm(keys, generator=g, device=device)
+    u = torch.rand(nnz, generator=g, device=device, dtype=torch.float64) * cdf[-1]
+    r = torch.searchsorted(cdf, u).clamp_(max=keys - 1)
+    idx = perm[r].sort().values.contiguous()
+    idx[-1] = keys - 1
+    idx[0] = 0                   # shard r's first key = shard r-1's last key (boundary segment)
+    return idx
+
+
+def algorithmic_bytes(nnz, feat, rows):
+    """each src row and index read once, each dst row written once."""
+    return nnz * (4 * feat + 8) + rows * 4 * feat
+
+
+def cpu_baseline(index, src, budget_s=25.0):
+    """Reference CPU index_scatter on this host, same inputs (bounded: at most ~budget_s seconds)."""
+    import numpy as np
+    idx = index.cpu().numpy()
+    s = src.cpu().numpy()
+    cores = os.cpu_count() or 1
+    res = {"unit": "edges/s", "sample": f"full workload ({NNZ} edges x {FEAT} feat -> {KEYS} rows), best of <=3 passes"}
+
+    def best_of(fn, reps=3):
+        best, spent = None, 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            spent += dt
+            if spent > budget_s / 3:
+                break
+        return best
+
+    from oracle import api as oracle, ref
+    # thread counts to try: all cores is not always the fastest on a many-socket host
+    tries = sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True)
+    port_t, port_n = min((best_of(lambda n=n: oracle.index_scatter_3pass(idx, s, "sum", threads=n, rows=KEYS), reps=2), n)
+                         for n in tries)
+    res["port_edges_per_s"] = NNZ / port_t
+    res["port_threads"] = port_n
+    if ref.available(omp=True):
+        t_omp, n_omp = min((best_of(lambda n=n: ref.index_scatter_cpu(idx, s, omp=True, threads=n, rows=KEYS), reps=2), n)
+                           for n in tries)
+        res.update(value=NNZ / t_omp, cores=n_omp, kind="reference", host_cores=cores,
+                   note="reference csrc/cpu/index_scatter_cpu.cpp compiled in place with -fopenmp, best of "
+                        f"{tries} threads; as shipped it sums src[index[n]] (touches only K distinct "
+                        "rows: optimistic for the CPU) and is single-threaded (setup.py has no -fopenmp)")
+        if ref.available(omp=False):
+            t_ser = best_of(lambda: ref.index_scatter_cpu(idx, s, omp=False, rows=KEYS), reps=2)
+            res["reference_as_shipped_serial_edges_per_s"] = NNZ / t_ser
+    else:
+        res.update(value=NNZ / port_t, cores=port_n, kind="port", host_cores=cores,
+                   note="oracle/_ref absent: timed the C restatement of the reference's 3-pass algorithm (OpenMP)")
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in this package)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    import geot_amd as geot
+    from geot_amd import hip, sharding
+
+    index = powerlaw_index(NNZ, KEYS, seed=rank, device=dev)          # rank-local keys 0..KEYS-1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    src = torch.rand(NNZ, FEAT, device=dev, generator=gen)
+
+    if distributed:
+        key_offset = rank * (KEYS - 1)                                 # neighbours share one key
+
+        def step():
+            return sharding.sharded_index_scatter(index, src, key_offset=key_offset)[0]
+    else:
+        def step():
+            return geot.index_scatter(0, src, index, "sum", True)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    edges_per_s = world * NNZ * args.steps / elapsed
+    alg = algorithmic_bytes(NNZ, FEAT, KEYS)
+
+    # ---- roofline of the dominant kernel: HIP events around the tile kernel, K more steps -------
+    hip.profile_enable(True)
+    hip.profile_reset()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    prof = hip.profile_read()
+    hip.profile_enable(False)
+    main_ms = prof["main_ms"] / max(prof["calls"], 1)
+    fix_ms = prof["fixup_ms"] / max(prof["calls"], 1)
+    achieved = alg / (main_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # kernel-only pace of the whole call (tile + fix-up), without the operator's host-side work
+    if rank == 0:
+        res = {
+            "metric": METRIC, "value": edges_per_s, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64 "
+                                   "(BASELINE.json configs[1])" + (" per GPU, boundary rows exchanged by RCCL all_gather" if distributed else ""),
+                       "nnz_per_gpu": NNZ, "rows_per_gpu": KEYS, "feat": FEAT, "index_dtype": "int64",
+                       "step": "geot.index_scatter(0, src, index, 'sum', True): index[-1].item() + alloc + tile kernel + fix-up kernel"},
+            "hbm_gbps_whole_call": world * alg * args.steps / elapsed / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "seg_tile_kernel<float,4,false,0,false,3>", "kernel_ms": main_ms,
+                         "fixup_kernel_ms": fix_ms, "algorithmic_bytes_per_launch": alg,
+                         "frac_tile_plus_fixup": alg / ((main_ms + fix_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        }
+        if not distributed and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(index, src)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed", "error": repr(e)}
+        print(json.dumps(res))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""Loader / builder for libgeot_hip.so, the C-ABI HIP library declared in include/geot_hip.h.
+
+The library is the product: there is NO fallback.  If it is missing or does not export the ABI
+the import of :mod:`geot_amd` fails loudly (the reference does the same for its ``_C`` module,
+geot/__init__.py:12-19: ``ImportError("Could not find module '_C' in ...")``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_NAME = "libgeot_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip")]
+HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
+
+GEOT_OK = 0
+GEOT_F32, GEOT_F64 = 0, 1
+GEOT_W_EDGE_MAJOR, GEOT_W_HEAD_MAJOR = 0, 1
+ABI_VERSION = 1
+
+#: every symbol include/geot_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes",
+    "geot_workspace_init", "geot_index_scatter", "geot_gather_scatter",
+    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows",
+    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_tune",
+]
+
+_lib = None
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + [HEADER])
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU; ~10 s)."""
+    if force or needs_build():
+        cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+               "-Wno-unused-value", "-I", os.path.join(_ROOT, "include"), *SOURCES, "-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library and attach prototypes.  Raises ImportError if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"Could not find '{LIB_NAME}' in {_HERE}: build it with `make lib` (or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`).  geot_amd has no fallback path.")
+    L = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export {missing}")
+    c_i64, c_int, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    L.geot_abi_version.restype = c_int
+    L.geot_last_error.restype = ctypes.c_char_p
+    L.geot_build_info.restype = ctypes.c_char_p
+    L.geot_workspace_bytes.restype = c_sz
+    L.geot_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]
+    L.geot_workspace_init.argtypes = [c_vp, c_sz, c_vp]
+    L.geot_index_scatter.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
+    L.geot_gather_scatter.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
+    L.geot_gather_weight_scatter.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
+    L.geot_mh_spmm.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
+    L.geot_sddmm_coo.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]
+    L.geot_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]
+    L.geot_profile_enable.argtypes = [c_int]
+    L.geot_profile_enable.restype = None
+    L.geot_profile_reset.restype = None
+    L.geot_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(c_i64)]
+    L.geot_tune.argtypes = [c_int, c_int, c_int, c_int]
+    L.geot_tune.restype = None
+    if L.geot_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {L.geot_abi_version()} != {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().geot_last_error().decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != GEOT_OK:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,190 @@
+"""Tensor-level doorway to the C ABI (include/geot_hip.h): raw pointers, sizes, current stream.
+
+These are the `*_cuda(...)` entry points of the reference (csrc/cuda/header_cuda.h:4-30) restated
+for the HIP library: the caller supplies the output tensor and its row count, nothing here
+synchronises with the host, allocates device memory per call (beyond the cached workspace) or
+touches the CPU.  The operator layer (geot_amd/ops.py) adds the reference's shape rule, checks
+and error texts on top.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.GEOT_F32, torch.float64: _lib.GEOT_F64}
+
+# one workspace per (device, stream): the C ABI allows reuse by one stream at a time
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _require_gpu(*tensors: torch.Tensor) -> torch.device:
+    dev = tensors[0].device
+    for t in tensors:
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "geot_amd runs on MI355X only: got a tensor on device "
+                f"'{t.device}'.  There is no CPU fallback in this package.")
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+    return dev
+
+
+_SCALAR_NAMES = {torch.int32: "Int", torch.int16: "Short", torch.int8: "Char", torch.uint8: "Byte",
+                 torch.int64: "Long", torch.float32: "Float", torch.float64: "Double",
+                 torch.float16: "Half", torch.bfloat16: "BFloat16", torch.bool: "Bool"}
+
+
+def _dtype_code(t: torch.Tensor, name: str) -> int:
+    if t.dtype not in _DT:
+        # the reference dispatches AT_DISPATCH_FLOATING_TYPES (csrc/cuda/index_scatter_cuda.cu:68)
+        raise RuntimeError(f'"{name}" not implemented for \'{_SCALAR_NAMES.get(t.dtype, str(t.dtype))}\'')
+    return _DT[t.dtype]
+
+
+def _index_ptr(t: torch.Tensor, name: str) -> int:
+    if t.dtype != torch.int64:
+        # reference: index.data_ptr<int64_t>() (csrc/cuda/index_scatter_cuda.cu:11) -> c10 error text
+        raise RuntimeError(f"expected scalar type Long but found {_SCALAR_NAMES.get(t.dtype, str(t.dtype))} ({name})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream_handle(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Cached scratch for the current stream; zero-initialised once (control words), reused after."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream_handle(dev))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces() -> None:
+    _workspaces.clear()
+
+
+def _ws_args(L, dev, nnz, feat, rows, dt):
+    nbytes = int(L.geot_workspace_bytes(nnz, feat, rows, dt))
+    ws = workspace(dev, nbytes)
+    return ws, ws.data_ptr(), ws.numel()
+
+
+def index_scatter_out(index: torch.Tensor, src: torch.Tensor, out: torch.Tensor, sorted: bool = True) -> torch.Tensor:
+    """out[index[e], :] += src[e, :] over a contiguous [nnz, F] view; `out` is [rows, F], written in full."""
+    dev = _require_gpu(index, src, out)
+    L = _lib.load()
+    dt = _dtype_code(src, "index_scatter_sorted" if sorted else "index_scatter_unsorted")
+    nnz = index.numel()
+    feat = src.numel() // nnz if nnz else (out.numel() // max(out.shape[0], 1))
+    rows = out.shape[0]
+    with torch.cuda.device(dev):
+        ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
+        rc = L.geot_index_scatter(_index_ptr(index, "index"), src.data_ptr(), out.data_ptr(), nnz, feat, rows,
+                                  dt, 1 if sorted else 0, wsp, wsn, _stream_handle(dev))
+    _lib.check(rc, "geot_index_scatter")
+    return out
+
+
+def gather_scatter_out(src_index, dst_index, src, out) -> torch.Tensor:
+    dev = _require_gpu(src_index, dst_index, src, out)
+    L = _lib.load()
+    dt = _dtype_code(src, "gather_scatter_sorted")
+    nnz, feat, rows = dst_index.numel(), src.shape[1], out.shape[0]
+    with torch.cuda.device(dev):
+        ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
+        rc = L.geot_gather_scatter(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
+                                   src.data_ptr(), out.data_ptr(), nnz, feat, src.shape[0], rows, dt,
+                                   wsp, wsn, _stream_handle(dev))
+    _lib.check(rc, "geot_gather_scatter")
+    return out
+
+
+def gather_weight_scatter_out(src_index, dst_index, weight, src, out) -> torch.Tensor:
+    dev = _require_gpu(src_index, dst_index, weight, src, out)
+    L = _lib.load()
+    dt = _dtype_code(src, "gather_weight_scatter_sorted")
+    if weight.dtype != src.dtype:
+        raise RuntimeError(f"expected weight of dtype {src.dtype} but found {weight.dtype}")
+    nnz, feat, rows = dst_index.numel(), src.shape[1], out.shape[0]
+    with torch.cuda.device(dev):
+        ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
+        rc = L.geot_gather_weight_scatter(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
+                                          weight.data_ptr(), src.data_ptr(), out.data_ptr(), nnz, feat,
+                                          src.shape[0], rows, dt, wsp, wsn, _stream_handle(dev))
+    _lib.check(rc, "geot_gather_weight_scatter")
+    return out
+
+
+def mh_spmm_out(src_index, dst_index, weight, src, out, head_major: bool) -> torch.Tensor:
+    dev = _require_gpu(src_index, dst_index, weight, src, out)
+    L = _lib.load()
+    dt = _dtype_code(src, "mh_spmm_sorted")
+    if weight.dtype != src.dtype:
+        raise RuntimeError(f"expected weight of dtype {src.dtype} but found {weight.dtype}")
+    nnz, heads, feat, rows = dst_index.numel(), src.shape[1], src.shape[2], out.shape[0]
+    with torch.cuda.device(dev):
+        ws, wsp, wsn = _ws_args(L, dev, nnz, heads * feat, rows, dt)
+        rc = L.geot_mh_spmm(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
+                            weight.data_ptr(), src.data_ptr(), out.data_ptr(), nnz, heads, feat, src.shape[0],
+                            rows, _lib.GEOT_W_HEAD_MAJOR if head_major else _lib.GEOT_W_EDGE_MAJOR, dt,
+                            wsp, wsn, _stream_handle(dev))
+    _lib.check(rc, "geot_mh_spmm")
+    return out
+
+
+def sddmm_coo_out(src_index, dst_index, mat_1, mat_2, out) -> torch.Tensor:
+    dev = _require_gpu(src_index, dst_index, mat_1, mat_2, out)
+    L = _lib.load()
+    dt = _dtype_code(mat_1, "sddmm_coo")
+    with torch.cuda.device(dev):
+        rc = L.geot_sddmm_coo(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
+                              mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), dst_index.numel(),
+                              mat_1.shape[1], mat_1.shape[0], mat_2.shape[0], dt, _stream_handle(dev))
+    _lib.check(rc, "geot_sddmm_coo")
+    return out
+
+
+def gather_rows_out(index, src, out) -> torch.Tensor:
+    dev = _require_gpu(index, src, out)
+    L = _lib.load()
+    dt = _dtype_code(src, "gather_rows")
+    nnz = index.numel()
+    feat = src.numel() // max(src.shape[0], 1)
+    with torch.cuda.device(dev):
+        rc = L.geot_gather_rows(_index_ptr(index, "index"), src.data_ptr(), out.data_ptr(), nnz, feat,
+                                src.shape[0], dt, _stream_handle(dev))
+    _lib.check(rc, "geot_gather_rows")
+    return out
+
+
+# ---- measurement hooks ---------------------------------------------------------------------------
+def profile_enable(on: bool) -> None:
+    _lib.load().geot_profile_enable(1 if on else 0)
+
+
+def profile_reset() -> None:
+    _lib.load().geot_profile_reset()
+
+
+def profile_read() -> dict:
+    a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    n = ctypes.c_int64()
+    _lib.load().geot_profile_read(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(n))
+    return {"main_ms": a.value, "fixup_ms": b.value, "aux_ms": c.value, "calls": n.value}
+
+
+def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2: int = -1) -> None:
+    _lib.load().geot_tune(edges_per_group, vec, nontemporal, lpr_log2)
+
+
+def build_info() -> str:
+    return _lib.load().geot_build_info().decode()

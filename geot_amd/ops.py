@@ -1,0 +1,337 @@
+"""The geot.* operator surface on top of the HIP library -- same names, argument order, shape rule
+and error texts as the reference, so PyG / torch_scatter style call sites are drop-in.
+
+What this file mirrors (paths relative to the reference tree):
+
+* Python wrappers      geot/index_scatter.py:5-8, geot/gather_scatter.py:3-39,
+                       geot/gather_weight_scatter.py:4-51, geot/mh_spmm.py:4-12
+* dispatcher shims     csrc/index_scatter.cpp:11-56, csrc/gather_scatter.cpp:13-34,
+                       csrc/gather_weight_scatter.cpp:11-49, csrc/mh_spmm.cpp:10-23
+* argument checks      csrc/cuda/index_scatter_cuda.cu:86-105, gather_scatter_cuda.cu:15-28,
+                       gather_weight_scatter_cuda.cu:22-39, mh_spmm_cuda.cu:20-38,
+                       csrc/reduceutils.h:5-22, csrc/cuda/wrapper/mh_spmm_base.h:38-49
+
+Ops registered in the torch dispatcher namespace ``geot`` (device key CUDA -- which is what a
+ROCm build of PyTorch calls the GPU):
+    geot::index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor
+    geot::gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor
+    geot::gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor
+    geot::sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor
+    geot::mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor
+plus the Python-defined custom ops geot::gather_scatter / geot::gather_weight_scatter with
+register_fake and register_autograd exactly where the reference has them.
+
+Deliberate differences (all documented in DESIGN.md):
+* the output row count still comes from ``index[-1].item() + 1`` (one D2H sync per call - part of
+  the reference contract), but the output is ``torch.empty``: the sorted kernels write every row
+  exactly once, so the reference's ``torch::zeros`` pass is not needed;
+* ``reduce`` other than "sum" raises instead of being silently ignored (the reference's GPU
+  kernels always add: csrc/cuda/index_scatter_cuda.cu:68-72 dispatches on it, the kernels do not
+  use it);
+* ``dim != 0`` is honoured (the reference validates ``dim`` but always reduces along dim 0,
+  csrc/cuda/index_scatter_cuda.cu:9-11);
+* CPU tensors raise: this package is the MI355X path and has no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip
+
+_REDUCE_ENUM = {"max": "max", "amax": "max", "mean": "mean", "min": "min", "amin": "min",
+                "sum": "sum", "prod": "prod"}
+
+
+def get_reduction_enum(reduce: str) -> str:
+    """csrc/reduceutils.h:5-22 -- same accepted spellings, same error text."""
+    if reduce in _REDUCE_ENUM:
+        return _REDUCE_ENUM[reduce]
+    raise RuntimeError(
+        f"reduce argument must be either sum, prod, mean, amax or amin, got {reduce}")
+
+
+def _only_sum(reduce: str, op: str) -> None:
+    kind = get_reduction_enum(reduce)
+    if kind != "sum":
+        raise NotImplementedError(
+            f"{op}: reduce='{reduce}' is not implemented on the HIP path (only 'sum'). "
+            "Note the reference's GPU kernels ignore `reduce` and always sum.")
+
+
+def _last_index_plus_one(index: torch.Tensor) -> int:
+    # csrc/index_scatter.cpp:30 -- index[-1].item<int64_t>(): a device->host copy + stream sync
+    return int(index[-1].item()) + 1
+
+
+def _reject_cpu(name: str):
+    def impl(*args, **kwargs):
+        raise RuntimeError(
+            f"geot::{name}: CPU tensors are not supported by geot_amd (MI355X-only package, no CPU "
+            "fallback).  Move the tensors to the GPU.")
+    return impl
+
+
+# --------------------------------------------------------------------------------------------------
+# dispatcher-level implementations (the reference's *_cuda_impl functions)
+# --------------------------------------------------------------------------------------------------
+def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce: str,
+                       sorted: bool) -> torch.Tensor:
+    # checks of index_scatter_cuda (csrc/cuda/index_scatter_cuda.cu:90-94), same texts
+    if not (0 <= dim < src.dim()):
+        raise RuntimeError("dim must be non-negative and less than input dimensions")
+    if index.dim() != 1:
+        raise RuntimeError("index must be 1 dimensional")
+    if src.size(dim) != index.size(0):
+        raise RuntimeError("index length must be equal to src dimension size")
+    _only_sum(reduce, "index_scatter")
+    rows = _last_index_plus_one(index)
+    moved = src if dim == 0 else src.movedim(dim, 0)
+    moved = moved.contiguous()
+    out_shape = list(moved.shape)
+    out_shape[0] = rows
+    out = torch.empty(out_shape, dtype=src.dtype, device=src.device)
+    hip.index_scatter_out(index.contiguous(), moved, out, sorted=sorted)
+    return out if dim == 0 else out.movedim(0, dim)
+
+
+def _check_gather(src_index, dst_index, src, ndim: int) -> None:
+    if not (src_index.dim() == dst_index.dim() == 1):
+        raise RuntimeError("src_index and dst_index must be 1 dimensional")
+    if src.dim() != ndim:
+        raise RuntimeError(f"src must be {ndim} dimensional")
+    if src_index.size(0) != dst_index.size(0):
+        raise RuntimeError("src_index and dst_index must have the same length")
+
+
+def _gather_scatter_gpu(src_index, dst_index, src, rows: Optional[int] = None) -> torch.Tensor:
+    _check_gather(src_index, dst_index, src, 2)
+    rows = _last_index_plus_one(dst_index) if rows is None else rows
+    out = torch.empty((rows, src.shape[1]), dtype=src.dtype, device=src.device)
+    return hip.gather_scatter_out(src_index.contiguous(), dst_index.contiguous(), src.contiguous(), out)
+
+
+def _gather_weight_scatter_gpu(src_index, dst_index, weight, src, rows: Optional[int] = None) -> torch.Tensor:
+    _check_gather(src_index, dst_index, src, 2)
+    if weight.dim() != 1 or weight.size(0) != dst_index.size(0):
+        raise RuntimeError("weight must be 1 dimensional with one value per edge")
+    rows = _last_index_plus_one(dst_index) if rows is None else rows
+    out = torch.empty((rows, src.shape[1]), dtype=src.dtype, device=src.device)
+    return hip.gather_weight_scatter_out(src_index.contiguous(), dst_index.contiguous(),
+                                         weight.contiguous(), src.contiguous(), out)
+
+
+def _sddmm_coo_gpu(src_index, dst_index, mat_1, mat_2) -> torch.Tensor:
+    # the reference casts the indices to int32 first (geot/gather_weight_scatter.py:10-11);
+    # both widths are accepted here, the kernel reads int64
+    if mat_1.dim() != 2 or mat_2.dim() != 2 or mat_1.shape[1] != mat_2.shape[1]:
+        raise RuntimeError("mat_1 and mat_2 must be 2 dimensional with the same feature dimension")
+    out = torch.empty((dst_index.size(0),), dtype=mat_1.dtype, device=mat_1.device)
+    return hip.sddmm_coo_out(src_index.to(torch.int64).contiguous(), dst_index.to(torch.int64).contiguous(),
+                             mat_1.contiguous(), mat_2.contiguous(), out)
+
+
+def _mh_spmm_gpu(src_index, dst_index, weight, src, reduce: str) -> torch.Tensor:
+    _check_gather(src_index, dst_index, src, 3)
+    _only_sum(reduce, "mh_spmm")
+    nnz = src_index.size(0)
+    # layout pick of csrc/cuda/wrapper/mh_spmm_base.h:38-49 ([nnz, H] first, then [H, nnz])
+    if weight.dim() != 2:
+        raise RuntimeError("Invalid weight size")
+    if weight.size(0) == nnz and weight.size(1) == src.size(1):
+        head_major = False
+    elif weight.size(1) == nnz and weight.size(0) == src.size(1):
+        head_major = True
+    else:
+        raise RuntimeError("Invalid weight size")
+    rows = _last_index_plus_one(dst_index)
+    out = torch.empty((rows, src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
+    return hip.mh_spmm_out(src_index.contiguous(), dst_index.contiguous(), weight.contiguous(),
+                           src.contiguous(), out, head_major)
+
+
+# --------------------------------------------------------------------------------------------------
+# schema registration (csrc/*.cpp TORCH_LIBRARY_FRAGMENT / TORCH_LIBRARY_IMPL)
+# --------------------------------------------------------------------------------------------------
+_lib_def = torch.library.Library("geot", "FRAGMENT")
+_lib_def.define("index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor")
+_lib_def.define("gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor")
+_lib_def.define("gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor")
+_lib_def.define("sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor")
+_lib_def.define("mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor")
+
+_lib_def.impl("index_scatter", _index_scatter_gpu, "CUDA")
+_lib_def.impl("gather_scatter_impl", lambda si, di, s: _gather_scatter_gpu(si, di, s), "CUDA")
+_lib_def.impl("gather_weight_scatter_impl", lambda si, di, w, s: _gather_weight_scatter_gpu(si, di, w, s), "CUDA")
+_lib_def.impl("sddmm_coo_impl", _sddmm_coo_gpu, "CUDA")
+_lib_def.impl("mh_spmm", _mh_spmm_gpu, "CUDA")
+for _name in ("index_scatter", "gather_scatter_impl", "gather_weight_scatter_impl", "sddmm_coo_impl", "mh_spmm"):
+    _lib_def.impl(_name, _reject_cpu(_name), "CPU")
+
+
+def _fake_rows(src_like: torch.Tensor, tail_shape) -> torch.Tensor:
+    ctx = torch.library.get_ctx()
+    rows = ctx.new_dynamic_size()
+    return src_like.new_empty([rows, *tail_shape])
+
+
+@torch.library.register_fake("geot::index_scatter")
+def _(dim, index, src, reduce, sorted):
+    ctx = torch.library.get_ctx()
+    shape = list(src.shape)
+    shape[dim] = ctx.new_dynamic_size()
+    return src.new_empty(shape)
+
+
+@torch.library.register_fake("geot::gather_scatter_impl")
+def _(src_index, dst_index, src):
+    return _fake_rows(src, [src.shape[1]])
+
+
+@torch.library.register_fake("geot::gather_weight_scatter_impl")
+def _(src_index, dst_index, weight, src):
+    return _fake_rows(src, [src.shape[1]])
+
+
+@torch.library.register_fake("geot::sddmm_coo_impl")
+def _(src_index, dst_index, mat_1, mat_2):
+    return mat_1.new_empty([dst_index.shape[0]])
+
+
+@torch.library.register_fake("geot::mh_spmm")
+def _(src_index, dst_index, weight, src, reduce):
+    return _fake_rows(src, [src.shape[1], src.shape[2]])
+
+
+# --------------------------------------------------------------------------------------------------
+# public functions (geot/*.py)
+# --------------------------------------------------------------------------------------------------
+def index_scatter(dim: int, src: torch.Tensor, index: torch.Tensor, reduce: str = "sum",
+                  sorted: bool = True) -> torch.Tensor:
+    """dst[index[i]] += src[i] along ``dim``; rows = index[-1] + 1 (geot/index_scatter.py:5-8).
+
+    Mind the argument order: Python takes (dim, src, index, ...), the dispatcher op takes
+    (dim, index, src, ...) -- exactly as in the reference.
+    """
+    return torch.ops.geot.index_scatter(dim, index, src, reduce, sorted)
+
+
+def gather_scatter_impl(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    return torch.ops.geot.gather_scatter_impl(src_index, dst_index, src)
+
+
+def gather_weight_scatter_impl(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor,
+                               src: torch.Tensor) -> torch.Tensor:
+    return torch.ops.geot.gather_weight_scatter_impl(src_index, dst_index, weight, src)
+
+
+def sddmm_coo_impl(src_index: torch.Tensor, dst_index: torch.Tensor, mat_1: torch.Tensor,
+                   mat_2: torch.Tensor) -> torch.Tensor:
+    """out[e] = <mat_1[dst_index[e]], mat_2[src_index[e]]>  (geot/gather_weight_scatter.py:8-12)."""
+    return torch.ops.geot.sddmm_coo_impl(src_index, dst_index, mat_1, mat_2)
+
+
+@torch.library.custom_op("geot::gather_scatter", mutates_args=())
+def _gather_scatter_op(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    return gather_scatter_impl(src_index, dst_index, src)
+
+
+@torch.library.register_fake("geot::gather_scatter")
+def _(src_index, dst_index, src):
+    return _fake_rows(src, [src.shape[1]])
+
+
+def _gs_setup_context(ctx, inputs, output):
+    src_index, dst_index, src = inputs
+    ctx.save_for_backward(src_index, dst_index)
+    ctx.src_rows = src.shape[0]
+
+
+def _sorted_by_source(src_index, dst_index):
+    # geot/gather_scatter.py:30-33: re-sort the edge list by source for the transposed product
+    _, perm = torch.sort(src_index, stable=True)
+    return perm, src_index[perm], dst_index[perm]
+
+
+def _gs_backward(ctx, grad):
+    """d/dsrc of gather_scatter = the same op on the transposed edge list (geot/gather_scatter.py:26-39).
+
+    Unlike the reference the result has src.shape[0] rows even when the last source node has no
+    out-edge (the reference returns max(src_index)+1 rows and autograd then rejects the shape).
+    """
+    src_index, dst_index = ctx.saved_tensors
+    grad = grad.contiguous()
+    _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+    g = _gather_scatter_gpu(src_index_bwd, dst_index_bwd, grad, rows=ctx.src_rows)
+    return None, None, g
+
+
+torch.library.register_autograd("geot::gather_scatter", _gs_backward, setup_context=_gs_setup_context)
+
+
+@torch.library.custom_op("geot::gather_weight_scatter", mutates_args=())
+def _gather_weight_scatter_op(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor,
+                              src: torch.Tensor) -> torch.Tensor:
+    return gather_weight_scatter_impl(src_index, dst_index, weight, src)
+
+
+@torch.library.register_fake("geot::gather_weight_scatter")
+def _(src_index, dst_index, weight, src):
+    return _fake_rows(src, [src.shape[1]])
+
+
+def _gws_setup_context(ctx, inputs, output):
+    src_index, dst_index, weight, src = inputs
+    ctx.save_for_backward(src_index, dst_index, weight, src)
+
+
+def _gws_backward(ctx, grad):
+    """geot/gather_weight_scatter.py:36-51.
+
+    d/dsrc   = gws on the transposed (source-sorted) edge list, as in the reference.
+    d/dweight[e] = <grad[dst_index[e]], src[src_index[e]]> in ORIGINAL edge order.  The reference
+    calls sddmm on the re-sorted lists with grad/src swapped, which returns the values in
+    source-sorted order and against the wrong rows (verified against dense
+    autograd); this is the mathematically correct gradient.
+    """
+    src_index, dst_index, weight, src = ctx.saved_tensors
+    grad = grad.contiguous()
+    perm, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+    src_grad = _gather_weight_scatter_gpu(src_index_bwd, dst_index_bwd, weight[perm], grad, rows=src.shape[0])
+    weight_grad = _sddmm_coo_gpu(src_index, dst_index, grad, src)
+    return None, None, weight_grad, src_grad
+
+
+torch.library.register_autograd("geot::gather_weight_scatter", _gws_backward, setup_context=_gws_setup_context)
+
+
+def gather_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor,
+                   reduce: str = "sum") -> torch.Tensor:
+    """dst[dst_index[e]] += src[src_index[e]], dst_index ascending (geot/gather_scatter.py:7-9).
+
+    The trailing ``reduce`` is accepted because the reference's own callers still pass it
+    (models/conv/spmm.py:8, test/test_gather_scatter.py:25); only 'sum' exists.
+    """
+    _only_sum(reduce, "gather_scatter")
+    return _gather_scatter_op(src_index, dst_index, src)
+
+
+def gather_weight_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor,
+                          src: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+    """dst[dst_index[e]] += weight[e] * src[src_index[e]] (geot/gather_weight_scatter.py:15-18)."""
+    _only_sum(reduce, "gather_weight_scatter")
+    return _gather_weight_scatter_op(src_index, dst_index, weight, src)
+
+
+def mh_spmm(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor, src: torch.Tensor,
+            reduce: str = "sum") -> torch.Tensor:
+    """Multi-head weighted SpMM, src [N, H, F], weight [nnz, H] or [H, nnz] (geot/mh_spmm.py:4-6)."""
+    return torch.ops.geot.mh_spmm(src_index, dst_index, weight, src, reduce)
+
+
+def mh_spmm_transposed(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor,
+                       src: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+    """geot/mh_spmm.py:8-12: transposes weight [nnz, H] -> [H, nnz] (contiguous) and calls mh_spmm."""
+    weight = weight.transpose(0, 1).contiguous()
+    return torch.ops.geot.mh_spmm(src_index, dst_index, weight, src, reduce)

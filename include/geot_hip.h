@@ -28,7 +28,8 @@
  *     (the reference requires torch::zeros, csrc/index_scatter.cpp:35, because it flushes with
  *     atomicAdd); rows with no edge come out as 0 exactly as in the reference;
  *   - `out_rows` is the reference's row rule, index[-1] + 1 (csrc/index_scatter.cpp:30-34),
- *     computed by the caller; keys outside [0, out_rows) are ignored (never written);
+ *     computed by the caller; a larger value is allowed (rows behind the last key come out 0);
+ *     keys outside [0, out_rows) are ignored (never written);
  *   - `workspace` is caller-owned scratch of at least geot_workspace_bytes(...) bytes, 256-B
  *     aligned.  Its first 256 bytes are control words that must be ZERO before the first call
  *     (geot_workspace_init, or any zeroing allocation); every call leaves them zero again, so a

@@ -1,0 +1,154 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/geot_hip.h declares, the host layer reproduces the reference's schemas / checks / error
+texts, and the product never touches the oracle.  No compute call is made (no GPU here).
+"""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+import geot_amd
+from geot_amd import _lib, ops
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "geot_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(geot_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert "geot_index_scatter" in names and "geot_mh_spmm" in names and len(names) >= 15
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(_lib.SYMBOLS) == names            # the Python loader binds the same list
+    assert L.geot_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in ctypes.cast(ctypes.CDLL(_lib.LIB_PATH).geot_build_info, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_library_is_gfx950_code_object():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    assert b"gfx942" not in blob and b"sm_80" not in blob     # single target, no dual paths
+
+
+def test_workspace_bytes_is_monotonic_upper_bound():
+    L = _lib.load()
+    a = L.geot_workspace_bytes(10_000_000, 64, 1_000_000, _lib.GEOT_F32)
+    b = L.geot_workspace_bytes(20_000_000, 64, 1_000_000, _lib.GEOT_F32)
+    c = L.geot_workspace_bytes(10_000_000, 64, 1_000_000, _lib.GEOT_F64)
+    assert 0 < a < b and a < c
+    assert L.geot_workspace_bytes(0, 1, 0, _lib.GEOT_F32) >= 256
+
+
+def test_schemas_match_reference_dispatcher():
+    # csrc/index_scatter.cpp:44-46, csrc/gather_scatter.cpp:16-17, csrc/gather_weight_scatter.cpp:12-16,
+    # csrc/mh_spmm.cpp:23 (inferred), geot/gather_scatter.py:7, geot/gather_weight_scatter.py:15
+    expect = {
+        "index_scatter": "geot::index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor",
+        "gather_scatter_impl": "geot::gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor",
+        "gather_weight_scatter_impl": "geot::gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor",
+        "sddmm_coo_impl": "geot::sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor",
+        "mh_spmm": "geot::mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor",
+        "gather_scatter": "geot::gather_scatter(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor",
+        "gather_weight_scatter": "geot::gather_weight_scatter(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor",
+    }
+    for name, schema in expect.items():
+        assert str(getattr(torch.ops.geot, name).default._schema) == schema
+
+
+def test_public_surface_matches_reference_package():
+    import inspect
+
+    import geot
+    for name in ("index_scatter", "gather_scatter", "gather_weight_scatter", "mh_spmm", "mh_spmm_transposed"):
+        assert getattr(geot, name) is getattr(geot_amd, name)
+    sig = inspect.signature(geot.index_scatter)
+    assert list(sig.parameters) == ["dim", "src", "index", "reduce", "sorted"]          # geot/index_scatter.py:5-7
+    assert sig.parameters["reduce"].default == "sum" and sig.parameters["sorted"].default is True
+    assert list(inspect.signature(geot.mh_spmm).parameters) == ["src_index", "dst_index", "weight", "src", "reduce"]
+
+
+def test_reduce_parsing_matches_reduceutils():
+    for r, k in (("sum", "sum"), ("mean", "mean"), ("min", "min"), ("amin", "min"), ("max", "max"),
+                 ("amax", "max"), ("prod", "prod")):
+        assert ops.get_reduction_enum(r) == k
+    with pytest.raises(RuntimeError, match="reduce argument must be either sum, prod, mean, amax or amin, got mul"):
+        ops.get_reduction_enum("mul")
+
+
+def test_argument_checks_carry_the_reference_texts():
+    src = torch.rand(6, 4)
+    idx = torch.tensor([0, 0, 1, 1, 2, 2])
+    with pytest.raises(RuntimeError, match="dim must be non-negative and less than input dimensions"):
+        ops._index_scatter_gpu(2, idx, src, "sum", True)
+    with pytest.raises(RuntimeError, match="dim must be non-negative and less than input dimensions"):
+        ops._index_scatter_gpu(-1, idx, src, "sum", True)
+    with pytest.raises(RuntimeError, match="index must be 1 dimensional"):
+        ops._index_scatter_gpu(0, idx.view(2, 3), src, "sum", True)
+    with pytest.raises(RuntimeError, match="index length must be equal to src dimension size"):
+        ops._index_scatter_gpu(0, idx[:5], src, "sum", True)
+    with pytest.raises(RuntimeError, match="reduce argument must be either"):
+        ops._index_scatter_gpu(0, idx, src, "bogus", True)
+    with pytest.raises(NotImplementedError, match="only 'sum'"):
+        ops._index_scatter_gpu(0, idx, src, "mean", True)
+    with pytest.raises(RuntimeError, match="src_index and dst_index must be 1 dimensional"):
+        ops._gather_scatter_gpu(idx.view(2, 3), idx, src)
+    with pytest.raises(RuntimeError, match="src must be 2 dimensional"):
+        ops._gather_scatter_gpu(idx, idx, src.view(6, 2, 2))
+    with pytest.raises(RuntimeError, match="src must be 3 dimensional"):
+        ops._mh_spmm_gpu(idx, idx, torch.rand(6, 2), src, "sum")
+    with pytest.raises(RuntimeError, match="Invalid weight size"):
+        ops._mh_spmm_gpu(idx, idx, torch.rand(5, 2), src.view(6, 2, 2), "sum")
+    with pytest.raises(IndexError):                       # index[-1] of an empty index, as in the reference
+        ops._index_scatter_gpu(0, idx[:0], src[:0], "sum", True)
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    src = torch.rand(6, 4)
+    idx = torch.tensor([0, 0, 1, 1, 2, 2])
+    for call in (lambda: geot_amd.index_scatter(0, src, idx),
+                 lambda: geot_amd.gather_scatter(idx, idx, src),
+                 lambda: geot_amd.gather_weight_scatter(idx, idx, torch.rand(6), src),
+                 lambda: geot_amd.mh_spmm(idx, idx, torch.rand(6, 2), src.view(6, 2, 2))):
+        with pytest.raises(RuntimeError, match="CPU tensors are not supported"):
+            call()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        geot_amd.hip.index_scatter_out(idx, src, torch.empty(3, 4))
+
+
+def test_fake_tensor_shape_rule():
+    """register_fake returns [dynamic, F] like the reference (geot/gather_scatter.py:12-18)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from torch.fx.experimental.symbolic_shapes import ShapeEnv
+    with FakeTensorMode(shape_env=ShapeEnv(), allow_non_fake_inputs=False):
+        si = torch.empty(50, dtype=torch.int64)
+        src = torch.empty(20, 8)
+        out = torch.ops.geot.gather_scatter(si, si, src)
+        assert out.dim() == 2 and out.shape[1] == 8 and isinstance(out.shape[0], torch.SymInt)
+        out = torch.ops.geot.gather_weight_scatter(si, si, torch.empty(50), src)
+        assert out.shape[1] == 8 and out.dtype == torch.float32
+        out = torch.ops.geot.index_scatter(0, si, torch.empty(50, 3, 2), "sum", True)
+        assert tuple(out.shape[1:]) == (3, 2)
+
+
+def test_product_never_touches_the_oracle():
+    """geot_amd/ (and the alias package) must not import, link or mention oracle/ or a CPU fallback."""
+    bad = []
+    for pkg in ("geot_amd", "geot"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".h")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"\boracle\b|libgeot_oracle|libgeot_ref", text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    import sys
+    assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules
+                   if getattr(sys.modules[m], "__file__", None) and "geot_amd" in (sys.modules[m].__file__ or ""))
