@@ -117,12 +117,18 @@ def main():
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in this package)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GEOT_DIST_BACKEND=gloo lets two test ranks share one GPU (RCCL refuses duplicate devices)
+    backend = os.environ.get("GEOT_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import geot_amd as geot
     from geot_amd import hip, sharding

@@ -98,14 +98,16 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     rec = torch.empty(2 + F, dtype=torch.float64, device=dev)
     rec[0], rec[1] = first_key, last_key
     rec[2:] = local[0].reshape(-1).to(torch.float64)
-    allrec = torch.empty(world * (2 + F), dtype=torch.float64, device=dev)
-    if exchange:
-        dist.all_gather_into_tensor(allrec, rec, group=group)
-    else:
-        keys = torch.empty(world * 2, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(keys, rec[:2].contiguous(), group=group)
-        allrec.view(world, 2 + F)[:, :2] = keys.view(world, 2)
-    allrec = allrec.view(world, 2 + F)
+    # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or two test
+    # ranks sharing one GPU) stages the few hundred bytes through the host
+    via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    cdev = torch.device("cpu") if via_host else dev
+    send = rec.to(cdev) if exchange else rec[:2].contiguous().to(cdev)
+    recv = torch.empty(world * send.numel(), dtype=torch.float64, device=cdev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.to(dev).view(world, -1)
+    allrec = torch.zeros(world, 2 + F, dtype=torch.float64, device=dev)
+    allrec[:, : recv.shape[1]] = recv
     keys_host = allrec[:, :2].to(torch.int64).cpu()
     firsts = [int(k) for k in keys_host[:, 0]]
     lasts = [int(k) for k in keys_host[:, 1]]
