@@ -361,19 +361,21 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 }
 
 // Second launch (= the only cross-workgroup ordering the sorted path needs):
-//  (a) one WAVE per tile: if the tile holds the FIRST carry of a chain (its head run continues
-//      from the previous tile, and that tile is where the run starts), add the chain's carries to
-//      the owner's row.  A hub run covers many whole tiles: their `single` bits are fetched 64 at
-//      a time (one meta word per lane + ballot) and the carry rows are summed by the wave's lane
-//      groups in parallel, then combined by xor-shuffles - a fixed order, so results are
-//      deterministic, and a 64-tile chain costs about as many memory round trips as a 1-tile one;
+//  (a) one LANE GROUP per tile (64/LPR tiles per wave): if the tile holds the FIRST carry of a
+//      chain (its head run continues from the previous tile, and that tile is where the run
+//      starts) the row  dst[k] = tail partial of tile t-1 + head partial of tile t  is written with
+//      a plain store.  Every address (two meta words, two carry rows) is independent of loaded
+//      data, so the whole pass is ONE memory round trip; no read-modify-write of dst.
+//      Hub runs that cover whole follow-on tiles are rare: they are finished wave-cooperatively
+//      afterwards (64 meta words per ballot window, rows summed by the wave's lane groups in
+//      parallel, xor-shuffle combine in a fixed order => deterministic);
 //  (b) zero-fill the large gaps the tile kernel recorded;
 //  (c) the last block to finish re-zeroes the two control words for the next call.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_t num_tiles) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << p.lpr_log2;
-  const int R = 64 >> p.lpr_log2;  // carry rows a wave sums in parallel
+  const int R = 64 >> p.lpr_log2; // lane groups per wave
   const int gq = lane >> p.lpr_log2;
   const int c = lane & (lpr - 1);
   T *dst = static_cast<T *>(p.dst);
@@ -382,86 +384,88 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
   __shared__ unsigned long long s_ngap;
   if (threadIdx.x == 0) s_ngap = p.ctrl[0];
 
-  const int64_t t = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (t >= 1 && t < num_tiles) { // wave-uniform from here on
-    // Every address below is known before any load returns: meta[t-1], meta[t..t+63], the
-    // owner's tail partial and this tile's head partial are all in flight together (one memory
-    // round trip); the row is then written with a plain store - no read-modify-write of dst.
-    const int64_t mp = p.meta[t - 1];
-    int64_t wt = t + lane;
-    const int64_t mw = p.meta[wt < num_tiles ? wt : num_tiles - 1]; // lane i <-> tile t+i
-    constexpr int J = 4;
-    T cv[J];
+  constexpr int J = 4;
+  const int64_t wave_t0 = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * R;
+  const int64_t t = wave_t0 + gq; // this lane group's tile
+  const bool valid = t >= 1 && t < num_tiles;
+  const int64_t tc = valid ? t : 1 < num_tiles ? 1 : 0; // clamped for the speculative loads
+  const int64_t m = valid ? p.meta[tc] : 0;
+  const int64_t mp = valid ? p.meta[tc - 1] : 2;
+  T cv[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int64_t f = (int64_t)j * lpr + c;
-      // lane group 0: owner's tail partial (slot 1 of tile t-1); group 1 (or 0 again when the
-      // wave holds one row): this tile's head partial.  Summed in a fixed order below.
-      T a = T(0);
-      if (f < F) {
-        if (gq == 0) a = carry[((t - 1) * 2 + 1) * F + f];
-        if (R == 1) a += carry[(t * 2) * F + f];
-        else if (gq == 1) a = carry[(t * 2) * F + f];
+  for (int j = 0; j < J; ++j) {
+    const int64_t f = (int64_t)j * lpr + c;
+    cv[j] = (valid && f < F) ? carry[((tc - 1) * 2 + 1) * F + f] + carry[(tc * 2) * F + f] : T(0);
+  }
+  const bool first = valid && (m & 1) && !(mp & 2);
+  const int64_t k = m >> 2;
+  if (first && !(m & 2)) {
+    for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
+      if (fb > 0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int64_t f = fb + (int64_t)j * lpr + c;
+          cv[j] = f < F ? carry[((t - 1) * 2 + 1) * F + f] + carry[(t * 2) * F + f] : T(0);
+        }
       }
-      cv[j] = a;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int64_t f = fb + (int64_t)j * lpr + c;
+        if (f < F) dst[k * F + f] = cv[j];
+      }
     }
-    const int64_t m = __shfl(mw, 0, 64);
-    if ((m & 1) && !(mp & 2)) {
-      const int64_t k = m >> 2;
-      for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
-        if (fb > 0) { // wide rows: further feature chunks (first chunk was prefetched above)
+  }
+
+  // hub chains (wave-uniform loop over the groups that found one)
+  unsigned long long hubs = __ballot(first && (m & 2) && c == 0);
+  while (hubs) {
+    const int src_lane = __builtin_ctzll(hubs);
+    hubs &= hubs - 1;
+    const int64_t th = __shfl(t, src_lane, 64);
+    const int64_t kh = __shfl(k, src_lane, 64);
+    for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
+      T hv[J];
 #pragma unroll
-          for (int j = 0; j < J; ++j) {
-            const int64_t f = fb + (int64_t)j * lpr + c;
-            T a = T(0);
-            if (f < F) {
-              if (gq == 0) a = carry[((t - 1) * 2 + 1) * F + f];
-              if (R == 1) a += carry[(t * 2) * F + f];
-              else if (gq == 1) a = carry[(t * 2) * F + f];
+      for (int j = 0; j < J; ++j) {
+        const int64_t f = fb + (int64_t)j * lpr + c;
+        hv[j] = (gq == 0 && f < F) ? carry[((th - 1) * 2 + 1) * F + f] + carry[(th * 2) * F + f] : T(0);
+      }
+      // tile x+1 joins the chain for as long as tile x is `single`; 64 tiles per window
+      int64_t wb = th;
+      for (;;) {
+        const int64_t wt = wb + lane;
+        const int64_t mcur = p.meta[wt < num_tiles ? wt : num_tiles - 1];
+        const unsigned long long S = __ballot((mcur & 2) && (wt < num_tiles));
+        const int nn = ~S ? __builtin_ctzll(~S) : 64; // tiles wb+1 .. wb+nn join the chain
+        const int64_t hi = wb + nn;
+        for (int64_t i = wb + 1 + gq; i <= hi; i += (int64_t)R * 4) {
+          T cr[4][J];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t tt = i + (int64_t)q * R;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+              const int64_t f = fb + (int64_t)j * lpr + c;
+              cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : T(0);
             }
-            cv[j] = a;
           }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < J; ++j) hv[j] += cr[q][j];
         }
-        if (m & 2) {
-          // hub: tile x+1 joins the chain for as long as tile x is `single`; 64 tiles per window
-          int64_t wb = t;
-          int64_t mcur = mw;
-          for (;;) {
-            const unsigned long long S = __ballot((mcur & 2) && (wb + lane < num_tiles));
-            const int nn = ~S ? __builtin_ctzll(~S) : 64; // tiles wb+1 .. wb+nn join the chain
-            const int64_t hi = wb + nn;
-            for (int64_t i = wb + 1 + gq; i <= hi; i += (int64_t)R * 4) {
-              T cr[4][J];
+        if (nn < 64) break;
+        wb += 64;
+      }
+      for (int off = lpr; off < 64; off <<= 1) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int64_t tt = i + (int64_t)q * R;
+        for (int j = 0; j < J; ++j) hv[j] += __shfl_xor(hv[j], off, 64);
+      }
+      if (gq == 0) {
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                  const int64_t f = fb + (int64_t)j * lpr + c;
-                  cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : T(0);
-                }
-              }
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < J; ++j) cv[j] += cr[q][j];
-            }
-            if (nn < 64) break;
-            wb += 64;
-            wt = wb + lane;
-            mcur = p.meta[wt < num_tiles ? wt : num_tiles - 1];
-          }
-        }
-        for (int off = lpr; off < 64; off <<= 1) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) cv[j] += __shfl_xor(cv[j], off, 64);
-        }
-        if (gq == 0) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            const int64_t f = fb + (int64_t)j * lpr + c;
-            if (f < F) dst[k * F + f] = cv[j];
-          }
+        for (int j = 0; j < J; ++j) {
+          const int64_t f = fb + (int64_t)j * lpr + c;
+          if (f < F) dst[kh * F + f] = hv[j];
         }
       }
     }
@@ -757,7 +761,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   if (prof) HIP_TRY(hipEventRecord(rec.e2, st));
   rec.has_fix = false;
   if (nnz > 0 && sorted) {
-    int64_t blocks = (P.num_tiles + kThreads / 64 - 1) / (kThreads / 64); // one wave per tile
+    const int64_t tiles_per_block = (kThreads / 64) * (64 >> P.lpr_log2); // one lane group per tile
+    int64_t blocks = (P.num_tiles + tiles_per_block - 1) / tiles_per_block;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((seg_fixup_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p,
                        P.num_tiles);

@@ -296,6 +296,37 @@ def test_backward_when_last_node_has_no_out_edge(geot):
     assert torch.allclose(src.grad[:2], torch.full((2, 8), 2.0, device="cuda"))
 
 
+def test_row_rule_is_verified_on_every_call(geot, oracle):
+    """The row count remembered for an index tensor is only a guess: index[-1] is read back and checked
+    on every call.  `.data` writes change the content without bumping the version counter."""
+    rng = np.random.default_rng(21)
+    index_h = sorted_index(rng, 4000, 300)
+    src_h = rng.random((4000, 32), dtype=np.float32)
+    index, src = dev(index_h), dev(src_h)
+    for _ in range(3):                                           # first call learns, later ones speculate
+        out = geot.index_scatter(0, src, index)
+        assert out.shape[0] == 300
+    v0 = index._version
+    index.data[-1] = 450                                         # more rows, same identity + version
+    index_h[-1] = 450
+    assert index._version == v0
+    out = geot.index_scatter(0, src, index)
+    assert out.shape[0] == 451
+    assert_close_to_oracle(out, oracle.index_scatter(index_h, src_h, acc64=True),
+                           oracle.index_scatter(index_h, np.abs(src_h), acc64=True), "grown")
+    index.data[-1] = 299                                         # fewer rows again
+    index_h[-1] = 299
+    for _ in range(2):
+        out = geot.index_scatter(0, src, index)
+        assert out.shape[0] == 300
+        assert_close_to_oracle(out, oracle.index_scatter(index_h, src_h, acc64=True),
+                               oracle.index_scatter(index_h, np.abs(src_h), acc64=True), "shrunk")
+    si = dev(rng.integers(0, 300, 4000).astype(np.int64))
+    for last in (299, 320, 299):
+        index.data[-1] = last
+        assert geot.gather_scatter(si, index, src[:300].contiguous()).shape[0] == last + 1
+
+
 def test_out_rows_larger_than_last_key(geot):
     """C ABI: out_rows may exceed index[-1]+1; the extra rows are zero-filled (small and large tails)."""
     from geot_amd import hip

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Timing of the gather ops on the synthetic stand-ins of BASELINE.json configs[2] / configs[3]
+(ogbn-products-scale gws F=128 vs rocSPARSE CSR SpMM; Reddit-scale mh_spmm H=4 F=64), kernels only
+(hipEvents via torch.cuda.Event on the current stream; the ops' .item() is outside the bracket because
+the *_out doorway is used).  Developer tool: numbers are quoted in DESIGN.md, not a bench.py line.
+
+    python tools/bench_ops.py [--scale 1.0] [--iters 20]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import powerlaw_index  # noqa: E402
+
+import geot_amd  # noqa: E402
+from geot_amd import hip  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def graph(nodes, nnz, seed, dev):
+    dst = powerlaw_index(nnz, nodes, seed, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed + 1)
+    src_index = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    return src_index, dst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    print(hip.build_info())
+
+    # ---- cfg3: gather_weight_scatter, ogbn-products scale (2.45M nodes, ~124M directed edges), F=128
+    nodes, nnz, F = int(2_449_029 * args.scale), int(123_718_280 * args.scale), 128
+    si, di = graph(nodes, nnz, 7, dev)
+    w = torch.rand(nnz, device=dev)
+    x = torch.rand(nodes, F, device=dev)
+    out = torch.empty(nodes, F, device=dev)
+    uniq = torch.unique(si).numel()
+    comp = nnz * 20 + uniq * 4 * F + nodes * 4 * F
+    t = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), args.iters)
+    print(f"cfg3 gws   nodes={nodes} nnz={nnz} F={F}: {t:.3f} ms  {nnz / t / 1e6:.2f} Gedge/s  "
+          f"compulsory {comp / 1e9:.2f} GB -> {comp / t / 1e9:.2f} TB/s ({comp / t / 1e9 / 8 * 100:.1f}% of 8 TB/s)")
+    t2 = timeit(lambda: hip.gather_scatter_out(si, di, x, out), args.iters)
+    print(f"cfg3 gs    (same graph, no weights): {t2:.3f} ms  {nnz / t2 / 1e6:.2f} Gedge/s")
+    # rocSPARSE CSR SpMM through torch.sparse (hipSPARSE/rocSPARSE backend), same matrix
+    crow = torch.zeros(nodes + 1, dtype=torch.int64, device=dev)
+    crow[1:] = torch.cumsum(torch.bincount(di, minlength=nodes), 0)
+    A = torch.sparse_csr_tensor(crow, si, w, size=(nodes, nodes))
+    ref = torch.sparse.mm(A, x)
+    hip.gather_weight_scatter_out(si, di, w, x, out)
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    t3 = timeit(lambda: torch.sparse.mm(A, x), max(3, args.iters // 2))
+    print(f"cfg3 rocSPARSE CSR SpMM (torch.sparse.mm): {t3:.3f} ms  {nnz / t3 / 1e6:.2f} Gedge/s   "
+          f"-> ours is {t3 / t:.2f}x faster; max rel diff {err:.2e}")
+    A32 = torch.sparse_csr_tensor(crow.int(), si.int(), w, size=(nodes, nodes))
+    t4 = timeit(lambda: torch.sparse.mm(A32, x), max(3, args.iters // 2))
+    print(f"cfg3 rocSPARSE CSR SpMM, int32 indices:    {t4:.3f} ms  -> ours is {t4 / t:.2f}x faster")
+    del A, A32, ref, x, out, w, si, di, crow
+    torch.cuda.empty_cache()
+
+    # ---- cfg4: mh_spmm, Reddit scale (232,965 nodes, 114.6M edges), H=4, F=64
+    nodes, nnz, H, F = int(232_965 * args.scale), int(114_615_892 * args.scale), 4, 64
+    si, di = graph(nodes, nnz, 11, dev)
+    w = torch.rand(nnz, H, device=dev)
+    wt = w.t().contiguous()
+    x = torch.rand(nodes, H, F, device=dev)
+    out = torch.empty(nodes, H, F, device=dev)
+    comp = nnz * (16 + 4 * H) + 2 * nodes * 4 * H * F
+    t = timeit(lambda: hip.mh_spmm_out(si, di, w, x, out, False), args.iters)
+    print(f"cfg4 mh_spmm [nnz,H] nodes={nodes} nnz={nnz} H={H} F={F}: {t:.3f} ms  {nnz / t / 1e6:.2f} Gedge/s  "
+          f"compulsory {comp / 1e9:.2f} GB -> {comp / t / 1e9:.2f} TB/s")
+    t2 = timeit(lambda: hip.mh_spmm_out(si, di, wt, x, out, True), args.iters)
+    print(f"cfg4 mh_spmm [H,nnz]: {t2:.3f} ms  {nnz / t2 / 1e6:.2f} Gedge/s")
+
+
+if __name__ == "__main__":
+    main()

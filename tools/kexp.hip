@@ -93,6 +93,61 @@ __global__ void onetrip_kernel(const float *__restrict__ a, float *__restrict__ 
   b[w * stride + lane] = a[w * stride + lane] + 1.f;
 }
 
+// pure row writes: one 256-B row store per lane group per step, rows contiguous per group chunk
+template <bool NTS>
+__global__ __launch_bounds__(256) void wonly_kernel(float *__restrict__ dst, int64_t nrows, int rows_per_group) {
+  const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const int64_t base = ((int64_t)blockIdx.x * 16 + g) * rows_per_group;
+  f4 v = {1.f, 2.f, 3.f, 4.f};
+  for (int i = 0; i < rows_per_group; ++i) {
+    const int64_t r = base + i;
+    if (r < nrows) {
+      if (NTS) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(dst + r * F) + c);
+      else *(reinterpret_cast<f4 *>(dst + r * F) + c) = v;
+    }
+  }
+}
+
+// clean mixed skeleton: no modulo / 64-bit math in the row loop.  Each group walks CG rows and stores
+// its running sum every S rows to consecutive dst rows (group-contiguous), 32-bit offsets.
+template <int U, int S, bool NTL, bool NTS, bool STORE>
+__global__ __launch_bounds__(256) void mix_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                   float *sink, int64_t nrows, int cg) {
+  const int tid = threadIdx.x;
+  const int g = tid >> 4, c = tid & 15;
+  const int te = 16 * cg;
+  const int64_t ts = (int64_t)blockIdx.x * te;
+  const char *tb = reinterpret_cast<const char *>(src + ts * F);
+  const int64_t out0 = (ts + (int64_t)g * cg) / S;   // first dst row of this group
+  char *ob = reinterpret_cast<char *>(dst + out0 * F);
+  const int n = (int)((nrows - ts) < te ? (nrows - ts) : te);
+  f4 acc = {0, 0, 0, 0};
+  unsigned oo = c * 16;
+  int cnt = 0;
+  for (int b = 0; b < cg; b += U) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int r = g * cg + b + u;
+      r = r < n ? r : n - 1;
+      const f4 *p = reinterpret_cast<const f4 *>(tb + ((unsigned)r * 256u + (unsigned)c * 16u));
+      v[u] = NTL ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc += v[u];
+      if (STORE && ++cnt == S) {
+        cnt = 0;
+        f4 *q = reinterpret_cast<f4 *>(ob + oo);
+        if (NTS) __builtin_nontemporal_store(acc, q); else *q = acc;
+        oo += 256;
+        acc = f4{0, 0, 0, 0};
+      }
+    }
+  }
+  if (acc[0] == 123.456f) sink[0] = acc[0] + acc[1];
+}
+
 static float ms_of(hipEvent_t a, hipEvent_t b) { float m; CK(hipEventElapsedTime(&m, a, b)); return m; }
 
 template <typename Fn> static double timeit(Fn fn, int iters = 10) {
@@ -154,6 +209,41 @@ int main() {
   RUN2(8, 0, true, false, 10, 64, 0, 1, true, "W2 LDS-staged burst + nt stores");
   RUN2(16, 0, true, false, 10, 32, 0, 1, true, "W2 LDS-staged burst + nt stores");
   RUN2(8, 0, true, true, 10, 32, 8, 1, true, "W2 persistent LDS-staged burst + nt stores");
+  {
+    const int64_t nout = 1000000; // 256 MB, like dst of the graded config
+    for (int rpg : {3, 13, 51}) {
+      const unsigned grid = (unsigned)((nout + 16 * rpg - 1) / (16 * rpg));
+      double a = timeit([&] { hipLaunchKernelGGL((wonly_kernel<false>), dim3(grid), dim3(256), 0, 0, dst, nout, rpg); }, 20);
+      double b = timeit([&] { hipLaunchKernelGGL((wonly_kernel<true>), dim3(grid), dim3(256), 0, 0, dst, nout, rpg); }, 20);
+      printf("pure row writes 256 MB, %2d rows/group grid=%-6u plain %.4f ms %.2f TB/s | nt %.4f ms %.2f TB/s\n", rpg, grid, a, 0.256 / a, b, 0.256 / b);
+    }
+  }
+  RUN2(16, 0, true, false, 10, 32, 0, 0, false, "W  U=16 nt loads, plain stores");
+  RUN2(16, 0, true, false, 10, 64, 0, 0, false, "W  U=16 nt loads, plain stores");
+  RUN2(16, 0, true, false, 10, 64, 0, 0, true, "W  U=16 nt loads, nt stores");
+  RUN2(8, 0, true, false, 10, 64, 0, 0, true, "W  U=8 nt loads, nt stores");
+  RUN2(8, 0, true, false, 20, 64, 0, 0, true, "W  U=8 nt, store/20 rows");
+  RUN2(8, 0, true, false, 5, 64, 0, 0, true, "W  U=8 nt, store/5 rows");
+#define MIX(U, S, NTL, NTS, STORE, CG, LABEL)                                                               \
+  {                                                                                                        \
+    const int cg = CG; const unsigned grid = (unsigned)((nrows + 16 * cg - 1) / (16 * cg));                \
+    double ms = timeit([&] { hipLaunchKernelGGL((mix_kernel<U, S, NTL, NTS, STORE>), dim3(grid), dim3(256), 0, 0, src, dst, sink, nrows, cg); }, 20); \
+    const double b = (double)bytes + (STORE ? (double)bytes / S : 0);                                      \
+    printf("MIX %-34s U=%-2d S=%-2d cg=%-3d %.4f ms  %.2f TB/s\n", LABEL, U, S, cg, ms, b / ms / 1e9);     \
+  }
+  MIX(8, 8, true, false, false, 64, "reads only");
+  MIX(8, 8, true, false, true, 64, "nt loads, plain stores");
+  MIX(8, 8, true, true, true, 64, "nt loads, nt stores");
+  MIX(8, 8, false, false, true, 64, "plain loads, plain stores");
+  MIX(8, 16, true, false, true, 64, "nt loads, plain stores");
+  MIX(8, 16, true, true, true, 64, "nt loads, nt stores");
+  MIX(8, 4, true, false, true, 64, "nt loads, plain stores");
+  MIX(8, 8, true, false, true, 32, "nt loads, plain stores");
+  MIX(8, 8, true, true, true, 32, "nt loads, nt stores");
+  MIX(16, 8, true, false, true, 64, "nt loads, plain stores");
+  MIX(16, 8, true, true, true, 64, "nt loads, nt stores");
+  MIX(16, 8, true, true, true, 32, "nt loads, nt stores");
+  MIX(4, 8, true, true, true, 64, "nt loads, nt stores");
   // boundary cost probes: W kernel followed by a small second kernel, timed as a pair
   {
     const int cg = 64; const int64_t nt = (nrows + 16 * cg - 1) / (16 * cg);
