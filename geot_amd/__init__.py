@@ -14,6 +14,9 @@ _lib.load()  # raises ImportError if the HIP library is not built
 
 from . import hip  # noqa: E402
 from .ops import (  # noqa: E402
+    coo_to_csr,
+    csr_gws,
+    csr_gws_impl,
     gather_scatter,
     gather_scatter_impl,
     gather_weight_scatter,
@@ -29,5 +32,6 @@ __version__ = "0.1.0"
 
 __all__ = [
     "index_scatter", "gather_scatter", "gather_weight_scatter", "mh_spmm", "mh_spmm_transposed",
+    "csr_gws", "coo_to_csr", "csr_gws_impl",
     "gather_scatter_impl", "gather_weight_scatter_impl", "sddmm_coo_impl", "get_reduction_enum", "hip",
 ]

@@ -27,6 +27,7 @@ SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows",
+    "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_tune",
 ]
 
@@ -84,6 +85,10 @@ def load() -> ctypes.CDLL:
     L.geot_mh_spmm.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_sddmm_coo.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]
     L.geot_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]
+    L.geot_csr_workspace_bytes.restype = c_sz
+    L.geot_csr_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]
+    L.geot_csr_gws.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
+    L.geot_coo_to_csr.argtypes = [c_vp, c_i64, c_i64, c_vp, c_int, c_vp]
     L.geot_profile_enable.argtypes = [c_int]
     L.geot_profile_enable.restype = None
     L.geot_profile_reset.restype = None

@@ -546,6 +546,45 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const int64_t *in
   }
 }
 
+// CSR row pointers -> per-edge row ids (dst_index) so that csr_gws can run on the tile kernel.
+// One lane group of 16 per row, rows round-robin over groups; a hub row is filled by its group in
+// 16-edge steps (the pass moves 8 B per edge: ~3 % of a gws call at F=128).
+template <typename PTR>
+__global__ __launch_bounds__(kThreads) void csr_expand_kernel(const PTR *__restrict__ indptr,
+                                                              int64_t nrow, int64_t nnz,
+                                                              int64_t *__restrict__ dst_index) {
+  const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+  for (int64_t r = (int64_t)blockIdx.x * (kThreads / 16) + g; r < nrow;
+       r += (int64_t)gridDim.x * (kThreads / 16)) {
+    int64_t lo = (int64_t)indptr[r], hi = (int64_t)indptr[r + 1];
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > nnz ? nnz : hi;
+    for (int64_t e = lo + c; e < hi; e += 16) dst_index[e] = r;
+  }
+}
+
+// COO row ids -> CSR row pointers.  hist pass (int32 atomics: the reference's coo_to_hist kernel,
+// geot/triton/coo_to_csr.py:14-26, does the same) ...
+__global__ __launch_bounds__(kThreads) void coo_hist_kernel(const int64_t *__restrict__ row, int64_t nnz,
+                                                            int64_t nrow, int *__restrict__ hist) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kThreads) {
+    const int64_t r = row[e];
+    if ((uint64_t)r < (uint64_t)nrow) atomicAdd(hist + r, 1);
+  }
+}
+
+// ... and for an ascending row array the atomic-free form: the thread that sees the key jump at edge e
+// writes rowptr[prev+1 .. cur] = e.
+__global__ __launch_bounds__(kThreads) void coo_sorted_to_csr_kernel(const int64_t *__restrict__ row, int64_t nnz,
+                                                                      int64_t nrow, int *__restrict__ rowptr) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e <= nnz; e += (int64_t)gridDim.x * kThreads) {
+    const int64_t prev = e > 0 ? row[e - 1] : -1;
+    int64_t cur = e < nnz ? row[e] : nrow;
+    if (cur > nrow) cur = nrow; // (a descending step writes nothing: garbage in, memory-safe out)
+    for (int64_t r = (prev < -1 ? -1 : prev) + 1; r <= cur; ++r) rowptr[r] = (int)e;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -925,6 +964,52 @@ int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t n
   if (dtype == GEOT_F32) return run_gather_rows<float>(index, src, dst, nnz, feat, src_rows, st);
   if (dtype == GEOT_F64) return run_gather_rows<double>(index, src, dst, nnz, feat, src_rows, st);
   return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+}
+
+size_t geot_csr_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype) {
+  return geot_workspace_bytes(nnz, feat, out_rows, dtype) + up256((size_t)(nnz > 0 ? nnz : 1) * sizeof(int64_t));
+}
+
+int geot_csr_gws(const int64_t *indptr, const int64_t *indices, const void *weight, const void *src,
+                 void *dst, int64_t nrow, int64_t nnz, int64_t feat, int64_t src_rows, int64_t out_rows,
+                 int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+  if (nrow < 0 || nnz < 0 || out_rows < nrow) return fail(GEOT_EINVAL, "csr_gws: bad sizes");
+  if (!workspace || ((uintptr_t)workspace & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
+  const size_t seg = geot_workspace_bytes(nnz, feat, out_rows, dtype);
+  const size_t need = seg + up256((size_t)(nnz > 0 ? nnz : 1) * sizeof(int64_t));
+  if (workspace_bytes < need) return fail(GEOT_EWORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t *dst_index = reinterpret_cast<int64_t *>(static_cast<char *>(workspace) + seg);
+  if (nnz > 0) {
+    if (!indptr) return fail(GEOT_EINVAL, "null indptr");
+    int64_t blocks = (nrow + kThreads / 16 - 1) / (kThreads / 16);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((csr_expand_kernel<int64_t>), dim3((unsigned)blocks), dim3(kThreads), 0, st, indptr, nrow, nnz, dst_index);
+    HIP_TRY(hipGetLastError());
+  }
+  if (weight)
+    return run_typed(dtype, 2, true, indices, dst_index, weight, src, dst, nnz, feat, 1, src_rows, out_rows, workspace, seg, stream);
+  return run_typed(dtype, 1, true, indices, dst_index, nullptr, src, dst, nnz, feat, 1, src_rows, out_rows, workspace, seg, stream);
+}
+
+int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *rowptr, int assume_sorted,
+                    void *stream) {
+  if (nnz < 0 || nrow < 0 || !rowptr || (nnz > 0 && !coo_row)) return fail(GEOT_EINVAL, "coo_to_csr: bad arguments");
+  if (nnz >= ((int64_t)1 << 31)) return fail(GEOT_EUNSUPPORTED, "coo_to_csr: int32 row pointers need nnz < 2^31");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t blocks = (nnz + 1 + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  if (assume_sorted) {
+    hipLaunchKernelGGL(coo_sorted_to_csr_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, coo_row, nnz, nrow, rowptr);
+  } else {
+    // hist into rowptr[1..nrow], the caller turns it into an inclusive prefix sum
+    HIP_TRY(hipMemsetAsync(rowptr, 0, (size_t)(nrow + 1) * sizeof(int32_t), st));
+    hipLaunchKernelGGL(coo_hist_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, coo_row, nnz, nrow, rowptr + 1);
+  }
+  HIP_TRY(hipGetLastError());
+  return GEOT_OK;
 }
 
 void geot_profile_enable(int on) { g_prof.on = on != 0; }

@@ -166,6 +166,38 @@ def gather_rows_out(index, src, out) -> torch.Tensor:
     return out
 
 
+def csr_gws_out(indptr, indices, weight, src, out) -> torch.Tensor:
+    """out[r] = sum_{e in [indptr[r], indptr[r+1])} weight[e] * src[indices[e]]; weight None = ones."""
+    tensors = [indptr, indices, src, out] + ([weight] if weight is not None else [])
+    dev = _require_gpu(*tensors)
+    L = _lib.load()
+    dt = _dtype_code(src, "csr_gws")
+    nrow, nnz, feat, rows = indptr.numel() - 1, indices.numel(), src.shape[1], out.shape[0]
+    with torch.cuda.device(dev):
+        nbytes = int(L.geot_csr_workspace_bytes(nnz, feat, rows, dt))
+        ws = workspace(dev, nbytes)
+        rc = L.geot_csr_gws(_index_ptr(indptr, "indptr"), _index_ptr(indices, "indices"),
+                            None if weight is None else weight.data_ptr(), src.data_ptr(), out.data_ptr(),
+                            nrow, nnz, feat, src.shape[0], rows, dt, ws.data_ptr(), ws.numel(), _stream_handle(dev))
+    _lib.check(rc, "geot_csr_gws")
+    return out
+
+
+def coo_to_csr_out(coo_row, rowptr, assume_sorted: bool = False) -> torch.Tensor:
+    """rowptr int32 [nrow+1] from COO row ids (int64).  Unsorted input: finishes with a prefix sum."""
+    dev = _require_gpu(coo_row, rowptr)
+    L = _lib.load()
+    if rowptr.dtype != torch.int32:
+        raise RuntimeError("rowptr must be int32")
+    with torch.cuda.device(dev):
+        rc = L.geot_coo_to_csr(_index_ptr(coo_row, "coo_row"), coo_row.numel(), rowptr.numel() - 1,
+                               rowptr.data_ptr(), 1 if assume_sorted else 0, _stream_handle(dev))
+    _lib.check(rc, "geot_coo_to_csr")
+    if not assume_sorted:
+        torch.cumsum(rowptr, 0, dtype=torch.int32, out=rowptr)
+    return rowptr
+
+
 # ---- measurement hooks ---------------------------------------------------------------------------
 def profile_enable(on: bool) -> None:
     _lib.load().geot_profile_enable(1 if on else 0)

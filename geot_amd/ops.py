@@ -235,6 +235,21 @@ def _mh_spmm_gpu(src_index, dst_index, weight, src, reduce: str) -> torch.Tensor
     return _with_row_rule(dst_index, launch)
 
 
+def _csr_gws_gpu(indptr, indices, weight, src) -> torch.Tensor:
+    """csrc/csr_gws.cpp:24-35: any integer dtype for indptr/indices (the reference casts to int32, the
+    kernel here reads int64); the output has indptr.size(0) rows as in the reference (the last row is
+    always zero - SURVEY.md quirk Q9, kept so the op is a drop-in; see csr_gws(..., rows=) below)."""
+    if indptr.dim() != 1 or indices.dim() != 1:
+        raise RuntimeError("indptr and indices must be 1 dimensional")
+    if src.dim() != 2:
+        raise RuntimeError("src must be 2 dimensional")
+    if weight.dim() != 1 or weight.size(0) != indices.size(0):
+        raise RuntimeError("weight must be 1 dimensional with one value per nonzero")
+    out = torch.empty((indptr.size(0), src.shape[1]), dtype=src.dtype, device=src.device)
+    return hip.csr_gws_out(indptr.to(torch.int64).contiguous(), indices.to(torch.int64).contiguous(),
+                           weight.contiguous(), src.contiguous(), out)
+
+
 # --------------------------------------------------------------------------------------------------
 # schema registration (csrc/*.cpp TORCH_LIBRARY_FRAGMENT / TORCH_LIBRARY_IMPL)
 # --------------------------------------------------------------------------------------------------
@@ -245,12 +260,15 @@ _lib_def.define("gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, 
 _lib_def.define("sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor")
 _lib_def.define("mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor")
 
+_lib_def.define("csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src) -> Tensor")
+_lib_def.impl("csr_gws_impl", _csr_gws_gpu, "CUDA")
 _lib_def.impl("index_scatter", _index_scatter_gpu, "CUDA")
 _lib_def.impl("gather_scatter_impl", lambda si, di, s: _gather_scatter_gpu(si, di, s), "CUDA")
 _lib_def.impl("gather_weight_scatter_impl", lambda si, di, w, s: _gather_weight_scatter_gpu(si, di, w, s), "CUDA")
 _lib_def.impl("sddmm_coo_impl", _sddmm_coo_gpu, "CUDA")
 _lib_def.impl("mh_spmm", _mh_spmm_gpu, "CUDA")
-for _name in ("index_scatter", "gather_scatter_impl", "gather_weight_scatter_impl", "sddmm_coo_impl", "mh_spmm"):
+for _name in ("index_scatter", "gather_scatter_impl", "gather_weight_scatter_impl", "sddmm_coo_impl", "mh_spmm",
+              "csr_gws_impl"):
     _lib_def.impl(_name, _reject_cpu(_name), "CPU")
 
 
@@ -281,6 +299,11 @@ def _(src_index, dst_index, weight, src):
 @torch.library.register_fake("geot::sddmm_coo_impl")
 def _(src_index, dst_index, mat_1, mat_2):
     return mat_1.new_empty([dst_index.shape[0]])
+
+
+@torch.library.register_fake("geot::csr_gws_impl")
+def _(indptr, indices, weight, src):
+    return src.new_empty([indptr.shape[0], src.shape[1]])
 
 
 @torch.library.register_fake("geot::mh_spmm")
@@ -419,3 +442,40 @@ def mh_spmm_transposed(src_index: torch.Tensor, dst_index: torch.Tensor, weight:
     """geot/mh_spmm.py:8-12: transposes weight [nnz, H] -> [H, nnz] (contiguous) and calls mh_spmm."""
     weight = weight.transpose(0, 1).contiguous()
     return torch.ops.geot.mh_spmm(src_index, dst_index, weight, src, reduce)
+
+
+# --------------------------------------------------------------------------------------------------
+# CSR path (SURVEY.md section 8 row f2): geot/csr_gws.py:3-37, geot/match_replace/format_transform.py:5-25
+# --------------------------------------------------------------------------------------------------
+def csr_gws_impl(csrptr: torch.Tensor, csrind: torch.Tensor, weight: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    return torch.ops.geot.csr_gws_impl(csrptr, csrind, weight, src)
+
+
+@torch.library.custom_op("geot::csr_gws", mutates_args=())
+def csr_gws(csrptr: torch.Tensor, csrind: torch.Tensor, weight: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """CSR weighted SpMM: out[r] = sum_e weight[e] * src[csrind[e]] over the row's nonzeros
+    (geot/csr_gws.py:25-28).  Output rows = csrptr.size(0) as in the reference."""
+    return csr_gws_impl(csrptr, csrind, weight, src)
+
+
+@torch.library.register_fake("geot::csr_gws")
+def _(csrptr, csrind, weight, src):
+    ctx = torch.library.get_ctx()
+    return src.new_empty([ctx.new_dynamic_size(), src.shape[1]])
+
+
+@torch.library.custom_op("geot::coo_to_csr", mutates_args=())
+def coo_to_csr(coo_row: torch.Tensor) -> torch.Tensor:
+    """COO row ids -> int32 CSR row pointers of length max(coo_row)+2
+    (geot/match_replace/format_transform.py:5-18).  Any order of coo_row is accepted."""
+    if coo_row.dim() != 1:
+        raise RuntimeError("coo_row must be 1 dimensional")
+    nrow = int(coo_row.max().item()) + 1
+    rowptr = torch.empty(nrow + 1, dtype=torch.int32, device=coo_row.device)
+    return hip.coo_to_csr_out(coo_row.to(torch.int64).contiguous(), rowptr, assume_sorted=False)
+
+
+@torch.library.register_fake("geot::coo_to_csr")
+def _(coo_row):
+    ctx = torch.library.get_ctx()
+    return coo_row.new_empty([ctx.new_dynamic_size()], dtype=torch.int32)

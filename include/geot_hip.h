@@ -113,6 +113,26 @@ int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const voi
 int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
                      int64_t feat, int64_t src_rows, int dtype, void *stream);
 
+/* ---- CSR path ("next" row f2 of SURVEY.md section 8) ---------------------------------------
+ * geot_csr_gws  <- csr_gws_cuda   csrc/cuda/header_cuda.h:19-21 (impl csrc/cuda/csr_gws_cuda.cu,
+ *                                 kernel csrc/cuda/csr_gws_kernel.cuh:12-186)
+ * dst[r, :] = sum over e in [indptr[r], indptr[r+1]) of weight[e] * src[indices[e], :]
+ * indptr has nrow+1 entries; weight may be NULL (all ones).  out_rows >= nrow (the reference shim
+ * allocates indptr.size(0) = nrow+1 rows, csrc/csr_gws.cpp:29-31; rows >= nrow come out 0).
+ * Workspace: geot_csr_workspace_bytes (the per-edge row ids are expanded into it). */
+size_t geot_csr_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype);
+int geot_csr_gws(const int64_t *indptr, const int64_t *indices, const void *weight, const void *src,
+                 void *dst, int64_t nrow, int64_t nnz, int64_t feat, int64_t src_rows,
+                 int64_t out_rows, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* geot_coo_to_csr <- geot::coo_to_csr  geot/match_replace/format_transform.py:5-18 (+ the Triton
+ * histogram geot/triton/coo_to_csr.py:14-26).  rowptr is int32[nrow+1] like the reference's.
+ * assume_sorted != 0: coo_row ascending -> rowptr is final on return (atomic-free);
+ * assume_sorted == 0: any order -> rowptr[0] = 0, rowptr[1+r] = count of r (int32 atomics); the
+ *                     caller finishes with an inclusive prefix sum over rowptr. */
+int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *rowptr,
+                    int assume_sorted, void *stream);
+
 /* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
  * With profiling on, every segment-reduction call records hipEvents around its kernels on
  * the call's stream; geot_profile_read waits for them and returns the accumulated device

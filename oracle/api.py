@@ -204,3 +204,28 @@ def gather_rows(index, src):
                                            _i64(index.shape[0]), _i64(F), _i64(src.shape[0]))
     _check(rc, "gather_rows")
     return out
+
+
+def csr_gws(indptr, indices, weight, src, out_rows: int | None = None, acc64: bool = False):
+    """out[r] = sum_e weight[e] * src[indices[e]] over row r's nonzeros; out_rows defaults to
+    len(indptr) (the reference shim's row count, csrc/csr_gws.cpp:29-31)."""
+    indptr, indices = _idx(indptr), _idx(indices)
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float32)
+    nrow = indptr.shape[0] - 1
+    rows = indptr.shape[0] if out_rows is None else int(out_rows)
+    out = np.empty((rows, src.shape[1]), dtype=np.float32)
+    name = "geot_oracle_csr_gws_f32" + ("_acc64" if acc64 else "")
+    rc = getattr(lib(), name)(_ptr(indptr), _ptr(indices), None if w is None else _ptr(w), _ptr(src), _ptr(out),
+                              _i64(nrow), _i64(src.shape[1]), _i64(src.shape[0]), _i64(rows))
+    _check(rc, name)
+    return out
+
+
+def coo_to_csr(coo_row, nrow: int | None = None):
+    coo_row = _idx(coo_row)
+    nrow = int(coo_row.max()) + 1 if nrow is None else int(nrow)
+    rowptr = np.empty(nrow + 1, dtype=np.int32)
+    rc = lib().geot_oracle_coo_to_csr(_ptr(coo_row), _i64(coo_row.shape[0]), _i64(nrow), _ptr(rowptr))
+    _check(rc, "coo_to_csr")
+    return rowptr

@@ -318,3 +318,46 @@ int geot_oracle_gather_rows_f32(const int64_t *index, const float *src, float *o
   for (int64_t e = 0; e < nnz; e++) memcpy(out + e * F, src + index[e] * F, (size_t)F * sizeof(float));
   return ORACLE_OK;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * csr_gws: out[r] = sum_{e in [indptr[r], indptr[r+1])} src[indices[e]] * weight[e]
+ * csrc/csr_gws.cpp:24-35 (output has indptr.size(0) = nrow+1 rows, the extra row stays 0),
+ * kernel csrc/cuda/csr_gws_kernel.cuh:12-186; comparator test/test_csr_gws.py:16-25.
+ * weight == NULL -> ones.  Sequential in nonzero order; acc64 variant for the error bound.
+ * ------------------------------------------------------------------------------------------ */
+#define DEF_CSR(NAME, ACC)                                                                     \
+  int NAME(const int64_t *indptr, const int64_t *indices, const float *weight, const float *src, \
+           float *out, int64_t nrow, int64_t F, int64_t src_rows, int64_t out_rows) {         \
+    if (nrow < 0 || F < 0 || out_rows < nrow) return ORACLE_EINVAL;                           \
+    for (int64_t r = 0; r < nrow; r++)                                                        \
+      if (indptr[r] > indptr[r + 1] || indptr[r] < 0) return ORACLE_EINVAL;                   \
+    for (int64_t i = 0; i < out_rows * F; i++) out[i] = 0.0f;                                 \
+    for (int64_t r = 0; r < nrow; r++) {                                                      \
+      for (int64_t j = 0; j < F; j++) {                                                       \
+        ACC s = 0;                                                                            \
+        for (int64_t e = indptr[r]; e < indptr[r + 1]; e++) {                                 \
+          if (indices[e] < 0 || indices[e] >= src_rows) return ORACLE_ERANGE;                 \
+          const float p = weight ? src[indices[e] * F + j] * weight[e] : src[indices[e] * F + j]; \
+          s = (ACC)(s + (ACC)p);                                                              \
+        }                                                                                     \
+        out[r * F + j] = (float)s;                                                            \
+      }                                                                                       \
+    }                                                                                         \
+    return ORACLE_OK;                                                                         \
+  }
+
+DEF_CSR(geot_oracle_csr_gws_f32, float)
+DEF_CSR(geot_oracle_csr_gws_f32_acc64, double)
+
+/* coo_to_csr: int32 row pointers of length nrow+1 = [0, cumsum(histogram(coo_row))]
+ * geot/match_replace/format_transform.py:5-18 (hist by geot/triton/coo_to_csr.py:14-26). */
+int geot_oracle_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *rowptr) {
+  if (nnz < 0 || nrow < 0) return ORACLE_EINVAL;
+  for (int64_t r = 0; r <= nrow; r++) rowptr[r] = 0;
+  for (int64_t e = 0; e < nnz; e++) {
+    if (coo_row[e] < 0 || coo_row[e] >= nrow) return ORACLE_ERANGE;
+    rowptr[coo_row[e] + 1]++;
+  }
+  for (int64_t r = 0; r < nrow; r++) rowptr[r + 1] += rowptr[r];
+  return ORACLE_OK;
+}
