@@ -37,7 +37,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kU = 8;          // row loads in flight per lane
 constexpr int kGapInline = 16; // gaps up to this many rows are zeroed by the lane group itself
-constexpr int kMinLprLog2 = 2; // lane groups are at least 4 lanes wide (<= 64 groups per block)
+constexpr int kMinLprLog2 = 2; // lane groups are at least 4 lanes wide (1-2 lane groups measured slower:
+                               // 512 LDS partials per tile make the merge the bottleneck)
 constexpr int64_t kNoKey = -2; // key of the padding edges behind the end of the edge list (-1 = before edge 0)
 
 struct SegParams {
@@ -360,6 +361,41 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   }
 }
 
+// Unsorted index, few output rows: LDS-binned atomics.  When the whole [K, F] output fits in LDS,
+// every block accumulates its share of the edges into an LDS copy with ds_add (LDS float atomics:
+// no global contention, any key order), then adds its copy to dst with ONE global atomic per
+// element.  Global atomic traffic drops from nnz*F to blocks*K*F, and the pathological "every
+// workgroup adds into the same few rows" case (14x slower than spread atomics on MI355X) never
+// happens.  dst is zero-filled by the launcher.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void seg_lds_bin_kernel(const int64_t *__restrict__ index,
+                                                               const T *__restrict__ src,
+                                                               T *__restrict__ dst, int64_t nnz,
+                                                               int64_t F, int64_t K, int lpr_log2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T *tab = reinterpret_cast<T *>(smem);
+  const int64_t n = K * F;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) tab[i] = T(0);
+  __syncthreads();
+  const int lpr = 1 << lpr_log2;
+  const int ng = kThreads >> lpr_log2;
+  const int g = threadIdx.x >> lpr_log2, c = threadIdx.x & (lpr - 1);
+  // contiguous chunk of edges per block (coalesced rows), lane group per row
+  const int64_t per = (nnz + gridDim.x - 1) / gridDim.x;
+  const int64_t e0 = (int64_t)blockIdx.x * per;
+  const int64_t e1 = e0 + per < nnz ? e0 + per : nnz;
+  for (int64_t e = e0 + g; e < e1; e += ng) {
+    const int64_t k = index[e];
+    if ((uint64_t)k >= (uint64_t)K) continue;
+    for (int64_t f = c; f < F; f += lpr) atomicAdd(&tab[k * F + f], src[e * F + f]);
+  }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+    const T v = tab[i];
+    if (v != T(0)) atomicAdd(dst + i, v);
+  }
+}
+
 // Second launch (= the only cross-workgroup ordering the sorted path needs):
 //  (a) one LANE GROUP per tile (64/LPR tiles per wave): if the tile holds the FIRST carry of a
 //      chain (its head run continues from the previous tile, and that tile is where the run
@@ -649,11 +685,14 @@ inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 // vec_unit: the feature granule that must stay inside one vector (F, or F per head for mh_spmm)
 // hw: weights staged in LDS per edge (0, 1 or H); gather: src offsets staged in LDS
 Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, bool aligned16,
-               bool gather, int hw) {
+               bool gather, int hw, bool atomic_flush = false) {
   Plan P;
   const int maxvec = 16 / tsize; // 16 B per lane
   int vec = 1;
-  if (aligned16) {
+  // atomic flushes want one element per lane: a lane group then adds LPR*4 contiguous bytes per
+  // instruction (256 B at F>=64), the only shape that reaches the chip's float-atomic rate
+  // (measured 2x over the 16-B-per-lane layout, whose atomics stride by 16 B)
+  if (aligned16 && !atomic_flush) {
     if (vec_unit % maxvec == 0) vec = maxvec;
     else if (maxvec >= 4 && vec_unit % 2 == 0) vec = 2;
   }
@@ -671,7 +710,8 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   if (cg < 16) cg = 16;
   cg = (cg + 15) / 16 * 16;
   if (cg > 256) cg = 256;
-  // bound the tile: <= 2048 edges, <= ~64 KB of LDS, and 32-bit byte offsets inside a tile
+  // bound the tile: <= 2048 edges (4096 when the rows are so narrow that 256 groups x 16 edges is
+  // the smallest legal tile), <= ~64 KB of LDS, and 32-bit byte offsets inside a tile
   while (cg > 16 && ((int64_t)ng * cg > 2048 ||
                      smem_layout(l, cg, vec, tsize, gather, hw).bytes > 64 * 1024 ||
                      (int64_t)ng * cg * F * tsize >= ((int64_t)1 << 31)))
@@ -738,7 +778,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   const bool al = is_aligned16(src) && is_aligned16(dst) && is_aligned16(ws);
   const int hw = mode <= 1 ? 0 : (mode == 2 ? 1 : (int)H);
   if (hw > 64) return fail(GEOT_EUNSUPPORTED, "more than 64 heads");
-  const Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw);
+  const Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
   if (!ws || ws_bytes < P.total) return fail(GEOT_EWORKSPACE, "workspace too small");
   if (((uintptr_t)ws & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
 
@@ -783,6 +823,16 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   if (nnz > 0) {
     if (!sorted) {
       if (mode != 0) return fail(GEOT_EUNSUPPORTED, "unsorted is index_scatter only");
+      const size_t tab_bytes = (size_t)K * (size_t)F * sizeof(T);
+      if (tab_bytes <= 48 * 1024 && g_tune.lpr_log2 != 7) {   // (lpr_log2 = 7: test knob, forces the direct path)
+        int l = ceil_log2(F);
+        if (l > 6) l = 6;
+        int64_t blocks = (nnz + 4095) / 4096;                  // >= 4096 edges per block, <= 4 blocks per CU
+        if (blocks > 1024) blocks = 1024;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL((seg_lds_bin_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), tab_bytes, st,
+                           dst_index, static_cast<const T *>(src), static_cast<T *>(dst), nnz, F, K, l);
+      } else
       rc = dispatch_vec<T, false, 0, true>(p, P, st, nt);
     } else {
       switch (mode) {

@@ -218,6 +218,14 @@ static int cmd_check() {
     v.back() = 4999;
     run_case({100000, 5000, 64, 1, 0, false, "unsorted atomics F=64"}, v, seed); seed++;
     run_case({100000, 5000, 33, 1, 0, false, "unsorted atomics F=33"}, v, seed); seed++;
+    std::vector<int64_t> few(200000);
+    for (auto &x : few) x = (int64_t)(rng() % 10);
+    few.back() = 9;
+    run_case({200000, 10, 32, 1, 0, false, "unsorted, 10 keys (LDS-binned) F=32"}, few, seed); seed++;
+    run_case({200000, 10, 7, 1, 0, false, "unsorted, 10 keys (LDS-binned) F=7"}, few, seed); seed++;
+    for (auto &x : few) x = (int64_t)(rng() % 300);
+    few.back() = 299;
+    run_case({200000, 300, 40, 1, 0, false, "unsorted, 300 keys x 40 (LDS-binned, 48 KB)"}, few, seed); seed++;
     auto s = uniform_sorted(1000, 10, seed);
     run_case({1000, 10, 32, 1, 0, false, "reference test: sorted data, sorted=False"}, s, seed); seed++;
   }
@@ -326,8 +334,9 @@ static int cmd_sweep(int64_t nnz, int64_t K, int64_t F, int iters, int one_cg = 
            mm / calls, fm / calls, am / calls, worst);
   }
   // atomic (sorted=0) for comparison: what the reference's flush strategy costs here
-  {
-    geot_tune(0, 0, -1, -1);
+  for (int avec : {0, 1}) {
+    geot_tune(0, avec, -1, -1);
+    printf("[atomic path vec=%d] ", avec);
     const size_t wsb = geot_workspace_bytes(nnz, F, K, GEOT_F32);
     DBuf<char> ws(wsb);
     geot_workspace_init(ws.p, wsb, nullptr);
@@ -341,12 +350,44 @@ static int cmd_sweep(int64_t nnz, int64_t K, int64_t F, int iters, int one_cg = 
   return 0;
 }
 
+static int cmd_unsorted(int64_t nnz, int64_t F) {
+  std::mt19937_64 rng(5);
+  std::vector<float> src((size_t)nnz * F, 0.5f);
+  DBuf<float> d_src(src);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int64_t K : {10, 100, 1000, 100000, 1000000}) {
+    std::vector<int64_t> idx(nnz);
+    for (auto &x : idx) x = (int64_t)(rng() % (uint64_t)K);
+    idx.back() = K - 1;
+    DBuf<int64_t> d_idx(idx);
+    DBuf<float> d_dst((size_t)K * F);
+    for (int direct : {0, 1}) {
+      geot_tune(0, 0, -1, direct ? 7 : -1);
+      const size_t wsb = geot_workspace_bytes(nnz, F, K, GEOT_F32);
+      DBuf<char> ws(wsb);
+      geot_workspace_init(ws.p, wsb, nullptr);
+      for (int i = 0; i < 2; ++i) geot_index_scatter(d_idx.p, d_src.p, d_dst.p, nnz, F, K, GEOT_F32, 0, ws.p, wsb, nullptr);
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 5; ++i) geot_index_scatter(d_idx.p, d_src.p, d_dst.p, nnz, F, K, GEOT_F32, 0, ws.p, wsb, nullptr);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      const double ms = time_ms(e0, e1) / 5;
+      auto got = d_dst.down();
+      double tot = 0; for (float v : got) tot += v;
+      printf("unsorted random keys K=%-8ld F=%ld nnz=%ld %s: %.4f ms  %.2f Gedge/s  (sum check %.6g vs %.6g)\n", (long)K, (long)F,
+             (long)nnz, direct ? "direct atomics " : (K * F * 4 <= 48 * 1024 ? "LDS-binned     " : "direct (auto)  "), ms, nnz / ms / 1e6, tot, 0.5 * nnz * F);
+    }
+  }
+  geot_tune(0, 0, -1, -1);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   setvbuf(stdout, nullptr, _IOLBF, 0);
   const std::string cmd = argc > 1 ? argv[1] : "check";
   printf("%s\n", geot_build_info());
   if (cmd == "check") return cmd_check();
   if (cmd == "copy") return cmd_copy();
+  if (cmd == "unsorted") return cmd_unsorted(argc > 2 ? atoll(argv[2]) : 10000000, argc > 3 ? atoll(argv[3]) : 32);
   if (cmd == "sweep") {
     const int64_t nnz = argc > 2 ? atoll(argv[2]) : 10000000;
     const int64_t K = argc > 3 ? atoll(argv[3]) : 1000000;
