@@ -50,6 +50,7 @@ struct SegParams {
   void *carry;              // [num_tiles, 2, F] slot 0: head partial (run continues from the
                             //   previous tile); slot 1: tail partial (run starts here, continues)
   int64_t *meta;            // [num_tiles]      first_key*4 + head_continues + 2*single_key_tile
+  int64_t *ccnt;            // [num_tiles, 2]   edge counts of the two carry slots (mean only)
   unsigned long long *ctrl; // [0] large-gap count, [1] fix-up ticket; zero between calls
   int64_t *gap_list;        // pairs (first_row, n_rows)
   int64_t gap_cap;
@@ -89,6 +90,25 @@ __device__ __forceinline__ void store_vec(T *p, const T (&v)[VEC]) {
   else *reinterpret_cast<V *>(p) = x;
 }
 
+// Reductions of the reference's CPU path (csrc/cpu/index_scatter_cpu.cpp:124-134; init / update /
+// write of ATen/native/cpu/ReduceUtils.h).  Codes follow csrc/reducetype.h:3.
+enum { RED_MAX = 0, RED_MEAN = 1, RED_MIN = 2, RED_SUM = 3, RED_PROD = 4 };
+
+template <typename T, int RED> __device__ __forceinline__ T red_ident() {
+  if constexpr (RED == RED_PROD) return T(1);
+  else if constexpr (RED == RED_MAX) return -INFINITY;
+  else if constexpr (RED == RED_MIN) return INFINITY;
+  else return T(0);
+}
+
+// ATen's _max/_min propagate NaN: isnan(y) ? y : max(x, y)
+template <typename T, int RED> __device__ __forceinline__ T red_op(T x, T y) {
+  if constexpr (RED == RED_PROD) return x * y;
+  else if constexpr (RED == RED_MAX) return (y != y) ? y : (x < y ? y : x);
+  else if constexpr (RED == RED_MIN) return (y != y) ? y : (y < x ? y : x);
+  else return x + y;
+}
+
 // LDS carve-up, shared by kernel and launcher.  te (edges per tile) is a multiple of 64.
 struct SmemLayout {
   int te;
@@ -99,6 +119,7 @@ struct SmemLayout {
   size_t off_p;    // T     [2*ng][FB]
   size_t off_w;    // T     [te*hw]  : edge weights, edge-major
   size_t off_pv;   // int   [2*ng]   : valid flags of the partials
+  size_t off_cnt;  // int   [2*ng]   : edge counts of the partials (mean)
   size_t bytes;
 };
 
@@ -117,13 +138,14 @@ __host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec,
   L.off_w = o;    o += (size_t)tsize * L.te * hw;
   o = (o + 7) & ~(size_t)7;
   L.off_pv = o;   o += sizeof(int) * (size_t)(2 * ng);
+  L.off_cnt = o;  o += sizeof(int) * (size_t)(2 * ng);
   L.bytes = (o + 15) & ~(size_t)15;
   return L;
 }
 
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // NT   : bit 0 non-temporal row loads, bit 1 non-temporal dst stores
-template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT>
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
 __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
@@ -143,6 +165,8 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   T *pL = reinterpret_cast<T *>(smem + L.off_p);
   T *wL = reinterpret_cast<T *>(smem + L.off_w);
   int *pvL = reinterpret_cast<int *>(smem + L.off_pv);
+  int *cntL = reinterpret_cast<int *>(smem + L.off_cnt);
+  constexpr bool MEAN = RED == RED_MEAN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -254,9 +278,10 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 
   T acc[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] = T(0);
+  for (int i = 0; i < VEC; ++i) acc[i] = red_ident<T, RED>();
   int64_t cur = keysL[1 + gs];
   bool first = true;
+  int cnt = 0; // edges in the current run (mean)
   if constexpr (!ATOMIC) {
     const int64_t kprev = keysL[gs];
     if (cur > kprev + 1) gapfill(kprev + 1, cur);
@@ -282,20 +307,29 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         } else {
           if (first) {
             store_vec<T, VEC>(pL + (size_t)(2 * g) * FB + c * VEC, acc);
-            if (c == 0) pkL[2 * g] = cur;
+            if (c == 0) {
+              pkL[2 * g] = cur;
+              if constexpr (MEAN) cntL[2 * g] = cnt;
+            }
             first = false;
           } else if (active && (uint64_t)cur < (uint64_t)K) {
+            if constexpr (MEAN) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] = acc[i] / T(cnt);
+            }
             store_vec<T, VEC, NTS>(dstf + cur * F, acc);
           }
           if (knew > cur + 1) gapfill(cur + 1, knew);
         }
         cur = knew;
+        cnt = 0;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = T(0);
+        for (int i = 0; i < VEC; ++i) acc[i] = red_ident<T, RED>();
       }
+      if constexpr (MEAN) ++cnt;
       if constexpr (WMODE == 0) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i];
+        for (int i = 0; i < VEC; ++i) acc[i] = red_op<T, RED>(acc[i], v[u][i]);
       } else {
         const T w = WMODE == 1 ? wL[gs + b + u] : wL[(gs + b + u) * hw + hh];
 #pragma unroll
@@ -320,6 +354,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if (c == 0) {
       pkL[slot] = cur;
       pvL[slot] = 1;
+      if constexpr (MEAN) cntL[slot] = cnt;
     }
   }
 
@@ -341,21 +376,31 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sum[q] = pL[(size_t)i * FB + c * VEC + q];
     bool at_end = true; // the merged run reaches the last edge of the tile
+    int64_t csum = MEAN ? cntL[i] : 0;
     for (int j = i + 1; j < ne; ++j) {
       if (!pvL[j]) continue;
       if (pkL[j] != k) { at_end = false; break; }
+      if constexpr (MEAN) csum += cntL[j];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) sum[q] += pL[(size_t)j * FB + c * VEC + q];
+      for (int q = 0; q < VEC; ++q) sum[q] = red_op<T, RED>(sum[q], pL[(size_t)j * FB + c * VEC + q]);
+    }
+    const int cslot_id = (i == 0 && k == kprev_tile) ? 0 : ((at_end && k == knext_tile) ? 1 : -1);
+    if constexpr (MEAN) {
+      if (cslot_id >= 0 && c == 0 && blockIdx.y == 0) p.ccnt[tile * 2 + cslot_id] = csum;
     }
     if (!active) continue;
     T *cslot = static_cast<T *>(p.carry) + (tile * 2) * F + f0;
-    if (i == 0 && k == kprev_tile) {
+    if (cslot_id == 0) {
       // continues a run that started in an earlier tile: slot 0, added by seg_fixup_kernel
       store_vec<T, VEC>(cslot, sum);
-    } else if (at_end && k == knext_tile) {
+    } else if (cslot_id == 1) {
       // starts here and continues into the next tile: slot 1; seg_fixup_kernel writes the row
       store_vec<T, VEC>(cslot + F, sum);
     } else if ((uint64_t)k < (uint64_t)K) {
+      if constexpr (MEAN) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) sum[q] = sum[q] / T(csum);
+      }
       store_vec<T, VEC, NTS>(dstf + k * F, sum);
     }
   }
@@ -407,8 +452,9 @@ __global__ __launch_bounds__(kThreads) void seg_lds_bin_kernel(const int64_t *__
 //      parallel, xor-shuffle combine in a fixed order => deterministic);
 //  (b) zero-fill the large gaps the tile kernel recorded;
 //  (c) the last block to finish re-zeroes the two control words for the next call.
-template <typename T>
+template <typename T, int RED = RED_SUM>
 __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_t num_tiles) {
+  constexpr bool MEAN = RED == RED_MEAN;
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << p.lpr_log2;
   const int R = 64 >> p.lpr_log2; // lane groups per wave
@@ -431,23 +477,25 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int64_t f = (int64_t)j * lpr + c;
-    cv[j] = (valid && f < F) ? carry[((tc - 1) * 2 + 1) * F + f] + carry[(tc * 2) * F + f] : T(0);
+    cv[j] = (valid && f < F) ? red_op<T, RED>(carry[((tc - 1) * 2 + 1) * F + f], carry[(tc * 2) * F + f]) : T(0);
   }
   const bool first = valid && (m & 1) && !(mp & 2);
   const int64_t k = m >> 2;
   if (first && !(m & 2)) {
+    T inv_div = T(1);
+    if constexpr (MEAN) inv_div = T(p.ccnt[(t - 1) * 2 + 1] + p.ccnt[t * 2]);
     for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
       if (fb > 0) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int64_t f = fb + (int64_t)j * lpr + c;
-          cv[j] = f < F ? carry[((t - 1) * 2 + 1) * F + f] + carry[(t * 2) * F + f] : T(0);
+          cv[j] = f < F ? red_op<T, RED>(carry[((t - 1) * 2 + 1) * F + f], carry[(t * 2) * F + f]) : T(0);
         }
       }
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int64_t f = fb + (int64_t)j * lpr + c;
-        if (f < F) dst[k * F + f] = cv[j];
+        if (f < F) dst[k * F + f] = MEAN ? cv[j] / inv_div : cv[j];
       }
     }
   }
@@ -464,8 +512,11 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int64_t f = fb + (int64_t)j * lpr + c;
-        hv[j] = (gq == 0 && f < F) ? carry[((th - 1) * 2 + 1) * F + f] + carry[(th * 2) * F + f] : T(0);
+        hv[j] = (gq == 0 && f < F) ? red_op<T, RED>(carry[((th - 1) * 2 + 1) * F + f], carry[(th * 2) * F + f])
+                                   : red_ident<T, RED>();
       }
+      int64_t hcnt = 0; // mean: edges of the whole chain (every lane computes the same value)
+      if constexpr (MEAN) hcnt = p.ccnt[(th - 1) * 2 + 1] + p.ccnt[th * 2];
       // tile x+1 joins the chain for as long as tile x is `single`; 64 tiles per window
       int64_t wb = th;
       for (;;) {
@@ -482,26 +533,29 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
 #pragma unroll
             for (int j = 0; j < J; ++j) {
               const int64_t f = fb + (int64_t)j * lpr + c;
-              cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : T(0);
+              cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : red_ident<T, RED>();
             }
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < J; ++j) hv[j] += cr[q][j];
+            for (int j = 0; j < J; ++j) hv[j] = red_op<T, RED>(hv[j], cr[q][j]);
+        }
+        if constexpr (MEAN) {
+          for (int64_t tt = wb + 1; tt <= hi; ++tt) hcnt += p.ccnt[tt * 2];
         }
         if (nn < 64) break;
         wb += 64;
       }
       for (int off = lpr; off < 64; off <<= 1) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) hv[j] += __shfl_xor(hv[j], off, 64);
+        for (int j = 0; j < J; ++j) hv[j] = red_op<T, RED>(hv[j], __shfl_xor(hv[j], off, 64));
       }
       if (gq == 0) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int64_t f = fb + (int64_t)j * lpr + c;
-          if (f < F) dst[kh * F + f] = hv[j];
+          if (f < F) dst[kh * F + f] = MEAN ? hv[j] / T(hcnt) : hv[j];
         }
       }
     }
@@ -668,7 +722,7 @@ int fail(int code, const std::string &msg) {
 struct Plan {
   int vec, lpr_log2, cg, te;
   int64_t num_tiles, nfb;
-  size_t meta_off, carry_off, list_off, total; // ctrl block sits at offset 0
+  size_t meta_off, cnt_off, carry_off, list_off, total; // ctrl block sits at offset 0
   int64_t gap_cap;
 };
 
@@ -724,20 +778,43 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   if (P.nfb < 1) P.nfb = 1;
   const size_t nt = (size_t)(P.num_tiles > 0 ? P.num_tiles : 1);
   P.meta_off = kCtrlBytes;
-  P.carry_off = P.meta_off + up256(nt * sizeof(int64_t));
+  P.cnt_off = P.meta_off + up256(nt * sizeof(int64_t));
+  P.carry_off = P.cnt_off + up256(nt * 2 * sizeof(int64_t));
   P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * tsize);
   P.gap_cap = K / kGapInline + 2;
   P.total = P.list_off + up256((size_t)P.gap_cap * 16);
   return P;
 }
 
-template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT>
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
 void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
   const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(T), GATHER, hw);
   dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
-  hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT>), grid, dim3(kThreads),
+  hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads),
                      L.bytes, st, p);
+}
+
+// non-sum reductions: index_scatter, sorted, streamed operand -> fixed nt policy (loads + stores)
+template <typename T, int RED>
+int dispatch_reduce(const SegParams &p, const Plan &P, hipStream_t st) {
+  constexpr int MAXV = 16 / (int)sizeof(T);
+  if (P.vec == MAXV) launch_tile<T, MAXV, false, 0, false, 3, RED>(p, P, st);
+  else if (MAXV >= 4 && P.vec == 2) launch_tile<T, 2, false, 0, false, 3, RED>(p, P, st);
+  else if (P.vec == 1) launch_tile<T, 1, false, 0, false, 3, RED>(p, P, st);
+  else return fail(GEOT_EINVAL, "internal: bad vector width");
+  return GEOT_OK;
+}
+
+template <typename T>
+void launch_fixup(const SegParams &p, int64_t blocks, int64_t num_tiles, int red, hipStream_t st) {
+  switch (red) {
+  case RED_MAX: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_MAX>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
+  case RED_MEAN: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_MEAN>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
+  case RED_MIN: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_MIN>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
+  case RED_PROD: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_PROD>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
+  default: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_SUM>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
+  }
 }
 
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC>
@@ -767,7 +844,9 @@ template <typename T>
 int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_t *dst_index,
                    const void *weight, const void *src, void *dst, int64_t nnz, int64_t F,
                    int64_t H, int64_t src_rows, int64_t K, void *ws, size_t ws_bytes,
-                   hipStream_t st) {
+                   hipStream_t st, int red = RED_SUM) {
+  if (red != RED_SUM && (mode != 0 || !sorted))
+    return fail(GEOT_EUNSUPPORTED, "non-sum reductions: sorted index_scatter only");
   if (nnz < 0 || F < 0 || K < 0 || src_rows < 0 || H < 1) return fail(GEOT_EINVAL, "negative size");
   if (K == 0 || F == 0) return GEOT_OK;
   if (!dst || (nnz > 0 && (!dst_index || !src))) return fail(GEOT_EINVAL, "null pointer");
@@ -791,6 +870,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.dst = dst;
   p.ctrl = reinterpret_cast<unsigned long long *>(wsc);
   p.meta = reinterpret_cast<int64_t *>(wsc + P.meta_off);
+  p.ccnt = reinterpret_cast<int64_t *>(wsc + P.cnt_off);
   p.carry = wsc + P.carry_off;
   p.gap_list = reinterpret_cast<int64_t *>(wsc + P.list_off);
   p.gap_cap = P.gap_cap;
@@ -836,7 +916,15 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
       rc = dispatch_vec<T, false, 0, true>(p, P, st, nt);
     } else {
       switch (mode) {
-      case 0: rc = dispatch_vec<T, false, 0, false>(p, P, st, nt); break;
+      case 0:
+        switch (red) {
+        case RED_MAX: rc = dispatch_reduce<T, RED_MAX>(p, P, st); break;
+        case RED_MEAN: rc = dispatch_reduce<T, RED_MEAN>(p, P, st); break;
+        case RED_MIN: rc = dispatch_reduce<T, RED_MIN>(p, P, st); break;
+        case RED_PROD: rc = dispatch_reduce<T, RED_PROD>(p, P, st); break;
+        default: rc = dispatch_vec<T, false, 0, false>(p, P, st, nt); break;
+        }
+        break;
       case 1: rc = dispatch_vec<T, true, 0, false>(p, P, st, nt); break;
       case 2: rc = dispatch_vec<T, true, 1, false>(p, P, st, nt); break;
       case 3: rc = dispatch_vec<T, true, 2, false>(p, P, st, nt); break;
@@ -853,8 +941,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     const int64_t tiles_per_block = (kThreads / 64) * (64 >> P.lpr_log2); // one lane group per tile
     int64_t blocks = (P.num_tiles + tiles_per_block - 1) / tiles_per_block;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((seg_fixup_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p,
-                       P.num_tiles);
+    launch_fixup<T>(p, blocks, P.num_tiles, red, st);
     HIP_TRY(hipGetLastError());
     rec.has_fix = true;
   }
@@ -868,12 +955,12 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
 
 int run_typed(int dtype, int mode, bool sorted, const int64_t *si, const int64_t *di,
               const void *w, const void *src, void *dst, int64_t nnz, int64_t F, int64_t H,
-              int64_t src_rows, int64_t K, void *ws, size_t wsb, void *stream) {
+              int64_t src_rows, int64_t K, void *ws, size_t wsb, void *stream, int red = RED_SUM) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == GEOT_F32)
-    return run_segment_op<float>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st);
+    return run_segment_op<float>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
   if (dtype == GEOT_F64)
-    return run_segment_op<double>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st);
+    return run_segment_op<double>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
   return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
 }
 
@@ -954,7 +1041,8 @@ size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dty
   // upper bound over every plan the launcher can pick for these sizes: the smallest tile is
   // 4 lane groups (64 lanes per row) x 16 edges
   const size_t nt = (size_t)(nnz / 64 + 1);
-  return kCtrlBytes + up256(nt * sizeof(int64_t)) + up256(nt * 2 * (size_t)feat * tsize) +
+  return kCtrlBytes + up256(nt * sizeof(int64_t)) + up256(nt * 2 * sizeof(int64_t)) +
+         up256(nt * 2 * (size_t)feat * tsize) +
          up256((size_t)(out_rows / kGapInline + 2) * 16);
 }
 
@@ -969,6 +1057,14 @@ int geot_index_scatter(const int64_t *index, const void *src, void *dst, int64_t
                        size_t workspace_bytes, void *stream) {
   return run_typed(dtype, 0, sorted != 0, nullptr, index, nullptr, src, dst, nnz, feat, 1, nnz,
                    out_rows, workspace, workspace_bytes, stream);
+}
+
+int geot_index_scatter_reduce(const int64_t *index, const void *src, void *dst, int64_t nnz,
+                              int64_t feat, int64_t out_rows, int dtype, int reduce, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+  if (reduce < GEOT_REDUCE_MAX || reduce > GEOT_REDUCE_PROD) return fail(GEOT_EINVAL, "bad reduce code");
+  return run_typed(dtype, 0, true, nullptr, index, nullptr, src, dst, nnz, feat, 1, nnz, out_rows,
+                   workspace, workspace_bytes, stream, reduce);
 }
 
 int geot_gather_scatter(const int64_t *src_index, const int64_t *dst_index, const void *src,

@@ -78,9 +78,28 @@ def _ws_args(L, dev, nnz, feat, rows, dt):
     return ws, ws.data_ptr(), ws.numel()
 
 
-def index_scatter_out(index: torch.Tensor, src: torch.Tensor, out: torch.Tensor, sorted: bool = True) -> torch.Tensor:
-    """out[index[e], :] += src[e, :] over a contiguous [nnz, F] view; `out` is [rows, F], written in full."""
+_REDUCE_CODES = {"max": 0, "mean": 1, "min": 2, "sum": 3, "prod": 4}  # csrc/reducetype.h:3
+
+
+def index_scatter_out(index: torch.Tensor, src: torch.Tensor, out: torch.Tensor, sorted: bool = True,
+                      reduce: str = "sum") -> torch.Tensor:
+    """out[index[e], :] (+)= src[e, :] over a contiguous [nnz, F] view; `out` is [rows, F], written in full.
+    reduce: 'sum' | 'mean' | 'min' | 'max' | 'prod' (non-sum: sorted index only)."""
     dev = _require_gpu(index, src, out)
+    if reduce != "sum":
+        if not sorted:
+            raise NotImplementedError("index_scatter: unsorted index supports reduce='sum' only")
+        L = _lib.load()
+        dt = _dtype_code(src, "index_scatter_sorted")
+        nnz = index.numel()
+        feat = src.numel() // nnz if nnz else (out.numel() // max(out.shape[0], 1))
+        rows = out.shape[0]
+        with torch.cuda.device(dev):
+            ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
+            rc = L.geot_index_scatter_reduce(_index_ptr(index, "index"), src.data_ptr(), out.data_ptr(), nnz, feat,
+                                             rows, dt, _REDUCE_CODES[reduce], wsp, wsn, _stream_handle(dev))
+        _lib.check(rc, "geot_index_scatter_reduce")
+        return out
     L = _lib.load()
     dt = _dtype_code(src, "index_scatter_sorted" if sorted else "index_scatter_unsorted")
     nnz = index.numel()

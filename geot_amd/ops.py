@@ -26,9 +26,10 @@ Deliberate differences (all documented in DESIGN.md):
   every call (part of the reference contract), but the read-back overlaps the kernels (see
   ``_with_row_rule``) and the output is ``torch.empty``: the sorted kernels write every row exactly
   once, so the reference's ``torch::zeros`` pass is not needed;
-* ``reduce`` other than "sum" raises instead of being silently ignored (the reference's GPU
-  kernels always add: csrc/cuda/index_scatter_cuda.cu:68-72 dispatches on it, the kernels do not
-  use it);
+* ``reduce``: index_scatter implements sum / mean / min(amin) / max(amax) / prod with the semantics of
+  the reference's CPU path (csrc/cpu/index_scatter_cpu.cpp:124-134); the reference's GPU kernels
+  parse the argument but always add (csrc/cuda/index_scatter_cuda.cu:68-72).  The gather ops only
+  have 'sum' (as in the reference) and raise for anything else;
 * ``dim != 0`` is honoured (the reference validates ``dim`` but always reduces along dim 0,
   csrc/cuda/index_scatter_cuda.cu:9-11);
 * CPU tensors raise: this package is the MI355X path and has no CPU fallback.
@@ -153,7 +154,9 @@ def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce:
         raise RuntimeError("index must be 1 dimensional")
     if src.size(dim) != index.size(0):
         raise RuntimeError("index length must be equal to src dimension size")
-    _only_sum(reduce, "index_scatter")
+    kind = get_reduction_enum(reduce)
+    if kind != "sum" and not sorted:
+        raise NotImplementedError(f"index_scatter: reduce='{reduce}' needs sorted=True (unsorted supports 'sum')")
     moved = src if dim == 0 else src.movedim(dim, 0)
     moved = moved.contiguous()
     index = index.contiguous()
@@ -162,7 +165,7 @@ def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce:
         out_shape = list(moved.shape)
         out_shape[0] = rows
         out = torch.empty(out_shape, dtype=src.dtype, device=src.device)
-        return hip.index_scatter_out(index, moved, out, sorted=sorted)
+        return hip.index_scatter_out(index, moved, out, sorted=sorted, reduce=kind)
 
     out = _with_row_rule(index, launch)
     return out if dim == 0 else out.movedim(0, dim)

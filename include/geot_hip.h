@@ -85,6 +85,15 @@ int geot_index_scatter(const int64_t *index, const void *src, void *dst, int64_t
                        int64_t feat, int64_t out_rows, int dtype, int sorted, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* Sorted index_scatter with any reduction of the reference's CPU path
+ * (csrc/cpu/index_scatter_cpu.cpp:124-134; the reference's GPU kernels only ever add).
+ * reduce: GEOT_REDUCE_* (same order as csrc/reducetype.h:3).  mean divides by the edge count;
+ * min/max propagate NaN like ATen; rows without edges come out 0 for every reduction. */
+enum { GEOT_REDUCE_MAX = 0, GEOT_REDUCE_MEAN = 1, GEOT_REDUCE_MIN = 2, GEOT_REDUCE_SUM = 3, GEOT_REDUCE_PROD = 4 };
+int geot_index_scatter_reduce(const int64_t *index, const void *src, void *dst, int64_t nnz,
+                              int64_t feat, int64_t out_rows, int dtype, int reduce,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
 /* dst[dst_index[e], :] += src[src_index[e], :]     dst_index ascending */
 int geot_gather_scatter(const int64_t *src_index, const int64_t *dst_index, const void *src,
                         void *dst, int64_t nnz, int64_t feat, int64_t src_rows,

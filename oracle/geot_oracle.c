@@ -127,9 +127,10 @@ static inline float red_init_f32(int red) {
   }
 }
 
-/* ATen's _max/_min propagate NaN (ReduceUtils.h:108-135) */
-static inline float red_max_f32(float x, float y) { return isnan(y) ? y : (x > y ? x : y); }
-static inline float red_min_f32(float x, float y) { return isnan(y) ? y : (x < y ? x : y); }
+/* ATen's _max/_min propagate NaN (ReduceUtils.h:108-135): isnan(y) ? y : std::max(x, y), and
+ * std::max(x, y) = (x < y) ? y : x keeps an accumulator that is already NaN. */
+static inline float red_max_f32(float x, float y) { return isnan(y) ? y : (x < y ? y : x); }
+static inline float red_min_f32(float x, float y) { return isnan(y) ? y : (y < x ? y : x); }
 
 int geot_oracle_index_scatter_3pass_f32(const int64_t *index, const float *src, float *out,
                                         int64_t nnz, int64_t F, int64_t K, int red,

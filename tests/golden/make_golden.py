@@ -138,7 +138,16 @@ def reduce_cases():
     out = dict(index=index, src=src)
     for red in ("sum", "mean", "min", "max", "prod"):
         out[f"ref_{red}"] = oref.index_scatter_cpu(index, src, reduce=red)
-    return {"reductions": out}
+    # NaN propagation of min/max (ATen _min/_max): NaNs early, in the middle and at the end of segments,
+    # F = 21 so that both the vectorised body and the scalar tail of ATen's map2 are exercised
+    index2 = sorted_index(rng, 300, 25)
+    src2 = rng.standard_normal((300, 21)).astype(np.float32)
+    for pos in (0, 7, 150, 151, 298, 299):
+        src2[pos, rng.integers(0, 21, 4)] = np.nan
+    nan = dict(index=index2, src=src2)
+    for red in ("min", "max", "sum"):
+        nan[f"ref_{red}"] = oref.index_scatter_cpu(index2, src2, reduce=red)
+    return {"reductions": out, "reductions_nan": nan}
 
 
 def gather_cases():

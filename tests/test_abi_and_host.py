@@ -96,8 +96,11 @@ def test_argument_checks_carry_the_reference_texts():
         ops._index_scatter_gpu(0, idx[:5], src, "sum", True)
     with pytest.raises(RuntimeError, match="reduce argument must be either"):
         ops._index_scatter_gpu(0, idx, src, "bogus", True)
+    with pytest.raises(NotImplementedError, match="needs sorted=True"):
+        ops._index_scatter_gpu(0, idx, src, "mean", False)
     with pytest.raises(NotImplementedError, match="only 'sum'"):
-        ops._index_scatter_gpu(0, idx, src, "mean", True)
+        ops._gather_scatter_gpu  # noqa: B018  (exists)
+        ops._only_sum("mean", "gather_scatter")
     with pytest.raises(RuntimeError, match="src_index and dst_index must be 1 dimensional"):
         ops._gather_scatter_gpu(idx.view(2, 3), idx, src)
     with pytest.raises(RuntimeError, match="src must be 2 dimensional"):

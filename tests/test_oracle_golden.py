@@ -70,6 +70,12 @@ def test_reductions_match_reference_cpu_path(oracle):
         assert np.all(ours[17] == 0)                                   # empty key stays 0 for every reduce
     with pytest.raises(ValueError, match="reduce argument must be either sum, prod, mean, amax or amin, got foo"):
         oracle.index_scatter_3pass(index, src, reduce="foo")
+    # NaN propagation of min / max / sum, bit-for-bit (NaN positions included) against the compiled reference
+    g = load_golden("reductions.npz")["reductions_nan"]
+    for red in ("min", "max", "sum"):
+        ours = oracle.index_scatter_3pass(g["index"], g["src"][g["index"]], reduce=red)
+        np.testing.assert_array_equal(ours, g[f"ref_{red}"], err_msg="nan " + red)
+        assert np.isnan(ours).any()
 
 
 def test_segment_table_int64_bookkeeping(oracle):
