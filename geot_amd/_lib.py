@@ -28,7 +28,7 @@ SYMBOLS = [
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
-    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_tune",
+    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_tune", "geot_set_option",
 ]
 
 _lib = None

@@ -145,7 +145,7 @@ __host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec,
 
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // NT   : bit 0 non-temporal row loads, bit 1 non-temporal dst stores
-template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM, int U = kU>
 __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if (hh >= (int)p.H) hh = (int)p.H - 1;
   }
 
-  T v[kU][VEC];
+  T v[U][VEC];
   auto load_batch = [&](int b) {
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
+    for (int u = 0; u < U; ++u) {
       int r = gs + b + u;
       r = r < n ? r : n - 1; // padding rows re-read the last valid row; their sum is discarded
       if constexpr (GATHER) load_vec<T, VEC, NTL>(tbase + (offL[r] + fbytes), v[u]);
@@ -293,9 +293,10 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 
   for (int b = 0;;) {
     unsigned m8 = mask8L[(gs + b) >> 3];
-    if (b == 0) m8 &= 0xFEu; // the group's first edge opens its first run, it does not end one
+    if constexpr (U == 16) m8 |= (unsigned)mask8L[((gs + b) >> 3) + 1] << 8;
+    if (b == 0) m8 &= ~1u; // the group's first edge opens its first run, it does not end one
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (m8 & (1u << u)) {
         // the run of `cur` ends in front of local edge gs+b+u
         const int64_t knew = keysL[1 + gs + b + u];
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         for (int i = 0; i < VEC; ++i) acc[i] += v[u][i] * w;
       }
     }
-    b += kU;
+    b += U;
     if (b >= cg) break;
     load_batch(b);
   }
@@ -684,6 +685,7 @@ struct Tune {
   int cg = 0, vec = 0, nt = -1, lpr_log2 = -1;
 };
 Tune g_tune;
+int g_unroll = 0; // 0 = rule, 8 / 16 = forced
 
 struct Prof {
   bool on = false;
@@ -720,7 +722,7 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 struct Plan {
-  int vec, lpr_log2, cg, te;
+  int vec, lpr_log2, cg, te, unroll;
   int64_t num_tiles, nfb;
   size_t meta_off, cnt_off, carry_off, list_off, total; // ctrl block sits at offset 0
   int64_t gap_cap;
@@ -759,8 +761,10 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   if (g_tune.lpr_log2 >= 0 && g_tune.lpr_log2 <= 6 && g_tune.lpr_log2 >= l) l = g_tune.lpr_log2;
   P.lpr_log2 = l;
   const int ng = kThreads >> l;
-  // default: tiles of ~1024 edges (measured best on the graded shape: fewer tiles, short fix-up)
-  int cg = g_tune.cg > 0 ? g_tune.cg : 1024 / ng;
+  // Shape-keyed rule (the role of the reference's generated decision tree, wrapper/*_rule.h, re-measured
+  // on MI355X with `tools/kbench sweep`): streamed rows (index_scatter) like ~512-edge tiles, gathered
+  // rows ~1024; 16 row loads in flight per lane pay off only at 16 lanes per row (F in (32, 64], fp32).
+  int cg = g_tune.cg > 0 ? g_tune.cg : (gather ? 1024 : 512) / ng;
   if (cg < 16) cg = 16;
   cg = (cg + 15) / 16 * 16;
   if (cg > 256) cg = 256;
@@ -772,6 +776,8 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
     cg -= 16;
   P.cg = cg;
   P.te = ng * cg;
+  P.unroll = (!gather && !atomic_flush && tsize == 4 && vec == 4 && l == 4 && cg % 16 == 0) ? 16 : 8;
+  if (g_unroll == 8 || (g_unroll == 16 && cg % 16 == 0 && tsize == 4 && vec == 4)) P.unroll = g_unroll;
   P.num_tiles = nnz > 0 ? (nnz + P.te - 1) / P.te : 0;
   const int64_t fb = ((int64_t)1 << l) * vec;
   P.nfb = (F + fb - 1) / fb;
@@ -830,6 +836,14 @@ void dispatch_nt(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
 template <typename T, bool GATHER, int WMODE, bool ATOMIC>
 int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
   constexpr int MAXV = 16 / (int)sizeof(T);
+  if constexpr (!GATHER && WMODE == 0 && !ATOMIC && sizeof(T) == 4) {
+    if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 3) {   // 16 row loads in flight per lane
+      const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
+      dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED_SUM, 16>), grid, dim3(kThreads), L.bytes, st, p);
+      return GEOT_OK;
+    }
+  }
   if (P.vec == MAXV) dispatch_nt<T, MAXV, GATHER, WMODE, ATOMIC>(p, P, st, nt);
   else if (MAXV >= 4 && P.vec == 2) dispatch_nt<T, 2, GATHER, WMODE, ATOMIC>(p, P, st, nt);
   else if (P.vec == 1) dispatch_nt<T, 1, GATHER, WMODE, ATOMIC>(p, P, st, nt);
@@ -1194,6 +1208,10 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
   if (aux_ms) *aux_ms = g_prof.aux_ms;
   if (calls) *calls = g_prof.calls;
   return GEOT_OK;
+}
+
+void geot_set_option(const char *name, int value) {
+  if (name && std::string(name) == "unroll") g_unroll = value;
 }
 
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {

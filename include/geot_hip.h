@@ -155,6 +155,8 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
  * width in elements (0 = auto), non-temporal policy (-1 = auto; bit 0 = row loads, bit 1 = dst
  * stores), lanes per row log2 (-1 = auto). */
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
+/* named experiment switches: "unroll" = 8 | 16 row loads in flight per lane (fp32 index_scatter) */
+void geot_set_option(const char *name, int value);
 
 #ifdef __cplusplus
 }

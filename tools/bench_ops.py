@@ -57,6 +57,15 @@ def main():
     out = torch.empty(nodes, F, device=dev)
     uniq = torch.unique(si).numel()
     comp = nnz * 20 + uniq * 4 * F + nodes * 4 * F
+    for cg in (32, 64, 128, 256):
+        hip.tune(edges_per_group=cg)
+        tt = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
+        print(f"   gws tile sweep: edges_per_group={cg}: {tt:.3f} ms")
+    for nt in (0, 1, 2, 3):
+        hip.tune(nontemporal=nt)
+        tt = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
+        print(f"   gws nt policy {nt}: {tt:.3f} ms")
+    hip.tune()
     t = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), args.iters)
     print(f"cfg3 gws   nodes={nodes} nnz={nnz} F={F}: {t:.3f} ms  {nnz / t / 1e6:.2f} Gedge/s  "
           f"compulsory {comp / 1e9:.2f} GB -> {comp / t / 1e9:.2f} TB/s ({comp / t / 1e9 / 8 * 100:.1f}% of 8 TB/s)")
