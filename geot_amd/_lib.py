@@ -18,7 +18,7 @@ SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 
 GEOT_OK = 0
-GEOT_F32, GEOT_F64 = 0, 1
+GEOT_F32, GEOT_F64, GEOT_F16, GEOT_BF16 = 0, 1, 2, 3
 GEOT_W_EDGE_MAJOR, GEOT_W_HEAD_MAJOR = 0, 1
 ABI_VERSION = 1
 

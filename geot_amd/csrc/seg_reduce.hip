@@ -61,30 +61,42 @@ struct SegParams {
   int cg;                   // edges per lane-group sub-chunk (multiple of 16)
 };
 
+// Storage types: float, double, and the 16-bit types with fp32 accumulation (the reference's CPU path
+// accumulates half/bfloat16 in an fp32 buffer and converts once at the end,
+// csrc/cpu/index_scatter_cpu.cpp:78-86,114-116).
+typedef _Float16 half_t;
+typedef __bf16 bf16_t;
+template <typename T> struct AccOf { typedef T type; };
+template <> struct AccOf<half_t> { typedef float type; };
+template <> struct AccOf<bf16_t> { typedef float type; };
+
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
 template <typename T> struct VecOf<T, 1> { typedef T type; };
 
+// load VEC storage elements (one 16-B access at full width), widen to the accumulator type
 template <typename T, int VEC, bool NT>
-__device__ __forceinline__ void load_vec(const void *p, T (&v)[VEC]) {
+__device__ __forceinline__ void load_vec(const void *p, typename AccOf<T>::type (&v)[VEC]) {
   using V = typename VecOf<T, VEC>::type;
+  using A = typename AccOf<T>::type;
   V x;
   if constexpr (NT) x = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
   else x = *reinterpret_cast<const V *>(p);
-  if constexpr (VEC == 1) v[0] = x;
+  if constexpr (VEC == 1) v[0] = (A)x;
   else {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = x[i];
+    for (int i = 0; i < VEC; ++i) v[i] = (A)x[i];
   }
 }
 
+// narrow to the storage type (one rounding, at the very end) and store
 template <typename T, int VEC, bool NT = false>
-__device__ __forceinline__ void store_vec(T *p, const T (&v)[VEC]) {
+__device__ __forceinline__ void store_vec(T *p, const typename AccOf<T>::type (&v)[VEC]) {
   using V = typename VecOf<T, VEC>::type;
   V x;
-  if constexpr (VEC == 1) x = v[0];
+  if constexpr (VEC == 1) x = (T)v[0];
   else {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) x[i] = v[i];
+    for (int i = 0; i < VEC; ++i) x[i] = (T)v[i];
   }
   if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
   else *reinterpret_cast<V *>(p) = x;
@@ -148,12 +160,13 @@ __host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec,
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM, int U = kU>
 __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using A = typename AccOf<T>::type; // accumulator / LDS / carry type
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
   const int lpr = 1 << p.lpr_log2;
   const int ng = kThreads >> p.lpr_log2;
   const int cg = p.cg;
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
-  const SmemLayout L = smem_layout(p.lpr_log2, cg, VEC, (int)sizeof(T), GATHER, hw);
+  const SmemLayout L = smem_layout(p.lpr_log2, cg, VEC, (int)sizeof(A), GATHER, hw);
   const int te = L.te;
   const int FB = lpr * VEC;
 
@@ -162,8 +175,8 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   int64_t *pkL = reinterpret_cast<int64_t *>(smem + L.off_pk);
   unsigned long long *maskL = reinterpret_cast<unsigned long long *>(smem + L.off_mask);
   const unsigned char *mask8L = smem + L.off_mask;
-  T *pL = reinterpret_cast<T *>(smem + L.off_p);
-  T *wL = reinterpret_cast<T *>(smem + L.off_w);
+  A *pL = reinterpret_cast<A *>(smem + L.off_p);
+  A *wL = reinterpret_cast<A *>(smem + L.off_w);
   int *pvL = reinterpret_cast<int *>(smem + L.off_pv);
   int *cntL = reinterpret_cast<int *>(smem + L.off_cnt);
   constexpr bool MEAN = RED == RED_MEAN;
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if (hh >= (int)p.H) hh = (int)p.H - 1;
   }
 
-  T v[U][VEC];
+  A v[U][VEC];
   auto load_batch = [&](int b) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -226,16 +239,16 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       if ((uint64_t)row >= (uint64_t)p.src_rows) row = 0; // out-of-range gather index: memory-safe
       offL[i] = row * (int64_t)rb;
     }
-    if constexpr (WMODE == 1) wL[i] = ge < p.nnz ? weight[ge] : T(0);
+    if constexpr (WMODE == 1) wL[i] = ge < p.nnz ? (A)weight[ge] : A(0);
   }
   if constexpr (WMODE == 2) {
     const int64_t base = ts * p.H, lim = p.nnz * p.H;
-    for (int j = tid; j < te * hw; j += kThreads) wL[j] = base + j < lim ? weight[base + j] : T(0);
+    for (int j = tid; j < te * hw; j += kThreads) wL[j] = base + j < lim ? (A)weight[base + j] : A(0);
   }
   if constexpr (WMODE == 3) {
     for (int j = tid; j < te * hw; j += kThreads) {
       const int h = j / te, i = j - h * te;
-      wL[i * hw + h] = ts + i < p.nnz ? weight[(int64_t)h * p.nnz + ts + i] : T(0);
+      wL[i * hw + h] = ts + i < p.nnz ? (A)weight[(int64_t)h * p.nnz + ts + i] : A(0);
     }
   }
   if (tid == 0) keysL[te + 1] = ts + te < p.nnz ? p.dst_index[ts + te] : kNoKey;
@@ -262,9 +275,9 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     const int64_t cnt = hi - lo;
     if (cnt <= kGapInline) {
       if (active) {
-        T z[VEC];
+        A z[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) z[i] = T(0);
+        for (int i = 0; i < VEC; ++i) z[i] = A(0);
         for (int64_t r = lo; r < hi; ++r) store_vec<T, VEC, NTS>(dstf + r * F, z);
       }
     } else if (c == 0 && blockIdx.y == 0) {
@@ -276,9 +289,9 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
   };
 
-  T acc[VEC];
+  A acc[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] = red_ident<T, RED>();
+  for (int i = 0; i < VEC; ++i) acc[i] = red_ident<A, RED>();
   int64_t cur = keysL[1 + gs];
   bool first = true;
   int cnt = 0; // edges in the current run (mean)
@@ -301,13 +314,15 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         // the run of `cur` ends in front of local edge gs+b+u
         const int64_t knew = keysL[1 + gs + b + u];
         if constexpr (ATOMIC) {
-          if (active && (uint64_t)cur < (uint64_t)K) {
+          if constexpr (sizeof(T) >= 4) { // float atomics exist for fp32 / fp64 only
+            if (active && (uint64_t)cur < (uint64_t)K) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+              for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+            }
           }
         } else {
           if (first) {
-            store_vec<T, VEC>(pL + (size_t)(2 * g) * FB + c * VEC, acc);
+            store_vec<A, VEC>(pL + (size_t)(2 * g) * FB + c * VEC, acc);
             if (c == 0) {
               pkL[2 * g] = cur;
               if constexpr (MEAN) cntL[2 * g] = cnt;
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
           } else if (active && (uint64_t)cur < (uint64_t)K) {
             if constexpr (MEAN) {
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) acc[i] = acc[i] / T(cnt);
+              for (int i = 0; i < VEC; ++i) acc[i] = acc[i] / A(cnt);
             }
             store_vec<T, VEC, NTS>(dstf + cur * F, acc);
           }
@@ -325,14 +340,14 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         cur = knew;
         cnt = 0;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = red_ident<T, RED>();
+        for (int i = 0; i < VEC; ++i) acc[i] = red_ident<A, RED>();
       }
       if constexpr (MEAN) ++cnt;
       if constexpr (WMODE == 0) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = red_op<T, RED>(acc[i], v[u][i]);
+        for (int i = 0; i < VEC; ++i) acc[i] = red_op<A, RED>(acc[i], v[u][i]);
       } else {
-        const T w = WMODE == 1 ? wL[gs + b + u] : wL[(gs + b + u) * hw + hh];
+        const A w = WMODE == 1 ? wL[gs + b + u] : wL[(gs + b + u) * hw + hh];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] += v[u][i] * w;
       }
@@ -344,14 +359,16 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 
   // the group's last run
   if constexpr (ATOMIC) {
-    if (active && (uint64_t)cur < (uint64_t)K) {
+    if constexpr (sizeof(T) >= 4) {
+      if (active && (uint64_t)cur < (uint64_t)K) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+        for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+      }
     }
     return;
   } else {
     const int slot = 2 * g + (first ? 0 : 1);
-    store_vec<T, VEC>(pL + (size_t)slot * FB + c * VEC, acc);
+    store_vec<A, VEC>(pL + (size_t)slot * FB + c * VEC, acc);
     if (c == 0) {
       pkL[slot] = cur;
       pvL[slot] = 1;
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       leader = pkL[pi] != k;
     }
     if (!leader) continue;
-    T sum[VEC];
+    A sum[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sum[q] = pL[(size_t)i * FB + c * VEC + q];
     bool at_end = true; // the merged run reaches the last edge of the tile
@@ -383,24 +400,24 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       if (pkL[j] != k) { at_end = false; break; }
       if constexpr (MEAN) csum += cntL[j];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) sum[q] = red_op<T, RED>(sum[q], pL[(size_t)j * FB + c * VEC + q]);
+      for (int q = 0; q < VEC; ++q) sum[q] = red_op<A, RED>(sum[q], pL[(size_t)j * FB + c * VEC + q]);
     }
     const int cslot_id = (i == 0 && k == kprev_tile) ? 0 : ((at_end && k == knext_tile) ? 1 : -1);
     if constexpr (MEAN) {
       if (cslot_id >= 0 && c == 0 && blockIdx.y == 0) p.ccnt[tile * 2 + cslot_id] = csum;
     }
     if (!active) continue;
-    T *cslot = static_cast<T *>(p.carry) + (tile * 2) * F + f0;
+    A *cslot = static_cast<A *>(p.carry) + (tile * 2) * F + f0;
     if (cslot_id == 0) {
       // continues a run that started in an earlier tile: slot 0, added by seg_fixup_kernel
-      store_vec<T, VEC>(cslot, sum);
+      store_vec<A, VEC>(cslot, sum);
     } else if (cslot_id == 1) {
       // starts here and continues into the next tile: slot 1; seg_fixup_kernel writes the row
-      store_vec<T, VEC>(cslot + F, sum);
+      store_vec<A, VEC>(cslot + F, sum);
     } else if ((uint64_t)k < (uint64_t)K) {
       if constexpr (MEAN) {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) sum[q] = sum[q] / T(csum);
+        for (int q = 0; q < VEC; ++q) sum[q] = sum[q] / A(csum);
       }
       store_vec<T, VEC, NTS>(dstf + k * F, sum);
     }
@@ -456,13 +473,14 @@ __global__ __launch_bounds__(kThreads) void seg_lds_bin_kernel(const int64_t *__
 template <typename T, int RED = RED_SUM>
 __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_t num_tiles) {
   constexpr bool MEAN = RED == RED_MEAN;
+  using A = typename AccOf<T>::type;
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << p.lpr_log2;
   const int R = 64 >> p.lpr_log2; // lane groups per wave
   const int gq = lane >> p.lpr_log2;
   const int c = lane & (lpr - 1);
   T *dst = static_cast<T *>(p.dst);
-  const T *carry = static_cast<const T *>(p.carry);
+  const A *carry = static_cast<const A *>(p.carry);
   const int64_t F = p.F;
   __shared__ unsigned long long s_ngap;
   if (threadIdx.x == 0) s_ngap = p.ctrl[0];
@@ -474,29 +492,29 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
   const int64_t tc = valid ? t : 1 < num_tiles ? 1 : 0; // clamped for the speculative loads
   const int64_t m = valid ? p.meta[tc] : 0;
   const int64_t mp = valid ? p.meta[tc - 1] : 2;
-  T cv[J];
+  A cv[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int64_t f = (int64_t)j * lpr + c;
-    cv[j] = (valid && f < F) ? red_op<T, RED>(carry[((tc - 1) * 2 + 1) * F + f], carry[(tc * 2) * F + f]) : T(0);
+    cv[j] = (valid && f < F) ? red_op<A, RED>(carry[((tc - 1) * 2 + 1) * F + f], carry[(tc * 2) * F + f]) : A(0);
   }
   const bool first = valid && (m & 1) && !(mp & 2);
   const int64_t k = m >> 2;
   if (first && !(m & 2)) {
-    T inv_div = T(1);
-    if constexpr (MEAN) inv_div = T(p.ccnt[(t - 1) * 2 + 1] + p.ccnt[t * 2]);
+    A inv_div = A(1);
+    if constexpr (MEAN) inv_div = A(p.ccnt[(t - 1) * 2 + 1] + p.ccnt[t * 2]);
     for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
       if (fb > 0) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int64_t f = fb + (int64_t)j * lpr + c;
-          cv[j] = f < F ? red_op<T, RED>(carry[((t - 1) * 2 + 1) * F + f], carry[(t * 2) * F + f]) : T(0);
+          cv[j] = f < F ? red_op<A, RED>(carry[((t - 1) * 2 + 1) * F + f], carry[(t * 2) * F + f]) : A(0);
         }
       }
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int64_t f = fb + (int64_t)j * lpr + c;
-        if (f < F) dst[k * F + f] = MEAN ? cv[j] / inv_div : cv[j];
+        if (f < F) dst[k * F + f] = (T)(MEAN ? cv[j] / inv_div : cv[j]);
       }
     }
   }
@@ -509,12 +527,12 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
     const int64_t th = __shfl(t, src_lane, 64);
     const int64_t kh = __shfl(k, src_lane, 64);
     for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
-      T hv[J];
+      A hv[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int64_t f = fb + (int64_t)j * lpr + c;
-        hv[j] = (gq == 0 && f < F) ? red_op<T, RED>(carry[((th - 1) * 2 + 1) * F + f], carry[(th * 2) * F + f])
-                                   : red_ident<T, RED>();
+        hv[j] = (gq == 0 && f < F) ? red_op<A, RED>(carry[((th - 1) * 2 + 1) * F + f], carry[(th * 2) * F + f])
+                                   : red_ident<A, RED>();
       }
       int64_t hcnt = 0; // mean: edges of the whole chain (every lane computes the same value)
       if constexpr (MEAN) hcnt = p.ccnt[(th - 1) * 2 + 1] + p.ccnt[th * 2];
@@ -527,20 +545,20 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
         const int nn = ~S ? __builtin_ctzll(~S) : 64; // tiles wb+1 .. wb+nn join the chain
         const int64_t hi = wb + nn;
         for (int64_t i = wb + 1 + gq; i <= hi; i += (int64_t)R * 4) {
-          T cr[4][J];
+          A cr[4][J];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int64_t tt = i + (int64_t)q * R;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
               const int64_t f = fb + (int64_t)j * lpr + c;
-              cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : red_ident<T, RED>();
+              cr[q][j] = (tt <= hi && f < F) ? carry[(tt * 2) * F + f] : red_ident<A, RED>();
             }
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < J; ++j) hv[j] = red_op<T, RED>(hv[j], cr[q][j]);
+            for (int j = 0; j < J; ++j) hv[j] = red_op<A, RED>(hv[j], cr[q][j]);
         }
         if constexpr (MEAN) {
           for (int64_t tt = wb + 1; tt <= hi; ++tt) hcnt += p.ccnt[tt * 2];
@@ -550,13 +568,13 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
       }
       for (int off = lpr; off < 64; off <<= 1) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) hv[j] = red_op<T, RED>(hv[j], __shfl_xor(hv[j], off, 64));
+        for (int j = 0; j < J; ++j) hv[j] = red_op<A, RED>(hv[j], __shfl_xor(hv[j], off, 64));
       }
       if (gq == 0) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
           const int64_t f = fb + (int64_t)j * lpr + c;
-          if (f < F) dst[kh * F + f] = MEAN ? hv[j] / T(hcnt) : hv[j];
+          if (f < F) dst[kh * F + f] = (T)(MEAN ? hv[j] / A(hcnt) : hv[j]);
         }
       }
     }
@@ -597,12 +615,13 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
   const int g = threadIdx.x >> lpr_log2;
   const int c = threadIdx.x & (lpr - 1);
   for (int64_t e = (int64_t)blockIdx.x * ng + g; e < nnz; e += (int64_t)gridDim.x * ng) {
+    using A = typename AccOf<T>::type;
     const int64_t r1 = dst_index[e], r2 = src_index[e];
-    T s = T(0);
+    A s = A(0);
     if ((uint64_t)r1 < (uint64_t)rows1 && (uint64_t)r2 < (uint64_t)rows2) {
       const T *a = m1 + r1 * F, *b = m2 + r2 * F;
       for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
-        T x[VEC], y[VEC];
+        A x[VEC], y[VEC];
         load_vec<T, VEC, false>(a + f, x);
         load_vec<T, VEC, false>(b + f, y);
 #pragma unroll
@@ -610,7 +629,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
       }
     }
     for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (c == 0) out[e] = s;
+    if (c == 0) out[e] = (T)s;
   }
 }
 
@@ -626,11 +645,11 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const int64_t *in
     const int64_t r = index[e];
     const bool ok = (uint64_t)r < (uint64_t)src_rows;
     for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
-      T x[VEC];
+      typename AccOf<T>::type x[VEC];
       if (ok) load_vec<T, VEC, false>(src + r * F + f, x);
       else {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) x[i] = T(0);
+        for (int i = 0; i < VEC; ++i) x[i] = 0;
       }
       store_vec<T, VEC>(dst + e * F + f, x);
     }
@@ -741,7 +760,8 @@ inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 // vec_unit: the feature granule that must stay inside one vector (F, or F per head for mh_spmm)
 // hw: weights staged in LDS per edge (0, 1 or H); gather: src offsets staged in LDS
 Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, bool aligned16,
-               bool gather, int hw, bool atomic_flush = false) {
+               bool gather, int hw, bool atomic_flush = false, int asize = 0) {
+  if (asize == 0) asize = tsize < 4 ? 4 : tsize; // accumulator size: fp32 for the 16-bit storage types
   Plan P;
   const int maxvec = 16 / tsize; // 16 B per lane
   int vec = 1;
@@ -771,7 +791,7 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   // bound the tile: <= 2048 edges (4096 when the rows are so narrow that 256 groups x 16 edges is
   // the smallest legal tile), <= ~64 KB of LDS, and 32-bit byte offsets inside a tile
   while (cg > 16 && ((int64_t)ng * cg > 2048 ||
-                     smem_layout(l, cg, vec, tsize, gather, hw).bytes > 64 * 1024 ||
+                     smem_layout(l, cg, vec, asize, gather, hw).bytes > 64 * 1024 ||
                      (int64_t)ng * cg * F * tsize >= ((int64_t)1 << 31)))
     cg -= 16;
   P.cg = cg;
@@ -786,7 +806,7 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   P.meta_off = kCtrlBytes;
   P.cnt_off = P.meta_off + up256(nt * sizeof(int64_t));
   P.carry_off = P.cnt_off + up256(nt * 2 * sizeof(int64_t));
-  P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * tsize);
+  P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * asize);
   P.gap_cap = K / kGapInline + 2;
   P.total = P.list_off + up256((size_t)P.gap_cap * 16);
   return P;
@@ -795,7 +815,7 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
 void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
-  const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(T), GATHER, hw);
+  const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(typename AccOf<T>::type), GATHER, hw);
   dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
   hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads),
                      L.bytes, st, p);
@@ -917,6 +937,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   if (nnz > 0) {
     if (!sorted) {
       if (mode != 0) return fail(GEOT_EUNSUPPORTED, "unsorted is index_scatter only");
+      if constexpr (sizeof(T) < 4) return fail(GEOT_EUNSUPPORTED, "unsorted index needs float32/float64 (float atomics)");
       const size_t tab_bytes = (size_t)K * (size_t)F * sizeof(T);
       if (tab_bytes <= 48 * 1024 && g_tune.lpr_log2 != 7) {   // (lpr_log2 = 7: test knob, forces the direct path)
         int l = ceil_log2(F);
@@ -924,10 +945,12 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
         int64_t blocks = (nnz + 4095) / 4096;                  // >= 4096 edges per block, <= 4 blocks per CU
         if (blocks > 1024) blocks = 1024;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL((seg_lds_bin_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), tab_bytes, st,
-                           dst_index, static_cast<const T *>(src), static_cast<T *>(dst), nnz, F, K, l);
-      } else
-      rc = dispatch_vec<T, false, 0, true>(p, P, st, nt);
+        if constexpr (sizeof(T) >= 4)
+          hipLaunchKernelGGL((seg_lds_bin_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), tab_bytes, st,
+                             dst_index, static_cast<const T *>(src), static_cast<T *>(dst), nnz, F, K, l);
+      } else if constexpr (sizeof(T) >= 4) {
+        rc = dispatch_vec<T, false, 0, true>(p, P, st, nt);
+      }
     } else {
       switch (mode) {
       case 0:
@@ -975,7 +998,11 @@ int run_typed(int dtype, int mode, bool sorted, const int64_t *si, const int64_t
     return run_segment_op<float>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
   if (dtype == GEOT_F64)
     return run_segment_op<double>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
-  return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+  if (dtype == GEOT_F16)
+    return run_segment_op<half_t>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
+  if (dtype == GEOT_BF16)
+    return run_segment_op<bf16_t>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
+  return fail(GEOT_EINVAL, "dtype must be GEOT_F32, GEOT_F64, GEOT_F16 or GEOT_BF16");
 }
 
 template <typename T> int pick_row_vec(int64_t F, const void *a, const void *b) {
@@ -1048,7 +1075,7 @@ const char *geot_last_error(void) { return g_err.c_str(); }
 const char *geot_build_info(void) { return "libgeot_hip gfx950 (CDNA4) built " __DATE__ " " __TIME__; }
 
 size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype) {
-  const int tsize = dtype == GEOT_F64 ? 8 : 4;
+  const int tsize = dtype == GEOT_F64 ? 8 : 4; // accumulator size (fp32 for the 16-bit types)
   if (nnz < 0) nnz = 0;
   if (feat < 1) feat = 1;
   if (out_rows < 0) out_rows = 0;
@@ -1115,7 +1142,9 @@ int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const voi
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == GEOT_F32) return run_sddmm<float>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
   if (dtype == GEOT_F64) return run_sddmm<double>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
-  return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+  if (dtype == GEOT_F16) return run_sddmm<half_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
+  if (dtype == GEOT_BF16) return run_sddmm<bf16_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
+  return fail(GEOT_EINVAL, "bad dtype");
 }
 
 int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
@@ -1123,7 +1152,9 @@ int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t n
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == GEOT_F32) return run_gather_rows<float>(index, src, dst, nnz, feat, src_rows, st);
   if (dtype == GEOT_F64) return run_gather_rows<double>(index, src, dst, nnz, feat, src_rows, st);
-  return fail(GEOT_EINVAL, "dtype must be GEOT_F32 or GEOT_F64");
+  if (dtype == GEOT_F16) return run_gather_rows<half_t>(index, src, dst, nnz, feat, src_rows, st);
+  if (dtype == GEOT_BF16) return run_gather_rows<bf16_t>(index, src, dst, nnz, feat, src_rows, st);
+  return fail(GEOT_EINVAL, "bad dtype");
 }
 
 size_t geot_csr_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype) {

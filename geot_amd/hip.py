@@ -15,7 +15,8 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: _lib.GEOT_F32, torch.float64: _lib.GEOT_F64}
+_DT = {torch.float32: _lib.GEOT_F32, torch.float64: _lib.GEOT_F64,
+       torch.float16: _lib.GEOT_F16, torch.bfloat16: _lib.GEOT_BF16}  # 16-bit: fp32 accumulation
 
 # one workspace per (device, stream): the C ABI allows reuse by one stream at a time
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}

@@ -61,7 +61,9 @@ enum {
   GEOT_EUNSUPPORTED = -4
 };
 
-enum { GEOT_F32 = 0, GEOT_F64 = 1 };
+/* GEOT_F16 / GEOT_BF16: 16-bit storage, fp32 accumulation, one rounding at the end (what the reference's
+ * CPU path does, csrc/cpu/index_scatter_cpu.cpp:78-86); sorted calls only (no 16-bit float atomics). */
+enum { GEOT_F32 = 0, GEOT_F64 = 1, GEOT_F16 = 2, GEOT_BF16 = 3 };
 
 /* weight layouts of geot_mh_spmm (csrc/cuda/wrapper/mh_spmm_base.h:38-49) */
 enum { GEOT_W_EDGE_MAJOR = 0 /* [nnz, H] */, GEOT_W_HEAD_MAJOR = 1 /* [H, nnz] */ };

@@ -61,8 +61,11 @@ def index_scatter_cpu(index, src, reduce: str = "sum", sorted: bool = True, omp:
     """The reference's index_scatter_cpu on (index, src) exactly as shipped."""
     index = np.ascontiguousarray(index, dtype=np.int64)
     src = np.ascontiguousarray(src)
-    if src.dtype not in (np.float32, np.float64):
-        raise TypeError("float32/float64 only")
+    # bfloat16 travels as raw uint16 bit patterns (numpy has no bf16): pass dtype_code=3 explicitly
+    code = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.float16): 2,
+            np.dtype(np.uint16): 3}.get(src.dtype)
+    if code is None:
+        raise TypeError("float32 / float64 / float16 / uint16(=bfloat16 bits) only")
     nnz = index.shape[0]
     F = int(np.prod(src.shape[1:], dtype=np.int64)) if src.ndim > 1 else 1
     K = int(index[-1]) + 1 if rows is None else int(rows)
@@ -73,7 +76,7 @@ def index_scatter_cpu(index, src, reduce: str = "sum", sorted: bool = True, omp:
     rc = L.geot_ref_index_scatter_cpu(
         index.ctypes.data_as(ctypes.c_void_p), src.ctypes.data_as(ctypes.c_void_p),
         out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(nnz), ctypes.c_int64(F),
-        ctypes.c_int64(K), ctypes.c_int(0 if src.dtype == np.float32 else 1),
+        ctypes.c_int64(K), ctypes.c_int(code),
         reduce.encode(), ctypes.c_int(1 if sorted else 0))
     if rc != 0:
         raise RuntimeError(L.geot_ref_last_error().decode())

@@ -29,14 +29,15 @@ void geot_ref_set_num_threads(int n) {
   if (n > 0) at::set_num_threads(n);
 }
 
-// dtype: 0 = float32, 1 = float64.  out must hold K*F elements; it is zero-filled here
+// dtype: 0 = float32, 1 = float64, 2 = float16, 3 = bfloat16 (the set the reference's CPU path
+// dispatches, csrc/cpu/index_scatter_cpu.cpp:127-133).  out must hold K*F elements; it is zero-filled here
 // exactly as torch::zeros does in csrc/index_scatter.cpp:21.
 int geot_ref_index_scatter_cpu(const int64_t *index, const void *src, void *out, int64_t nnz,
                                int64_t F, int64_t K, int dtype, const char *reduce,
                                int sorted) {
   try {
-    auto st = dtype == 0 ? at::kFloat : at::kDouble;
-    auto esz = dtype == 0 ? sizeof(float) : sizeof(double);
+    auto st = dtype == 0 ? at::kFloat : dtype == 1 ? at::kDouble : dtype == 2 ? at::kHalf : at::kBFloat16;
+    size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : 2;
     auto opts = at::TensorOptions().dtype(st).device(at::kCPU);
     at::Tensor idx = at::from_blob(const_cast<int64_t *>(index), {nnz},
                                    at::TensorOptions().dtype(at::kLong));

@@ -114,6 +114,15 @@ def index_scatter_cases():
     # mixed-sign data (cancellation), normal distribution
     add("signed", sorted_index(rng, 800, 50), rng.standard_normal((800, 16)).astype(np.float32))
 
+    # 16-bit storage types of the reference CPU path (fp32 accumulate, one rounding at the end);
+    # bfloat16 is stored as raw uint16 bit patterns
+    idx16 = sorted_index(rng, 700, 60)
+    s16 = rng.standard_normal((700, 24)).astype(np.float32)
+    h = s16.astype(np.float16)
+    cases["f16"] = dict(index=idx16, src=h, rows=np.int64(60), ref_out=oref.index_scatter_cpu(idx16, h))
+    b = torch.from_numpy(s16).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    cases["bf16_bits"] = dict(index=idx16, src=b, rows=np.int64(60), ref_out=oref.index_scatter_cpu(idx16, b))
+
     # cfg1 (BASELINE.json configs[0]): 100k x 32 -> 10k segments; inputs regenerated from the seed
     rng1 = np.random.default_rng(0)
     index = sorted_index(rng1, 100_000, 10_000)
