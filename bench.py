@@ -203,7 +203,7 @@ def main():
             "hbm_gbps_whole_call": world * alg * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "seg_tile_kernel<float,4,false,0,false,3>", "kernel_ms": main_ms,
+                         "kernel": "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>", "kernel_ms": main_ms,
                          "fixup_kernel_ms": fix_ms, "algorithmic_bytes_per_launch": alg,
                          "frac_tile_plus_fixup": alg / ((main_ms + fix_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         }

@@ -139,6 +139,37 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     return local, first_row
 
 
+def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch.Tensor,
+                           src: torch.Tensor, weight_shard: Optional[torch.Tensor] = None,
+                           group: Optional[dist.ProcessGroup] = None,
+                           local_op: Optional[Callable] = None, exchange: bool = True,
+                           key_offset: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """Row-sharded gather_scatter / gather_weight_scatter (BASELINE.json configs[4]).
+
+    The edge list (src_index, dst_index[, weight]) is sharded by contiguous dst-sorted edge ranges
+    exactly like :func:`sharded_index_scatter`; ``src`` (node features) is REPLICATED on every rank
+    (56.9 GB per GPU at papers100M scale fits 288 GB).  Same boundary-row
+    exchange, same return value.  ``local_op(src_index, dst_index_local, weight, src, rows)``
+    defaults to the HIP operators.
+    """
+    if local_op is None:
+        from . import hip
+
+        def local_op(si, di, w, x, rows):
+            out = torch.empty((rows, x.shape[1]), dtype=x.dtype, device=x.device)
+            if w is None:
+                return hip.gather_scatter_out(si.contiguous(), di, x, out)
+            return hip.gather_weight_scatter_out(si.contiguous(), di, w.contiguous(), x, out)
+
+    def as_index_scatter(index_local, _unused, rows):
+        return local_op(src_index_shard, index_local, weight_shard, src, rows)
+
+    # the per-edge operand is only used for its feature shape: hand over one row of src
+    proto = src[:1].expand(dst_index_shard.numel(), *src.shape[1:])
+    return sharded_index_scatter(dst_index_shard, proto, group=group, local_op=as_index_scatter,
+                                 exchange=exchange, key_offset=key_offset)
+
+
 def shard_edges(index: torch.Tensor, src: torch.Tensor, world: int, rank: int, aligned: bool = False):
     """Slice a replicated (index, src) pair for ``rank`` (helper for tests and examples)."""
     cuts = segment_aligned_cuts(index, world) if aligned else equal_edge_cuts(index.numel(), world)

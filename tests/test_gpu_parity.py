@@ -422,6 +422,40 @@ def test_16bit_storage_fp32_accumulate(geot, oracle, dtype):
         geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=False)
 
 
+def test_calls_are_hipgraph_capturable(geot, oracle):
+    """The C-ABI calls do no allocation, no host sync and no per-call memset: capture once, replay."""
+    from geot_amd import hip
+    rng = np.random.default_rng(8)
+    index_h = powerlaw_index(200_000, 15_000, 6)
+    index = dev(index_h)
+    src = torch.rand(200_000, 64, device="cuda")
+    out = torch.empty(15_000, 64, device="cuda")
+    si = dev(rng.integers(0, 15_000, 200_000).astype(np.int64))
+    w = torch.rand(200_000, device="cuda")
+    x = torch.rand(15_000, 64, device="cuda")
+    out2 = torch.empty(15_000, 64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hip.index_scatter_out(index, src, out)                       # warm-up on the capture stream (workspace)
+        hip.gather_weight_scatter_out(si, index, w, x, out2)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            hip.index_scatter_out(index, src, out)
+            hip.gather_weight_scatter_out(si, index, w, x, out2)
+    for rep in range(3):
+        src.uniform_()                                               # new inputs, same addresses
+        x.uniform_()
+        out.fill_(float("nan"))
+        out2.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = torch.zeros_like(out).index_add_(0, index, src)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-4)
+        ref2 = torch.zeros_like(out2).index_add_(0, index, x[si] * w[:, None])
+        assert torch.allclose(out2, ref2, rtol=1e-5, atol=1e-4)
+
+
 def test_out_rows_larger_than_last_key(geot):
     """C ABI: out_rows may exceed index[-1]+1; the extra rows are zero-filled (small and large tails)."""
     from geot_amd import hip

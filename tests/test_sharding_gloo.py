@@ -95,6 +95,51 @@ def test_segment_aligned_cuts_need_no_exchange(name):
     np.testing.assert_array_equal(got, api.index_scatter(case["index"], case["src"]))   # bit-exact: no re-association
 
 
+def _gather_worker(rank, world, port, case, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geot_amd import sharding
+        from oracle import api
+
+        def local_op(si, di, w, x, rows):
+            return torch.from_numpy(api.gather_weight_scatter(si.numpy(), di.numpy(), None if w is None else w.numpy(),
+                                                              x.numpy(), rows=rows))
+        cuts = sharding.equal_edge_cuts(len(case["dst"]), world)
+        sl = slice(cuts[rank], cuts[rank + 1])
+        t = torch.from_numpy
+        out, first = sharding.sharded_gather_scatter(t(case["si"][sl]), t(case["dst"][sl]), t(case["x"]),
+                                                     weight_shard=t(case["w"][sl]), local_op=local_op)
+        q.put((rank, first, out.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gather_weight_scatter_replicated_src():
+    from oracle import api
+    rng = np.random.default_rng(9)
+    nodes, nnz, F = 200, 6000, 8
+    case = dict(dst=powerlaw_index(nnz, nodes, 2), si=rng.integers(0, nodes, nnz).astype(np.int64),
+                w=rng.random(nnz, dtype=np.float32), x=rng.random((nodes, F), dtype=np.float32))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, case, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(3)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = np.concatenate([o for _, _, o in res])
+    full = api.gather_weight_scatter(case["si"], case["dst"], case["w"], case["x"], acc64=True)
+    assert got.shape == full.shape and res[0][1] == 0
+    np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)
+
+
 def test_cut_helpers():
     from geot_amd import sharding
     assert sharding.equal_edge_cuts(10, 4) == [0, 2, 5, 7, 10]
