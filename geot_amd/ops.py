@@ -482,3 +482,45 @@ def coo_to_csr(coo_row: torch.Tensor) -> torch.Tensor:
 def _(coo_row):
     ctx = torch.library.get_ctx()
     return coo_row.new_empty([ctx.new_dynamic_size()], dtype=torch.int32)
+
+
+# --------------------------------------------------------------------------------------------------
+# Row-count-explicit variants used by the FX rewrite (geot_amd/match_replace.py): the rewritten graph
+# must keep the shape of the index_add it replaces (dst.shape[0] rows), which the `index[-1]+1` rule
+# cannot promise.  Static output shape => no dynamic-size fake tensor, no D2H read-back at all.
+# --------------------------------------------------------------------------------------------------
+_lib_def.define("gather_scatter_rows(Tensor src_index, Tensor dst_index, Tensor src, SymInt rows) -> Tensor")
+_lib_def.define("gather_weight_scatter_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor")
+_lib_def.define("mh_spmm_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor")
+
+
+def _mh_spmm_rows_gpu(src_index, dst_index, weight, src, rows):
+    _check_gather(src_index, dst_index, src, 3)
+    if weight.dim() != 2 or weight.size(0) != src_index.size(0) or weight.size(1) != src.size(1):
+        raise RuntimeError("Invalid weight size")
+    out = torch.empty((int(rows), src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
+    return hip.mh_spmm_out(src_index.contiguous(), dst_index.contiguous(), weight.contiguous(), src.contiguous(),
+                           out, False)
+
+
+_lib_def.impl("gather_scatter_rows", lambda si, di, s, rows: _gather_scatter_gpu(si, di, s, rows=int(rows)), "CUDA")
+_lib_def.impl("gather_weight_scatter_rows",
+              lambda si, di, w, s, rows: _gather_weight_scatter_gpu(si, di, w, s, rows=int(rows)), "CUDA")
+_lib_def.impl("mh_spmm_rows", _mh_spmm_rows_gpu, "CUDA")
+for _name in ("gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm_rows"):
+    _lib_def.impl(_name, _reject_cpu(_name), "CPU")
+
+
+@torch.library.register_fake("geot::gather_scatter_rows")
+def _(src_index, dst_index, src, rows):
+    return src.new_empty([rows, src.shape[1]])
+
+
+@torch.library.register_fake("geot::gather_weight_scatter_rows")
+def _(src_index, dst_index, weight, src, rows):
+    return src.new_empty([rows, src.shape[1]])
+
+
+@torch.library.register_fake("geot::mh_spmm_rows")
+def _(src_index, dst_index, weight, src, rows):
+    return src.new_empty([rows, src.shape[1], src.shape[2]])

@@ -84,6 +84,17 @@ def main():
     A32 = torch.sparse_csr_tensor(crow.int(), si.int(), w, size=(nodes, nodes))
     t4 = timeit(lambda: torch.sparse.mm(A32, x), max(3, args.iters // 2))
     print(f"cfg3 rocSPARSE CSR SpMM, int32 indices:    {t4:.3f} ms  -> ours is {t4 / t:.2f}x faster")
+    # backward pieces (row f1): SDDMM (d/dweight of gws) and the row gather (backward of index_scatter)
+    g = torch.rand(nodes, F, device=dev)
+    dw = torch.empty(nnz, device=dev)
+    t5 = timeit(lambda: hip.sddmm_coo_out(si, di, g, x, dw), max(3, args.iters // 2))
+    gathered = nnz * 2 * 4 * F
+    print(f"cfg3 sddmm_coo F={F}: {t5:.3f} ms  {nnz / t5 / 1e6:.2f} Gedge/s  gathered {gathered / 1e9:.1f} GB -> {gathered / t5 / 1e9:.2f} TB/s")
+    sub = 20_000_000
+    rows_out = torch.empty(sub, F, device=dev)
+    t6 = timeit(lambda: hip.gather_rows_out(di[:sub], x, rows_out), max(3, args.iters // 2))
+    print(f"gather_rows {sub} x F={F} (sorted index): {t6:.3f} ms  {(sub * 4 * F * 2) / t6 / 1e9:.2f} TB/s (read+write)")
+    del g, dw, rows_out
     del A, A32, ref, x, out, w, si, di, crow
     torch.cuda.empty_cache()
 
