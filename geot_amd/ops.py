@@ -373,7 +373,8 @@ def _gs_backward(ctx, grad):
     src_index, dst_index = ctx.saved_tensors
     grad = grad.contiguous()
     _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
-    g = _gather_scatter_gpu(src_index_bwd, dst_index_bwd, grad, rows=ctx.src_rows)
+    # through the dispatcher (opaque to torch.compile / AOT autograd), with the row count made explicit
+    g = torch.ops.geot.gather_scatter_rows(src_index_bwd, dst_index_bwd, grad, ctx.src_rows)
     return None, None, g
 
 
@@ -408,8 +409,9 @@ def _gws_backward(ctx, grad):
     src_index, dst_index, weight, src = ctx.saved_tensors
     grad = grad.contiguous()
     perm, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
-    src_grad = _gather_weight_scatter_gpu(src_index_bwd, dst_index_bwd, weight[perm], grad, rows=src.shape[0])
-    weight_grad = _sddmm_coo_gpu(src_index, dst_index, grad, src)
+    src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight[perm], grad,
+                                                         src.shape[0])
+    weight_grad = torch.ops.geot.sddmm_coo_impl(src_index, dst_index, grad, src)
     return None, None, weight_grad, src_grad
 
 
@@ -524,3 +526,26 @@ def _(src_index, dst_index, weight, src, rows):
 @torch.library.register_fake("geot::mh_spmm_rows")
 def _(src_index, dst_index, weight, src, rows):
     return src.new_empty([rows, src.shape[1], src.shape[2]])
+
+
+def _gs_rows_setup(ctx, inputs, output):
+    src_index, dst_index, src, _rows = inputs
+    ctx.save_for_backward(src_index, dst_index)
+    ctx.src_rows = src.shape[0]
+
+
+def _gs_rows_backward(ctx, grad):
+    return (*_gs_backward(ctx, grad), None)
+
+
+def _gws_rows_setup(ctx, inputs, output):
+    src_index, dst_index, weight, src, _rows = inputs
+    ctx.save_for_backward(src_index, dst_index, weight, src)
+
+
+def _gws_rows_backward(ctx, grad):
+    return (*_gws_backward(ctx, grad), None)
+
+
+torch.library.register_autograd("geot::gather_scatter_rows", _gs_rows_backward, setup_context=_gs_rows_setup)
+torch.library.register_autograd("geot::gather_weight_scatter_rows", _gws_rows_backward, setup_context=_gws_rows_setup)

@@ -76,3 +76,42 @@ def test_rewritten_models_match_eager_on_gpu(sort_edges):
         ref = model(*args)
         assert got.shape == ref.shape                                       # row count preserved (dst.shape[0])
         assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_ops_run_under_torch_compile():
+    """The dispatcher ops carry fake/meta implementations, so torch.compile can trace through call sites
+    (the reference's test/compile scripts do the same with its ops)."""
+    import geot_amd as geot
+    x, ei, w = _inputs(n=4000, nnz=80_000, f=32, device="cuda", seed=5)
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+
+    def f(x, w):
+        h = geot.gather_weight_scatter(col, row, w, x)
+        return torch.relu(h) * 2.0
+
+    ref = f(x, w)
+    out = torch.compile(f)(x, w)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+    from geot_amd.match_replace import pattern_transform
+    ep = pattern_transform(GCNLike(32, 32).cuda(), (x, ei, w))
+    mod = ep.module()
+    out2 = torch.compile(mod)(x, ei, w)
+    assert torch.allclose(out2, mod(x, ei, w), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_rewritten_model_is_trainable():
+    """Gradients through the fused ops of a rewritten graph equal the eager model's."""
+    from geot_amd.match_replace import pattern_transform
+    torch.manual_seed(1)
+    model = GCNLike(16, 16).cuda()
+    x, ei, w = _inputs(n=1500, nnz=30_000, f=16, device="cuda", seed=7)
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ep = pattern_transform(model, (x, ei, w))
+    ep.module()(x1, ei, w1).square().sum().backward()
+    model(x2, ei, w2).square().sum().backward()
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(w1.grad, w2.grad, rtol=1e-3, atol=1e-3)
