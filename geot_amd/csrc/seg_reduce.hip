@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "geot_hip.h"
@@ -36,6 +37,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kU = 8;          // row loads in flight per lane
+constexpr int kNarrowMaxF = 7; // fp32 rows up to this width use seg_narrow_kernel (measured: 1.35-2.7x; tie at 8)
 constexpr int kGapInline = 16; // gaps up to this many rows are zeroed by the lane group itself
 constexpr int kMinLprLog2 = 2; // lane groups are at least 4 lanes wide (1-2 lane groups measured slower:
                                // 512 LDS partials per tile make the merge the bottleneck)
@@ -424,6 +426,188 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   }
 }
 
+// Narrow rows (F <= 8 fp32): lane-per-edge segmented scan.  This is the reference's "PR" idea
+// (segreduce_pr_sorted_kernel, csrc/cuda/index_scatter_kernel.cuh:48-126: edges across lanes, segmented
+// shuffle scan, atomicAdd per segment start) re-done for wave64 without atomics:
+//   * a wave owns S steps of 64 consecutive edges; lane l of a step owns edge l: key and the F values are
+//     loaded straight into registers, fully coalesced (64*F*4 contiguous bytes per step), all S steps in
+//     flight at once; no LDS staging of keys;
+//   * run starts come from one __ballot per step; the inclusive segmented scan is 6 __shfl_up rounds whose
+//     "may I add lane l-d" test is a shift/mask of that ballot (no flag shuffles);
+//   * the run that is open at the end of a step is carried to the next step in registers (readlane 63);
+//   * a lane that ends a run stores it (plain store); the chunk's first and last run go to LDS and are
+//     merged / carried exactly like the lane groups of seg_tile_kernel (same meta / carry format, same
+//     seg_fixup_kernel), so every dst row is still written exactly once and results are deterministic.
+template <int F, int S>
+__global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
+  constexpr int NW = kThreads / 64; // waves = "groups" of the tile merge
+  __shared__ int64_t pkL[2 * NW];
+  __shared__ int pvL[2 * NW];
+  __shared__ float pL[2 * NW][8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int te = kThreads * S;
+  const int64_t tile = blockIdx.x;
+  const int64_t ts = tile * (int64_t)te;
+  const int64_t cs = ts + (int64_t)wv * (S * 64); // this wave's chunk
+  const int64_t nnz = p.nnz, K = p.K;
+  const int64_t *__restrict__ index = p.dst_index;
+  const float *__restrict__ src = static_cast<const float *>(p.src);
+  float *__restrict__ dst = static_cast<float *>(p.dst);
+
+  // ---- all S steps in flight ---------------------------------------------------------------------------
+  int64_t k[S];
+  float v[S][F];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t e = cs + s * 64 + lane;
+    const bool ok = e < nnz;
+    k[s] = ok ? index[e] : kNoKey;
+    const int64_t ec = ok ? e : nnz - 1; // padding edges re-read the last edge, their run is discarded
+    if constexpr (F == 1) v[s][0] = __builtin_nontemporal_load(src + ec);
+    else if constexpr (F == 2) {
+      const float2 t = *reinterpret_cast<const float2 *>(src + ec * 2);
+      v[s][0] = t.x; v[s][1] = t.y;
+    } else if constexpr (F == 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(src + ec * 4);
+      v[s][0] = t.x; v[s][1] = t.y; v[s][2] = t.z; v[s][3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < F; ++i) v[s][i] = src[ec * F + i];
+    }
+  }
+  int64_t kbefore = -1; // key of the edge in front of the chunk
+  if (cs > 0) kbefore = cs - 1 < nnz ? index[cs - 1] : kNoKey;
+
+  auto gapfill = [&](int64_t lo, int64_t hi) { // executed by ONE lane
+    if (hi <= lo || lo < 0 || hi > K) return;
+    const int64_t cnt = hi - lo;
+    if (cnt <= kGapInline) {
+      for (int64_t r = lo; r < hi; ++r)
+#pragma unroll
+        for (int i = 0; i < F; ++i) dst[r * F + i] = 0.f;
+    } else {
+      const unsigned long long slot = atomicAdd(&p.ctrl[0], 1ull);
+      if ((int64_t)slot < p.gap_cap) {
+        p.gap_list[2 * slot] = lo;
+        p.gap_list[2 * slot + 1] = cnt;
+      }
+    }
+  };
+
+  if (lane == 0) {
+    pvL[2 * wv] = 1;
+    pvL[2 * wv + 1] = 0;
+  }
+  float csum[F]; // the run that is open at the step boundary (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < F; ++i) csum[i] = 0.f;
+  int64_t klast = __shfl(k[0], 0, 64); // the chunk's first edge opens its first run (no run ends there)
+  int nrun = 0;                        // runs of this chunk that have already ended
+  if (lane == 0 && klast > kbefore + 1) gapfill(kbefore + 1, klast);
+
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    int64_t kp = __shfl_up(k[s], 1, 64);
+    if (lane == 0) kp = klast;
+    const bool h = k[s] != kp;
+    const unsigned long long hb = __ballot(h);
+    if (h && k[s] > kp + 1) gapfill(kp + 1, k[s]);
+    if ((hb & 1ull) && lane == 0) {
+      // the run carried in ended exactly at the step boundary: nobody in this step continues it
+      if (nrun == 0) {
+#pragma unroll
+        for (int i = 0; i < F; ++i) pL[2 * wv][i] = csum[i];
+        pkL[2 * wv] = klast;
+      } else if ((uint64_t)klast < (uint64_t)K) {
+#pragma unroll
+        for (int i = 0; i < F; ++i) dst[klast * F + i] = csum[i];
+      }
+    }
+    float x[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) x[i] = v[s][i];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      // lane l may add lane l-d iff no run starts in (l-d, l]
+      const bool can = lane >= d && ((hb >> (lane - d + 1)) & ((1ull << d) - 1ull)) == 0;
+#pragma unroll
+      for (int i = 0; i < F; ++i) {
+        const float y = __shfl_up(x[i], d, 64);
+        if (can) x[i] += y;
+      }
+    }
+    const unsigned long long upto = hb & ((2ull << lane) - 1ull); // run starts at or before this lane
+    if (upto == 0) {                                              // still inside the run carried in
+#pragma unroll
+      for (int i = 0; i < F; ++i) x[i] += csum[i];
+    }
+    const bool ends = lane < 63 && ((hb >> (lane + 1)) & 1ull);
+    if (ends) {
+      if (nrun + __popcll(upto) == 0) { // the chunk's first run: merged after the barrier
+#pragma unroll
+        for (int i = 0; i < F; ++i) pL[2 * wv][i] = x[i];
+        pkL[2 * wv] = k[s];
+      } else if ((uint64_t)k[s] < (uint64_t)K) {
+        if constexpr (F == 2) *reinterpret_cast<float2 *>(dst + k[s] * 2) = float2{x[0], x[1]};
+        else if constexpr (F == 4) *reinterpret_cast<float4 *>(dst + k[s] * 4) = float4{x[0], x[1], x[2], x[3]};
+        else {
+#pragma unroll
+          for (int i = 0; i < F; ++i) dst[k[s] * F + i] = x[i];
+        }
+      }
+    }
+    // carry the open run to the next step
+#pragma unroll
+    for (int i = 0; i < F; ++i) csum[i] = __shfl(x[i], 63, 64);
+    klast = __shfl(k[s], 63, 64);
+    nrun += __popcll(hb);
+  }
+  if (lane == 0) { // the chunk's last run (or its only one)
+    const int slot = 2 * wv + (nrun == 0 ? 0 : 1);
+#pragma unroll
+    for (int i = 0; i < F; ++i) pL[slot][i] = csum[i];
+    pkL[slot] = klast;
+    pvL[slot] = 1;
+  }
+  __syncthreads();
+
+  // ---- tile bookkeeping + merge of the 2*NW partials (same rules as seg_tile_kernel) -------------------
+  const int64_t rem = nnz - ts;
+  const int n = rem < (int64_t)te ? (int)rem : te;
+  const int64_t kprev_tile = ts > 0 ? index[ts - 1] : -1;
+  const int64_t knext_tile = ts + n < nnz ? index[ts + n] : kNoKey;
+  if (tid == 0) {
+    const int64_t kf = index[ts], kl = index[ts + n - 1];
+    const int64_t head = kf == kprev_tile;
+    const int64_t single = head && kl == kf && knext_tile == kf;
+    p.meta[tile] = (uint64_t)kf < (uint64_t)K ? (kf * 4 + head + 2 * single) : 0;
+    if (tile == (int64_t)gridDim.x - 1) gapfill(kl + 1, K); // rows behind the last key
+  }
+  const bool active = lane < F;
+  float *carry = static_cast<float *>(p.carry);
+  for (int i = wv; i < 2 * NW; i += NW) {
+    if (!pvL[i]) continue;
+    const int64_t key = pkL[i];
+    bool leader = true;
+    if (!(i & 1) && i > 0) {
+      const int pi = pvL[i - 1] ? i - 1 : i - 2;
+      leader = pkL[pi] != key;
+    }
+    if (!leader) continue;
+    float sum = active ? pL[i][lane] : 0.f;
+    bool at_end = true;
+    for (int j = i + 1; j < 2 * NW; ++j) {
+      if (!pvL[j]) continue;
+      if (pkL[j] != key) { at_end = false; break; }
+      if (active) sum += pL[j][lane];
+    }
+    if (!active) continue;
+    if (i == 0 && key == kprev_tile) carry[(tile * 2) * F + lane] = sum;
+    else if (at_end && key == knext_tile) carry[(tile * 2 + 1) * F + lane] = sum;
+    else if ((uint64_t)key < (uint64_t)K) dst[key * F + lane] = sum;
+  }
+}
+
 // Unsorted index, few output rows: LDS-binned atomics.  When the whole [K, F] output fits in LDS,
 // every block accumulates its share of the edges into an LDS copy with ds_add (LDS float atomics:
 // no global contention, any key order), then adds its copy to dst with ONE global atomic per
@@ -705,6 +889,7 @@ struct Tune {
 };
 Tune g_tune;
 int g_unroll = 0; // 0 = rule, 8 / 16 = forced
+int g_narrow = 1; // lane-per-edge kernel for F <= 8 fp32 (0 = use the lane-group kernel)
 
 struct Prof {
   bool on = false;
@@ -891,7 +1076,22 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   const bool al = is_aligned16(src) && is_aligned16(dst) && is_aligned16(ws);
   const int hw = mode <= 1 ? 0 : (mode == 2 ? 1 : (int)H);
   if (hw > 64) return fail(GEOT_EUNSUPPORTED, "more than 64 heads");
-  const Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
+  Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
+  if (std::is_same<T, float>::value && mode == 0 && sorted && red == RED_SUM && F <= kNarrowMaxF && g_narrow) {
+    // seg_narrow_kernel: tiles of 256 lanes x S steps; 4 lanes per row in the fix-up kernel
+    const int te = kThreads * (F <= 2 ? 8 : 4);
+    const Plan Q = make_plan(nnz, F, F, K, (int)sizeof(T), false, false, 0);
+    P = Q;
+    P.te = te;
+    P.num_tiles = nnz > 0 ? (nnz + te - 1) / te : 0;
+    P.nfb = 1;
+    P.lpr_log2 = 2;
+    const size_t nt = (size_t)(P.num_tiles > 0 ? P.num_tiles : 1);
+    P.cnt_off = P.meta_off + up256(nt * sizeof(int64_t));
+    P.carry_off = P.cnt_off + up256(nt * 2 * sizeof(int64_t));
+    P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * sizeof(float));
+    P.total = P.list_off + up256((size_t)P.gap_cap * 16);
+  }
   if (!ws || ws_bytes < P.total) return fail(GEOT_EWORKSPACE, "workspace too small");
   if (((uintptr_t)ws & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
 
@@ -952,6 +1152,25 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
         rc = dispatch_vec<T, false, 0, true>(p, P, st, nt);
       }
     } else {
+      bool narrow = false;
+      if constexpr (sizeof(T) == 4 && std::is_same<T, float>::value) {
+        // narrow fp32 rows: lane-per-edge scan kernel (its tile size was fixed by the plan below)
+        if (mode == 0 && red == RED_SUM && F <= kNarrowMaxF && g_narrow) {
+          const dim3 grid((unsigned)P.num_tiles), blk(kThreads);
+          switch ((int)F) {
+          case 1: hipLaunchKernelGGL((seg_narrow_kernel<1, 8>), grid, blk, 0, st, p); break;
+          case 2: hipLaunchKernelGGL((seg_narrow_kernel<2, 8>), grid, blk, 0, st, p); break;
+          case 3: hipLaunchKernelGGL((seg_narrow_kernel<3, 4>), grid, blk, 0, st, p); break;
+          case 4: hipLaunchKernelGGL((seg_narrow_kernel<4, 4>), grid, blk, 0, st, p); break;
+          case 5: hipLaunchKernelGGL((seg_narrow_kernel<5, 4>), grid, blk, 0, st, p); break;
+          case 6: hipLaunchKernelGGL((seg_narrow_kernel<6, 4>), grid, blk, 0, st, p); break;
+          case 7: hipLaunchKernelGGL((seg_narrow_kernel<7, 4>), grid, blk, 0, st, p); break;
+          default: hipLaunchKernelGGL((seg_narrow_kernel<8, 4>), grid, blk, 0, st, p); break;
+          }
+          narrow = true;
+        }
+      }
+      if (!narrow)
       switch (mode) {
       case 0:
         switch (red) {
@@ -1243,6 +1462,7 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
 
 void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
+  if (name && std::string(name) == "narrow") g_narrow = value;
 }
 
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {

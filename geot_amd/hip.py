@@ -238,5 +238,13 @@ def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2
     _lib.load().geot_tune(edges_per_group, vec, nontemporal, lpr_log2)
 
 
+def set_option(name: str, value: int) -> None:
+    """Named experiment switches of the library ("unroll": 0|8|16, "narrow": 0|1)."""
+    L = _lib.load()
+    L.geot_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.geot_set_option.restype = None
+    L.geot_set_option(name.encode(), int(value))
+
+
 def build_info() -> str:
     return _lib.load().geot_build_info().decode()

@@ -96,6 +96,31 @@ def test_feature_widths(geot, oracle, F):
     check_index_scatter(geot, oracle, index, rng.random((3000, F), dtype=np.float32), what=f"F={F}")
 
 
+@pytest.mark.parametrize("narrow", [1, 0])
+def test_narrow_rows_both_kernels(geot, oracle, narrow):
+    """F <= 7 fp32 has two implementations (lane-per-edge scan / lane groups): both must hold parity on
+    every segment shape, including runs that end exactly on the 64-edge step boundaries."""
+    from geot_amd import hip
+    hip.set_option("narrow", narrow)
+    try:
+        rng = np.random.default_rng(40 + narrow)
+        shapes = {
+            "powerlaw": powerlaw_index(150_000, 12_000, 3),
+            "hub": np.sort(np.concatenate([np.full(9000, 5), rng.integers(0, 40, 3000)])).astype(np.int64),
+            "runs_of_64": np.repeat(np.arange(700, dtype=np.int64), 64),       # every run ends on a step boundary
+            "runs_of_32": np.repeat(np.arange(1500, dtype=np.int64) * 2, 32),
+            "units": np.arange(9000, dtype=np.int64),
+            "gaps": np.sort(rng.integers(0, 500, 8000)).astype(np.int64) * 19 + 7,
+            "tiny": np.array([0, 0, 3], dtype=np.int64),
+        }
+        for name, index in shapes.items():
+            for F in (1, 2, 3, 4, 5, 6, 7, 8):
+                src = rng.standard_normal((len(index), F)).astype(np.float32)
+                check_index_scatter(geot, oracle, index, src, what=f"narrow={narrow} {name} F={F}")
+    finally:
+        hip.set_option("narrow", 1)
+
+
 @pytest.mark.parametrize("nnz,keys", [(1, 1), (2, 1), (63, 5), (64, 64), (65, 7), (511, 40), (512, 512), (513, 3),
                                       (2047, 100), (2048, 2048), (2049, 9), (100_003, 997)])
 def test_ragged_tile_boundaries(geot, oracle, nnz, keys):
