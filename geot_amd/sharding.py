@@ -51,6 +51,48 @@ def _default_local_op(index_local: torch.Tensor, src_local: torch.Tensor, rows: 
     return hip.index_scatter_out(index_local, src_local.contiguous(), out, sorted=True)
 
 
+# (first_key, last_key) of every rank's shard, remembered per index identity: GNN edge lists are static,
+# so the ownership decisions below are almost always the same as last time.  They are only a GUESS:
+# the keys travel with every exchange and are verified on the host after the work has been queued
+# (the wait overlaps the kernels); a mismatch redoes the ownership step with the true keys.
+_ends_seen: dict = {}
+
+
+def _ident(index: torch.Tensor, world: int, rank: int, key_offset):
+    return (index.device.type, index.device.index, index.data_ptr(), index.numel(), index._version, world, rank,
+            key_offset)
+
+
+def _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange):
+    """Ownership rules given every rank's (first_key, last_key): returns (rows, first_row)."""
+    first_key, last_key = firsts[rank], lasts[rank]
+    owns_first = rank == 0 or lasts[rank - 1] != first_key
+    if not exchange and not owns_first:
+        raise RuntimeError("exchange=False but a segment straddles the cut between ranks "
+                           f"{rank - 1} and {rank}")
+    if exchange:
+        # add the first-row partials of the following ranks that continue my last key, in rank order
+        r2 = rank + 1
+        tail = None
+        while r2 < world and firsts[r2] == last_key:
+            part = allrows[r2].to(local.dtype).view(feat_shape)
+            tail = part if tail is None else tail + part
+            if lasts[r2] != last_key:
+                break  # that rank has further keys: the run ends inside it
+            r2 += 1
+        if tail is not None:
+            local[-1] += tail  # in place (the caller keeps a copy of this row in case the step is redone)
+    # my rows: (last_key_{rank-1}, last_key]; drop a first row owned by a lower rank,
+    # prepend zero rows for the empty keys between the previous rank's last key and my first key
+    prev_last = lasts[rank - 1] if rank > 0 else -1
+    if not owns_first:
+        return local[1:], first_key + 1
+    gap = first_key - (prev_last + 1)
+    if gap > 0:
+        local = torch.cat([local.new_zeros((gap,) + feat_shape), local])
+    return local, prev_last + 1
+
+
 def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
                           group: Optional[dist.ProcessGroup] = None,
                           local_op: Optional[Callable] = None,
@@ -65,10 +107,19 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     ``index_scatter(0, src, index)`` of the unsharded problem.
 
     ``exchange=False`` asserts the cuts are segment-aligned (no key is shared by two ranks) and
-    skips the collective.
+    skips the row exchange.
 
     ``key_offset``: the shard's index is already rank-local and its first key is 0
     (global key = local key + key_offset); saves the pass that re-bases the keys.
+
+    Host synchronisation without stalling the GPU, and without ever issuing a second collective
+    (every rank always makes exactly ONE all_gather per call, so ranks cannot fall out of step):
+      1. this rank's end keys are remembered per index identity; the local kernels are launched for the
+         remembered row count while the D2H copy of the real end keys completes underneath; a mismatch
+         relaunches the LOCAL kernels only - nothing has been sent yet;
+      2. the all_gather carries every rank's exact keys and first-row partial;
+      3. the ownership step is queued with the other ranks' remembered keys and verified afterwards; a
+         mismatch redoes that step locally from the rows already received.
     """
     local_op = local_op or _default_local_op
     world = dist.get_world_size(group)
@@ -78,65 +129,78 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     feat_shape = tuple(src_shard.shape[1:])
     F = int(src_shard[0].numel())
     dev = src_shard.device
+    ident = _ident(index_shard, world, rank, key_offset)
+    guess = _ends_seen.get(ident)
 
-    # local reduction on keys shifted to start at 0: rows [first_key, last_key]
-    if key_offset is None:
-        ends = torch.stack([index_shard[0], index_shard[-1]]).cpu()  # one D2H sync, as index[-1].item()
-        first_key, last_key = int(ends[0]), int(ends[1])
-        local = local_op(index_shard - first_key, src_shard, last_key - first_key + 1)
+    def run_local(lo, hi):
+        if key_offset is None:
+            return local_op(index_shard - lo if lo else index_shard, src_shard, hi - lo + 1)
+        out = local_op(index_shard, src_shard, hi + 1)
+        return out[lo:] if lo else out
+
+    # ---- 1. local reduction, rows [first_key, last_key] ------------------------------------------------
+    ends_dev = torch.stack([index_shard[0], index_shard[-1]])
+    if guess is None:
+        ends = ends_dev.cpu()                                       # first call: D2H sync, as index[-1].item()
+        lo, hi = int(ends[0]), int(ends[1])
+        local = run_local(lo, hi)
     else:
-        local_rows = int(index_shard[-1].item()) + 1               # the operator's row rule
-        first_key, last_key = key_offset, key_offset + local_rows - 1
-        local = local_op(index_shard, src_shard, local_rows)
+        lo, hi = guess["local_ends"]
+        if dev.type == "cuda":
+            host = torch.empty(2, dtype=torch.int64).pin_memory()
+            host.copy_(ends_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            local = run_local(lo, hi)                               # queued behind the copy
+            ev.synchronize()
+            true_ends = (int(host[0]), int(host[1]))
+        else:                                                       # host tensors: nothing to overlap
+            true_ends = (int(ends_dev[0]), int(ends_dev[1]))
+            local = run_local(*true_ends)
+        if true_ends != (lo, hi):                                   # index changed under the same identity
+            if dev.type == "cuda":                                  # (the HIP kernels ignore out-of-range keys)
+                local = run_local(*true_ends)
+            lo, hi = true_ends
+            guess = None
+    first_key, last_key = (key_offset or 0) + lo, (key_offset or 0) + hi
+    head = local[0]
 
     if world == 1:
+        _ends_seen[ident] = {"local_ends": (lo, hi)}
         if first_key > 0:
             local = torch.cat([local.new_zeros((first_key,) + feat_shape), local])
         return local, 0
 
-    # boundary record: [first_key, last_key, first_row(F)] per rank, gathered by everyone
+    # ---- 2. the one collective: [first_key, last_key, first_row(F)] of every rank ------------------------
     rec = torch.empty(2 + F, dtype=torch.float64, device=dev)
     rec[0], rec[1] = first_key, last_key
-    rec[2:] = local[0].reshape(-1).to(torch.float64)
+    rec[2:] = head.reshape(-1).to(torch.float64)
     # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or two test
     # ranks sharing one GPU) stages the few hundred bytes through the host
     via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
     cdev = torch.device("cpu") if via_host else dev
-    send = rec.to(cdev) if exchange else rec[:2].contiguous().to(cdev)
+    send = (rec if exchange else rec[:2].contiguous()).to(cdev)
     recv = torch.empty(world * send.numel(), dtype=torch.float64, device=cdev)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.to(dev).view(world, -1)
-    allrec = torch.zeros(world, 2 + F, dtype=torch.float64, device=dev)
-    allrec[:, : recv.shape[1]] = recv
-    keys_host = allrec[:, :2].to(torch.int64).cpu()
-    firsts = [int(k) for k in keys_host[:, 0]]
-    lasts = [int(k) for k in keys_host[:, 1]]
+    allrows = recv[:, 2:] if exchange else None
 
-    # a rank owns key k if it is the lowest rank holding edges of k
-    owns_first = rank == 0 or lasts[rank - 1] != first_key
-    if not exchange and not owns_first:
-        raise RuntimeError("exchange=False but a segment straddles the cut between ranks "
-                           f"{rank - 1} and {rank}")
-    # add the first-row partials of the following ranks that continue my last key, in rank order
-    if exchange:
-        r2 = rank + 1
-        while r2 < world and firsts[r2] == last_key:
-            local[-1] += allrec[r2, 2:].to(local.dtype).view(feat_shape)
-            if lasts[r2] != last_key:
-                break  # that rank has further keys: the run ends inside it
-            r2 += 1
-    # my rows: (last_key_{rank-1}, last_key]; drop a first row owned by a lower rank,
-    # prepend zero rows for the empty keys between the previous rank's last key and my first key
-    prev_last = lasts[rank - 1] if rank > 0 else -1
-    if not owns_first:
-        local = local[1:]
-        first_row = first_key + 1
-    else:
-        gap = first_key - (prev_last + 1)
-        if gap > 0:
-            local = torch.cat([local.new_zeros((gap,) + feat_shape), local])
-        first_row = prev_last + 1
-    return local, first_row
+    # ---- 3. ownership --------------------------------------------------------------------------------------
+    out = None
+    saved_last = local[-1].clone()   # the ownership step adds into this row in place; a redo restores it
+    if guess is not None and "firsts" in guess and guess["firsts"][rank] == first_key and guess["lasts"][rank] == last_key:
+        out = _apply_boundaries(local, head, allrows, guess["firsts"], guess["lasts"], rank, world, feat_shape, exchange)
+    keys_host = recv[:, :2].to(torch.int64).cpu()                   # host sync; the work above is already queued
+    firsts = [int(v) for v in keys_host[:, 0]]
+    lasts = [int(v) for v in keys_host[:, 1]]
+    if out is None or firsts != guess["firsts"] or lasts != guess["lasts"]:
+        if out is not None:
+            local[-1] = saved_last
+        out = _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange)
+    _ends_seen[ident] = {"local_ends": (lo, hi), "firsts": firsts, "lasts": lasts}
+    if len(_ends_seen) > 64:
+        _ends_seen.pop(next(iter(_ends_seen)))
+    return out
 
 
 def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch.Tensor,

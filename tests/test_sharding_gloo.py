@@ -140,6 +140,62 @@ def test_sharded_gather_weight_scatter_replicated_src():
     np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)
 
 
+def _repeat_worker(rank, world, port, case, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geot_amd import sharding
+        index = torch.from_numpy(case["index"].copy())
+        src = torch.from_numpy(case["src"])
+        cuts = sharding.equal_edge_cuts(index.numel(), world)
+        ish, ssh = index[cuts[rank]:cuts[rank + 1]], src[cuts[rank]:cuts[rank + 1]]
+        outs = []
+        for it in range(4):
+            if it == 2 and rank == world - 1:
+                ish.data += 5                       # same tensor identity and version, different keys:
+            out, first = sharding.sharded_index_scatter(ish, ssh, local_op=_oracle_local_op)
+            outs.append((first, out.numpy().copy()))
+        q.put((rank, outs))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_repeated_calls_use_and_verify_remembered_keys():
+    """Calls 2+ take the speculative path (remembered end keys / ownership); call 3 changes the last rank's
+    keys under the same tensor identity: every rank must notice and still produce the exact result, with
+    exactly one collective per call on every rank (no hang)."""
+    from oracle import api
+    rng = np.random.default_rng(17)
+    case = dict(index=powerlaw_index(6000, 400, 5), src=rng.random((6000, 4), dtype=np.float32))
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_repeat_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cuts = [(6000 * r) // world for r in range(world + 1)]
+    for it in range(4):
+        index = case["index"].copy()
+        if it >= 2:
+            index[cuts[world - 1]:] += 5
+        full = api.index_scatter(index, case["src"], acc64=True)
+        got = np.concatenate([res[r][it][1] for r in range(world)])
+        assert got.shape == full.shape, (it, got.shape, full.shape)
+        np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)
+        row = 0
+        for r in range(world):
+            assert res[r][it][0] == row
+            row += res[r][it][1].shape[0]
+
+
 def test_cut_helpers():
     from geot_amd import sharding
     assert sharding.equal_edge_cuts(10, 4) == [0, 2, 5, 7, 10]
