@@ -111,6 +111,34 @@ def main():
           f"compulsory {comp / 1e9:.2f} GB -> {comp / t / 1e9:.2f} TB/s")
     t2 = timeit(lambda: hip.mh_spmm_out(si, di, wt, x, out, True), args.iters)
     print(f"cfg4 mh_spmm [H,nnz]: {t2:.3f} ms  {nnz / t2 / 1e6:.2f} Gedge/s")
+    del si, di, w, wt, x, out
+    torch.cuda.empty_cache()
+
+    # ---- cfg5: gather_scatter, papers100M scale, ONE GPU's shard of 8: 1/8 of 1.6157 B edges, 1/8 of the
+    #      111.06 M dst rows, src (all 111.06 M nodes x 128) replicated = 56.9 GB
+    if args.scale >= 1.0:
+        nodes_all, F = 111_059_956, 128
+        nnz, rows = 1_615_685_872 // 8, 111_059_956 // 8
+        di = powerlaw_index(nnz, rows, 13, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(14)
+        si = torch.randint(0, nodes_all, (nnz,), device=dev, generator=g)
+        x = torch.rand(nodes_all, F, device=dev)
+        out = torch.empty(rows, F, device=dev)
+        hip.gather_scatter_out(si, di, x, out)
+        torch.cuda.synchronize()
+        # checks at full size: a handful of rows against a float64 torch reduction, and the hub
+        counts = torch.bincount(di, minlength=rows)
+        offs = torch.cumsum(counts, 0) - counts
+        for k in [int(counts.argmax()), 0, rows - 1, rows // 2, 12345]:
+            seg = x[si[offs[k]: offs[k] + counts[k]]].double().sum(0)
+            assert torch.allclose(out[k].double(), seg, rtol=1e-5, atol=1e-6), k
+        assert out[counts == 0].abs().sum().item() == 0
+        t = timeit(lambda: hip.gather_scatter_out(si, di, x, out), 3)
+        gathered = nnz * 4 * F
+        print(f"cfg5 shard (1/8): gather_scatter nnz={nnz} rows={rows} F={F}, src {x.numel() * 4 / 1e9:.1f} GB resident: "
+              f"{t:.3f} ms  {nnz / t / 1e6:.2f} Gedge/s  gathered {gathered / 1e9:.0f} GB -> {gathered / t / 1e9:.2f} TB/s; "
+              f"peak memory {torch.cuda.max_memory_allocated() / 1e9:.0f} GB")
 
 
 if __name__ == "__main__":
