@@ -9,7 +9,7 @@ HIPFLAGS = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Iinclude -Wno-unused-val
 LIB = geot_amd/libgeot_hip.so
 SRC = geot_amd/csrc/seg_reduce.hip
 
-.PHONY: all lib tools oracle ref clean
+.PHONY: all lib tools shim oracle ref clean
 all: lib tools
 
 lib: $(LIB)
@@ -21,11 +21,21 @@ tools/kbench: tools/kbench.cpp $(LIB) include/geot_hip.h
 	$(HIPCC) -O2 --offload-arch=$(ARCH) -std=c++17 -Iinclude tools/kbench.cpp -Lgeot_amd -lgeot_hip \
 	  -Wl,-rpath,'$$ORIGIN/../geot_amd' -o $@
 
+# optional PyTorch dispatcher plugin over the C ABI (path A): geot_amd/_C.so
+TORCH_DIR := $(shell python3 -c "import os,torch;print(os.path.dirname(torch.__file__))")
+CXXABI    := $(shell python3 -c "import torch;print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")
+shim: geot_amd/_C.so
+geot_amd/_C.so: geot_amd/csrc/torch_shim.cpp $(LIB) include/geot_hip.h
+	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=$(CXXABI) \
+	  -Iinclude -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
+	  geot_amd/csrc/torch_shim.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -lc10 -lc10_hip \
+	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
+
 oracle:
 	$(MAKE) -C oracle oracle
 ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f $(LIB) tools/kbench
+	rm -f $(LIB) tools/kbench geot_amd/_C.so
 	$(MAKE) -C oracle clean

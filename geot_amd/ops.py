@@ -549,3 +549,44 @@ def _gws_rows_backward(ctx, grad):
 
 torch.library.register_autograd("geot::gather_scatter_rows", _gs_rows_backward, setup_context=_gs_rows_setup)
 torch.library.register_autograd("geot::gather_weight_scatter_rows", _gws_rows_backward, setup_context=_gws_rows_setup)
+
+
+# --------------------------------------------------------------------------------------------------
+# backward of index_scatter: d/dsrc[e] = grad[index[e]] - the row gather the
+# reference ships as gather_eb_sorted_kernel (csrc/cuda/index_scatter_kernel.cuh:266-315) but never wires
+# to an op.  sum only (mean / min / max / prod have no backward here, as in the reference).
+# --------------------------------------------------------------------------------------------------
+_lib_def.define("gather_rows(Tensor index, Tensor src) -> Tensor")
+
+
+def _gather_rows_gpu(index, src):
+    src = src.contiguous()
+    out = torch.empty((index.size(0),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    return hip.gather_rows_out(index.contiguous(), src, out)
+
+
+_lib_def.impl("gather_rows", _gather_rows_gpu, "CUDA")
+_lib_def.impl("gather_rows", _reject_cpu("gather_rows"), "CPU")
+
+
+@torch.library.register_fake("geot::gather_rows")
+def _(index, src):
+    return src.new_empty([index.shape[0], *src.shape[1:]])
+
+
+def _is_setup(ctx, inputs, output):
+    dim, index, src, reduce, _sorted = inputs
+    ctx.save_for_backward(index)
+    ctx.dim, ctx.reduce = dim, reduce
+
+
+def _is_backward(ctx, grad):
+    if get_reduction_enum(ctx.reduce) != "sum":
+        raise NotImplementedError(f"index_scatter: backward is implemented for reduce='sum' only (got '{ctx.reduce}')")
+    (index,) = ctx.saved_tensors
+    g = grad if ctx.dim == 0 else grad.movedim(ctx.dim, 0)
+    out = torch.ops.geot.gather_rows(index, g.contiguous())
+    return None, None, (out if ctx.dim == 0 else out.movedim(0, ctx.dim)), None, None
+
+
+torch.library.register_autograd("geot::index_scatter", _is_backward, setup_context=_is_setup)

@@ -17,6 +17,21 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_native_builds():
+    """A fresh checkout has no binaries (they are git-ignored): build the product library with hipcc
+    (cross-compiles for gfx950 without a GPU) before anything imports geot_amd.  This lives in the TEST
+    harness on purpose - the package itself never builds or falls back, it fails loudly."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_geot_lib_bootstrap", os.path.join(ROOT, "geot_amd", "_lib.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.needs_build():
+        mod.build()
+
+
+_ensure_native_builds()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (HIP kernels are executed)")
 

@@ -311,6 +311,22 @@ def test_sddmm_and_autograd_against_golden(geot, oracle):
                                rtol=RTOL)
 
 
+def test_index_scatter_backward_is_a_row_gather(geot):
+    index = dev(powerlaw_index(30_000, 2000, 4))
+    for shape, dim in (((30_000, 48), 0), ((30_000, 3, 5), 0), ((7, 30_000), 1)):
+        src = torch.rand(*shape, device="cuda", requires_grad=True)
+        ref_src = src.detach().clone().requires_grad_(True)
+        out = geot.index_scatter(dim, src, index)
+        g = torch.rand_like(out)
+        out.backward(g)
+        zeros = torch.zeros_like(out)
+        zeros.index_add(dim, index, ref_src).backward(g)
+        assert torch.equal(src.grad, ref_src.grad)                     # a pure gather: exact
+    with pytest.raises(NotImplementedError, match="backward is implemented for reduce='sum'"):
+        src = torch.rand(30_000, 4, device="cuda", requires_grad=True)
+        geot.index_scatter(0, src, index, "max").sum().backward()
+
+
 def test_backward_when_last_node_has_no_out_edge(geot):
     """The reference returns max(src_index)+1 grad rows (shape error); here grad has src.shape[0] rows."""
     si = torch.tensor([0, 1, 1, 0], device="cuda")
