@@ -70,3 +70,49 @@ def test_sharded_hip_operator_matches_unsharded():
     assert res[0][1] == 0 and sum(n for _, _, n, _ in res) == 20_007
     for (r0, f0, n0, _), (r1, f1, n1, _) in zip(res, res[1:]):
         assert f0 + n0 == f1
+
+
+def test_rccl_calls_used_by_the_multi_gpu_path_work_here():
+    """Single-rank "nccl" (= RCCL) group: the exact collective calls bench.py / sharding.py make at N > 1."""
+    script = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+send = torch.arange(66, dtype=torch.float64, device=dev)
+recv = torch.empty(66, dtype=torch.float64, device=dev)
+dist.all_gather_into_tensor(recv, send)
+t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(recv, send) and t.item() == 1.5 and dist.get_backend() == "nccl"
+dist.destroy_process_group()
+print("RCCL OK")
+'''
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "RCCL OK" in p.stdout, p.stderr[-2000:]
+
+
+def test_bench_json_contract_single_gpu():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line"
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["metric"] == "aggregated edges/sec + HBM GB/s, index_scatter feat=64 sorted sum" and r["unit"] == "edges/s"
+    assert r["n_gpus"] == 1 and r["steps"] == 5 and r["warmup"] == 2 and r["higher_is_better"] is True
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None and "workload" in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
+    assert rf["traffic"] is None or rf["traffic"] > 2.8e9
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["unit"] == "edges/s" and cb["cores"] >= 1 and cb["value"] > 1e6
+    assert r["value"] > 1e9 and abs(r["value"] - 10_000_000 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
