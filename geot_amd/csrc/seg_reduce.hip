@@ -1,27 +1,29 @@
 // seg_reduce.hip -- MI355X (gfx950 / CDNA4) segment-reduction kernels behind include/geot_hip.h.
 //
-// One tile kernel serves index_scatter / gather_scatter / gather_weight_scatter / mh_spmm
-// (the reference has four copies of the same control flow:
-//  csrc/cuda/index_scatter_kernel.cuh:135-201, gather_scatter_kernel.cuh:118-186,
-//  gather_weight_scatter_kernel.cuh:118-185, mh_spmm_kernel.cuh:28-213).  It is NOT that
-// control flow: the reference flushes every run with atomicAdd into a zeroed dst; here the
-// sorted path has no global atomics, writes every dst row exactly once and is deterministic.
+// Kernels in this file (details, measurements and the roofline of each: DESIGN.md section 3):
+//   seg_tile_kernel     index_scatter / gather_scatter / gather_weight_scatter / mh_spmm, sorted index, any
+//                       reduction, fp32 / fp64 / half / bfloat16 (fp32 accumulate); also the atomic flush
+//                       used for an unsorted index.  The reference has four copies of one control flow
+//                       (csrc/cuda/index_scatter_kernel.cuh:135-201, gather_scatter_kernel.cuh:118-186,
+//                       gather_weight_scatter_kernel.cuh:118-185, mh_spmm_kernel.cuh:28-213) that flush
+//                       every run with atomicAdd into a zeroed dst; this is a different algorithm: no
+//                       global atomics, every dst row written exactly once, deterministic.
+//   seg_narrow_kernel   fp32 rows of 1..7 values: lane-per-edge segmented shuffle scan.
+//   seg_fixup_kernel    second launch: finishes the runs that straddle tiles, zero-fills large gaps.
+//   seg_lds_bin_kernel  unsorted index with an output that fits in LDS: LDS-binned atomics.
+//   sddmm_coo_kernel, gather_rows_kernel, csr_expand_kernel, coo_*_kernel   backward / CSR helpers.
 //
-// Design (details in DESIGN.md):
+// Sorted path in one paragraph:
 //   * edge-balanced tiles: block b owns edges [b*TE, (b+1)*TE) whatever the segment lengths are;
-//   * 256 threads = 4 wave64; a "lane group" of LPR lanes (LPR*VEC >= min(F, 64*VEC)) owns one
-//     row at a time, 16 B per lane (VEC=4 fp32) so a wave instruction moves 64/LPR whole rows;
-//   * each lane group walks CG consecutive edges of the tile keeping the running sum in
-//     registers with U row loads in flight; interior runs are stored straight to dst with plain
-//     coalesced stores; the group's first and last run go to LDS;
-//   * after one barrier the LDS partials of the tile are merged in edge order: runs that are
-//     complete inside the tile are stored; a run that continues from the previous tile goes to
-//     carry[tile]; a run that continues into the next tile is stored as the owner's partial;
-//   * seg_fixup_kernel (second launch = the only cross-workgroup ordering needed) adds the
-//     carries of follow-on tiles to the owner's row in tile order and zero-fills large gaps;
-//   * empty keys (gaps) are zero-filled by the lane group that sees the key jump: dst needs no
-//     memset pass (the reference's torch::zeros is 9 % of the traffic at the graded config).
-//   * unsorted mode: same walk, every run flushed with float atomics into a zeroed dst.
+//   * 256 threads = 4 wave64; a "lane group" of LPR lanes owns one row at a time, 16 B per lane, so a
+//     wave instruction moves 64/LPR whole rows; each group walks CG consecutive edges with U row loads
+//     in flight, running sum in registers; run starts come from wave ballots made while the keys are
+//     staged in LDS; interior runs are stored straight to dst; a group's first and last run go to LDS;
+//   * after one barrier the tile's LDS partials are merged in edge order: complete runs are stored, a
+//     run continuing FROM the previous tile goes to carry[tile][0], one continuing INTO the next tile
+//     to carry[tile][1];
+//   * seg_fixup_kernel writes dst[k] = tail + head (+ whole follow-on tiles of a hub) with plain stores;
+//   * empty keys are zero-filled by whoever sees the key jump: dst needs no memset pass.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -36,7 +38,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kU = 8;          // row loads in flight per lane
+constexpr int kU = 8;          // row loads in flight per lane (16 where the plan rule says so)
 constexpr int kNarrowMaxF = 7; // fp32 rows up to this width use seg_narrow_kernel (measured: 1.35-2.7x; tie at 8)
 constexpr int kGapInline = 16; // gaps up to this many rows are zeroed by the lane group itself
 constexpr int kMinLprLog2 = 2; // lane groups are at least 4 lanes wide (1-2 lane groups measured slower:
