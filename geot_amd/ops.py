@@ -89,7 +89,11 @@ _tls = threading.local()
 
 
 def _rows_key(index: torch.Tensor):
-    return (index.device.index, index.data_ptr(), index.numel(), index._version)
+    try:
+        version = index._version
+    except RuntimeError:      # inference tensors keep no version counter: do not speculate on them
+        return None
+    return (index.device.index, index.data_ptr(), index.numel(), version)
 
 
 def _remember_rows(key, rows: int) -> None:
@@ -120,10 +124,11 @@ def _with_row_rule(index: torch.Tensor, launch):
     if index.numel() == 0:
         return launch(_last_index_plus_one(index))          # raises IndexError like the reference
     key = _rows_key(index)
-    guess = _rows_seen.get(key) if _SPECULATE else None
+    guess = _rows_seen.get(key) if (_SPECULATE and key is not None) else None
     if guess is None:
         rows = _last_index_plus_one(index)
-        _remember_rows(key, rows)
+        if key is not None:
+            _remember_rows(key, rows)
         return launch(rows)
     slot = _begin_row_readback(index)
     out = launch(guess)

@@ -59,8 +59,11 @@ _ends_seen: dict = {}
 
 
 def _ident(index: torch.Tensor, world: int, rank: int, key_offset):
-    return (index.device.type, index.device.index, index.data_ptr(), index.numel(), index._version, world, rank,
-            key_offset)
+    try:
+        version = index._version
+    except RuntimeError:      # inference tensors keep no version counter: never remembered
+        return None
+    return (index.device.type, index.device.index, index.data_ptr(), index.numel(), version, world, rank, key_offset)
 
 
 def _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange):
@@ -130,7 +133,7 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     F = int(src_shard[0].numel())
     dev = src_shard.device
     ident = _ident(index_shard, world, rank, key_offset)
-    guess = _ends_seen.get(ident)
+    guess = _ends_seen.get(ident) if ident is not None else None
 
     def run_local(lo, hi):
         if key_offset is None:
@@ -166,7 +169,8 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     head = local[0]
 
     if world == 1:
-        _ends_seen[ident] = {"local_ends": (lo, hi)}
+        if ident is not None:
+            _ends_seen[ident] = {"local_ends": (lo, hi)}
         if first_key > 0:
             local = torch.cat([local.new_zeros((first_key,) + feat_shape), local])
         return local, 0
@@ -197,7 +201,8 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         if out is not None:
             local[-1] = saved_last
         out = _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange)
-    _ends_seen[ident] = {"local_ends": (lo, hi), "firsts": firsts, "lasts": lasts}
+    if ident is not None:
+        _ends_seen[ident] = {"local_ends": (lo, hi), "firsts": firsts, "lasts": lasts}
     if len(_ends_seen) > 64:
         _ends_seen.pop(next(iter(_ends_seen)))
     return out

@@ -497,6 +497,22 @@ def test_calls_are_hipgraph_capturable(geot, oracle):
         assert torch.allclose(out2, ref2, rtol=1e-5, atol=1e-4)
 
 
+def test_inference_mode_and_no_grad(geot, oracle):
+    rng = np.random.default_rng(50)
+    index_h = sorted_index(rng, 3000, 200)
+    src_h = rng.random((3000, 16), dtype=np.float32)
+    hi = oracle.index_scatter(index_h, src_h, acc64=True)
+    with torch.inference_mode():
+        index, src = dev(index_h), dev(src_h)                       # inference tensors: no version counter
+        for _ in range(3):
+            assert_close_to_oracle(geot.index_scatter(0, src, index), hi, hi, "inference_mode")
+        x = torch.rand(200, 16, device="cuda")
+        si = torch.randint(0, 200, (3000,), device="cuda")
+        assert geot.gather_scatter(si, index, x).shape == (200, 16)
+    with torch.no_grad():
+        assert_close_to_oracle(geot.index_scatter(0, dev(src_h), dev(index_h)), hi, hi, "no_grad")
+
+
 def test_out_rows_larger_than_last_key(geot):
     """C ABI: out_rows may exceed index[-1]+1; the extra rows are zero-filled (small and large tails)."""
     from geot_amd import hip
