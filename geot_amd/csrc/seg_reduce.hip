@@ -1295,17 +1295,44 @@ const char *geot_last_error(void) { return g_err.c_str(); }
 
 const char *geot_build_info(void) { return "libgeot_hip gfx950 (CDNA4) built " __DATE__ " " __TIME__; }
 
+// exact need of every plan the launcher can pick for these sizes (storage alignment unknown here:
+// both vector widths are priced), so the answer is tight: cfg2 needs ~11 MB, not a 64-edge-tile bound
+static size_t plan_bytes(int64_t nnz, int64_t feat, int64_t vec_unit, int64_t out_rows, int tsize, bool gather,
+                         int hw) {
+  size_t best = 0;
+  for (int aligned = 0; aligned < 2; ++aligned)
+    for (int atomic_flush = 0; atomic_flush < (gather ? 1 : 2); ++atomic_flush) {
+      const Plan P = make_plan(nnz, feat, vec_unit, out_rows, tsize, aligned != 0, gather, hw, atomic_flush != 0);
+      if (P.total > best) best = P.total;
+    }
+  return best;
+}
+
+static int storage_size(int dtype) { return dtype == GEOT_F64 ? 8 : (dtype == GEOT_F32 ? 4 : 2); }
+
 size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype) {
-  const int tsize = dtype == GEOT_F64 ? 8 : 4; // accumulator size (fp32 for the 16-bit types)
+  const int tsize = storage_size(dtype);
   if (nnz < 0) nnz = 0;
   if (feat < 1) feat = 1;
   if (out_rows < 0) out_rows = 0;
-  // upper bound over every plan the launcher can pick for these sizes: the smallest tile is
-  // 4 lane groups (64 lanes per row) x 16 edges
-  const size_t nt = (size_t)(nnz / 64 + 1);
-  return kCtrlBytes + up256(nt * sizeof(int64_t)) + up256(nt * 2 * sizeof(int64_t)) +
-         up256(nt * 2 * (size_t)feat * tsize) +
-         up256((size_t)(out_rows / kGapInline + 2) * 16);
+  size_t need = plan_bytes(nnz, feat, feat, out_rows, tsize, false, 0);          // index_scatter (+ unsorted)
+  const size_t g = plan_bytes(nnz, feat, feat, out_rows, tsize, true, 1);        // gather_scatter / gws
+  if (g > need) need = g;
+  if (feat <= kNarrowMaxF) {                                                      // seg_narrow_kernel tiles
+    const size_t nt = (size_t)(nnz / (kThreads * 4) + 1);
+    const size_t nb = kCtrlBytes + up256(nt * 8) + up256(nt * 16) + up256(nt * 2 * (size_t)feat * 4) +
+                      up256((size_t)(out_rows / kGapInline + 2) * 16);
+    if (nb > need) need = nb;
+  }
+  return need;
+}
+
+size_t geot_mh_workspace_bytes(int64_t nnz, int64_t heads, int64_t feat, int64_t out_rows, int dtype) {
+  if (nnz < 0) nnz = 0;
+  if (heads < 1) heads = 1;
+  if (feat < 1) feat = 1;
+  if (out_rows < 0) out_rows = 0;
+  return plan_bytes(nnz, heads * feat, feat, out_rows, storage_size(dtype), true, (int)heads);
 }
 
 int geot_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {

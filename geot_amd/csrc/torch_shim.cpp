@@ -146,7 +146,7 @@ at::Tensor mh_spmm_impl(at::Tensor si, at::Tensor di, at::Tensor weight, at::Ten
   si = si.contiguous(); di = di.contiguous(); weight = weight.contiguous(); src = src.contiguous();
   at::Tensor out = at::empty({rows, src.size(1), src.size(2)}, src.options());
   const int dt = dtype_code(src, "mh_spmm_sorted");
-  auto &ws = workspace(src, geot_workspace_bytes(nnz, src.size(1) * src.size(2), rows, dt));
+  auto &ws = workspace(src, geot_mh_workspace_bytes(nnz, src.size(1), src.size(2), rows, dt));
   int rc = geot_mh_spmm(si.data_ptr<int64_t>(), di.data_ptr<int64_t>(), weight.data_ptr(), src.data_ptr(), out.data_ptr(),
                         nnz, src.size(1), src.size(2), src.size(0), rows, layout, dt, ws.data_ptr(), ws.numel(),
                         current_stream(src));

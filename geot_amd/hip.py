@@ -152,7 +152,8 @@ def mh_spmm_out(src_index, dst_index, weight, src, out, head_major: bool) -> tor
         raise RuntimeError(f"expected weight of dtype {src.dtype} but found {weight.dtype}")
     nnz, heads, feat, rows = dst_index.numel(), src.shape[1], src.shape[2], out.shape[0]
     with torch.cuda.device(dev):
-        ws, wsp, wsn = _ws_args(L, dev, nnz, heads * feat, rows, dt)
+        ws = workspace(dev, int(L.geot_mh_workspace_bytes(nnz, heads, feat, rows, dt)))
+        wsp, wsn = ws.data_ptr(), ws.numel()
         rc = L.geot_mh_spmm(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
                             weight.data_ptr(), src.data_ptr(), out.data_ptr(), nnz, heads, feat, src.shape[0],
                             rows, _lib.GEOT_W_HEAD_MAJOR if head_major else _lib.GEOT_W_EDGE_MAJOR, dt,

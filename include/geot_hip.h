@@ -75,6 +75,8 @@ const char *geot_build_info(void); /* "gfx950 <date> ..." */
 /* Scratch needed by any of the segment-reduction calls below for an edge list of `nnz`
  * edges, `feat` values per output row (H*F for mh_spmm) and `out_rows` output rows. */
 size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype);
+/* geot_mh_spmm stages heads weights per edge in LDS, so its tiles (and scratch) depend on `heads` */
+size_t geot_mh_workspace_bytes(int64_t nnz, int64_t heads, int64_t feat, int64_t out_rows, int dtype);
 
 /* Zero the control words of a freshly allocated workspace (asynchronous on `stream`). */
 int geot_workspace_init(void *workspace, size_t workspace_bytes, void *stream);

@@ -45,6 +45,8 @@ def test_workspace_bytes_is_monotonic_upper_bound():
     c = L.geot_workspace_bytes(10_000_000, 64, 1_000_000, _lib.GEOT_F64)
     assert 0 < a < b and a < c
     assert L.geot_workspace_bytes(0, 1, 0, _lib.GEOT_F32) >= 256
+    assert a < 32 << 20                                   # tight: the graded config needs ~11 MB of scratch
+    assert L.geot_mh_workspace_bytes(1_000_000, 64, 32, 10_000, _lib.GEOT_F32) > L.geot_mh_workspace_bytes(1_000_000, 4, 32, 10_000, _lib.GEOT_F32) // 8
 
 
 def test_schemas_match_reference_dispatcher():

@@ -118,7 +118,7 @@ static void run_case(const Case &c, const std::vector<int64_t> &dst_index, uint6
   DBuf<int64_t> d_di(dst_index), d_si(sidx);
   DBuf<float> d_src(src), d_w(w), d_dst((size_t)K * F);
   CK(hipMemset(d_dst.p, 0xFF, std::max<size_t>((size_t)K * F * 4, 4))); // poison: NaN pattern
-  const size_t wsb = geot_workspace_bytes(nnz, F, K, GEOT_F32);
+  const size_t wsb = c.mode >= 3 ? geot_mh_workspace_bytes(nnz, c.H, c.F, K, GEOT_F32) : geot_workspace_bytes(nnz, F, K, GEOT_F32);
   DBuf<char> ws(wsb);
   CK(hipMemset(ws.p, 0xFF, wsb)); // poison everything, then zero only the control words
   geot_workspace_init(ws.p, wsb, nullptr);
