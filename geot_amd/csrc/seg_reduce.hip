@@ -63,6 +63,7 @@ struct SegParams {
   uint32_t rowbytes;        // F * sizeof(T)
   int lpr_log2;             // lanes per row, log2
   int cg;                   // edges per lane-group sub-chunk (multiple of 16)
+  int xcd_swizzle;          // gather modes: contiguous tile ranges per XCD
 };
 
 // Storage types: float, double, and the 16-bit types with fp32 accumulation (the reference's CPU path
@@ -187,7 +188,16 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int64_t tile = blockIdx.x;
+  // Gather modes: blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so give
+  // every XCD a CONTIGUOUS range of tiles - neighbouring dst rows of a graph with locality gather
+  // overlapping src rows, which then hit in that XCD's L2.  Pure placement: any mapping is correct.
+  int64_t tile = blockIdx.x;
+  if constexpr (GATHER) {
+    if (p.xcd_swizzle) {
+      const int64_t nb = gridDim.x, per = nb / 8;
+      if (tile < per * 8) tile = (tile % 8) * per + tile / 8; // bijective on [0, 8*per); the tail keeps its id
+    }
+  }
   const int64_t ts = tile * (int64_t)te;
   const int64_t rem = p.nnz - ts;
   const int n = rem < (int64_t)te ? (int)rem : te; // valid edges in this tile, >= 1
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if (cur > kprev + 1) gapfill(kprev + 1, cur);
     // rows behind the last key (a caller may ask for more rows than index[-1]+1, e.g. the
     // backward pass wants src.shape[0] rows): zero-filled by the last tile
-    if (tile == (int64_t)gridDim.x - 1 && g == 0) gapfill(keysL[n] + 1, K);
+    if (tile == (int64_t)gridDim.x - 1 && g == 0) gapfill(keysL[n] + 1, K); // (tile is the remapped id)
   }
   if constexpr (GATHER) load_batch(0);
 
@@ -891,6 +901,7 @@ struct Tune {
 };
 Tune g_tune;
 int g_unroll = 0; // 0 = rule, 8 / 16 = forced
+int g_xcd = 1;    // XCD-aware tile mapping for the gather modes
 int g_narrow = 1; // lane-per-edge kernel for F <= 8 fp32 (0 = use the lane-group kernel)
 
 struct Prof {
@@ -1119,6 +1130,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.rowbytes = (uint32_t)(F * (int64_t)sizeof(T));
   p.lpr_log2 = P.lpr_log2;
   p.cg = P.cg;
+  p.xcd_swizzle = g_xcd;
 
   // non-temporal policy: the streamed operand of index_scatter is read exactly once -> nt loads
   // (measured +13 % with the store mix of this op) and nt dst stores (a further ~5 %);
@@ -1492,6 +1504,7 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
 void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
+  if (name && std::string(name) == "xcd") g_xcd = value;
 }
 
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {

@@ -288,6 +288,25 @@ def test_gather_ops_random_graphs(geot, oracle, nodes, nnz, F):
         assert_close_to_oracle(geot.mh_spmm(dev(si), dev(di), dev(np.ascontiguousarray(wh.T)), dev(s3)), hi, hi, "mh^T")
 
 
+@pytest.mark.parametrize("xcd", [1, 0])
+def test_gather_ops_under_both_tile_mappings(geot, oracle, xcd):
+    """The XCD-aware block->tile remap of the gather modes is pure placement: results identical either way
+    (tile counts that are and are not multiples of 8, partial last tile, hubs)."""
+    from geot_amd import hip
+    hip.set_option("xcd", xcd)
+    try:
+        rng = np.random.default_rng(60)
+        for nodes, nnz, F in ((4000, 70_000, 32), (900, 8192 + 5, 64), (20_000, 1024 * 8, 16), (50, 30_000, 128)):
+            si = rng.integers(0, nodes, nnz).astype(np.int64)
+            di = powerlaw_index(nnz, nodes, nodes)
+            w = rng.random(nnz, dtype=np.float32)
+            src = rng.random((nodes, F), dtype=np.float32)
+            hi = oracle.gather_weight_scatter(si, di, w, src, acc64=True)
+            assert_close_to_oracle(geot.gather_weight_scatter(dev(si), dev(di), dev(w), dev(src)), hi, hi, f"xcd={xcd}")
+    finally:
+        hip.set_option("xcd", 1)
+
+
 def test_sddmm_and_autograd_against_golden(geot, oracle):
     g = load_golden("pyref_autograd.npz")["pyref_autograd"]
     si, di = dev(g["src_index"]), dev(g["dst_index"])

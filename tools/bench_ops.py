@@ -66,6 +66,17 @@ def main():
         tt = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
         print(f"   gws nt policy {nt}: {tt:.3f} ms")
     hip.tune()
+    # graph WITH locality: sources within +-2000 rows of the destination (what a reordered real graph looks like)
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(99)
+    si_loc = (di + torch.randint(-2000, 2001, (nnz,), device=dev, generator=g2)).clamp_(0, nodes - 1)
+    for xcd in (0, 1, 0, 1):
+        hip.set_option("xcd", xcd)
+        tl = timeit(lambda: hip.gather_weight_scatter_out(si_loc, di, w, x, out), max(3, args.iters // 2))
+        tr = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
+        print(f"   gws xcd_swizzle={xcd}: local graph {tl:.3f} ms ({nnz / tl / 1e6:.1f} Gedge/s) | random graph {tr:.3f} ms")
+    hip.set_option("xcd", 1)
+    del si_loc
     t = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), args.iters)
     print(f"cfg3 gws   nodes={nodes} nnz={nnz} F={F}: {t:.3f} ms  {nnz / t / 1e6:.2f} Gedge/s  "
           f"compulsory {comp / 1e9:.2f} GB -> {comp / t / 1e9:.2f} TB/s ({comp / t / 1e9 / 8 * 100:.1f}% of 8 TB/s)")
