@@ -799,33 +799,60 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
 }
 
 // out[e] = <m1[d[e]], m2[s[e]]>; one lane group of LPR lanes per edge, xor-shuffle reduce.
+// Every block owns a CONTIGUOUS chunk of edges (dst-sorted edges share their m1 row, neighbours share
+// m2 rows on graphs with locality) and chunks are handed to the XCDs in contiguous ranges (see the
+// gather modes of seg_tile_kernel): both operands then hit in the XCD's L2 instead of 8 L2s.
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_index,
                                                              const int64_t *dst_index,
                                                              const T *m1, const T *m2, T *out,
                                                              int64_t nnz, int64_t F,
                                                              int64_t rows1, int64_t rows2,
-                                                             int lpr_log2) {
+                                                             int lpr_log2, int64_t chunk, int xcd_swizzle) {
   const int lpr = 1 << lpr_log2;
   const int ng = kThreads >> lpr_log2;
   const int g = threadIdx.x >> lpr_log2;
   const int c = threadIdx.x & (lpr - 1);
-  for (int64_t e = (int64_t)blockIdx.x * ng + g; e < nnz; e += (int64_t)gridDim.x * ng) {
-    using A = typename AccOf<T>::type;
-    const int64_t r1 = dst_index[e], r2 = src_index[e];
-    A s = A(0);
-    if ((uint64_t)r1 < (uint64_t)rows1 && (uint64_t)r2 < (uint64_t)rows2) {
-      const T *a = m1 + r1 * F, *b = m2 + r2 * F;
-      for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
-        A x[VEC], y[VEC];
-        load_vec<T, VEC, false>(a + f, x);
-        load_vec<T, VEC, false>(b + f, y);
+  int64_t blk = blockIdx.x;
+  if (xcd_swizzle) {
+    const int64_t nb = gridDim.x, per = nb / 8;
+    if (blk < per * 8) blk = (blk % 8) * per + blk / 8;
+  }
+  const int64_t e0 = blk * chunk;
+  const int64_t e1 = e0 + chunk < nnz ? e0 + chunk : nnz;
+  using A = typename AccOf<T>::type;
+  constexpr int UE = 4; // edges in flight per lane group: indices first, then all rows, then the dots
+  for (int64_t eb = e0 + (int64_t)g * UE; eb < e1; eb += (int64_t)ng * UE) {
+    int64_t r1[UE], r2[UE];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s += x[i] * y[i];
-      }
+    for (int u = 0; u < UE; ++u) {
+      const int64_t e = eb + u < e1 ? eb + u : e1 - 1;
+      r1[u] = dst_index[e];
+      r2[u] = src_index[e];
+      if ((uint64_t)r1[u] >= (uint64_t)rows1 || (uint64_t)r2[u] >= (uint64_t)rows2) r1[u] = -1;
     }
-    for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (c == 0) out[e] = (T)s;
+    A s[UE];
+#pragma unroll
+    for (int u = 0; u < UE; ++u) s[u] = A(0);
+    for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
+      A x[UE][VEC], y[UE][VEC];
+#pragma unroll
+      for (int u = 0; u < UE; ++u) {
+        const int64_t a1 = r1[u] < 0 ? 0 : r1[u], a2 = r1[u] < 0 ? 0 : r2[u];
+        load_vec<T, VEC, false>(m1 + a1 * F + f, x[u]);
+        load_vec<T, VEC, false>(m2 + a2 * F + f, y[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UE; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[u] += x[u][i] * y[u][i];
+    }
+#pragma unroll
+    for (int u = 0; u < UE; ++u) {
+      A v = r1[u] < 0 ? A(0) : s[u];
+      for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (c == 0 && eb + u < e1) out[eb + u] = (T)v;
+    }
   }
 }
 
@@ -1257,17 +1284,17 @@ int run_sddmm(const int64_t *si, const int64_t *di, const void *m1, const void *
   int l = ceil_log2((F + vec - 1) / vec);
   if (l > 6) l = 6;
   const int ng = kThreads >> l;
-  int64_t blocks = (nnz + ng - 1) / ng;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  int64_t chunk = (int64_t)ng * 64;                       // 64 edges per lane group and block
+  int64_t blocks = (nnz + chunk - 1) / chunk;
   const T *a = static_cast<const T *>(m1), *b = static_cast<const T *>(m2);
   T *o = static_cast<T *>(out);
   constexpr int MAXV = 16 / (int)sizeof(T);
   if (vec == MAXV)
-    hipLaunchKernelGGL((sddmm_coo_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l);
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd);
   else if (vec == 2 && MAXV >= 4)
-    hipLaunchKernelGGL((sddmm_coo_kernel<T, 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l);
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd);
   else
-    hipLaunchKernelGGL((sddmm_coo_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l);
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd);
   HIP_TRY(hipGetLastError());
   return GEOT_OK;
 }

@@ -56,6 +56,14 @@ def _default_local_op(index_local: torch.Tensor, src_local: torch.Tensor, rows: 
 # the keys travel with every exchange and are verified on the host after the work has been queued
 # (the wait overlaps the kernels); a mismatch redoes the ownership step with the true keys.
 _ends_seen: dict = {}
+_tls = __import__("threading").local()
+
+
+def _pinned_slot():
+    slot = getattr(_tls, "slot", None)
+    if slot is None:
+        slot = _tls.slot = (torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+    return slot
 
 
 def _ident(index: torch.Tensor, world: int, rank: int, key_offset):
@@ -150,9 +158,8 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     else:
         lo, hi = guess["local_ends"]
         if dev.type == "cuda":
-            host = torch.empty(2, dtype=torch.int64).pin_memory()
+            host, ev = _pinned_slot()
             host.copy_(ends_dev, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             local = run_local(lo, hi)                               # queued behind the copy
             ev.synchronize()
@@ -176,9 +183,8 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         return local, 0
 
     # ---- 2. the one collective: [first_key, last_key, first_row(F)] of every rank ------------------------
-    rec = torch.empty(2 + F, dtype=torch.float64, device=dev)
-    rec[0], rec[1] = first_key, last_key
-    rec[2:] = head.reshape(-1).to(torch.float64)
+    # built from device tensors only (no scalar host->device writes on the step path)
+    rec = torch.cat([ends_dev.to(torch.float64) + float(key_offset or 0), head.reshape(-1).to(torch.float64)])
     # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or two test
     # ranks sharing one GPU) stages the few hundred bytes through the host
     via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"

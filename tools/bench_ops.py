@@ -98,6 +98,14 @@ def main():
     # backward pieces (row f1): SDDMM (d/dweight of gws) and the row gather (backward of index_scatter)
     g = torch.rand(nodes, F, device=dev)
     dw = torch.empty(nnz, device=dev)
+    si_loc = (di + torch.randint(-2000, 2001, (nnz,), device=dev)).clamp_(0, nodes - 1)
+    for xcd in (0, 1):
+        hip.set_option("xcd", xcd)
+        ta = timeit(lambda: hip.sddmm_coo_out(si_loc, di, g, x, dw), 3)
+        tb = timeit(lambda: hip.sddmm_coo_out(si, di, g, x, dw), 3)
+        print(f"   sddmm xcd_swizzle={xcd}: local graph {ta:.3f} ms | random graph {tb:.3f} ms")
+    hip.set_option("xcd", 1)
+    del si_loc
     t5 = timeit(lambda: hip.sddmm_coo_out(si, di, g, x, dw), max(3, args.iters // 2))
     gathered = nnz * 2 * 4 * F
     print(f"cfg3 sddmm_coo F={F}: {t5:.3f} ms  {nnz / t5 / 1e6:.2f} Gedge/s  gathered {gathered / 1e9:.1f} GB -> {gathered / t5 / 1e9:.2f} TB/s")
