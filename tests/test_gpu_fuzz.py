@@ -1,0 +1,94 @@
+"""Seeded fuzzing of the HIP path against the oracle: random sizes, key distributions (runs, gaps, hubs,
+leading empty rows), feature widths, reductions and ops.  Deterministic (fixed seeds), a few seconds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def random_index(rng, nnz):
+    kind = rng.integers(0, 6)
+    if kind == 0:                                   # uniform keys
+        keys = int(rng.integers(1, max(2, nnz * 2)))
+        idx = np.sort(rng.integers(0, keys, nnz))
+    elif kind == 1:                                 # long runs
+        keys = int(rng.integers(1, max(2, nnz // 50 + 2)))
+        idx = np.sort(rng.integers(0, keys, nnz))
+    elif kind == 2:                                 # sparse keys with gaps of random size
+        idx = np.cumsum(rng.integers(0, int(rng.choice([2, 5, 40, 300])), nnz))
+    elif kind == 3:                                 # one hub + noise
+        hub = int(rng.integers(0, 20))
+        idx = np.sort(np.concatenate([np.full(nnz - nnz // 4, hub), rng.integers(0, 40, nnz // 4)]))
+    elif kind == 4:                                 # unit segments with an offset
+        idx = np.arange(nnz) + int(rng.integers(0, 100))
+    else:                                           # runs whose lengths are multiples of 64 / 16 (step boundaries)
+        reps = int(rng.choice([16, 64, 128]))
+        idx = np.repeat(np.arange(nnz // reps + 1), reps)[:nnz]
+    return idx.astype(np.int64)
+
+
+def close(got, hi, mag, tol=1e-5):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    return got.shape == hi.shape and np.all(np.abs(got - hi) <= tol * mag + 1e-30) and np.all(got[mag == 0] == 0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_index_scatter(oracle, seed):
+    import geot_amd as geot
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(40):
+        nnz = int(rng.choice([1, 2, 3, 63, 64, 65, 500, 1023, 1024, 1025, 4096, 20_000, int(rng.integers(1, 60_000))]))
+        F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 24, 32, 33, 64, 96, 128, 130, 256, int(rng.integers(1, 300))]))
+        index = random_index(rng, nnz)
+        src = rng.standard_normal((nnz, F)).astype(np.float32)
+        red = str(rng.choice(["sum", "sum", "sum", "mean", "min", "max"]))
+        t_idx, t_src = torch.from_numpy(index).cuda(), torch.from_numpy(src).cuda()
+        out = geot.index_scatter(0, t_src, t_idx, red, True)
+        what = f"seed={seed} nnz={nnz} F={F} red={red} keys={index[-1] + 1}"
+        if red == "sum":
+            hi = oracle.index_scatter(index, src, acc64=True)
+            mag = oracle.index_scatter(index, np.abs(src), acc64=True)
+            assert close(out, hi, mag), what
+            assert close(geot.index_scatter(0, t_src, t_idx, "sum", False), hi, mag), what + " (sorted=False)"
+        else:
+            ref = oracle.index_scatter_3pass(index, src, reduce=red)
+            got = out.cpu().numpy()
+            assert got.shape == ref.shape, what
+            if red == "mean":
+                assert np.allclose(got, ref, rtol=1e-4, atol=1e-5), what
+            else:
+                assert np.array_equal(got, ref), what
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_gather_ops(oracle, seed):
+    import geot_amd as geot
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(25):
+        nnz = int(rng.choice([1, 64, 65, 1000, 1024, 5000, int(rng.integers(1, 40_000))]))
+        F = int(rng.choice([1, 3, 4, 8, 16, 32, 48, 64, 100, 128, int(rng.integers(1, 200))]))
+        di = random_index(rng, nnz)
+        nodes = int(di[-1]) + 1 + int(rng.integers(0, 50))
+        si = rng.integers(0, nodes, nnz).astype(np.int64)
+        w = rng.random(nnz, dtype=np.float32)
+        x = rng.standard_normal((nodes, F)).astype(np.float32)
+        t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+        hi = oracle.gather_weight_scatter(si, di, w, x, acc64=True)
+        mag = oracle.gather_weight_scatter(si, di, w, np.abs(x), acc64=True)
+        assert close(geot.gather_weight_scatter(t(si), t(di), t(w), t(x)), hi, mag), (seed, nnz, F)
+        hi = oracle.gather_scatter(si, di, x, acc64=True)
+        mag = oracle.gather_scatter(si, di, np.abs(x), acc64=True)
+        assert close(geot.gather_scatter(t(si), t(di), t(x)), hi, mag), (seed, nnz, F)
+        H = int(rng.choice([1, 2, 3, 4, 8]))
+        Fh = int(rng.choice([1, 2, 4, 6, 16, 32]))
+        x3 = rng.standard_normal((nodes, H, Fh)).astype(np.float32)
+        wh = rng.random((nnz, H), dtype=np.float32)
+        hi = oracle.mh_spmm(si, di, wh, x3, acc64=True)
+        mag = oracle.mh_spmm(si, di, wh, np.abs(x3), acc64=True)
+        assert close(geot.mh_spmm(t(si), t(di), t(wh), t(x3)), hi, mag), (seed, nnz, H, Fh)
+        if nnz != H:   # weight.size(0)==nnz picks the [nnz,H] layout first, as in the reference
+            assert close(geot.mh_spmm(t(si), t(di), t(np.ascontiguousarray(wh.T)), t(x3)), hi, mag), (seed, nnz, H, Fh, "T")
+        sd = geot.sddmm_coo_impl(t(si), t(di), t(x[: int(di[-1]) + 1 if False else nodes]), t(x))
+        ref = oracle.sddmm_coo(si, di, x, x, acc64=True)
+        assert np.allclose(sd.cpu().numpy(), ref, rtol=1e-4, atol=1e-4), (seed, nnz, F, "sddmm")
