@@ -64,6 +64,7 @@ struct SegParams {
   int lpr_log2;             // lanes per row, log2
   int cg;                   // edges per lane-group sub-chunk (multiple of 16)
   int xcd_swizzle;          // gather modes: contiguous tile ranges per XCD
+  int nt_keys;              // non-temporal key loads (with nt row loads)
 };
 
 // Storage types: float, double, and the 16-bit types with fp32 accumulation (the reference's CPU path
@@ -241,7 +242,11 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   for (int i0 = (tid >> 6) * 64; i0 < te; i0 += kThreads) {
     const int i = i0 + lane;
     const int64_t ge = ts + i;
-    const int64_t k = ge < p.nnz ? p.dst_index[ge] : kNoKey;
+    int64_t k = kNoKey;
+    if (ge < p.nnz) {
+      if (NTL && p.nt_keys) k = __builtin_nontemporal_load(p.dst_index + ge); // keys are read once as well
+      else k = p.dst_index[ge];
+    }
     int64_t kp = __shfl_up(k, 1, 64);
     if (lane == 0) kp = ge > 0 ? (ge - 1 < p.nnz ? p.dst_index[ge - 1] : kNoKey) : -1;
     keysL[1 + i] = k;
@@ -929,6 +934,7 @@ struct Tune {
 Tune g_tune;
 int g_unroll = 0; // 0 = rule, 8 / 16 = forced
 int g_xcd = 1;    // XCD-aware tile mapping for the gather modes
+int g_nt_keys = 0; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
 int g_narrow = 1; // lane-per-edge kernel for F <= 8 fp32 (0 = use the lane-group kernel)
 
 struct Prof {
@@ -1158,6 +1164,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.lpr_log2 = P.lpr_log2;
   p.cg = P.cg;
   p.xcd_swizzle = g_xcd;
+  p.nt_keys = g_nt_keys;
 
   // non-temporal policy: the streamed operand of index_scatter is read exactly once -> nt loads
   // (measured +13 % with the store mix of this op) and nt dst stores (a further ~5 %);
@@ -1532,6 +1539,7 @@ void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "xcd") g_xcd = value;
+  if (name && std::string(name) == "nt_keys") g_nt_keys = value;
 }
 
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {

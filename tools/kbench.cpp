@@ -303,6 +303,7 @@ static int cmd_sweep(int64_t nnz, int64_t K, int64_t F, int iters, int one_cg = 
   for (int cg : {64, 128, 256}) vs.push_back({cg, 1, 1, -1});
   vs.push_back({32, 4, 1, 5});
   if (one_cg >= 0) { vs.clear(); vs.push_back({one_cg, one_vec, one_nt, -1}); }
+  if (getenv("KB_NTKEYS")) { geot_set_option("nt_keys", atoi(getenv("KB_NTKEYS"))); printf("nt_keys=%s ", getenv("KB_NTKEYS")); }
   if (getenv("KB_NARROW")) { geot_set_option("narrow", atoi(getenv("KB_NARROW"))); printf("narrow=%s ", getenv("KB_NARROW")); }
   if (one_cg >= 0 && getenv("KB_UNROLL")) { geot_set_option("unroll", atoi(getenv("KB_UNROLL"))); printf("unroll=%s ", getenv("KB_UNROLL")); }
   for (const V &v : vs) {
