@@ -139,6 +139,19 @@ def _with_row_rule(index: torch.Tensor, launch):
     return out
 
 
+# GEOT_CHECK_SORTED=1: validate the "ascending index" precondition of the sorted kernels on every call
+# (one extra pass over the index + a host sync - a debugging aid, off by default).  The reference's sorted
+# kernels flush with atomics, so they still add up correctly on an unsorted index as long as index[-1] is
+# the maximum; the atomic-free kernels here do not.
+_CHECK_SORTED = os.environ.get("GEOT_CHECK_SORTED", "0") == "1"
+
+
+def _assert_sorted(index: torch.Tensor, name: str) -> None:
+    if _CHECK_SORTED and index.numel() > 1 and not bool((index[1:] >= index[:-1]).all()):
+        raise RuntimeError(f"{name} is not sorted in ascending order (required when sorted=True; "
+                           "pass sorted=False to geot.index_scatter for an unsorted index)")
+
+
 def _reject_cpu(name: str):
     def impl(*args, **kwargs):
         raise RuntimeError(
@@ -165,6 +178,8 @@ def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce:
     moved = src if dim == 0 else src.movedim(dim, 0)
     moved = moved.contiguous()
     index = index.contiguous()
+    if sorted:
+        _assert_sorted(index, "index")
 
     def launch(rows: int) -> torch.Tensor:
         out_shape = list(moved.shape)
@@ -179,6 +194,7 @@ def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce:
 def _check_gather(src_index, dst_index, src, ndim: int) -> None:
     if not (src_index.dim() == dst_index.dim() == 1):
         raise RuntimeError("src_index and dst_index must be 1 dimensional")
+    _assert_sorted(dst_index, "dst_index")
     if src.dim() != ndim:
         raise RuntimeError(f"src must be {ndim} dimensional")
     if src_index.size(0) != dst_index.size(0):

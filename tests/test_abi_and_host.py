@@ -115,6 +115,17 @@ def test_argument_checks_carry_the_reference_texts():
         ops._index_scatter_gpu(0, idx[:0], src[:0], "sum", True)
 
 
+def test_optional_sortedness_check(monkeypatch):
+    monkeypatch.setattr(ops, "_CHECK_SORTED", True)
+    src = torch.rand(4, 2)
+    with pytest.raises(RuntimeError, match="index is not sorted in ascending order"):
+        ops._index_scatter_gpu(0, torch.tensor([0, 2, 1, 2]), src, "sum", True)
+    with pytest.raises(RuntimeError, match="dst_index is not sorted"):
+        ops._gather_scatter_gpu(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 2, 1, 2]), src)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # sorted=False skips the check and reaches the doorway
+        ops._index_scatter_gpu(0, torch.tensor([0, 2, 1, 2]), src, "sum", False)
+
+
 def test_cpu_tensors_fail_loudly_no_fallback():
     src = torch.rand(6, 4)
     idx = torch.tensor([0, 0, 1, 1, 2, 2])
