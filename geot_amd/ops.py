@@ -379,10 +379,47 @@ def _gs_setup_context(ctx, inputs, output):
     ctx.src_rows = src.shape[0]
 
 
-def _sorted_by_source(src_index, dst_index):
-    # geot/gather_scatter.py:30-33: re-sort the edge list by source for the transposed product
+# The backward needs the edge list sorted by SOURCE (the transposed graph).  The reference re-sorts on
+# every backward call (geot/gather_scatter.py:30-33); GNN graphs are static, so the permutation is kept
+# per (src_index, dst_index) identity+version.  It lives behind an opaque dispatcher op so that
+# torch.compile / AOT autograd never trace into the cache.
+_lib_def.define("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)")
+_transposed: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_TRANSPOSED_MAX = int(os.environ.get("GEOT_TRANSPOSE_CACHE", "4"))   # entries; each holds 3 int64 tensors of nnz
+
+
+def _transpose_edges_gpu(src_index, dst_index):
+    key = None
+    if _TRANSPOSED_MAX > 0:
+        try:
+            key = (src_index.device.index, src_index.data_ptr(), dst_index.data_ptr(), src_index.numel(),
+                   src_index._version, dst_index._version)
+        except RuntimeError:          # inference tensors: no version counter
+            key = None
+    if key is not None and key in _transposed:
+        _transposed.move_to_end(key)
+        return _transposed[key]
     _, perm = torch.sort(src_index, stable=True)
-    return perm, src_index[perm], dst_index[perm]
+    res = (perm, src_index[perm], dst_index[perm])
+    if key is not None:
+        _transposed[key] = res
+        while len(_transposed) > _TRANSPOSED_MAX:
+            _transposed.popitem(last=False)
+    return res
+
+
+_lib_def.impl("transpose_edges", _transpose_edges_gpu, "CUDA")
+_lib_def.impl("transpose_edges", _reject_cpu("transpose_edges"), "CPU")
+
+
+@torch.library.register_fake("geot::transpose_edges")
+def _(src_index, dst_index):
+    return src_index.new_empty(src_index.shape), src_index.new_empty(src_index.shape), dst_index.new_empty(dst_index.shape)
+
+
+def _sorted_by_source(src_index, dst_index):
+    """(perm, edges' sources ascending, their destinations): the transposed edge list."""
+    return torch.ops.geot.transpose_edges(src_index, dst_index)
 
 
 def _gs_backward(ctx, grad):

@@ -95,6 +95,25 @@ def main():
     A32 = torch.sparse_csr_tensor(crow.int(), si.int(), w, size=(nodes, nodes))
     t4 = timeit(lambda: torch.sparse.mm(A32, x), max(3, args.iters // 2))
     print(f"cfg3 rocSPARSE CSR SpMM, int32 indices:    {t4:.3f} ms  -> ours is {t4 / t:.2f}x faster")
+    # training step: forward + backward of gws through autograd (transposed edge list cached vs re-sorted)
+    import geot_amd.ops as gops
+    xg = x.clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+
+    def train_step():
+        y = geot_amd.gather_weight_scatter(si, di, wg, xg)
+        y.backward(torch.ones_like(y))
+        xg.grad = None
+        wg.grad = None
+
+    t_cached = timeit(train_step, 3)
+    keep = gops._TRANSPOSED_MAX
+    gops._TRANSPOSED_MAX = 0
+    gops._transposed.clear()
+    t_resort = timeit(train_step, 3)
+    gops._TRANSPOSED_MAX = keep
+    print(f"cfg3 gws fwd+bwd (autograd): {t_cached:.2f} ms with the cached transposed edge list, {t_resort:.2f} ms re-sorting every call")
+    del xg, wg
     # backward pieces (row f1): SDDMM (d/dweight of gws) and the row gather (backward of index_scatter)
     g = torch.rand(nodes, F, device=dev)
     dw = torch.empty(nnz, device=dev)
