@@ -346,6 +346,28 @@ def test_index_scatter_backward_is_a_row_gather(geot):
         geot.index_scatter(0, src, index, "max").sum().backward()
 
 
+def test_backward_reuses_and_invalidates_the_transposed_edge_list(geot):
+    """The source-sorted edge list is remembered per tensor identity+version; an in-place edit (version bump)
+    must produce a fresh one.  Gradients are compared with dense autograd each time."""
+    torch.manual_seed(3)
+    n, nnz, F = 300, 6000, 8
+    di = torch.sort(torch.randint(0, n, (nnz,), device="cuda")).values
+    di[-1] = n - 1
+    si = torch.randint(0, n, (nnz,), device="cuda")
+    w0 = torch.rand(nnz, device="cuda")
+    x0 = torch.rand(n, F, device="cuda")
+    g = torch.rand(n, F, device="cuda")
+    for it in range(4):
+        if it == 2:
+            si[:100] = torch.randint(0, n, (100,), device="cuda")     # in-place edit: bumps si._version
+        x1, w1 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        x2, w2 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        geot.gather_weight_scatter(si, di, w1, x1).backward(g)
+        torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w2[:, None]).backward(g)
+        assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4), it
+        assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-4), it
+
+
 def test_backward_when_last_node_has_no_out_edge(geot):
     """The reference returns max(src_index)+1 grad rows (shape error); here grad has src.shape[0] rows."""
     si = torch.tensor([0, 1, 1, 0], device="cuda")
