@@ -839,12 +839,25 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
     A s[UE];
 #pragma unroll
     for (int u = 0; u < UE; ++u) s[u] = A(0);
+    // dst-sorted edges: the UE edges of a group usually share their m1 row - load it once (wave-uniform
+    // test per group would diverge; a per-group predicate on the load is enough)
+    bool same = true;
+#pragma unroll
+    for (int u = 1; u < UE; ++u) same = same && (r1[u] == r1[0]);
     for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
       A x[UE][VEC], y[UE][VEC];
+      load_vec<T, VEC, false>(m1 + (r1[0] < 0 ? 0 : r1[0]) * F + f, x[0]);
 #pragma unroll
       for (int u = 0; u < UE; ++u) {
         const int64_t a1 = r1[u] < 0 ? 0 : r1[u], a2 = r1[u] < 0 ? 0 : r2[u];
-        load_vec<T, VEC, false>(m1 + a1 * F + f, x[u]);
+        if (u > 0) {
+          if (same) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) x[u][i] = x[0][i];
+          } else {
+            load_vec<T, VEC, false>(m1 + a1 * F + f, x[u]);
+          }
+        }
         load_vec<T, VEC, false>(m2 + a2 * F + f, y[u]);
       }
 #pragma unroll
