@@ -59,9 +59,31 @@ def _stream_handle(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+class _on_device:
+    """Device guard that costs nothing when `dev` is already current (the common case)."""
+    __slots__ = ("dev", "prev")
+
+    def __init__(self, dev: torch.device):
+        self.dev = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def workspace(dev: torch.device, nbytes: int, stream: Optional[int] = None) -> torch.Tensor:
     """Cached scratch for the current stream; zero-initialised once (control words), reused after."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream_handle(dev))
+    stream = _stream_handle(dev) if stream is None else stream
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
@@ -71,11 +93,20 @@ def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
 
 def release_workspaces() -> None:
     _workspaces.clear()
+    _ws_bytes.clear()
 
 
-def _ws_args(L, dev, nnz, feat, rows, dt):
-    nbytes = int(L.geot_workspace_bytes(nnz, feat, rows, dt))
-    ws = workspace(dev, nbytes)
+_ws_bytes: Dict[tuple, int] = {}
+
+
+def _ws_args(L, dev, nnz, feat, rows, dt, stream: Optional[int] = None):
+    key = (nnz, feat, rows, dt)
+    nbytes = _ws_bytes.get(key)
+    if nbytes is None:
+        if len(_ws_bytes) > 256:
+            _ws_bytes.clear()
+        nbytes = _ws_bytes[key] = int(L.geot_workspace_bytes(nnz, feat, rows, dt))
+    ws = workspace(dev, nbytes, stream)
     return ws, ws.data_ptr(), ws.numel()
 
 
@@ -95,7 +126,7 @@ def index_scatter_out(index: torch.Tensor, src: torch.Tensor, out: torch.Tensor,
         nnz = index.numel()
         feat = src.numel() // nnz if nnz else (out.numel() // max(out.shape[0], 1))
         rows = out.shape[0]
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
             rc = L.geot_index_scatter_reduce(_index_ptr(index, "index"), src.data_ptr(), out.data_ptr(), nnz, feat,
                                              rows, dt, _REDUCE_CODES[reduce], wsp, wsn, _stream_handle(dev))
@@ -106,10 +137,11 @@ def index_scatter_out(index: torch.Tensor, src: torch.Tensor, out: torch.Tensor,
     nnz = index.numel()
     feat = src.numel() // nnz if nnz else (out.numel() // max(out.shape[0], 1))
     rows = out.shape[0]
-    with torch.cuda.device(dev):
-        ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
+    with _on_device(dev):
+        st = _stream_handle(dev)
+        ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt, st)
         rc = L.geot_index_scatter(_index_ptr(index, "index"), src.data_ptr(), out.data_ptr(), nnz, feat, rows,
-                                  dt, 1 if sorted else 0, wsp, wsn, _stream_handle(dev))
+                                  dt, 1 if sorted else 0, wsp, wsn, st)
     _lib.check(rc, "geot_index_scatter")
     return out
 
@@ -119,7 +151,7 @@ def gather_scatter_out(src_index, dst_index, src, out) -> torch.Tensor:
     L = _lib.load()
     dt = _dtype_code(src, "gather_scatter_sorted")
     nnz, feat, rows = dst_index.numel(), src.shape[1], out.shape[0]
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
         rc = L.geot_gather_scatter(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
                                    src.data_ptr(), out.data_ptr(), nnz, feat, src.shape[0], rows, dt,
@@ -135,7 +167,7 @@ def gather_weight_scatter_out(src_index, dst_index, weight, src, out) -> torch.T
     if weight.dtype != src.dtype:
         raise RuntimeError(f"expected weight of dtype {src.dtype} but found {weight.dtype}")
     nnz, feat, rows = dst_index.numel(), src.shape[1], out.shape[0]
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
         rc = L.geot_gather_weight_scatter(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
                                           weight.data_ptr(), src.data_ptr(), out.data_ptr(), nnz, feat,
@@ -151,7 +183,7 @@ def mh_spmm_out(src_index, dst_index, weight, src, out, head_major: bool) -> tor
     if weight.dtype != src.dtype:
         raise RuntimeError(f"expected weight of dtype {src.dtype} but found {weight.dtype}")
     nnz, heads, feat, rows = dst_index.numel(), src.shape[1], src.shape[2], out.shape[0]
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ws = workspace(dev, int(L.geot_mh_workspace_bytes(nnz, heads, feat, rows, dt)))
         wsp, wsn = ws.data_ptr(), ws.numel()
         rc = L.geot_mh_spmm(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
@@ -166,7 +198,7 @@ def sddmm_coo_out(src_index, dst_index, mat_1, mat_2, out) -> torch.Tensor:
     dev = _require_gpu(src_index, dst_index, mat_1, mat_2, out)
     L = _lib.load()
     dt = _dtype_code(mat_1, "sddmm_coo")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.geot_sddmm_coo(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
                               mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), dst_index.numel(),
                               mat_1.shape[1], mat_1.shape[0], mat_2.shape[0], dt, _stream_handle(dev))
@@ -180,7 +212,7 @@ def gather_rows_out(index, src, out) -> torch.Tensor:
     dt = _dtype_code(src, "gather_rows")
     nnz = index.numel()
     feat = src.numel() // max(src.shape[0], 1)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.geot_gather_rows(_index_ptr(index, "index"), src.data_ptr(), out.data_ptr(), nnz, feat,
                                 src.shape[0], dt, _stream_handle(dev))
     _lib.check(rc, "geot_gather_rows")
@@ -194,7 +226,7 @@ def csr_gws_out(indptr, indices, weight, src, out) -> torch.Tensor:
     L = _lib.load()
     dt = _dtype_code(src, "csr_gws")
     nrow, nnz, feat, rows = indptr.numel() - 1, indices.numel(), src.shape[1], out.shape[0]
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         nbytes = int(L.geot_csr_workspace_bytes(nnz, feat, rows, dt))
         ws = workspace(dev, nbytes)
         rc = L.geot_csr_gws(_index_ptr(indptr, "indptr"), _index_ptr(indices, "indices"),
@@ -210,7 +242,7 @@ def coo_to_csr_out(coo_row, rowptr, assume_sorted: bool = False) -> torch.Tensor
     L = _lib.load()
     if rowptr.dtype != torch.int32:
         raise RuntimeError("rowptr must be int32")
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = L.geot_coo_to_csr(_index_ptr(coo_row, "coo_row"), coo_row.numel(), rowptr.numel() - 1,
                                rowptr.data_ptr(), 1 if assume_sorted else 0, _stream_handle(dev))
     _lib.check(rc, "geot_coo_to_csr")
