@@ -1108,6 +1108,14 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
       return GEOT_OK;
     }
   }
+  if constexpr (GATHER && WMODE <= 1 && !ATOMIC && sizeof(T) == 4) {
+    if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 0) {   // gather modes, default cache policy
+      const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), true, WMODE);
+      dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, true, WMODE, false, 0, RED_SUM, 16>), grid, dim3(kThreads), L.bytes, st, p);
+      return GEOT_OK;
+    }
+  }
   if (P.vec == MAXV) dispatch_nt<T, MAXV, GATHER, WMODE, ATOMIC>(p, P, st, nt);
   else if (MAXV >= 4 && P.vec == 2) dispatch_nt<T, 2, GATHER, WMODE, ATOMIC>(p, P, st, nt);
   else if (P.vec == 1) dispatch_nt<T, 1, GATHER, WMODE, ATOMIC>(p, P, st, nt);

@@ -61,6 +61,14 @@ def main():
         hip.tune(edges_per_group=cg)
         tt = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
         print(f"   gws tile sweep: edges_per_group={cg}: {tt:.3f} ms")
+    for un in (8, 16, 8, 16):
+        hip.set_option("unroll", un)
+        for cg in (64, 128):
+            hip.tune(edges_per_group=cg)
+            tt = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
+            print(f"   gws unroll={un} edges_per_group={cg}: {tt:.3f} ms")
+    hip.set_option("unroll", 0)
+    hip.tune()
     for nt in (0, 1, 2, 3):
         hip.tune(nontemporal=nt)
         tt = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), max(3, args.iters // 2))
