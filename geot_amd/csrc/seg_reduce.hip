@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       } else {
         const A w = WMODE == 1 ? wL[gs + b + u] : wL[(gs + b + u) * hw + hh];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] += v[u][i] * w;
+        for (int i = 0; i < VEC; ++i) acc[i] = red_op<A, RED>(acc[i], v[u][i] * w);
       }
     }
     b += U;
@@ -1065,15 +1065,24 @@ void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
                      L.bytes, st, p);
 }
 
-// non-sum reductions: index_scatter, sorted, streamed operand -> fixed nt policy (loads + stores)
-template <typename T, int RED>
-int dispatch_reduce(const SegParams &p, const Plan &P, hipStream_t st) {
+// non-sum reductions, sorted index.  index_scatter: streamed operand -> nt loads + stores;
+// gather_scatter / gather_weight_scatter (PyG-style aggr= mean / max / ... over the messages): default policy
+template <typename T, int RED, bool GATHER, int WMODE>
+int dispatch_reduce_mode(const SegParams &p, const Plan &P, hipStream_t st) {
   constexpr int MAXV = 16 / (int)sizeof(T);
-  if (P.vec == MAXV) launch_tile<T, MAXV, false, 0, false, 3, RED>(p, P, st);
-  else if (MAXV >= 4 && P.vec == 2) launch_tile<T, 2, false, 0, false, 3, RED>(p, P, st);
-  else if (P.vec == 1) launch_tile<T, 1, false, 0, false, 3, RED>(p, P, st);
+  constexpr int NTP = GATHER ? 0 : 3;
+  if (P.vec == MAXV) launch_tile<T, MAXV, GATHER, WMODE, false, NTP, RED>(p, P, st);
+  else if (MAXV >= 4 && P.vec == 2) launch_tile<T, 2, GATHER, WMODE, false, NTP, RED>(p, P, st);
+  else if (P.vec == 1) launch_tile<T, 1, GATHER, WMODE, false, NTP, RED>(p, P, st);
   else return fail(GEOT_EINVAL, "internal: bad vector width");
   return GEOT_OK;
+}
+
+template <typename T, int RED>
+int dispatch_reduce(const SegParams &p, const Plan &P, hipStream_t st, int mode) {
+  if (mode == 0) return dispatch_reduce_mode<T, RED, false, 0>(p, P, st);
+  if (mode == 1) return dispatch_reduce_mode<T, RED, true, 0>(p, P, st);
+  return dispatch_reduce_mode<T, RED, true, 1>(p, P, st);
 }
 
 template <typename T>
@@ -1131,8 +1140,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
                    const void *weight, const void *src, void *dst, int64_t nnz, int64_t F,
                    int64_t H, int64_t src_rows, int64_t K, void *ws, size_t ws_bytes,
                    hipStream_t st, int red = RED_SUM) {
-  if (red != RED_SUM && (mode != 0 || !sorted))
-    return fail(GEOT_EUNSUPPORTED, "non-sum reductions: sorted index_scatter only");
+  if (red != RED_SUM && (mode > 2 || !sorted))
+    return fail(GEOT_EUNSUPPORTED, "non-sum reductions: sorted index_scatter / gather_scatter / gather_weight_scatter only");
   if (nnz < 0 || F < 0 || K < 0 || src_rows < 0 || H < 1) return fail(GEOT_EINVAL, "negative size");
   if (K == 0 || F == 0) return GEOT_OK;
   if (!dst || (nnz > 0 && (!dst_index || !src))) return fail(GEOT_EINVAL, "null pointer");
@@ -1239,17 +1248,16 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
           narrow = true;
         }
       }
-      if (!narrow)
-      switch (mode) {
-      case 0:
+      if (!narrow && red != RED_SUM) {
         switch (red) {
-        case RED_MAX: rc = dispatch_reduce<T, RED_MAX>(p, P, st); break;
-        case RED_MEAN: rc = dispatch_reduce<T, RED_MEAN>(p, P, st); break;
-        case RED_MIN: rc = dispatch_reduce<T, RED_MIN>(p, P, st); break;
-        case RED_PROD: rc = dispatch_reduce<T, RED_PROD>(p, P, st); break;
-        default: rc = dispatch_vec<T, false, 0, false>(p, P, st, nt); break;
+        case RED_MAX: rc = dispatch_reduce<T, RED_MAX>(p, P, st, mode); break;
+        case RED_MEAN: rc = dispatch_reduce<T, RED_MEAN>(p, P, st, mode); break;
+        case RED_MIN: rc = dispatch_reduce<T, RED_MIN>(p, P, st, mode); break;
+        default: rc = dispatch_reduce<T, RED_PROD>(p, P, st, mode); break;
         }
-        break;
+      } else if (!narrow)
+      switch (mode) {
+      case 0: rc = dispatch_vec<T, false, 0, false>(p, P, st, nt); break;
       case 1: rc = dispatch_vec<T, true, 0, false>(p, P, st, nt); break;
       case 2: rc = dispatch_vec<T, true, 1, false>(p, P, st, nt); break;
       case 3: rc = dispatch_vec<T, true, 2, false>(p, P, st, nt); break;
@@ -1421,6 +1429,14 @@ int geot_index_scatter_reduce(const int64_t *index, const void *src, void *dst, 
   if (reduce < GEOT_REDUCE_MAX || reduce > GEOT_REDUCE_PROD) return fail(GEOT_EINVAL, "bad reduce code");
   return run_typed(dtype, 0, true, nullptr, index, nullptr, src, dst, nnz, feat, 1, nnz, out_rows,
                    workspace, workspace_bytes, stream, reduce);
+}
+
+int geot_gather_reduce(const int64_t *src_index, const int64_t *dst_index, const void *weight, const void *src,
+                       void *dst, int64_t nnz, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype,
+                       int reduce, void *workspace, size_t workspace_bytes, void *stream) {
+  if (reduce < GEOT_REDUCE_MAX || reduce > GEOT_REDUCE_PROD) return fail(GEOT_EINVAL, "bad reduce code");
+  return run_typed(dtype, weight ? 2 : 1, true, src_index, dst_index, weight, src, dst, nnz, feat, 1, src_rows,
+                   out_rows, workspace, workspace_bytes, stream, reduce);
 }
 
 int geot_gather_scatter(const int64_t *src_index, const int64_t *dst_index, const void *src,

@@ -18,6 +18,8 @@ from . import _lib
 _DT = {torch.float32: _lib.GEOT_F32, torch.float64: _lib.GEOT_F64,
        torch.float16: _lib.GEOT_F16, torch.bfloat16: _lib.GEOT_BF16}  # 16-bit: fp32 accumulation
 
+_REDUCE_CODES = {"max": 0, "mean": 1, "min": 2, "sum": 3, "prod": 4}  # csrc/reducetype.h:3
+
 # one workspace per (device, stream): the C ABI allows reuse by one stream at a time
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
 
@@ -110,9 +112,6 @@ def _ws_args(L, dev, nnz, feat, rows, dt, stream: Optional[int] = None):
     return ws, ws.data_ptr(), ws.numel()
 
 
-_REDUCE_CODES = {"max": 0, "mean": 1, "min": 2, "sum": 3, "prod": 4}  # csrc/reducetype.h:3
-
-
 def index_scatter_out(index: torch.Tensor, src: torch.Tensor, out: torch.Tensor, sorted: bool = True,
                       reduce: str = "sum") -> torch.Tensor:
     """out[index[e], :] (+)= src[e, :] over a contiguous [nnz, F] view; `out` is [rows, F], written in full.
@@ -157,6 +156,22 @@ def gather_scatter_out(src_index, dst_index, src, out) -> torch.Tensor:
                                    src.data_ptr(), out.data_ptr(), nnz, feat, src.shape[0], rows, dt,
                                    wsp, wsn, _stream_handle(dev))
     _lib.check(rc, "geot_gather_scatter")
+    return out
+
+
+def gather_reduce_out(src_index, dst_index, weight, src, out, reduce: str) -> torch.Tensor:
+    """out[d] = reduce over the messages (weight[e] *) src[src_index[e]] of row d; weight may be None."""
+    tensors = [src_index, dst_index, src, out] + ([weight] if weight is not None else [])
+    dev = _require_gpu(*tensors)
+    L = _lib.load()
+    dt = _dtype_code(src, "gather_scatter_sorted")
+    nnz, feat, rows = dst_index.numel(), src.shape[1], out.shape[0]
+    with _on_device(dev):
+        ws, wsp, wsn = _ws_args(L, dev, nnz, feat, rows, dt)
+        rc = L.geot_gather_reduce(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
+                                  None if weight is None else weight.data_ptr(), src.data_ptr(), out.data_ptr(),
+                                  nnz, feat, src.shape[0], rows, dt, _REDUCE_CODES[reduce], wsp, wsn, _stream_handle(dev))
+    _lib.check(rc, "geot_gather_reduce")
     return out
 
 

@@ -57,6 +57,12 @@ def get_reduction_enum(reduce: str) -> str:
         f"reduce argument must be either sum, prod, mean, amax or amin, got {reduce}")
 
 
+def _aggr_kind(reduce: str) -> str:
+    """`reduce` of the gather ops as PyG call sites pass it (models/conv/gcnconv.py:259 forwards self.aggr):
+    the reference's spellings plus PyG's 'add'."""
+    return "sum" if reduce == "add" else get_reduction_enum(reduce)
+
+
 def _only_sum(reduce: str, op: str) -> None:
     kind = get_reduction_enum(reduce)
     if kind != "sum":
@@ -481,22 +487,51 @@ def _gws_backward(ctx, grad):
 torch.library.register_autograd("geot::gather_weight_scatter", _gws_backward, setup_context=_gws_setup_context)
 
 
+_lib_def.define("gather_reduce(Tensor src_index, Tensor dst_index, Tensor? weight, Tensor src, str reduce) -> Tensor")
+
+
+def _gather_reduce_gpu(src_index, dst_index, weight, src, reduce):
+    _check_gather(src_index, dst_index, src, 2)
+    kind = _aggr_kind(reduce)
+    src_index, dst_index, src = src_index.contiguous(), dst_index.contiguous(), src.contiguous()
+    weight = None if weight is None else weight.contiguous()
+
+    def launch(nrows: int) -> torch.Tensor:
+        out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
+        return hip.gather_reduce_out(src_index, dst_index, weight, src, out, kind)
+
+    return _with_row_rule(dst_index, launch)
+
+
+_lib_def.impl("gather_reduce", _gather_reduce_gpu, "CUDA")
+_lib_def.impl("gather_reduce", _reject_cpu("gather_reduce"), "CPU")
+
+
+@torch.library.register_fake("geot::gather_reduce")
+def _(src_index, dst_index, weight, src, reduce):
+    return _fake_rows(src, [src.shape[1]])
+
+
 def gather_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor,
                    reduce: str = "sum") -> torch.Tensor:
     """dst[dst_index[e]] += src[src_index[e]], dst_index ascending (geot/gather_scatter.py:7-9).
 
-    The trailing ``reduce`` is accepted because the reference's own callers still pass it
-    (models/conv/spmm.py:8, test/test_gather_scatter.py:25); only 'sum' exists.
+    The trailing ``reduce`` is what the reference's own callers pass (models/conv/spmm.py:5-8 forwards the
+    layer's ``aggr``; test/test_gather_scatter.py:25): 'sum' / 'add' run the differentiable op of the
+    reference; 'mean' / 'min' / 'max' / 'prod' aggregate the messages of every row (forward only).
     """
-    _only_sum(reduce, "gather_scatter")
-    return _gather_scatter_op(src_index, dst_index, src)
+    if _aggr_kind(reduce) == "sum":
+        return _gather_scatter_op(src_index, dst_index, src)
+    return torch.ops.geot.gather_reduce(src_index, dst_index, None, src, reduce)
 
 
 def gather_weight_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor,
                           src: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
-    """dst[dst_index[e]] += weight[e] * src[src_index[e]] (geot/gather_weight_scatter.py:15-18)."""
-    _only_sum(reduce, "gather_weight_scatter")
-    return _gather_weight_scatter_op(src_index, dst_index, weight, src)
+    """dst[dst_index[e]] += weight[e] * src[src_index[e]] (geot/gather_weight_scatter.py:15-18); ``reduce`` as in
+    :func:`gather_scatter` (models/conv/spmm.py:10-14)."""
+    if _aggr_kind(reduce) == "sum":
+        return _gather_weight_scatter_op(src_index, dst_index, weight, src)
+    return torch.ops.geot.gather_reduce(src_index, dst_index, weight, src, reduce)
 
 
 def mh_spmm(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor, src: torch.Tensor,

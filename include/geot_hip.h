@@ -98,6 +98,14 @@ int geot_index_scatter_reduce(const int64_t *index, const void *src, void *dst, 
                               int64_t feat, int64_t out_rows, int dtype, int reduce,
                               void *workspace, size_t workspace_bytes, void *stream);
 
+/* dst[dst_index[e], :] = reduce over e of (weight[e] *) src[src_index[e], :]; weight may be NULL.
+ * The message-passing aggregations of PyG call sites (the reference's models forward their `aggr` as the
+ * trailing `reduce`, models/conv/spmm.py:5-14): sum / mean / min / max / prod over the messages of a row. */
+int geot_gather_reduce(const int64_t *src_index, const int64_t *dst_index, const void *weight,
+                       const void *src, void *dst, int64_t nnz, int64_t feat, int64_t src_rows,
+                       int64_t out_rows, int dtype, int reduce, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* dst[dst_index[e], :] += src[src_index[e], :]     dst_index ascending */
 int geot_gather_scatter(const int64_t *src_index, const int64_t *dst_index, const void *src,
                         void *dst, int64_t nnz, int64_t feat, int64_t src_rows,

@@ -101,8 +101,8 @@ def test_argument_checks_carry_the_reference_texts():
     with pytest.raises(NotImplementedError, match="needs sorted=True"):
         ops._index_scatter_gpu(0, idx, src, "mean", False)
     with pytest.raises(NotImplementedError, match="only 'sum'"):
-        ops._gather_scatter_gpu  # noqa: B018  (exists)
-        ops._only_sum("mean", "gather_scatter")
+        ops._only_sum("mean", "mh_spmm")
+    assert ops._aggr_kind("add") == "sum" and ops._aggr_kind("amax") == "max"
     with pytest.raises(RuntimeError, match="src_index and dst_index must be 1 dimensional"):
         ops._gather_scatter_gpu(idx.view(2, 3), idx, src)
     with pytest.raises(RuntimeError, match="src must be 2 dimensional"):

@@ -307,6 +307,32 @@ def test_gather_ops_under_both_tile_mappings(geot, oracle, xcd):
         hip.set_option("xcd", 1)
 
 
+@pytest.mark.parametrize("reduce", ["add", "sum", "mean", "max", "min", "prod"])
+def test_gather_ops_take_pyg_aggr_as_reduce(geot, reduce):
+    """models/conv/spmm.py forwards the layer's aggr as the trailing argument of the gather ops."""
+    rng = np.random.default_rng(70)
+    for nodes, nnz, F in ((400, 9000, 32), (3000, 50_000, 7), (60, 40_000, 64)):
+        di_h = powerlaw_index(nnz, nodes, nodes)
+        si = dev(rng.integers(0, nodes, nnz).astype(np.int64))
+        di = dev(di_h)
+        x = dev((rng.random((nodes, F), dtype=np.float32) * (0.3 if reduce == "prod" else 1.0) + (0.85 if reduce == "prod" else 0.0)))
+        w = dev(rng.random(nnz, dtype=np.float32) + 0.5)
+        kind = {"add": "sum", "max": "amax", "min": "amin"}.get(reduce, reduce)
+        for weight in (None, w):
+            msg = x[si] if weight is None else x[si] * weight[:, None]
+            ref = torch.zeros(nodes, F, device="cuda").scatter_reduce(0, di[:, None].expand(-1, F), msg, kind, include_self=False)
+            out = geot.gather_scatter(si, di, x, reduce) if weight is None else geot.gather_weight_scatter(si, di, weight, x, reduce)
+            assert out.shape == ref.shape
+            if reduce in ("max", "min"):
+                assert torch.equal(out, ref)
+            elif reduce == "prod":
+                assert torch.allclose(out, ref, rtol=1e-2, atol=1e-30)
+            else:
+                assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="reduce argument must be either"):
+        geot.gather_scatter(si, di, x, "median")
+
+
 def test_sddmm_and_autograd_against_golden(geot, oracle):
     g = load_golden("pyref_autograd.npz")["pyref_autograd"]
     si, di = dev(g["src_index"]), dev(g["dst_index"])
