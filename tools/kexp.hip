@@ -110,7 +110,17 @@ __global__ __launch_bounds__(256) void wonly_kernel(float *__restrict__ dst, int
 
 // clean mixed skeleton: no modulo / 64-bit math in the row loop.  Each group walks CG rows and stores
 // its running sum every S rows to consecutive dst rows (group-contiguous), 32-bit offsets.
-template <int U, int S, bool NTL, bool NTS, bool STORE>
+template <int SP> __device__ __forceinline__ void store_policy(f4 *q, f4 v) {
+  if constexpr (SP == 0) *q = v;
+  else if constexpr (SP == 1) __builtin_nontemporal_store(v, q);
+  else if constexpr (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(q), "v"(v) : "memory");
+  else if constexpr (SP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+  else if constexpr (SP == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
+  else if constexpr (SP == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(q), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(q), "v"(v) : "memory");
+}
+
+template <int U, int S, bool NTL, bool NTS, bool STORE, int SP = -1>
 __global__ __launch_bounds__(256) void mix_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                    float *sink, int64_t nrows, int cg) {
   const int tid = threadIdx.x;
@@ -139,7 +149,8 @@ __global__ __launch_bounds__(256) void mix_kernel(const float *__restrict__ src,
       if (STORE && ++cnt == S) {
         cnt = 0;
         f4 *q = reinterpret_cast<f4 *>(ob + oo);
-        if (NTS) __builtin_nontemporal_store(acc, q); else *q = acc;
+        if constexpr (SP >= 0) store_policy<SP>(q, acc);
+        else if (NTS) __builtin_nontemporal_store(acc, q); else *q = acc;
         oo += 256;
         acc = f4{0, 0, 0, 0};
       }
@@ -244,6 +255,25 @@ int main() {
   MIX(16, 8, true, true, true, 64, "nt loads, nt stores");
   MIX(16, 8, true, true, true, 32, "nt loads, nt stores");
   MIX(4, 8, true, true, true, 64, "nt loads, nt stores");
+#define MIXSP(SP, LABEL)                                                                                   \
+  {                                                                                                        \
+    const int cg = 32; const unsigned grid = (unsigned)((nrows + 16 * cg - 1) / (16 * cg));                \
+    double best = 1e9, sum = 0;                                                                            \
+    for (int rep = 0; rep < 3; ++rep) {                                                                    \
+      double ms = timeit([&] { hipLaunchKernelGGL((mix_kernel<16, 10, true, false, true, SP>), dim3(grid), dim3(256), 0, 0, src, dst, sink, nrows, cg); }, 20); \
+      best = ms < best ? ms : best; sum += ms;                                                             \
+    }                                                                                                      \
+    printf("STOREPOLICY %-22s U=16 S=10 cg=32: best %.4f ms  mean %.4f ms\n", LABEL, best, sum / 3);      \
+  }
+  for (int round = 0; round < 2; ++round) {
+    MIXSP(0, "plain");
+    MIXSP(1, "nt");
+    MIXSP(2, "sc0");
+    MIXSP(3, "sc1");
+    MIXSP(4, "sc0 sc1");
+    MIXSP(5, "sc1 nt");
+    MIXSP(6, "sc0 sc1 nt");
+  }
   // boundary cost probes: W kernel followed by a small second kernel, timed as a pair
   {
     const int cg = 64; const int64_t nt = (nrows + 16 * cg - 1) / (16 * cg);
