@@ -183,7 +183,6 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   const unsigned char *mask8L = smem + L.off_mask;
   A *pL = reinterpret_cast<A *>(smem + L.off_p);
   A *wL = reinterpret_cast<A *>(smem + L.off_w);
-  int *pvL = reinterpret_cast<int *>(smem + L.off_pv);
   int *cntL = reinterpret_cast<int *>(smem + L.off_cnt);
   constexpr bool MEAN = RED == RED_MEAN;
 
@@ -271,12 +270,6 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
   }
   if (tid == 0) keysL[te + 1] = ts + te < p.nnz ? p.dst_index[ts + te] : kNoKey;
-  if constexpr (!ATOMIC) {
-    if (c == 0) {
-      pvL[2 * g] = 1;
-      pvL[2 * g + 1] = 0;
-    }
-  }
   __syncthreads();
 
   if constexpr (!ATOMIC) {
@@ -386,12 +379,22 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
     return;
   } else {
+    // a group with a single run fills its second slot with the identity under the same key, so that
+    // every slot is valid and "same run" is plain key equality in the merge below
     const int slot = 2 * g + (first ? 0 : 1);
     store_vec<A, VEC>(pL + (size_t)slot * FB + c * VEC, acc);
+    if (first) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = red_ident<A, RED>();
+      store_vec<A, VEC>(pL + (size_t)(slot + 1) * FB + c * VEC, acc);
+    }
     if (c == 0) {
       pkL[slot] = cur;
-      pvL[slot] = 1;
       if constexpr (MEAN) cntL[slot] = cnt;
+      if (first) {
+        pkL[slot + 1] = cur;
+        if constexpr (MEAN) cntL[slot + 1] = 0;
+      }
     }
   }
 
@@ -401,25 +404,49 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   const int64_t knext_tile = keysL[n + 1];
   const int ne = 2 * ng;
   for (int i = g; i < ne; i += ng) {
-    if (!pvL[i]) continue;
     const int64_t k = pkL[i];
-    bool leader = true;
-    if (!(i & 1) && i > 0) {
-      const int pi = pvL[i - 1] ? i - 1 : i - 2; // previous valid partial
-      leader = pkL[pi] != k;
-    }
-    if (!leader) continue;
+    if (i > 0 && pkL[i - 1] == k) continue; // not the first partial of its run
     A sum[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sum[q] = pL[(size_t)i * FB + c * VEC + q];
     bool at_end = true; // the merged run reaches the last edge of the tile
     int64_t csum = MEAN ? cntL[i] : 0;
-    for (int j = i + 1; j < ne; ++j) {
-      if (!pvL[j]) continue;
-      if (pkL[j] != k) { at_end = false; break; }
-      if constexpr (MEAN) csum += cntL[j];
+    int j = i + 1;
+    if (j < ne) {
+      if (pkL[j] != k) at_end = false; // short runs (the common case) stop at the first probe
+      else {
+        if constexpr (MEAN) csum += cntL[j];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) sum[q] = red_op<A, RED>(sum[q], pL[(size_t)j * FB + c * VEC + q]);
+        for (int q = 0; q < VEC; ++q) sum[q] = red_op<A, RED>(sum[q], pL[(size_t)j * FB + c * VEC + q]);
+        // a long run (hub segment): walk it in batches of kMB slots whose LDS reads are independent,
+        // one round trip per batch instead of one per slot; partials are still added in edge order
+        constexpr int kMB = 8;
+        for (++j; j < ne; j += kMB) {
+          int64_t kk[kMB];
+          A val[kMB][VEC];
+          int cc[kMB];
+#pragma unroll
+          for (int t = 0; t < kMB; ++t) {
+            const int jj = j + t < ne ? j + t : ne - 1;
+            kk[t] = pkL[jj];
+            if constexpr (MEAN) cc[t] = cntL[jj];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) val[t][q] = pL[(size_t)jj * FB + c * VEC + q];
+          }
+          bool stop = false;
+#pragma unroll
+          for (int t = 0; t < kMB; ++t) {
+            const bool in = j + t < ne;
+            if (in && kk[t] != k) stop = true;
+            if (in && !stop) {
+              if constexpr (MEAN) csum += cc[t];
+#pragma unroll
+              for (int q = 0; q < VEC; ++q) sum[q] = red_op<A, RED>(sum[q], val[t][q]);
+            }
+          }
+          if (stop) { at_end = false; break; }
+        }
+      }
     }
     const int cslot_id = (i == 0 && k == kprev_tile) ? 0 : ((at_end && k == knext_tile) ? 1 : -1);
     if constexpr (MEAN) {
@@ -1022,13 +1049,23 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   int l = ceil_log2(lanes);
   if (l > 6) l = 6;
   if (l < kMinLprLog2) l = kMinLprLog2;
-  if (g_tune.lpr_log2 >= 0 && g_tune.lpr_log2 <= 6 && g_tune.lpr_log2 >= l) l = g_tune.lpr_log2;
+  const int natural = l;
+  // Shape-keyed rule (the role of the reference's generated decision tree, wrapper/*_rule.h, re-measured
+  // on MI355X with `tools/kbench sweep` and `tools/sweep_rule.py`, profiles/r01/sweep_rule*.{csv,txt}):
+  //  * rows of <= 4 lanes (F <= 16 fp32) get 8-lane groups although half the lanes then idle: 32 groups of
+  //    32 edges beat 64 groups of 16 wherever runs are long (-10..-35 %: half the LDS partials to merge)
+  //    and are neutral for gathers on short runs; streamed rows with short runs (nnz/K < 24) keep the
+  //    natural 4-lane groups (5-9 % better there); the atomic flush keeps one lane per element;
+  //  * streamed rows (index_scatter) like ~512-edge tiles, 512-B rows 256-edge tiles; gathered rows ~1024;
+  //  * 16 row loads in flight per lane pay off only at 16 lanes per row (F in (32, 64], fp32).
+  if (!atomic_flush && l < 3 && (gather || nnz >= 24 * (K > 0 ? K : 1))) l = 3;
+  if (g_tune.lpr_log2 >= natural && g_tune.lpr_log2 <= 6) l = g_tune.lpr_log2;
   P.lpr_log2 = l;
   const int ng = kThreads >> l;
-  // Shape-keyed rule (the role of the reference's generated decision tree, wrapper/*_rule.h, re-measured
-  // on MI355X with `tools/kbench sweep`): streamed rows (index_scatter) like ~512-edge tiles, gathered
-  // rows ~1024; 16 row loads in flight per lane pay off only at 16 lanes per row (F in (32, 64], fp32).
-  int cg = g_tune.cg > 0 ? g_tune.cg : (gather ? 1024 : 512) / ng;
+  int cg = (gather ? 1024 : 512) / ng;
+  if (l > natural) cg = 32;
+  if (!gather && tsize == 4 && l == 5) cg = 32;
+  if (g_tune.cg > 0) cg = g_tune.cg;
   if (cg < 16) cg = 16;
   cg = (cg + 15) / 16 * 16;
   if (cg > 256) cg = 256;

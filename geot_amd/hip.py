@@ -284,6 +284,7 @@ def profile_read() -> dict:
 
 def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2: int = -1) -> None:
     _lib.load().geot_tune(edges_per_group, vec, nontemporal, lpr_log2)
+    _ws_bytes.clear()  # the tile shape, hence the workspace need, follows the plan
 
 
 def set_option(name: str, value: int) -> None:
@@ -292,6 +293,7 @@ def set_option(name: str, value: int) -> None:
     L.geot_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.geot_set_option.restype = None
     L.geot_set_option(name.encode(), int(value))
+    _ws_bytes.clear()
 
 
 def build_info() -> str:
