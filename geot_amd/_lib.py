@@ -26,7 +26,7 @@ ABI_VERSION = 1
 SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes", "geot_mh_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
-    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows",
+    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_tune", "geot_set_option",
 ]
@@ -81,6 +81,7 @@ def load() -> ctypes.CDLL:
     L.geot_mh_workspace_bytes.restype = c_sz
     L.geot_mh_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_i64, c_int]
     L.geot_workspace_init.argtypes = [c_vp, c_sz, c_vp]
+    L.geot_index_probe.argtypes = [c_vp, c_i64, c_vp, c_vp]
     L.geot_index_scatter.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_index_scatter_reduce.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_gather_reduce.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]

@@ -901,6 +901,41 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
   }
 }
 
+// Row rule + precondition probe in one pass over the index: out[0] = index[nnz-1] (the reference's
+// index[-1].item() read, csrc/index_scatter.cpp:30), out[1] += number of descents index[i] > index[i+1]
+// found (0 <=> ascending, the precondition of the atomic-free kernels).  out[1] is zeroed by the launcher.
+__global__ __launch_bounds__(kThreads) void index_probe_kernel(const int64_t *__restrict__ index, int64_t nnz,
+                                                                 int64_t *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i + 1 < nnz; i += stride)
+    bad += index[i] > index[i + 1];
+  if (__ballot(bad != 0) != 0) { // rare on the inputs this is for: one atomic per wave that saw a descent
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) bad += __shfl_xor(bad, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(out + 1), (unsigned long long)bad);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = index[nnz - 1];
+}
+
+// small index: one workgroup, no atomics, no memset (one launch instead of two on a launch-bound call)
+__global__ __launch_bounds__(kThreads) void index_probe_small_kernel(const int64_t *__restrict__ index, int64_t nnz,
+                                                                       int64_t *__restrict__ out) {
+  __shared__ int part[kThreads / 64];
+  int bad = 0;
+  for (int64_t i = threadIdx.x; i + 1 < nnz; i += kThreads) bad += index[i] > index[i + 1];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) bad += __shfl_xor(bad, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bad;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < kThreads / 64; ++w) tot += part[w];
+    out[0] = index[nnz - 1];
+    out[1] = tot;
+  }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const int64_t *index, const T *src,
                                                                T *dst, int64_t nnz, int64_t F,
@@ -1523,6 +1558,22 @@ int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t n
   if (dtype == GEOT_F16) return run_gather_rows<half_t>(index, src, dst, nnz, feat, src_rows, st);
   if (dtype == GEOT_BF16) return run_gather_rows<bf16_t>(index, src, dst, nnz, feat, src_rows, st);
   return fail(GEOT_EINVAL, "bad dtype");
+}
+
+int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *stream) {
+  if (nnz <= 0 || !index || !out2) return fail(GEOT_EINVAL, "index_probe: needs a non-empty index and an output");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nnz <= 32768) {
+    hipLaunchKernelGGL(index_probe_small_kernel, dim3(1), dim3(kThreads), 0, st, index, nnz, out2);
+    HIP_TRY(hipGetLastError());
+    return GEOT_OK;
+  }
+  HIP_TRY(hipMemsetAsync(out2, 0, 2 * sizeof(int64_t), st));
+  int64_t blocks = (nnz + kThreads * 4 - 1) / (kThreads * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(index_probe_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, index, nnz, out2);
+  HIP_TRY(hipGetLastError());
+  return GEOT_OK;
 }
 
 size_t geot_csr_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dtype) {

@@ -59,10 +59,25 @@ at::Tensor index_scatter_impl(const int64_t dim, at::Tensor index, at::Tensor sr
   TORCH_CHECK(index.dim() == 1, "index must be 1 dimensional");
   TORCH_CHECK(src.size(dim) == index.size(0), "index length must be equal to src dimension size");
   const int red = reduce_code(reduce);
-  TORCH_CHECK(sorted || red == GEOT_REDUCE_SUM, "unsorted index supports reduce='sum' only");
-  const int64_t rows = rows_from_last(index);
   at::Tensor moved = (dim == 0 ? src : src.movedim(dim, 0)).contiguous();
   index = index.contiguous();
+  int64_t rows;
+  bool ascending = sorted;
+  if (sorted) {
+    rows = rows_from_last(index);
+  } else {
+    // sorted=False promises nothing: one pass over the index yields the row count and the number of
+    // descents in the same 16-byte read-back; an ascending index is served by the atomic-free kernels
+    // (the reference's own test and benchmark pass sorted=False with a sorted index)
+    TORCH_CHECK(index.numel() > 0, "index out of range: index[-1] of an empty index");
+    at::Tensor probe = at::empty({2}, index.options());
+    int prc = geot_index_probe(index.data_ptr<int64_t>(), index.numel(), probe.data_ptr<int64_t>(), current_stream(src));
+    TORCH_CHECK(prc == GEOT_OK, geot_last_error());
+    at::Tensor host = probe.cpu();
+    rows = host.data_ptr<int64_t>()[0] + 1;
+    ascending = host.data_ptr<int64_t>()[1] == 0;
+  }
+  TORCH_CHECK(ascending || red == GEOT_REDUCE_SUM, "an unsorted index supports reduce='sum' only");
   auto shape = moved.sizes().vec();
   shape[0] = rows;
   at::Tensor out = at::empty(shape, moved.options());
@@ -71,7 +86,7 @@ at::Tensor index_scatter_impl(const int64_t dim, at::Tensor index, at::Tensor sr
   auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, rows, dt));
   int rc = red == GEOT_REDUCE_SUM
                ? geot_index_scatter(index.data_ptr<int64_t>(), moved.data_ptr(), out.data_ptr(), nnz, feat, rows, dt,
-                                    sorted, ws.data_ptr(), ws.numel(), current_stream(src))
+                                    ascending, ws.data_ptr(), ws.numel(), current_stream(src))
                : geot_index_scatter_reduce(index.data_ptr<int64_t>(), moved.data_ptr(), out.data_ptr(), nnz, feat,
                                            rows, dt, red, ws.data_ptr(), ws.numel(), current_stream(src));
   TORCH_CHECK(rc == GEOT_OK, geot_last_error());

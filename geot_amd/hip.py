@@ -234,6 +234,17 @@ def gather_rows_out(index, src, out) -> torch.Tensor:
     return out
 
 
+def index_probe_out(index: torch.Tensor, out2: torch.Tensor) -> torch.Tensor:
+    """out2 (device int64[2]) <- [index[-1], number of descents]; asynchronous on the current stream."""
+    dev = _require_gpu(index, out2)
+    if out2.dtype != torch.int64 or out2.numel() < 2 or not out2.is_contiguous():
+        raise TypeError("index_probe: out2 must be a contiguous int64 tensor of 2 elements")
+    with _on_device(dev):
+        rc = _lib.load().geot_index_probe(_index_ptr(index, "index"), index.numel(), out2.data_ptr(), _stream_handle(dev))
+    _lib.check(rc, "geot_index_probe")
+    return out2
+
+
 def csr_gws_out(indptr, indices, weight, src, out) -> torch.Tensor:
     """out[r] = sum_{e in [indptr[r], indptr[r+1])} weight[e] * src[indices[e]]; weight None = ones."""
     tensors = [indptr, indices, src, out] + ([weight] if weight is not None else [])

@@ -134,6 +134,15 @@ int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const voi
 int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
                      int64_t feat, int64_t src_rows, int dtype, void *stream);
 
+/* Row rule and precondition in one pass (device int64 out2[2], written asynchronously on `stream`):
+ *   out2[0] = index[nnz-1]        <- the index[-1].item() read of csrc/index_scatter.cpp:30 and
+ *                                    csrc/gather_scatter.cpp:27 (output rows = out2[0] + 1)
+ *   out2[1] = number of positions with index[i] > index[i+1]  (0 <=> ascending)
+ * The reference's own test and benchmark pass sorted=False with a sorted index
+ * (test/test_index_scatter.py:14, benchmark/bench_index_scatter.py:32); a host layer that reads out2
+ * anyway for the row count can route such calls to the atomic-free kernels. */
+int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *stream);
+
 /* ---- CSR path ("next" row f2 of SURVEY.md section 8) ---------------------------------------
  * geot_csr_gws  <- csr_gws_cuda   csrc/cuda/header_cuda.h:19-21 (impl csrc/cuda/csr_gws_cuda.cu,
  *                                 kernel csrc/cuda/csr_gws_kernel.cuh:12-186)

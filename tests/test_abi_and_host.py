@@ -98,8 +98,6 @@ def test_argument_checks_carry_the_reference_texts():
         ops._index_scatter_gpu(0, idx[:5], src, "sum", True)
     with pytest.raises(RuntimeError, match="reduce argument must be either"):
         ops._index_scatter_gpu(0, idx, src, "bogus", True)
-    with pytest.raises(NotImplementedError, match="needs sorted=True"):
-        ops._index_scatter_gpu(0, idx, src, "mean", False)
     with pytest.raises(NotImplementedError, match="only 'sum'"):
         ops._only_sum("mean", "mh_spmm")
     assert ops._aggr_kind("add") == "sum" and ops._aggr_kind("amax") == "max"

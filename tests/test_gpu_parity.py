@@ -65,6 +65,21 @@ def test_index_scatter_golden(geot, oracle, case, sorted_flag):
     assert torch.allclose(out.cpu(), torch.from_numpy(g["torch_index_add"]), atol=1e-4)
 
 
+@pytest.mark.parametrize("case", sorted(c for c in IS_CASES if "index" in IS_CASES[c] and c not in ("f16", "bf16_bits")))
+def test_index_scatter_golden_atomic_flush(geot, oracle, case):
+    """The atomic (unsorted-index) kernels on the golden inputs, through the pointer-level doorway: the
+    operator would route these ascending indices to the atomic-free kernels."""
+    from geot_amd import hip
+    g = IS_CASES[case]
+    index, src = g["index"], g["src"]
+    rows = int(index[-1]) + 1
+    out = torch.empty((rows,) + tuple(src.shape[1:]), dtype=dev(src).dtype, device="cuda")
+    hip.index_scatter_out(dev(index), dev(src), out, sorted=False)
+    acc64 = src.dtype == np.float32
+    assert_close_to_oracle(out, oracle.index_scatter(index, src, rows=rows, acc64=acc64),
+                           oracle.index_scatter(index, np.abs(src), rows=rows, acc64=acc64), case + " atomic")
+
+
 def test_reference_test_shape_and_flags(geot, oracle):
     """test/test_index_scatter.py:5-23: 1000x32 rand, 10 keys, called with sorted=False on sorted data."""
     torch.manual_seed(0)
@@ -182,8 +197,54 @@ def test_sorted_path_is_deterministic_and_atomic_free(geot):
     a = geot.index_scatter(0, src, index)
     for _ in range(3):
         assert torch.equal(geot.index_scatter(0, src, index), a)      # bit-identical run to run
-    b = geot.index_scatter(0, src, index, sorted=False)                # float atomics: only close
-    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    b = geot.index_scatter(0, src, index, sorted=False)                # probe finds it ascending: same kernels
+    assert torch.equal(a, b)
+    from geot_amd import hip
+    c = hip.index_scatter_out(index, src, torch.empty_like(a), sorted=False)   # float atomics: only close
+    assert torch.allclose(a, c, rtol=1e-5, atol=1e-5)
+
+
+def test_sorted_false_is_routed_by_the_probe(geot, oracle, monkeypatch):
+    """sorted=False promises nothing: an ascending index is served by the atomic-free kernels (all
+    reductions), an index with descents by the atomic path (sum only); both sized by index[-1]+1."""
+    from geot_amd import hip, ops
+    rng = np.random.default_rng(77)
+    for nnz, K in ((3000, 200), (300_000, 20_000)):                   # below / above the speculation threshold
+        index = np.sort(rng.integers(0, K, nnz)).astype(np.int64)
+        index[-1] = K - 1
+        src = rng.random((nnz, 16), dtype=np.float32)
+        probe = hip.index_probe_out(dev(index), torch.empty(2, dtype=torch.int64, device="cuda")).cpu()
+        assert probe.tolist() == [K - 1, 0]
+        for red in ("sum", "mean", "max"):
+            a = geot.index_scatter(0, dev(src), dev(index), red, sorted=True)
+            for _ in range(2):                                        # second call takes the speculated order
+                b = geot.index_scatter(0, dev(src), dev(index), red, sorted=False)
+                if red == "sum" and nnz < ops._SPECULATE_MIN_EDGES:   # launch-bound fp32 sum: atomic path, no probe
+                    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+                else:
+                    assert torch.equal(a, b), (nnz, red)
+        shuffled = index.copy()
+        shuffled[:-1] = rng.permutation(shuffled[:-1])
+        descents = int((shuffled[:-1] > shuffled[1:]).sum())
+        probe = hip.index_probe_out(dev(shuffled), torch.empty(2, dtype=torch.int64, device="cuda")).cpu()
+        assert probe.tolist() == [K - 1, descents] and descents > 0
+        check_index_scatter(geot, oracle, shuffled, src, sorted=False, what=f"probe-routed unsorted {nnz}")
+        with pytest.raises(NotImplementedError, match="needs an ascending index"):
+            geot.index_scatter(0, dev(src), dev(shuffled), "mean", sorted=False)
+        # same tensor object, content changed in place between calls: the speculated (rows, ascending) pair
+        # must be re-verified, never trusted
+        t = dev(index)
+        first = geot.index_scatter(0, dev(src), t, "sum", sorted=False)
+        t.copy_(dev(shuffled))
+        second = geot.index_scatter(0, dev(src), t, "sum", sorted=False)
+        want = oracle.index_scatter(shuffled, src, acc64=True)
+        np.testing.assert_allclose(second.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+        assert first.shape == second.shape
+    monkeypatch.setattr(ops, "_PROBE_SORTED", False)                  # GEOT_PROBE_SORTED=0: atomic path as before
+    index = np.sort(rng.integers(0, 50, 4000)).astype(np.int64)
+    index[-1] = 49
+    src = rng.random((4000, 8), dtype=np.float32)
+    check_index_scatter(geot, oracle, index, src, sorted=False, what="probe routing off")
 
 
 def test_unsorted_index_with_sorted_false(geot, oracle):
@@ -528,8 +589,12 @@ def test_16bit_storage_fp32_accumulate(geot, oracle, dtype):
         mag = oracle.gather_weight_scatter(si, idx, w.float().numpy(), x.float().abs().numpy(), acc64=True)
         out = geot.gather_weight_scatter(dev(si), dev(idx), w.cuda(), x.cuda()).float().cpu().numpy()
         assert np.all(np.abs(out - hi) <= ulp * np.abs(hi) + 2e-5 * mag + 1e-6), ("gws", nnz, F)
+    # sorted=False: the probe finds this index ascending -> the same atomic-free kernels (16-bit storage is fine);
+    # an index with descents needs float atomics, which exist for float32/float64 only
+    assert torch.equal(geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=False),
+                       geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=True))
     with pytest.raises(RuntimeError, match="float32/float64"):
-        geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=False)
+        geot.index_scatter(0, s32.cuda(), dev(idx[::-1].copy()), "sum", sorted=False)
 
 
 def test_calls_are_hipgraph_capturable(geot, oracle):

@@ -31,6 +31,10 @@ assert close(ops.index_scatter(0, row, src, "sum", True), ref)
 assert close(ops.index_scatter(0, row, src, "sum", False), ref)
 cnt = torch.bincount(row, minlength=n).clamp(min=1).unsqueeze(1)
 assert close(ops.index_scatter(0, row, src, "mean", True), ref / cnt)
+assert close(ops.index_scatter(0, row, src, "mean", False), ref / cnt)          # probe: ascending -> atomic-free kernels
+perm = torch.randperm(nnz - 1, device=dev)
+shuf = torch.cat([row[:-1][perm], row[-1:]]); ssrc = torch.cat([src[:-1][perm], src[-1:]])
+assert close(ops.index_scatter(0, shuf, ssrc, "sum", False), ref)              # probe: descents -> atomic path
 assert close(ops.index_scatter(1, row, src.t().contiguous(), "sum", True), ref.t())
 assert close(ops.gather_scatter_impl(col, row, x), torch.zeros(n, F, device=dev).index_add_(0, row, x[col]))
 gws = torch.zeros(n, F, device=dev).index_add_(0, row, x[col] * w[:, None])

@@ -23,3 +23,4 @@ print(f"python op geot.index_scatter (row rule + empty + 2 kernels): {wall(lambd
 print(f"python doorway hip.index_scatter_out (no row rule):  {wall(lambda: hip.index_scatter_out(idx, src, out)):.1f} us/call")
 os.environ["X"]="1"
 subprocess.run([sys.executable, __file__, "shim"])
+print(f"python op geot.index_scatter sorted=False (probe + empty + 2 kernels): {wall(lambda: geot.index_scatter(0, src, idx, 'sum', False)):.1f} us/call")
