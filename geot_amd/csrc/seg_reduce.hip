@@ -65,6 +65,11 @@ struct SegParams {
   int cg;                   // edges per lane-group sub-chunk (multiple of 16)
   int xcd_swizzle;          // gather modes: contiguous tile ranges per XCD
   int nt_keys;              // non-temporal key loads (with nt row loads)
+  // long-run inputs (few keys, hub segments): per 64-tile window, the sum of the carries that join a
+  // chain when the whole window is one run (seg_wsum_kernel); null when the launcher did not ask for it
+  void *wsum;               // [windows][F] accumulators
+  int64_t *wcnt;            // [windows] edge counts (mean)
+  int *wflag;               // [windows] 1 = every tile of the window is `single`
 };
 
 // Storage types: float, double, and the 16-bit types with fp32 accumulation (the reference's CPU path
@@ -687,6 +692,47 @@ __global__ __launch_bounds__(kThreads) void seg_lds_bin_kernel(const int64_t *__
   }
 }
 
+// Long-run inputs only (few keys / hub segments; the launcher decides from nnz / K): one block per window of
+// 64 tiles.  If every tile of the window [64w, 64w+63] is `single` (one run that enters and leaves the tile),
+// then whenever tile 64w belongs to a chain, tiles 64w+1 .. 64w+64 join it: their slot-0 carries are summed
+// here in a fixed order, so that seg_fixup_kernel walks a hub chain 64 tiles per row instead of tile by tile
+// (10 M edges on ONE key: fix-up 0.81 ms -> a few tens of us).
+template <typename T, int RED = RED_SUM>
+__global__ __launch_bounds__(kThreads) void seg_wsum_kernel(SegParams p, int64_t num_tiles) {
+  using A = typename AccOf<T>::type;
+  const int64_t w = blockIdx.x;
+  const int64_t t0 = w * 64;
+  __shared__ int s_all;
+  if (threadIdx.x < 64) {
+    const int64_t t = t0 + threadIdx.x;
+    const bool single = t < num_tiles && (p.meta[t] & 2);
+    const unsigned long long S = __ballot(single);
+    if (threadIdx.x == 0) s_all = (S == ~0ull) && (t0 + 64 < num_tiles);
+  }
+  __syncthreads();
+  if (!s_all) {
+    if (threadIdx.x == 0) p.wflag[w] = 0;
+    return;
+  }
+  const A *carry = static_cast<const A *>(p.carry);
+  A *wsum = static_cast<A *>(p.wsum);
+  const int64_t F = p.F;
+  for (int64_t f = threadIdx.x; f < F; f += kThreads) {
+    A s = red_ident<A, RED>();
+#pragma unroll 16
+    for (int i = 1; i <= 64; ++i) s = red_op<A, RED>(s, carry[((t0 + i) * 2) * F + f]);
+    wsum[w * F + f] = s;
+  }
+  if (threadIdx.x == 0) {
+    if constexpr (RED == RED_MEAN) {
+      int64_t n = 0;
+      for (int i = 1; i <= 64; ++i) n += p.ccnt[(t0 + i) * 2];
+      p.wcnt[w] = n;
+    }
+    p.wflag[w] = 1;
+  }
+}
+
 // Second launch (= the only cross-workgroup ordering the sorted path needs):
 //  (a) one LANE GROUP per tile (64/LPR tiles per wave): if the tile holds the FIRST carry of a
 //      chain (its head run continues from the previous tile, and that tile is where the run
@@ -764,12 +810,16 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
       }
       int64_t hcnt = 0; // mean: edges of the whole chain (every lane computes the same value)
       if constexpr (MEAN) hcnt = p.ccnt[(th - 1) * 2 + 1] + p.ccnt[th * 2];
-      // tile x+1 joins the chain for as long as tile x is `single`; 64 tiles per window
+      // tile x+1 joins the chain for as long as tile x is `single`; 64 tiles per window.  With window sums
+      // (p.wflag) the first window is cut at the next multiple of 64, whole windows are then taken 64 at a
+      // time from seg_wsum_kernel's rows, and the tail is finished tile by tile again.
+      const int64_t nwin = (num_tiles + 63) >> 6;
       int64_t wb = th;
       for (;;) {
+        const int lim = p.wflag ? 64 - (int)(wb & 63) : 64;
         const int64_t wt = wb + lane;
         const int64_t mcur = p.meta[wt < num_tiles ? wt : num_tiles - 1];
-        const unsigned long long S = __ballot((mcur & 2) && (wt < num_tiles));
+        const unsigned long long S = __ballot((mcur & 2) && (wt < num_tiles) && lane < lim);
         const int nn = ~S ? __builtin_ctzll(~S) : 64; // tiles wb+1 .. wb+nn join the chain
         const int64_t hi = wb + nn;
         for (int64_t i = wb + 1 + gq; i <= hi; i += (int64_t)R * 4) {
@@ -791,8 +841,38 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
         if constexpr (MEAN) {
           for (int64_t tt = wb + 1; tt <= hi; ++tt) hcnt += p.ccnt[tt * 2];
         }
-        if (nn < 64) break;
-        wb += 64;
+        if (nn < lim) break;
+        wb += nn;
+        if (p.wflag) { // wb is a multiple of 64 and tile wb has joined
+          const A *wsum = static_cast<const A *>(p.wsum);
+          for (;;) {
+            const int64_t w0 = wb >> 6;
+            const int64_t wi = w0 + lane;
+            const unsigned long long Wm = __ballot(wi < nwin && p.wflag[wi] != 0);
+            const int nW = ~Wm ? __builtin_ctzll(~Wm) : 64; // windows w0 .. w0+nW-1 are one run each
+            for (int64_t i = w0 + gq; i < w0 + nW; i += (int64_t)R * 4) {
+              A cr[4][J];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int64_t ww = i + (int64_t)q * R;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                  const int64_t f = fb + (int64_t)j * lpr + c;
+                  cr[q][j] = (ww < w0 + nW && f < F) ? wsum[ww * F + f] : red_ident<A, RED>();
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < J; ++j) hv[j] = red_op<A, RED>(hv[j], cr[q][j]);
+            }
+            if constexpr (MEAN) {
+              for (int64_t ww = w0; ww < w0 + nW; ++ww) hcnt += p.wcnt[ww];
+            }
+            wb += (int64_t)64 * nW;
+            if (nW < 64) break;
+          }
+        }
       }
       for (int off = lpr; off < 64; off <<= 1) {
 #pragma unroll
@@ -1010,6 +1090,7 @@ Tune g_tune;
 int g_unroll = 0; // 0 = rule, 8 / 16 = forced
 int g_xcd = 1;    // XCD-aware tile mapping for the gather modes
 int g_nt_keys = 0; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
+int g_hub = -1;   // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
 int g_narrow = 1; // lane-per-edge kernel for F <= 8 fp32 (0 = use the lane-group kernel)
 
 struct Prof {
@@ -1049,7 +1130,7 @@ int fail(int code, const std::string &msg) {
 struct Plan {
   int vec, lpr_log2, cg, te, unroll;
   int64_t num_tiles, nfb;
-  size_t meta_off, cnt_off, carry_off, list_off, total; // ctrl block sits at offset 0
+  size_t meta_off, cnt_off, carry_off, list_off, wsum_off, wcnt_off, wflag_off, total; // ctrl block sits at offset 0
   int64_t gap_cap;
 };
 
@@ -1062,6 +1143,20 @@ inline int ceil_log2(int64_t x) {
 }
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace layout for P.num_tiles tiles: ctrl | meta | counts | carries | gap list | window sums
+inline void layout_workspace(Plan &P, int64_t F, int asize) {
+  const size_t nt = (size_t)(P.num_tiles > 0 ? P.num_tiles : 1);
+  const size_t nw = nt / 64 + 2;
+  P.meta_off = kCtrlBytes;
+  P.cnt_off = P.meta_off + up256(nt * sizeof(int64_t));
+  P.carry_off = P.cnt_off + up256(nt * 2 * sizeof(int64_t));
+  P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * asize);
+  P.wsum_off = P.list_off + up256((size_t)P.gap_cap * 16);
+  P.wcnt_off = P.wsum_off + up256(nw * (size_t)F * asize);
+  P.wflag_off = P.wcnt_off + up256(nw * sizeof(int64_t));
+  P.total = P.wflag_off + up256(nw * sizeof(int));
+}
 
 // vec_unit: the feature granule that must stay inside one vector (F, or F per head for mh_spmm)
 // hw: weights staged in LDS per edge (0, 1 or H); gather: src offsets staged in LDS
@@ -1118,13 +1213,8 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   const int64_t fb = ((int64_t)1 << l) * vec;
   P.nfb = (F + fb - 1) / fb;
   if (P.nfb < 1) P.nfb = 1;
-  const size_t nt = (size_t)(P.num_tiles > 0 ? P.num_tiles : 1);
-  P.meta_off = kCtrlBytes;
-  P.cnt_off = P.meta_off + up256(nt * sizeof(int64_t));
-  P.carry_off = P.cnt_off + up256(nt * 2 * sizeof(int64_t));
-  P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * asize);
   P.gap_cap = K / kGapInline + 2;
-  P.total = P.list_off + up256((size_t)P.gap_cap * 16);
+  layout_workspace(P, F, asize);
   return P;
 }
 
@@ -1165,6 +1255,18 @@ void launch_fixup(const SegParams &p, int64_t blocks, int64_t num_tiles, int red
   case RED_MIN: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_MIN>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
   case RED_PROD: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_PROD>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
   default: hipLaunchKernelGGL((seg_fixup_kernel<T, RED_SUM>), dim3((unsigned)blocks), dim3(kThreads), 0, st, p, num_tiles); break;
+  }
+}
+
+template <typename T>
+void launch_wsum(const SegParams &p, int64_t num_tiles, int red, hipStream_t st) {
+  const dim3 grid((unsigned)((num_tiles + 63) / 64)), blk(kThreads);
+  switch (red) {
+  case RED_MAX: hipLaunchKernelGGL((seg_wsum_kernel<T, RED_MAX>), grid, blk, 0, st, p, num_tiles); break;
+  case RED_MEAN: hipLaunchKernelGGL((seg_wsum_kernel<T, RED_MEAN>), grid, blk, 0, st, p, num_tiles); break;
+  case RED_MIN: hipLaunchKernelGGL((seg_wsum_kernel<T, RED_MIN>), grid, blk, 0, st, p, num_tiles); break;
+  case RED_PROD: hipLaunchKernelGGL((seg_wsum_kernel<T, RED_PROD>), grid, blk, 0, st, p, num_tiles); break;
+  default: hipLaunchKernelGGL((seg_wsum_kernel<T, RED_SUM>), grid, blk, 0, st, p, num_tiles); break;
   }
 }
 
@@ -1234,11 +1336,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     P.num_tiles = nnz > 0 ? (nnz + te - 1) / te : 0;
     P.nfb = 1;
     P.lpr_log2 = 2;
-    const size_t nt = (size_t)(P.num_tiles > 0 ? P.num_tiles : 1);
-    P.cnt_off = P.meta_off + up256(nt * sizeof(int64_t));
-    P.carry_off = P.cnt_off + up256(nt * 2 * sizeof(int64_t));
-    P.list_off = P.carry_off + up256(nt * 2 * (size_t)F * sizeof(float));
-    P.total = P.list_off + up256((size_t)P.gap_cap * 16);
+    layout_workspace(P, F, (int)sizeof(float));
   }
   if (!ws || ws_bytes < P.total) return fail(GEOT_EWORKSPACE, "workspace too small");
   if (((uintptr_t)ws & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
@@ -1267,6 +1365,14 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.cg = P.cg;
   p.xcd_swizzle = g_xcd;
   p.nt_keys = g_nt_keys;
+  // Long-run regime (few keys: global pooling, hub-dominated graphs): average run >= 4096 edges and enough
+  // tiles for a chain to span whole 64-tile windows -> one extra small launch (seg_wsum_kernel) between the
+  // tile kernel and the fix-up.  Everything else keeps two launches.  "hub" option: 1 forces, 0 forbids.
+  const bool use_wsum = sorted && P.num_tiles > 64 &&
+                        (g_hub == 1 || (g_hub < 0 && P.num_tiles >= 256 && nnz / 4096 >= K));
+  p.wsum = use_wsum ? wsc + P.wsum_off : nullptr;
+  p.wcnt = use_wsum ? reinterpret_cast<int64_t *>(wsc + P.wcnt_off) : nullptr;
+  p.wflag = use_wsum ? reinterpret_cast<int *>(wsc + P.wflag_off) : nullptr;
 
   // non-temporal policy: the streamed operand of index_scatter is read exactly once -> nt loads
   // (measured +13 % with the store mix of this op) and nt dst stores (a further ~5 %);
@@ -1346,6 +1452,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     const int64_t tiles_per_block = (kThreads / 64) * (64 >> P.lpr_log2); // one lane group per tile
     int64_t blocks = (P.num_tiles + tiles_per_block - 1) / tiles_per_block;
     if (blocks < 1) blocks = 1;
+    if (use_wsum) launch_wsum<T>(p, P.num_tiles, red, st);
     launch_fixup<T>(p, blocks, P.num_tiles, red, st);
     HIP_TRY(hipGetLastError());
     rec.has_fix = true;
@@ -1663,6 +1770,7 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
 void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
+  if (name && std::string(name) == "hub") g_hub = value;
   if (name && std::string(name) == "xcd") g_xcd = value;
   if (name && std::string(name) == "nt_keys") g_nt_keys = value;
 }

@@ -299,7 +299,7 @@ def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2
 
 
 def set_option(name: str, value: int) -> None:
-    """Named experiment switches of the library ("unroll": 0|8|16, "narrow": 0|1)."""
+    """Named experiment switches of the library ("unroll": 0|8|16, "narrow": 0|1, "hub": -1|0|1, "xcd", "nt_keys")."""
     L = _lib.load()
     L.geot_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.geot_set_option.restype = None

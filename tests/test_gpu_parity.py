@@ -551,6 +551,47 @@ def test_reductions_all_segment_shapes(geot, oracle, reduce, shape):
         np.testing.assert_array_equal(np.isnan(out), np.isnan(oracle.index_scatter_3pass(index, nanv, reduce=reduce)))
 
 
+@pytest.mark.parametrize("hub", [-1, 1, 0])
+def test_few_keys_long_chains(geot, oracle, hub):
+    """Global-pooling shaped inputs (a handful of keys, runs spanning hundreds of tiles): the chain of tile
+    carries is reduced through per-window sums (seg_wsum_kernel; hub=-1: the library's own nnz/K rule,
+    1: forced, 0: tile-by-tile walk) - every reduction, fp32 and bf16, streamed and gathered rows."""
+    from geot_amd import hip
+    rng = np.random.default_rng(41)
+    runs = [(0, 150_001), (1, 9), (2, 70_000), (7, 300), (8, 131_072 + 64 * 512), (9, 1), (30, 90_000)]
+    index = np.concatenate([np.full(n, k, dtype=np.int64) for k, n in runs])
+    nnz = len(index)
+    hip.set_option("hub", hub)
+    try:
+        for F in (64, 6, 24):
+            src = rng.random((nnz, F), dtype=np.float32) - 0.25
+            for reduce in ("sum", "mean", "max", "min"):
+                out = geot.index_scatter(0, dev(src), dev(index), reduce, True).cpu().numpy()
+                if reduce == "sum":
+                    hi = oracle.index_scatter(index, src, acc64=True)
+                    mag = oracle.index_scatter(index, np.abs(src), acc64=True)
+                    assert np.all(np.abs(out - hi) <= 2e-5 * mag + 1e-6), (F, reduce)
+                else:
+                    ref = oracle.index_scatter_3pass(index, src, reduce=reduce)
+                    if reduce == "mean":
+                        np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+                    else:
+                        np.testing.assert_array_equal(out, ref)
+                assert np.all(out[10:30] == 0) and np.all(out[3:7] == 0)
+        src = torch.from_numpy(rng.random((nnz, 64), dtype=np.float32)).to(torch.bfloat16)
+        out = geot.index_scatter(0, src.cuda(), dev(index), "sum", True).float().cpu().numpy()
+        hi = oracle.index_scatter(index, src.float().numpy(), acc64=True)
+        assert np.all(np.abs(out - hi) <= 2.0 ** -8 * np.abs(hi) + 1e-3)
+        si = rng.integers(0, 31, nnz).astype(np.int64)
+        x = rng.random((31, 32), dtype=np.float32)
+        w = rng.random(nnz, dtype=np.float32)
+        out = geot.gather_weight_scatter(dev(si), dev(index), dev(w), dev(x)).cpu().numpy()
+        hi = oracle.gather_weight_scatter(si, index, w, x, acc64=True)
+        assert np.all(np.abs(out - hi) <= 2e-5 * np.abs(hi) + 1e-6)
+    finally:
+        hip.set_option("hub", -1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_16bit_storage_fp32_accumulate(geot, oracle, dtype):
     """half / bfloat16 inputs: accumulate in fp32, round once (reference CPU semantics; golden = compiled reference)."""

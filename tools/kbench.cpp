@@ -179,6 +179,30 @@ static int cmd_check() {
     std::vector<int64_t> v2(50000, 5);
     run_case({50000, 6, 64, 1, 0, true, "single segment key 5 (rows 0-4 empty)"}, v2, seed); seed++;
   }
+  for (int hub : {1, 0}) { // hub chains across whole 64-tile windows: window sums (seg_wsum_kernel) forced on / off
+    geot_set_option("hub", hub);
+    const std::string tag = hub ? " [window sums]" : " [tile walk]";
+    for (int64_t F : {64, 5, 100}) {
+      std::vector<int64_t> one(300000, 0);
+      run_case({300000, 1, F, 1, 0, true, "one key, 300k edges F=" + std::to_string(F) + tag}, one, seed); seed++;
+    }
+    { // three hubs with short runs between them, chain ends at awkward offsets
+      std::vector<int64_t> v;
+      for (int i = 0; i < 70001; ++i) v.push_back(2);
+      for (int i = 0; i < 300; ++i) v.push_back(3 + i / 7);
+      for (int i = 0; i < 131072 + 513; ++i) v.push_back(50);
+      for (int i = 0; i < 99; ++i) v.push_back(51 + i);
+      for (int i = 0; i < 200000; ++i) v.push_back(400);
+      const int64_t n = (int64_t)v.size();
+      run_case({n, 401, 64, 1, 0, true, "three hubs + short runs F=64" + tag}, v, seed); seed++;
+      run_case({n, 401, 32, 1, 1, true, "three hubs gather_scatter F=32" + tag}, v, seed); seed++;
+      run_case({n, 401, 16, 1, 2, true, "three hubs gws F=16" + tag}, v, seed); seed++;
+      geot_tune(16, 0, -1, -1); // 64-edge tiles at F=64: thousands of tiles, hundreds of windows
+      run_case({n, 401, 64, 1, 0, true, "three hubs, small tiles F=64" + tag}, v, seed); seed++;
+      geot_tune(0, 0, -1, -1);
+    }
+  }
+  geot_set_option("hub", -1);
   { // all-unit segments
     std::vector<int64_t> v(20000);
     std::iota(v.begin(), v.end(), 0);
