@@ -51,10 +51,9 @@ def _default_local_op(index_local: torch.Tensor, src_local: torch.Tensor, rows: 
     return hip.index_scatter_out(index_local, src_local.contiguous(), out, sorted=True)
 
 
-# (first_key, last_key) of every rank's shard, remembered per index identity: GNN edge lists are static,
-# so the ownership decisions below are almost always the same as last time.  They are only a GUESS:
-# the keys travel with every exchange and are verified on the host after the work has been queued
-# (the wait overlaps the kernels); a mismatch redoes the ownership step with the true keys.
+# (first_key, last_key) of THIS rank's shard, remembered per index identity: GNN edge lists are static, so
+# the local row count is almost always the same as last time.  It is only a GUESS for launching the local
+# kernels early: the true keys are read back underneath them and verified before anything is sent.
 _ends_seen: dict = {}
 _tls = __import__("threading").local()
 
@@ -92,7 +91,7 @@ def _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_sha
                 break  # that rank has further keys: the run ends inside it
             r2 += 1
         if tail is not None:
-            local[-1] += tail  # in place (the caller keeps a copy of this row in case the step is redone)
+            local[-1] += tail  # in place: `local` is this call's own buffer
     # my rows: (last_key_{rank-1}, last_key]; drop a first row owned by a lower rank,
     # prepend zero rows for the empty keys between the previous rank's last key and my first key
     prev_last = lasts[rank - 1] if rank > 0 else -1
@@ -128,9 +127,10 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
       1. this rank's end keys are remembered per index identity; the local kernels are launched for the
          remembered row count while the D2H copy of the real end keys completes underneath; a mismatch
          relaunches the LOCAL kernels only - nothing has been sent yet;
-      2. the all_gather carries every rank's exact keys and first-row partial;
-      3. the ownership step is queued with the other ranks' remembered keys and verified afterwards; a
-         mismatch redoes that step locally from the rows already received.
+      2. the all_gather carries every rank's exact keys and first-row partial; one small D2H copy brings
+         the keys to the host (the only other host sync of the call);
+      3. the ownership step (add the following ranks' partials to my last row, drop / pad the first row)
+         is decided from those exact keys and queued behind everything else.
     """
     local_op = local_op or _default_local_op
     world = dist.get_world_size(group)
@@ -183,35 +183,31 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         return local, 0
 
     # ---- 2. the one collective: [first_key, last_key, first_row(F)] of every rank ------------------------
-    # built from device tensors only (no scalar host->device writes on the step path)
-    rec = torch.cat([ends_dev.to(torch.float64) + float(key_offset or 0), head.reshape(-1).to(torch.float64)])
+    # built from device tensors only (no scalar host->device writes on the step path): two small kernels
+    # write the record, the collective moves it, one small D2H copy brings every rank's keys to the host
+    n_rec = 2 + (F if exchange else 0)
+    rec = torch.empty(n_rec, dtype=torch.float64, device=dev)
+    torch.add(ends_dev, int(key_offset or 0), out=rec[:2])          # keys < 2^53: exact in float64
+    if exchange:
+        rec[2:].copy_(head.reshape(-1))
     # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or two test
     # ranks sharing one GPU) stages the few hundred bytes through the host
     via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
-    cdev = torch.device("cpu") if via_host else dev
-    send = (rec if exchange else rec[:2].contiguous()).to(cdev)
-    recv = torch.empty(world * send.numel(), dtype=torch.float64, device=cdev)
+    send = rec.cpu() if via_host else rec
+    recv = torch.empty(world * n_rec, dtype=torch.float64, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.to(dev).view(world, -1)
-    allrows = recv[:, 2:] if exchange else None
+    recv_host = recv.cpu().view(world, n_rec)                       # host sync: everything above is queued
+    firsts = [int(v) for v in recv_host[:, 0]]
+    lasts = [int(v) for v in recv_host[:, 1]]
+    allrows = recv.to(dev).view(world, n_rec)[:, 2:] if exchange else None
 
-    # ---- 3. ownership --------------------------------------------------------------------------------------
-    out = None
-    saved_last = local[-1].clone()   # the ownership step adds into this row in place; a redo restores it
-    if guess is not None and "firsts" in guess and guess["firsts"][rank] == first_key and guess["lasts"][rank] == last_key:
-        out = _apply_boundaries(local, head, allrows, guess["firsts"], guess["lasts"], rank, world, feat_shape, exchange)
-    keys_host = recv[:, :2].to(torch.int64).cpu()                   # host sync; the work above is already queued
-    firsts = [int(v) for v in keys_host[:, 0]]
-    lasts = [int(v) for v in keys_host[:, 1]]
-    if out is None or firsts != guess["firsts"] or lasts != guess["lasts"]:
-        if out is not None:
-            local[-1] = saved_last
-        out = _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange)
+    # ---- 3. ownership: at most two more small kernels, queued behind the local reduction -----------------
+    # (they run while the host is already preparing the next call)
     if ident is not None:
-        _ends_seen[ident] = {"local_ends": (lo, hi), "firsts": firsts, "lasts": lasts}
-    if len(_ends_seen) > 64:
-        _ends_seen.pop(next(iter(_ends_seen)))
-    return out
+        _ends_seen[ident] = {"local_ends": (lo, hi)}
+        if len(_ends_seen) > 64:
+            _ends_seen.pop(next(iter(_ends_seen)))
+    return _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange)
 
 
 def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch.Tensor,
