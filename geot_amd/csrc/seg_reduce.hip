@@ -8,8 +8,11 @@
 //                       gather_weight_scatter_kernel.cuh:118-185, mh_spmm_kernel.cuh:28-213) that flush
 //                       every run with atomicAdd into a zeroed dst; this is a different algorithm: no
 //                       global atomics, every dst row written exactly once, deterministic.
-//   seg_narrow_kernel   fp32 rows of 1..7 values: lane-per-edge segmented shuffle scan.
+//   seg_lane_kernel     fp32 rows of 1..8 values: a lane owns E consecutive edges, one segmented scan per wave.
+//   seg_narrow_kernel   the same rows, lane-per-edge segmented shuffle scan per 64 edges (fallback / option).
 //   seg_fixup_kernel    second launch: finishes the runs that straddle tiles, zero-fills large gaps.
+//   seg_wsum_kernel     few-key inputs only: pre-reduces the carries of whole 64-tile windows for the fix-up.
+//   index_probe_kernel  index[-1] and the number of descents of an index in one pass (row rule + sorted=False).
 //   seg_lds_bin_kernel  unsorted index with an output that fits in LDS: LDS-binned atomics.
 //   sddmm_coo_kernel, gather_rows_kernel, csr_expand_kernel, coo_*_kernel   backward / CSR helpers.
 //
@@ -39,7 +42,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kU = 8;          // row loads in flight per lane (16 where the plan rule says so)
-constexpr int kNarrowMaxF = 7; // fp32 rows up to this width use seg_narrow_kernel (measured: 1.35-2.7x; tie at 8)
+constexpr int kNarrowMaxF = 8; // fp32 rows up to this width use the narrow-row kernels (seg_lane_kernel / seg_narrow_kernel)
 constexpr int kGapInline = 16; // gaps up to this many rows are zeroed by the lane group itself
 constexpr int kMinLprLog2 = 2; // lane groups are at least 4 lanes wide (1-2 lane groups measured slower:
                                // 512 LDS partials per tile make the merge the bottleneck)
@@ -141,7 +144,6 @@ struct SmemLayout {
   size_t off_mask; // u64   [te/64]  : bit i = "edge i starts a new run" (wave ballots)
   size_t off_p;    // T     [2*ng][FB]
   size_t off_w;    // T     [te*hw]  : edge weights, edge-major
-  size_t off_pv;   // int   [2*ng]   : valid flags of the partials
   size_t off_cnt;  // int   [2*ng]   : edge counts of the partials (mean)
   size_t bytes;
 };
@@ -160,7 +162,6 @@ __host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec,
   L.off_p = o;    o += (size_t)2 * kThreads * vec * tsize; // 2*ng*FB, FB = lpr*vec
   L.off_w = o;    o += (size_t)tsize * L.te * hw;
   o = (o + 7) & ~(size_t)7;
-  L.off_pv = o;   o += sizeof(int) * (size_t)(2 * ng);
   L.off_cnt = o;  o += sizeof(int) * (size_t)(2 * ng);
   L.bytes = (o + 15) & ~(size_t)15;
   return L;
@@ -475,6 +476,54 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   }
 }
 
+// Tile bookkeeping + merge of the 2*NW wave partials of the narrow-row kernels (same rules as seg_tile_kernel:
+// meta word, two carry slots per tile, rows behind the last key zero-filled by the last tile).
+template <int F, int RED = RED_SUM, typename GapFill>
+__device__ __forceinline__ void narrow_tile_epilogue(const SegParams &p, const int64_t *pkL, const int *pvL,
+                                                     const float (*pL)[8], GapFill &gapfill, int te) {
+  constexpr int NW = kThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t ts = tile * (int64_t)te;
+  const int64_t nnz = p.nnz, K = p.K;
+  const int64_t *__restrict__ index = p.dst_index;
+  float *__restrict__ dst = static_cast<float *>(p.dst);
+  const int64_t rem = nnz - ts;
+  const int n = rem < (int64_t)te ? (int)rem : te;
+  const int64_t kprev_tile = ts > 0 ? index[ts - 1] : -1;
+  const int64_t knext_tile = ts + n < nnz ? index[ts + n] : kNoKey;
+  if (tid == 0) {
+    const int64_t kf = index[ts], kl = index[ts + n - 1];
+    const int64_t head = kf == kprev_tile;
+    const int64_t single = head && kl == kf && knext_tile == kf;
+    p.meta[tile] = (uint64_t)kf < (uint64_t)K ? (kf * 4 + head + 2 * single) : 0;
+    if (tile == (int64_t)gridDim.x - 1) gapfill(kl + 1, K); // rows behind the last key
+  }
+  const bool active = lane < F;
+  float *carry = static_cast<float *>(p.carry);
+  for (int i = wv; i < 2 * NW; i += NW) {
+    if (!pvL[i]) continue;
+    const int64_t key = pkL[i];
+    bool leader = true;
+    if (!(i & 1) && i > 0) {
+      const int pi = pvL[i - 1] ? i - 1 : i - 2;
+      leader = pkL[pi] != key;
+    }
+    if (!leader) continue;
+    float sum = active ? pL[i][lane] : 0.f;
+    bool at_end = true;
+    for (int j = i + 1; j < 2 * NW; ++j) {
+      if (!pvL[j]) continue;
+      if (pkL[j] != key) { at_end = false; break; }
+      if (active) sum = red_op<float, RED>(sum, pL[j][lane]);
+    }
+    if (!active) continue;
+    if (i == 0 && key == kprev_tile) carry[(tile * 2) * F + lane] = sum;
+    else if (at_end && key == knext_tile) carry[(tile * 2 + 1) * F + lane] = sum;
+    else if ((uint64_t)key < (uint64_t)K) dst[key * F + lane] = sum;
+  }
+}
+
 // Narrow rows (F <= 8 fp32): lane-per-edge segmented scan.  This is the reference's "PR" idea
 // (segreduce_pr_sorted_kernel, csrc/cuda/index_scatter_kernel.cuh:48-126: edges across lanes, segmented
 // shuffle scan, atomicAdd per segment start) re-done for wave64 without atomics:
@@ -620,41 +669,213 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
   }
   __syncthreads();
 
-  // ---- tile bookkeeping + merge of the 2*NW partials (same rules as seg_tile_kernel) -------------------
+  narrow_tile_epilogue<F>(p, pkL, pvL, pL, gapfill, te);
+}
+
+// Narrow rows, second formulation ("lane-sequential"): the lane-per-edge scan above spends ~240 VALU + 40 LDS
+// shuffle instructions per 64 edges on the segmented scan and its bookkeeping and is issue-bound at
+// ~3 TB/s.  Here a lane owns E CONSECUTIVE edges instead:
+//   * the tile's keys and values are loaded fully coalesced (16 B per lane per instruction, everything in
+//     flight at once) and staged in LDS, each lane's chunk padded by 16 B (8 B for the keys) so that the
+//     chunk reads that follow are at most 2-way bank conflicted;
+//   * every lane walks its E edges in registers: a run that starts and ends inside the chunk is stored
+//     straight to dst; the lane keeps its first-run partial ("head") and its last-run partial ("tail");
+//   * ONE segmented shuffle scan per wave - not one per 64 edges - joins the tails with the heads that
+//     continue them (the lane-level run structure comes from two ballots); the lane where a run ends stores
+//     it; the wave's first and last run go to LDS and from there through the same tile merge, carry slots
+//     and fix-up kernel as every other sorted kernel.
+// ~25 instructions per 64 edges instead of ~490: the kernel is memory-bound.
+template <int F, int E, int RED = RED_SUM>
+__global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
+  static_assert(RED != RED_MEAN, "mean carries counts: served by seg_tile_kernel");
+  constexpr int NW = kThreads / 64;
+  constexpr int te = kThreads * E;
+  constexpr int CW = E * F;      // floats per lane chunk (multiple of 4: E is)
+  constexpr int CWP = CW + 4;    // padded chunk stride, floats
+  constexpr int NV = CW / 4;     // float4 per lane chunk
+  static_assert(E % 4 == 0, "chunks must be whole float4s");
+  __shared__ __attribute__((aligned(16))) float valL[kThreads * CWP];
+  __shared__ int64_t pkL[2 * NW];
+  __shared__ int pvL[2 * NW];
+  __shared__ float pL[2 * NW][8];
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t ts = tile * (int64_t)te;
+  const int64_t nnz = p.nnz, K = p.K;
+  const int64_t *__restrict__ index = p.dst_index;
+  const float *__restrict__ src = static_cast<const float *>(p.src);
+  float *__restrict__ dst = static_cast<float *>(p.dst);
   const int64_t rem = nnz - ts;
   const int n = rem < (int64_t)te ? (int)rem : te;
+
+  // ---- stage the tile: coalesced loads, padded per-lane chunks in LDS ---------------------------------
+  {
+    const float *tsrc = src + ts * F;
+    const int nfl = n * F; // valid floats of this tile
+    f4_t v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = tid + kThreads * j; // float4 number inside the tile
+      if (q * 4 + 3 < nfl) v[j] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tsrc) + q);
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[j][i] = q * 4 + i < nfl ? tsrc[q * 4 + i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = tid + kThreads * j;
+      *reinterpret_cast<f4_t *>(valL + (q / NV) * CWP + (q % NV) * 4) = v[j];
+    }
+  }
+  // my E keys straight from global: 8*E contiguous bytes per lane, the E/2 16-B loads of a wave touch the same
+  // 32 cache lines back to back (keys are a third or less of the traffic here; no LDS spent on them)
+  int64_t mk[E];
+  {
+    typedef long long l2_t __attribute__((ext_vector_type(2)));
+    const int64_t e0 = ts + (int64_t)tid * E;
+    if (e0 + E <= nnz) {
+#pragma unroll
+      for (int j = 0; j < E / 2; ++j) {
+        const l2_t t = *reinterpret_cast<const l2_t *>(index + e0 + 2 * j);
+        mk[2 * j] = t[0];
+        mk[2 * j + 1] = t[1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < E; ++j) mk[j] = e0 + j < nnz ? index[e0 + j] : kNoKey;
+    }
+  }
   const int64_t kprev_tile = ts > 0 ? index[ts - 1] : -1;
-  const int64_t knext_tile = ts + n < nnz ? index[ts + n] : kNoKey;
-  if (tid == 0) {
-    const int64_t kf = index[ts], kl = index[ts + n - 1];
-    const int64_t head = kf == kprev_tile;
-    const int64_t single = head && kl == kf && knext_tile == kf;
-    p.meta[tile] = (uint64_t)kf < (uint64_t)K ? (kf * 4 + head + 2 * single) : 0;
-    if (tile == (int64_t)gridDim.x - 1) gapfill(kl + 1, K); // rows behind the last key
-  }
-  const bool active = lane < F;
-  float *carry = static_cast<float *>(p.carry);
-  for (int i = wv; i < 2 * NW; i += NW) {
-    if (!pvL[i]) continue;
-    const int64_t key = pkL[i];
-    bool leader = true;
-    if (!(i & 1) && i > 0) {
-      const int pi = pvL[i - 1] ? i - 1 : i - 2;
-      leader = pkL[pi] != key;
+  __syncthreads();
+
+  auto gapfill = [&](int64_t lo, int64_t hi) { // executed by ONE lane
+    if (hi <= lo || lo < 0 || hi > K) return;
+    const int64_t cnt = hi - lo;
+    if (cnt <= kGapInline) {
+      for (int64_t r = lo; r < hi; ++r)
+#pragma unroll
+        for (int i = 0; i < F; ++i) dst[r * F + i] = 0.f;
+    } else {
+      const unsigned long long slot = atomicAdd(&p.ctrl[0], 1ull);
+      if ((int64_t)slot < p.gap_cap) {
+        p.gap_list[2 * slot] = lo;
+        p.gap_list[2 * slot + 1] = cnt;
+      }
     }
-    if (!leader) continue;
-    float sum = active ? pL[i][lane] : 0.f;
-    bool at_end = true;
-    for (int j = i + 1; j < 2 * NW; ++j) {
-      if (!pvL[j]) continue;
-      if (pkL[j] != key) { at_end = false; break; }
-      if (active) sum += pL[j][lane];
+  };
+  auto store_row = [&](int64_t key, const float (&x)[F]) {
+    if ((uint64_t)key >= (uint64_t)K) return;
+    if constexpr (F == 4) *reinterpret_cast<float4 *>(dst + key * 4) = float4{x[0], x[1], x[2], x[3]};
+    else if constexpr (F == 2) *reinterpret_cast<float2 *>(dst + key * 2) = float2{x[0], x[1]};
+    else if constexpr (F == 8) {
+      *reinterpret_cast<float4 *>(dst + key * 8) = float4{x[0], x[1], x[2], x[3]};
+      *reinterpret_cast<float4 *>(dst + key * 8 + 4) = float4{x[4], x[5], x[6], x[7]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < F; ++i) dst[key * F + i] = x[i];
     }
-    if (!active) continue;
-    if (i == 0 && key == kprev_tile) carry[(tile * 2) * F + lane] = sum;
-    else if (at_end && key == knext_tile) carry[(tile * 2 + 1) * F + lane] = sum;
-    else if ((uint64_t)key < (uint64_t)K) dst[key * F + lane] = sum;
+  };
+
+  // ---- the lane's E edges, sequentially in registers --------------------------------------------------
+  const float *mv = valL + tid * CWP;
+  // last key in front of my chunk: the previous lane's last key; a wave's lane 0 asks global memory
+  int64_t kprev = __shfl_up(mk[E - 1], 1, 64);
+  if (lane == 0) {
+    const int64_t eb = ts + (int64_t)tid * E - 1;
+    kprev = tid == 0 ? kprev_tile : (eb < nnz ? index[eb] : kNoKey);
   }
+  float vals[CW];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const f4_t t = *reinterpret_cast<const f4_t *>(mv + 4 * j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vals[4 * j + i] = t[i];
+  }
+  int64_t cur = mk[0];
+  if (cur > kprev + 1) gapfill(kprev + 1, cur);
+  float acc[F], head[F];
+#pragma unroll
+  for (int i = 0; i < F; ++i) { acc[i] = vals[i]; head[i] = 0.f; }
+  bool single = true;  // all my edges so far belong to one run
+  int64_t khead = cur; // key of my first run
+#pragma unroll
+  for (int e = 1; e < E; ++e) {
+    const int64_t k = mk[e];
+    if (k != cur) {
+      if (single) {
+#pragma unroll
+        for (int i = 0; i < F; ++i) head[i] = acc[i];
+        single = false;
+      } else store_row(cur, acc); // a run that lies inside my chunk
+      if (k > cur + 1) gapfill(cur + 1, k);
+      cur = k;
+#pragma unroll
+      for (int i = 0; i < F; ++i) acc[i] = vals[e * F + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < F; ++i) acc[i] = red_op<float, RED>(acc[i], vals[e * F + i]);
+    }
+  }
+
+  // ---- one segmented scan per wave over the lanes' open runs ---------------------------------------------
+  // partial sequence in edge order: a single-run lane contributes [only], any other lane [head, tail].
+  const bool cont = lane > 0 && khead == kprev;            // my first run continues the previous lane's last run
+  const unsigned long long sb = __ballot(single);
+  const unsigned long long hb = __ballot(!(single && cont)); // scan heads: the open run restarts at this lane
+  float x[F];
+#pragma unroll
+  for (int i = 0; i < F; ++i) x[i] = acc[i];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const bool can = lane >= d && ((hb >> (lane - d + 1)) & ((1ull << d) - 1ull)) == 0;
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+      const float y = __shfl_up(x[i], d, 64);
+      if (can) x[i] = red_op<float, RED>(y, x[i]); // earlier edges on the left: the order the reference reduces in
+    }
+  }
+  float xprev[F]; // open-run total at the end of the previous lane
+#pragma unroll
+  for (int i = 0; i < F; ++i) xprev[i] = __shfl_up(x[i], 1, 64);
+  // does my FIRST partial belong to the wave's first run?  (every lane border before me continues, and every
+  // lane before me is single-run)
+  const unsigned long long brk = __ballot(lane > 0 && !(cont && ((sb >> (lane - 1)) & 1ull)));
+  const bool wave_first = (brk & ((2ull << lane) - 1ull)) == 0;
+  const unsigned long long cb = __ballot(cont);
+  if (lane == 0) {
+    pvL[2 * wv] = 1;
+    pvL[2 * wv + 1] = 0;
+  }
+  if (!single) { // my first run ends inside my chunk
+    float r[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) r[i] = cont ? red_op<float, RED>(xprev[i], head[i]) : head[i];
+    if (wave_first) {
+#pragma unroll
+      for (int i = 0; i < F; ++i) pL[2 * wv][i] = r[i];
+      pkL[2 * wv] = khead;
+    } else store_row(khead, r);
+  }
+  const bool my_only_is_wave_first = single && wave_first;
+  if (lane < 63) {
+    if (!((cb >> (lane + 1)) & 1ull)) { // my last run ends at the end of my chunk
+      if (my_only_is_wave_first) {
+#pragma unroll
+        for (int i = 0; i < F; ++i) pL[2 * wv][i] = x[i];
+        pkL[2 * wv] = cur;
+      } else store_row(cur, x);
+    }
+  } else { // the run that is open at the end of the wave
+    const int slot = 2 * wv + (my_only_is_wave_first ? 0 : 1);
+#pragma unroll
+    for (int i = 0; i < F; ++i) pL[slot][i] = x[i];
+    pkL[slot] = cur;
+    pvL[slot] = 1;
+  }
+  __syncthreads();
+  narrow_tile_epilogue<F, RED>(p, pkL, pvL, pL, gapfill, te);
 }
 
 // Unsorted index, few output rows: LDS-binned atomics.  When the whole [K, F] output fits in LDS,
@@ -1091,7 +1312,7 @@ int g_unroll = 0; // 0 = rule, 8 / 16 = forced
 int g_xcd = 1;    // XCD-aware tile mapping for the gather modes
 int g_nt_keys = 0; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
 int g_hub = -1;   // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
-int g_narrow = 1; // lane-per-edge kernel for F <= 8 fp32 (0 = use the lane-group kernel)
+int g_narrow = 1; // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
 
 struct Prof {
   bool on = false;
@@ -1158,6 +1379,10 @@ inline void layout_workspace(Plan &P, int64_t F, int asize) {
   P.total = P.wflag_off + up256(nw * sizeof(int));
 }
 
+int g_lane_e = 0; // experiment: 4 | 8 forces E of seg_lane_kernel where that instantiation exists (F <= 4)
+inline int lane_seq_edges(int64_t F) { return F <= 4 ? (g_lane_e == 4 ? 4 : 8) : 4; }  // E of seg_lane_kernel<F, E>
+constexpr int scan_steps(int64_t F) { return F <= 2 ? 8 : 4; }      // S of seg_narrow_kernel<F, S>
+
 // vec_unit: the feature granule that must stay inside one vector (F, or F per head for mh_spmm)
 // hw: weights staged in LDS per edge (0, 1 or H); gather: src offsets staged in LDS
 Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, bool aligned16,
@@ -1217,6 +1442,19 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   layout_workspace(P, F, asize);
   return P;
 }
+
+// plan of the two narrow-row kernels (fp32, F <= kNarrowMaxF): tiles of 256 lanes x E edges (or S steps);
+// 4 lanes per row in the fix-up kernel
+Plan narrow_plan(int64_t nnz, int64_t F, int64_t K, bool lane_seq) {
+  Plan P = make_plan(nnz, F, F, K, (int)sizeof(float), false, false, 0);
+  P.te = kThreads * (lane_seq ? lane_seq_edges(F) : scan_steps(F));
+  P.num_tiles = nnz > 0 ? (nnz + P.te - 1) / P.te : 0;
+  P.nfb = 1;
+  P.lpr_log2 = 2;
+  layout_workspace(P, F, (int)sizeof(float));
+  return P;
+}
+
 
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
 void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
@@ -1327,17 +1565,12 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   const int hw = mode <= 1 ? 0 : (mode == 2 ? 1 : (int)H);
   if (hw > 64) return fail(GEOT_EUNSUPPORTED, "more than 64 heads");
   Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
-  if (std::is_same<T, float>::value && mode == 0 && sorted && red == RED_SUM && F <= kNarrowMaxF && g_narrow) {
-    // seg_narrow_kernel: tiles of 256 lanes x S steps; 4 lanes per row in the fix-up kernel
-    const int te = kThreads * (F <= 2 ? 8 : 4);
-    const Plan Q = make_plan(nnz, F, F, K, (int)sizeof(T), false, false, 0);
-    P = Q;
-    P.te = te;
-    P.num_tiles = nnz > 0 ? (nnz + te - 1) / te : 0;
-    P.nfb = 1;
-    P.lpr_log2 = 2;
-    layout_workspace(P, F, (int)sizeof(float));
-  }
+  // narrow fp32 rows: lane-sequential kernel (sum / max / min / prod; needs a 16-B aligned src), or the
+  // lane-per-edge scan kernel (sum only; option "narrow" = 2, and the fallback for an unaligned src)
+  const bool narrow_ok = std::is_same<T, float>::value && mode == 0 && sorted && F <= kNarrowMaxF && g_narrow;
+  const bool lane_seq = narrow_ok && red != RED_MEAN && g_narrow == 1 && is_aligned16(src);
+  const bool narrow_path = lane_seq || (narrow_ok && red == RED_SUM);
+  if (narrow_path) P = narrow_plan(nnz, F, K, lane_seq);
   if (!ws || ws_bytes < P.total) return fail(GEOT_EWORKSPACE, "workspace too small");
   if (((uintptr_t)ws & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
 
@@ -1411,7 +1644,29 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
       bool narrow = false;
       if constexpr (sizeof(T) == 4 && std::is_same<T, float>::value) {
         // narrow fp32 rows: lane-per-edge scan kernel (its tile size was fixed by the plan below)
-        if (mode == 0 && red == RED_SUM && F <= kNarrowMaxF && g_narrow) {
+        if (lane_seq) {
+          const dim3 grid((unsigned)P.num_tiles), blk(kThreads);
+          const bool e8 = lane_seq_edges(F) == 8;
+#define GEOT_LANE_F(RED_)                                                                                          \
+  switch ((int)F) {                                                                                                \
+  case 1: if (e8) hipLaunchKernelGGL((seg_lane_kernel<1, 8, RED_>), grid, blk, 0, st, p); else hipLaunchKernelGGL((seg_lane_kernel<1, 4, RED_>), grid, blk, 0, st, p); break; \
+  case 2: if (e8) hipLaunchKernelGGL((seg_lane_kernel<2, 8, RED_>), grid, blk, 0, st, p); else hipLaunchKernelGGL((seg_lane_kernel<2, 4, RED_>), grid, blk, 0, st, p); break; \
+  case 3: if (e8) hipLaunchKernelGGL((seg_lane_kernel<3, 8, RED_>), grid, blk, 0, st, p); else hipLaunchKernelGGL((seg_lane_kernel<3, 4, RED_>), grid, blk, 0, st, p); break; \
+  case 4: if (e8) hipLaunchKernelGGL((seg_lane_kernel<4, 8, RED_>), grid, blk, 0, st, p); else hipLaunchKernelGGL((seg_lane_kernel<4, 4, RED_>), grid, blk, 0, st, p); break; \
+  case 5: hipLaunchKernelGGL((seg_lane_kernel<5, 4, RED_>), grid, blk, 0, st, p); break;                           \
+  case 6: hipLaunchKernelGGL((seg_lane_kernel<6, 4, RED_>), grid, blk, 0, st, p); break;                           \
+  case 7: hipLaunchKernelGGL((seg_lane_kernel<7, 4, RED_>), grid, blk, 0, st, p); break;                           \
+  default: hipLaunchKernelGGL((seg_lane_kernel<8, 4, RED_>), grid, blk, 0, st, p); break;                          \
+  }
+          switch (red) {
+          case RED_MAX: GEOT_LANE_F(RED_MAX) break;
+          case RED_MIN: GEOT_LANE_F(RED_MIN) break;
+          case RED_PROD: GEOT_LANE_F(RED_PROD) break;
+          default: GEOT_LANE_F(RED_SUM) break;
+          }
+#undef GEOT_LANE_F
+          narrow = true;
+        } else if (narrow_path) {
           const dim3 grid((unsigned)P.num_tiles), blk(kThreads);
           switch ((int)F) {
           case 1: hipLaunchKernelGGL((seg_narrow_kernel<1, 8>), grid, blk, 0, st, p); break;
@@ -1572,11 +1827,11 @@ size_t geot_workspace_bytes(int64_t nnz, int64_t feat, int64_t out_rows, int dty
   size_t need = plan_bytes(nnz, feat, feat, out_rows, tsize, false, 0);          // index_scatter (+ unsorted)
   const size_t g = plan_bytes(nnz, feat, feat, out_rows, tsize, true, 1);        // gather_scatter / gws
   if (g > need) need = g;
-  if (feat <= kNarrowMaxF) {                                                      // seg_narrow_kernel tiles
-    const size_t nt = (size_t)(nnz / (kThreads * 4) + 1);
-    const size_t nb = kCtrlBytes + up256(nt * 8) + up256(nt * 16) + up256(nt * 2 * (size_t)feat * 4) +
-                      up256((size_t)(out_rows / kGapInline + 2) * 16);
-    if (nb > need) need = nb;
+  if (feat <= kNarrowMaxF && dtype == GEOT_F32) {                                 // the narrow-row kernels' tiles
+    for (int lane_seq = 0; lane_seq < 2; ++lane_seq) {
+      const size_t nb = narrow_plan(nnz, feat, out_rows, lane_seq != 0).total;
+      if (nb > need) need = nb;
+    }
   }
   return need;
 }
@@ -1771,6 +2026,7 @@ void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "hub") g_hub = value;
+  if (name && std::string(name) == "lane_e") g_lane_e = value;
   if (name && std::string(name) == "xcd") g_xcd = value;
   if (name && std::string(name) == "nt_keys") g_nt_keys = value;
 }

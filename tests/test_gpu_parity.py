@@ -111,10 +111,12 @@ def test_feature_widths(geot, oracle, F):
     check_index_scatter(geot, oracle, index, rng.random((3000, F), dtype=np.float32), what=f"F={F}")
 
 
-@pytest.mark.parametrize("narrow", [1, 0])
+@pytest.mark.parametrize("narrow", [1, 2, 0])
 def test_narrow_rows_both_kernels(geot, oracle, narrow):
-    """F <= 7 fp32 has two implementations (lane-per-edge scan / lane groups): both must hold parity on
-    every segment shape, including runs that end exactly on the 64-edge step boundaries."""
+    """F <= 8 fp32 has three implementations (1: lane-sequential kernel, 2: lane-per-edge scan kernel,
+    0: lane groups): all must hold parity on every segment shape, including runs that end exactly on lane-chunk
+    (4 / 8 edges), 64-edge step and tile boundaries; the lane-sequential kernel also with max / min / prod and
+    with an unaligned src (falls back to the scan kernel)."""
     from geot_amd import hip
     hip.set_option("narrow", narrow)
     try:
@@ -132,6 +134,30 @@ def test_narrow_rows_both_kernels(geot, oracle, narrow):
             for F in (1, 2, 3, 4, 5, 6, 7, 8):
                 src = rng.standard_normal((len(index), F)).astype(np.float32)
                 check_index_scatter(geot, oracle, index, src, what=f"narrow={narrow} {name} F={F}")
+                if narrow == 1 and F in (1, 4, 7, 8):
+                    for red in ("max", "min", "prod"):
+                        s2 = (rng.random((len(index), F), dtype=np.float32) * 0.2 + 0.9) if red == "prod" else src
+                        out = geot.index_scatter(0, dev(s2), dev(index), red, True).cpu().numpy()
+                        ref = oracle.index_scatter_3pass(index, s2, reduce=red)
+                        if red == "prod":
+                            ok = np.isclose(out, ref, rtol=1e-2, atol=1e-30) | (np.abs(ref) < 1e-30)
+                            assert ok.mean() > 0.999, (name, F, red)
+                        else:
+                            np.testing.assert_array_equal(out, ref, err_msg=f"{name} F={F} {red}")
+            if narrow == 1:   # a src that is only 4-byte aligned: the lane-sequential kernel must not be used
+                base = torch.from_numpy(rng.standard_normal(len(index) * 3 + 1).astype(np.float32)).cuda()
+                view = base[1:].view(len(index), 3)
+                out = geot.index_scatter(0, view, dev(index), "sum", True)
+                ref = geot.index_scatter(0, view.clone(), dev(index), "sum", True)
+                assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+        # NaN propagation through the lane-sequential max / min (ATen semantics, positions exact)
+        if narrow == 1:
+            index = shapes["powerlaw"]
+            nanv = rng.random((len(index), 4), dtype=np.float32)
+            nanv[len(index) // 3, 2] = np.nan
+            for red in ("max", "min"):
+                out = geot.index_scatter(0, dev(nanv), dev(index), red, True).cpu().numpy()
+                np.testing.assert_array_equal(np.isnan(out), np.isnan(oracle.index_scatter_3pass(index, nanv, reduce=red)))
     finally:
         hip.set_option("narrow", 1)
 

@@ -37,7 +37,7 @@ template <typename T> struct DBuf {
   size_t n = 0;
   explicit DBuf(size_t n_) : n(n_) { CK(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 256))); }
   DBuf(const std::vector<T> &h) : DBuf(h.size()) { up(h); }
-  ~DBuf() { hipFree(p); }
+  ~DBuf() { (void)hipFree(p); }
   void up(const std::vector<T> &h) { if (!h.empty()) CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
   std::vector<T> down() const {
     std::vector<T> h(n);
@@ -328,6 +328,7 @@ static int cmd_sweep(int64_t nnz, int64_t K, int64_t F, int iters, int one_cg = 
   vs.push_back({32, 4, 1, 5});
   if (one_cg >= 0) { vs.clear(); vs.push_back({one_cg, one_vec, one_nt, -1}); }
   if (getenv("KB_NTKEYS")) { geot_set_option("nt_keys", atoi(getenv("KB_NTKEYS"))); printf("nt_keys=%s ", getenv("KB_NTKEYS")); }
+  if (getenv("KB_LANE_E")) { geot_set_option("lane_e", atoi(getenv("KB_LANE_E"))); printf("lane_e=%s ", getenv("KB_LANE_E")); }
   if (getenv("KB_NARROW")) { geot_set_option("narrow", atoi(getenv("KB_NARROW"))); printf("narrow=%s ", getenv("KB_NARROW")); }
   if (one_cg >= 0 && getenv("KB_UNROLL")) { geot_set_option("unroll", atoi(getenv("KB_UNROLL"))); printf("unroll=%s ", getenv("KB_UNROLL")); }
   for (const V &v : vs) {
