@@ -85,13 +85,13 @@ def _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_sha
         r2 = rank + 1
         tail = None
         while r2 < world and firsts[r2] == last_key:
-            part = allrows[r2].to(local.dtype).view(feat_shape)
+            part = allrows[r2].view(feat_shape)          # float64 record: exact transport of the fp32 / 16-bit row
             tail = part if tail is None else tail + part
             if lasts[r2] != last_key:
                 break  # that rank has further keys: the run ends inside it
             r2 += 1
         if tail is not None:
-            local[-1] += tail  # in place: `local` is this call's own buffer
+            local[-1].add_(tail)  # in place (one kernel): `local` is this call's own buffer
     # my rows: (last_key_{rank-1}, last_key]; drop a first row owned by a lower rank,
     # prepend zero rows for the empty keys between the previous rank's last key and my first key
     prev_last = lasts[rank - 1] if rank > 0 else -1
@@ -150,7 +150,9 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         return out[lo:] if lo else out
 
     # ---- 1. local reduction, rows [first_key, last_key] ------------------------------------------------
-    ends_dev = torch.stack([index_shard[0], index_shard[-1]])
+    ends_dev = index_shard[::max(index_shard.numel() - 1, 1)][:2]     # [first, last] as one strided view, no kernel
+    if ends_dev.numel() == 1:
+        ends_dev = ends_dev.expand(2)
     if guess is None:
         ends = ends_dev.cpu()                                       # first call: D2H sync, as index[-1].item()
         lo, hi = int(ends[0]), int(ends[1])
