@@ -1567,7 +1567,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
   // narrow fp32 rows: lane-sequential kernel (sum / max / min / prod; needs a 16-B aligned src), or the
   // lane-per-edge scan kernel (sum only; option "narrow" = 2, and the fallback for an unaligned src)
-  const bool narrow_ok = std::is_same<T, float>::value && mode == 0 && sorted && F <= kNarrowMaxF && g_narrow;
+  const bool narrow_ok = std::is_same<T, float>::value && mode == 0 && sorted && F <= kNarrowMaxF && g_narrow &&
+                         is_aligned16(dst); // both kernels store F = 2 / 4 / 8 rows as vectors
   const bool lane_seq = narrow_ok && red != RED_MEAN && g_narrow == 1 && is_aligned16(src);
   const bool narrow_path = lane_seq || (narrow_ok && red == RED_SUM);
   if (narrow_path) P = narrow_plan(nnz, F, K, lane_seq);

@@ -150,6 +150,13 @@ def test_narrow_rows_both_kernels(geot, oracle, narrow):
                 out = geot.index_scatter(0, view, dev(index), "sum", True)
                 ref = geot.index_scatter(0, view.clone(), dev(index), "sum", True)
                 assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+                for F in (2, 4):  # a dst that is only 4-byte aligned (pointer-level doorway): lane groups, scalar stores
+                    rows = int(index[-1]) + 1
+                    src = torch.from_numpy(rng.standard_normal((len(index), F)).astype(np.float32)).cuda()
+                    obase = torch.full((rows * F + 1,), float("nan"), device="cuda")
+                    got = hip.index_scatter_out(dev(index), src, obase[1:].view(rows, F), sorted=True)
+                    want = hip.index_scatter_out(dev(index), src, torch.empty(rows, F, device="cuda"), sorted=True)
+                    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5) and bool(torch.isnan(obase[0]))
         # NaN propagation through the lane-sequential max / min (ATen semantics, positions exact)
         if narrow == 1:
             index = shapes["powerlaw"]
