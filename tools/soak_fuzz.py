@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Soak fuzz of the HIP path against the oracle at sizes the unit tests do not reach (up to a few million
+edges: hundreds to thousands of tiles, so hub chains cross many 64-tile windows) with the library's internal
+switches drawn at random as well ("hub" window sums on/off/auto, the three narrow-row implementations, forced
+tile shapes).  Developer tool: `python tools/soak_fuzz.py [--iters 200] [--seed 0]`; exits non-zero on the
+first mismatch and prints the reproducer."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import geot_amd as geot  # noqa: E402
+from geot_amd import hip  # noqa: E402
+from oracle import api as oracle  # noqa: E402
+from test_gpu_fuzz import random_index  # noqa: E402
+
+
+def big_index(rng, nnz):
+    kind = rng.integers(0, 5)
+    if kind == 0:     # a few keys, long runs (global pooling)
+        keys = int(rng.integers(1, 12))
+        return np.sort(rng.integers(0, keys, nnz)).astype(np.int64)
+    if kind == 1:     # hubs of very different sizes between short runs
+        parts, k = [], 0
+        left = nnz
+        while left > 0:
+            n = int(min(left, rng.choice([1, 3, 17, 600, 40_000, 300_000])))
+            parts.append(np.full(n, k, dtype=np.int64))
+            k += int(rng.choice([1, 1, 2, 30]))
+            left -= n
+        return np.concatenate(parts)
+    if kind == 2:     # power law
+        w = np.arange(1, nnz // 10 + 2, dtype=np.float64) ** (-1 / 1.5)
+        return np.sort(rng.choice(len(w), nnz, p=w / w.sum())).astype(np.int64)
+    return random_index(rng, nnz)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    for it in range(a.iters):
+        nnz = int(rng.choice([70_000, 300_000, 1_000_000, int(rng.integers(50_000, 3_000_000))]))
+        F = int(rng.choice([1, 2, 4, 5, 8, 16, 31, 32, 64, 100, 128]))
+        if nnz * F > 120_000_000:
+            nnz = 120_000_000 // F
+        index = big_index(rng, nnz)
+        nnz = len(index)
+        hub, narrow = int(rng.choice([-1, 0, 1])), int(rng.choice([1, 1, 2, 0]))
+        cg = int(rng.choice([0, 0, 16, 32, 64]))
+        hip.set_option("hub", hub)
+        hip.set_option("narrow", narrow)
+        hip.tune(cg, 0, -1, -1)
+        red = str(rng.choice(["sum", "sum", "mean", "max", "min"]))
+        op = str(rng.choice(["is", "is", "is_unsorted_flag", "gws", "gs"]))
+        tag = f"it={it} op={op} nnz={nnz} F={F} keys={index[-1] + 1} red={red} hub={hub} narrow={narrow} cg={cg}"
+        src = rng.standard_normal((nnz, F)).astype(np.float32)
+        if op.startswith("is"):
+            out = geot.index_scatter(0, t(src), t(index), red, op == "is").cpu().numpy()
+            if red == "sum":
+                hi = oracle.index_scatter(index, src, acc64=True)
+                mag = oracle.index_scatter(index, np.abs(src), acc64=True)
+                ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= 2e-5 * mag + 1e-30) and np.all(out[mag == 0] == 0)
+            else:
+                ref = oracle.index_scatter_3pass(index, src, reduce=red)
+                ok = out.shape == ref.shape and (np.allclose(out, ref, rtol=2e-4, atol=2e-5) if red == "mean"
+                                                 else np.array_equal(out, ref))
+        else:
+            nodes = int(index[-1]) + 1 + int(rng.integers(0, 9))
+            si = rng.integers(0, nodes, nnz).astype(np.int64)
+            x = rng.standard_normal((nodes, F)).astype(np.float32)
+            if op == "gws":
+                w = rng.random(nnz, dtype=np.float32)
+                out = geot.gather_weight_scatter(t(si), t(index), t(w), t(x)).cpu().numpy()
+                hi = oracle.gather_weight_scatter(si, index, w, x, acc64=True)
+                mag = oracle.gather_weight_scatter(si, index, w, np.abs(x), acc64=True)
+            else:
+                out = geot.gather_scatter(t(si), t(index), t(x)).cpu().numpy()
+                hi = oracle.gather_scatter(si, index, x, acc64=True)
+                mag = oracle.gather_scatter(si, index, np.abs(x), acc64=True)
+            ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= 2e-5 * mag + 1e-30) and np.all(out[mag == 0] == 0)
+        if not ok:
+            print("MISMATCH", tag, flush=True)
+            sys.exit(1)
+        if it % 20 == 0:
+            print("ok", tag, flush=True)
+    hip.set_option("hub", -1); hip.set_option("narrow", 1); hip.tune(0, 0, -1, -1)
+    print(f"SOAK PASSED ({a.iters} cases, seed {a.seed})")
+
+
+if __name__ == "__main__":
+    main()
