@@ -480,10 +480,9 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 // meta word, two carry slots per tile, rows behind the last key zero-filled by the last tile).
 template <int F, int RED = RED_SUM, typename GapFill>
 __device__ __forceinline__ void narrow_tile_epilogue(const SegParams &p, const int64_t *pkL, const int *pvL,
-                                                     const float (*pL)[8], GapFill &gapfill, int te) {
+                                                     const float (*pL)[8], GapFill &gapfill, int te, int64_t tile) {
   constexpr int NW = kThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t tile = blockIdx.x;
   const int64_t ts = tile * (int64_t)te;
   const int64_t nnz = p.nnz, K = p.K;
   const int64_t *__restrict__ index = p.dst_index;
@@ -669,7 +668,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
   }
   __syncthreads();
 
-  narrow_tile_epilogue<F>(p, pkL, pvL, pL, gapfill, te);
+  narrow_tile_epilogue<F>(p, pkL, pvL, pL, gapfill, te, blockIdx.x);
 }
 
 // Narrow rows, second formulation ("lane-sequential"): the lane-per-edge scan above spends ~240 VALU + 40 LDS
@@ -685,7 +684,11 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
 //     it; the wave's first and last run go to LDS and from there through the same tile merge, carry slots
 //     and fix-up kernel as every other sorted kernel.
 // ~25 instructions per 64 edges instead of ~490: the kernel is memory-bound.
-template <int F, int E, int RED = RED_SUM>
+// MODE 0: streamed rows (index_scatter), staged through LDS as described.  MODE 1 / 2: gathered rows
+// (gather_scatter / gather_weight_scatter with a handful of features - SpMV at F = 1, label propagation,
+// per-head scalars): nothing to stage, every lane gathers the rows of its own E edges (E independent random
+// reads in flight per lane, 64 per instruction instead of the 8 that 8-lane groups with one active lane give).
+template <int F, int E, int RED = RED_SUM, int MODE = 0>
 __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   static_assert(RED != RED_MEAN, "mean carries counts: served by seg_tile_kernel");
   constexpr int NW = kThreads / 64;
@@ -694,13 +697,19 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   constexpr int CWP = CW + 4;    // padded chunk stride, floats
   constexpr int NV = CW / 4;     // float4 per lane chunk
   static_assert(E % 4 == 0, "chunks must be whole float4s");
-  __shared__ __attribute__((aligned(16))) float valL[kThreads * CWP];
+  __shared__ __attribute__((aligned(16))) float valL[MODE == 0 ? kThreads * CWP : 4];
   __shared__ int64_t pkL[2 * NW];
   __shared__ int pvL[2 * NW];
   __shared__ float pL[2 * NW][8];
   typedef float f4_t __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t tile = blockIdx.x;
+  int64_t tile = blockIdx.x;
+  if constexpr (MODE != 0) { // contiguous tile ranges per XCD, as in the gather modes of seg_tile_kernel
+    if (p.xcd_swizzle) {
+      const int64_t nb = gridDim.x, per = nb / 8;
+      if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+    }
+  }
   const int64_t ts = tile * (int64_t)te;
   const int64_t nnz = p.nnz, K = p.K;
   const int64_t *__restrict__ index = p.dst_index;
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   const int n = rem < (int64_t)te ? (int)rem : te;
 
   // ---- stage the tile: coalesced loads, padded per-lane chunks in LDS ---------------------------------
-  {
+  if constexpr (MODE == 0) {
     const float *tsrc = src + ts * F;
     const int nfl = n * F; // valid floats of this tile
     f4_t v[NV];
@@ -732,23 +741,78 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   // my E keys straight from global: 8*E contiguous bytes per lane, the E/2 16-B loads of a wave touch the same
   // 32 cache lines back to back (keys are a third or less of the traffic here; no LDS spent on them)
   int64_t mk[E];
-  {
-    typedef long long l2_t __attribute__((ext_vector_type(2)));
-    const int64_t e0 = ts + (int64_t)tid * E;
-    if (e0 + E <= nnz) {
+  const int64_t e0 = ts + (int64_t)tid * E;
+  const bool full = e0 + E <= nnz; // all my edges exist
+  typedef long long l2_t __attribute__((ext_vector_type(2)));
+  if (full) {
+#pragma unroll
+    for (int j = 0; j < E / 2; ++j) {
+      const l2_t t = *reinterpret_cast<const l2_t *>(index + e0 + 2 * j);
+      mk[2 * j] = t[0];
+      mk[2 * j + 1] = t[1];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < E; ++j) mk[j] = e0 + j < nnz ? index[e0 + j] : kNoKey;
+  }
+  float vals[CW];
+  if constexpr (MODE != 0) {
+    // my E source rows: indices and weights are contiguous per lane, the rows are E independent gathers
+    int64_t sr[E];
+    if (full) {
 #pragma unroll
       for (int j = 0; j < E / 2; ++j) {
-        const l2_t t = *reinterpret_cast<const l2_t *>(index + e0 + 2 * j);
-        mk[2 * j] = t[0];
-        mk[2 * j + 1] = t[1];
+        const l2_t t = *reinterpret_cast<const l2_t *>(p.src_index + e0 + 2 * j);
+        sr[2 * j] = t[0];
+        sr[2 * j + 1] = t[1];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < E; ++j) mk[j] = e0 + j < nnz ? index[e0 + j] : kNoKey;
+      for (int j = 0; j < E; ++j) sr[j] = e0 + j < nnz ? p.src_index[e0 + j] : 0;
+    }
+    float wv_[E];
+    if constexpr (MODE == 2) {
+      const float *w = static_cast<const float *>(p.weight);
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < E / 4; ++j) {
+          const f4_t t = *reinterpret_cast<const f4_t *>(w + e0 + 4 * j);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wv_[4 * j + i] = t[i];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) wv_[j] = e0 + j < nnz ? w[e0 + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      int64_t r = sr[j];
+      if ((uint64_t)r >= (uint64_t)p.src_rows) r = 0; // out-of-range gather index: memory-safe
+      const float *row = src + r * F;
+      if constexpr (F % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < F / 4; ++q) {
+          const f4_t t = *reinterpret_cast<const f4_t *>(row + 4 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) vals[j * F + 4 * q + i] = t[i];
+        }
+      } else if constexpr (F == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(row);
+        vals[j * F] = t.x;
+        vals[j * F + 1] = t.y;
+      } else {
+#pragma unroll
+        for (int i = 0; i < F; ++i) vals[j * F + i] = row[i];
+      }
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < F; ++i) vals[j * F + i] *= wv_[j];
+      }
     }
   }
   const int64_t kprev_tile = ts > 0 ? index[ts - 1] : -1;
-  __syncthreads();
+  if constexpr (MODE == 0) __syncthreads();
 
   auto gapfill = [&](int64_t lo, int64_t hi) { // executed by ONE lane
     if (hi <= lo || lo < 0 || hi > K) return;
@@ -779,19 +843,17 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   };
 
   // ---- the lane's E edges, sequentially in registers --------------------------------------------------
-  const float *mv = valL + tid * CWP;
+  const float *mv = MODE == 0 ? valL + tid * CWP : valL;
   // last key in front of my chunk: the previous lane's last key; a wave's lane 0 asks global memory
   int64_t kprev = __shfl_up(mk[E - 1], 1, 64);
-  if (lane == 0) {
-    const int64_t eb = ts + (int64_t)tid * E - 1;
-    kprev = tid == 0 ? kprev_tile : (eb < nnz ? index[eb] : kNoKey);
-  }
-  float vals[CW];
+  if (lane == 0) kprev = tid == 0 ? kprev_tile : (e0 - 1 < nnz ? index[e0 - 1] : kNoKey);
+  if constexpr (MODE == 0) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const f4_t t = *reinterpret_cast<const f4_t *>(mv + 4 * j);
+    for (int j = 0; j < NV; ++j) {
+      const f4_t t = *reinterpret_cast<const f4_t *>(mv + 4 * j);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vals[4 * j + i] = t[i];
+      for (int i = 0; i < 4; ++i) vals[4 * j + i] = t[i];
+    }
   }
   int64_t cur = mk[0];
   if (cur > kprev + 1) gapfill(kprev + 1, cur);
@@ -875,7 +937,7 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
     pvL[slot] = 1;
   }
   __syncthreads();
-  narrow_tile_epilogue<F, RED>(p, pkL, pvL, pL, gapfill, te);
+  narrow_tile_epilogue<F, RED>(p, pkL, pvL, pL, gapfill, te, tile);
 }
 
 // Unsorted index, few output rows: LDS-binned atomics.  When the whole [K, F] output fits in LDS,
@@ -1445,9 +1507,9 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
 
 // plan of the two narrow-row kernels (fp32, F <= kNarrowMaxF): tiles of 256 lanes x E edges (or S steps);
 // 4 lanes per row in the fix-up kernel
-Plan narrow_plan(int64_t nnz, int64_t F, int64_t K, bool lane_seq) {
+Plan narrow_plan(int64_t nnz, int64_t F, int64_t K, bool lane_seq, bool gather = false) {
   Plan P = make_plan(nnz, F, F, K, (int)sizeof(float), false, false, 0);
-  P.te = kThreads * (lane_seq ? lane_seq_edges(F) : scan_steps(F));
+  P.te = kThreads * (lane_seq ? (gather ? (F <= 4 ? 8 : 4) : lane_seq_edges(F)) : scan_steps(F));
   P.num_tiles = nnz > 0 ? (nnz + P.te - 1) / P.te : 0;
   P.nfb = 1;
   P.lpr_log2 = 2;
@@ -1567,11 +1629,14 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
   // narrow fp32 rows: lane-sequential kernel (sum / max / min / prod; needs a 16-B aligned src), or the
   // lane-per-edge scan kernel (sum only; option "narrow" = 2, and the fallback for an unaligned src)
-  const bool narrow_ok = std::is_same<T, float>::value && mode == 0 && sorted && F <= kNarrowMaxF && g_narrow &&
+  const bool narrow_ok = std::is_same<T, float>::value && mode <= 2 && sorted && F <= kNarrowMaxF && g_narrow &&
                          is_aligned16(dst); // both kernels store F = 2 / 4 / 8 rows as vectors
-  const bool lane_seq = narrow_ok && red != RED_MEAN && g_narrow == 1 && is_aligned16(src);
-  const bool narrow_path = lane_seq || (narrow_ok && red == RED_SUM);
-  if (narrow_path) P = narrow_plan(nnz, F, K, lane_seq);
+  // (the lane-sequential kernel reads its per-lane index / weight chunks and its rows as 16-B vectors)
+  const bool lane_seq = narrow_ok && red != RED_MEAN && g_narrow == 1 && is_aligned16(src) && is_aligned16(dst_index) &&
+                        (mode == 0 || is_aligned16(src_index)) && (mode != 2 || is_aligned16(weight)) &&
+                        (mode == 0 || red != RED_PROD);
+  const bool narrow_path = lane_seq || (narrow_ok && mode == 0 && red == RED_SUM);
+  if (narrow_path) P = narrow_plan(nnz, F, K, lane_seq, mode != 0);
   if (!ws || ws_bytes < P.total) return fail(GEOT_EWORKSPACE, "workspace too small");
   if (((uintptr_t)ws & 255) != 0) return fail(GEOT_EWORKSPACE, "workspace must be 256-byte aligned");
 
@@ -1659,12 +1724,38 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   case 7: hipLaunchKernelGGL((seg_lane_kernel<7, 4, RED_>), grid, blk, 0, st, p); break;                           \
   default: hipLaunchKernelGGL((seg_lane_kernel<8, 4, RED_>), grid, blk, 0, st, p); break;                          \
   }
-          switch (red) {
-          case RED_MAX: GEOT_LANE_F(RED_MAX) break;
-          case RED_MIN: GEOT_LANE_F(RED_MIN) break;
-          case RED_PROD: GEOT_LANE_F(RED_PROD) break;
-          default: GEOT_LANE_F(RED_SUM) break;
+#define GEOT_LANE_G(RED_, MODE_)                                                                                   \
+  switch ((int)F) {                                                                                                \
+  case 1: hipLaunchKernelGGL((seg_lane_kernel<1, 8, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  case 2: hipLaunchKernelGGL((seg_lane_kernel<2, 8, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  case 3: hipLaunchKernelGGL((seg_lane_kernel<3, 8, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  case 4: hipLaunchKernelGGL((seg_lane_kernel<4, 8, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  case 5: hipLaunchKernelGGL((seg_lane_kernel<5, 4, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  case 6: hipLaunchKernelGGL((seg_lane_kernel<6, 4, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  case 7: hipLaunchKernelGGL((seg_lane_kernel<7, 4, RED_, MODE_>), grid, blk, 0, st, p); break;                    \
+  default: hipLaunchKernelGGL((seg_lane_kernel<8, 4, RED_, MODE_>), grid, blk, 0, st, p); break;                   \
+  }
+          if (mode == 0) {
+            switch (red) {
+            case RED_MAX: GEOT_LANE_F(RED_MAX) break;
+            case RED_MIN: GEOT_LANE_F(RED_MIN) break;
+            case RED_PROD: GEOT_LANE_F(RED_PROD) break;
+            default: GEOT_LANE_F(RED_SUM) break;
+            }
+          } else if (mode == 1) {
+            switch (red) {
+            case RED_MAX: GEOT_LANE_G(RED_MAX, 1) break;
+            case RED_MIN: GEOT_LANE_G(RED_MIN, 1) break;
+            default: GEOT_LANE_G(RED_SUM, 1) break;
+            }
+          } else {
+            switch (red) {
+            case RED_MAX: GEOT_LANE_G(RED_MAX, 2) break;
+            case RED_MIN: GEOT_LANE_G(RED_MIN, 2) break;
+            default: GEOT_LANE_G(RED_SUM, 2) break;
+            }
           }
+#undef GEOT_LANE_G
 #undef GEOT_LANE_F
           narrow = true;
         } else if (narrow_path) {
