@@ -5,8 +5,12 @@ Metric (BASELINE.json): aggregated edges/sec + HBM GB/s, index_scatter feat=64 s
 Workload (BASELINE.json configs[1]): synthetic power-law 10M edges -> 1M nodes, feat=64, fp32,
 int64 index, generated on the device from fixed seeds (SURVEY.md section 8d generator).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the
+parent touches no GPU, spawns `python -m torch.distributed.run ... bench.py --gpus N ...` as a CHILD process,
+relays rank 0's JSON line and exits with the child's code.
 
 A step = one call of the drop-in operator ``geot.index_scatter(0, src, index, 'sum', True)`` on the
 resident inputs: the D2H read of index[-1] (the reference's row rule), the output allocation, the
@@ -14,18 +18,23 @@ tile kernel and the fix-up kernel.  N > 1 = weak scaling: every rank reduces its
 of a dst-sorted edge list whose neighbouring shards share their boundary key, and the partial
 boundary rows are exchanged with one small RCCL all_gather per step (geot_amd/sharding.py).
 
+--workload cfg5 (BASELINE.json configs[4]): gather_scatter, papers100M scale, feat=128; every rank holds 1/8 of
+the 1.6157 B edges and of the 111.06 M dst rows, src (all 111.06 M nodes = 56.9 GB) replicated; N = 8 is the full
+configuration, N = 1 one GPU's shard.  Not the headline line.
+
 One JSON line on rank 0.  `roofline` is the tile kernel alone (HIP events around it on its stream,
 over K extra steps); `cpu_baseline` is the reference's own CPU index_scatter (oracle/_ref, compiled
 from /root/reference in the build container) - or the oracle port when that library is absent -
-timed on this host on the same full-size inputs.
+timed on this host on the same full-size inputs; `secondary` (N = 1, headline workload) holds the two other
+single-GPU configurations of BASELINE.json, bounded to a couple of seconds: gather_weight_scatter at
+ogbn-products scale next to rocSPARSE's CSR SpMM on the same matrix, and mh_spmm at Reddit scale.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -33,11 +42,48 @@ if ROOT not in sys.path:
 
 NNZ, KEYS, FEAT = 10_000_000, 1_000_000, 64
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+HBM_COPY_GBPS = 6290.0           # measured float4 copy ceiling (same table)
 METRIC = "aggregated edges/sec + HBM GB/s, index_scatter feat=64 sorted sum"
+# BASELINE.json configs[4]: ogbn-papers100M scale, one GPU's share of 8
+CFG5_NODES, CFG5_EDGES, CFG5_FEAT = 111_059_956, 1_615_685_872, 128
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["cfg2", "cfg5"], default="cfg2")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink cfg5 / the secondary workloads (tests)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """N > 1 called as a plain script: start one process per GPU as CHILDREN (never re-exec: the parent has not
+    touched the GPU and never will), relay rank 0's JSON line, propagate failure."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout)
+        raise SystemExit(p.returncode or 1)
+    print(lines[-1])
+    raise SystemExit(0)
 
 
 def powerlaw_index(nnz, keys, seed, device):
     """Sorted int64 keys, w_k ~ rank^(-1/1.5), ranks randomly permuted, index[-1] = keys-1."""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     w = torch.arange(1, keys + 1, device=device, dtype=torch.float64) ** (-1.0 / 1.5)
@@ -58,7 +104,6 @@ def algorithmic_bytes(nnz, feat, rows):
 
 def cpu_baseline(index, src, budget_s=25.0):
     """Reference CPU index_scatter on this host, same inputs (bounded: at most ~budget_s seconds)."""
-    import numpy as np
     idx = index.cpu().numpy()
     s = src.cpu().numpy()
     cores = os.cpu_count() or 1
@@ -99,22 +144,103 @@ def cpu_baseline(index, src, budget_s=25.0):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def device_ms(fn, iters, warmup=2):
+    """Device time per call from HIP events on the current stream (the stream the *_out doorway launches on)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
 
+
+def secondary(dev, scale=1.0, iters=5):
+    """BASELINE.json configs[2] and configs[3] on synthetic stand-ins (same generator as the headline workload;
+    sources uniform-random: no locality to exploit).  Roofline = SURVEY.md 8(d) COMPULSORY bytes / kernel time /
+    8 TB/s - re-gathered rows served by the caches are not credited."""
+    import torch
+    import geot_amd as geot
+    from geot_amd import hip
+    from tools import rocsparse
+    res = {}
+
+    # ---- configs[2]: gather_weight_scatter, ogbn-products scale, F=128, vs rocSPARSE CSR SpMM ---------------
+    nodes, nnz, F = int(2_449_029 * scale), int(123_718_280 * scale), 128
+    di = powerlaw_index(nnz, nodes, 7, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    w = torch.rand(nnz, device=dev, generator=g)
+    x = torch.rand(nodes, F, device=dev, generator=g)
+    out = torch.empty(nodes, F, device=dev)
+    ms = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), iters)
+    op_ms = device_ms(lambda: geot.gather_weight_scatter(si, di, w, x), iters)
+    uniq = int(torch.unique(si).numel())
+    comp = nnz * 20 + uniq * 4 * F + nodes * 4 * F
+    entry = {"workload": f"gather_weight_scatter, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, feat={F}, "
+                         "fp32, int64 COO dst-sorted (stand-in of ogbn-products)",
+             "kernel_ms": ms, "op_ms_with_row_rule": op_ms, "edges_per_s": nnz / ms * 1e3,
+             "compulsory_bytes": comp, "distinct_src_rows": uniq,
+             "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": comp / ms / 1e6 / HBM_PEAK_GBPS},
+             "gathered_row_bytes": nnz * 4 * F, "gathered_row_gbps": nnz * 4 * F / ms / 1e6}
+    try:
+        best, table, y = rocsparse.best_csr_spmm(di, si, w, x, nodes, iters=max(2, iters // 2))
+        hip.gather_weight_scatter_out(si, di, w, x, out)
+        torch.cuda.synchronize()
+        entry.update(rocsparse_best_ms=best["ms"], rocsparse_best_algorithm=best["algorithm"],
+                     rocsparse_index_width="int32 CSR (geot: int64 COO)", rocsparse_preprocess="excluded from timing",
+                     rocsparse_preprocess_buffer_bytes=best.get("preprocess_buffer_bytes"),
+                     rocsparse_all=table, speedup_vs_rocsparse_best=best["ms"] / ms,
+                     max_rel_diff_vs_rocsparse=float(((y - out).abs().max() / out.abs().max()).item()))
+        del y
+    except Exception as e:               # the comparator must never take the measurement down with it
+        entry["rocsparse_error"] = repr(e)
+    res["gws_cfg3"] = entry
+    del di, si, w, x, out
+    torch.cuda.empty_cache()
+
+    # ---- configs[3]: mh_spmm, Reddit scale, heads=4 feat=64 ---------------------------------------------------
+    nodes, nnz, H, F = int(232_965 * scale), int(114_615_892 * scale), 4, 64
+    di = powerlaw_index(nnz, nodes, 11, dev)
+    g.manual_seed(12)
+    si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    w = torch.rand(nnz, H, device=dev, generator=g)
+    x = torch.rand(nodes, H, F, device=dev, generator=g)
+    out = torch.empty(nodes, H, F, device=dev)
+    ms = device_ms(lambda: hip.mh_spmm_out(si, di, w, x, out, False), iters)
+    op_ms = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters)
+    wt = w.t().contiguous()
+    ms_t = device_ms(lambda: hip.mh_spmm_out(si, di, wt, x, out, True), iters)
+    uniq = int(torch.unique(si).numel())
+    comp = nnz * (16 + 4 * H) + uniq * 4 * H * F + nodes * 4 * H * F
+    res["mh_spmm_cfg4"] = {
+        "workload": f"mh_spmm, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, heads={H} feat={F}, fp32 "
+                    "(stand-in of Reddit)",
+        "kernel_ms": ms, "kernel_ms_head_major_weights": ms_t, "op_ms_with_row_rule": op_ms,
+        "edges_per_s": nnz / ms * 1e3, "compulsory_bytes": comp, "distinct_src_rows": uniq,
+        "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": comp / ms / 1e6 / HBM_PEAK_GBPS},
+        "gathered_row_bytes": nnz * 4 * H * F, "gathered_row_gbps": nnz * 4 * H * F / ms / 1e6}
+    return res
+
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                     # never returns
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and not distributed:
-        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in this package)")
     # GEOT_DIST_BACKEND=gloo lets two test ranks share one GPU (RCCL refuses duplicate devices)
@@ -133,19 +259,49 @@ def main():
     import geot_amd as geot
     from geot_amd import hip, sharding
 
-    index = powerlaw_index(NNZ, KEYS, seed=rank, device=dev)          # rank-local keys 0..KEYS-1
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    src = torch.rand(NNZ, FEAT, device=dev, generator=gen)
-
-    if distributed:
-        key_offset = rank * (KEYS - 1)                                 # neighbours share one key
-
-        def step():
-            return sharding.sharded_index_scatter(index, src, key_offset=key_offset)[0]
+    timing = {}
+    if args.workload == "cfg2":
+        nnz, rows, feat = NNZ, KEYS, FEAT
+        index = powerlaw_index(nnz, rows, seed=rank, device=dev)          # rank-local keys 0..KEYS-1
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000 + rank)
+        src = torch.rand(nnz, feat, device=dev, generator=gen)
+        alg = algorithmic_bytes(nnz, feat, rows)
+        key_offset = rank * (rows - 1)                                     # neighbours share one key
+        if distributed:
+            def step():
+                return sharding.sharded_index_scatter(index, src, key_offset=key_offset, timing=timing)[0]
+        else:
+            def step():
+                return geot.index_scatter(0, src, index, "sum", True)
+        kernel = "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"
+        workload = ("index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64 (BASELINE.json configs[1])"
+                    + (" per GPU, boundary rows exchanged by RCCL all_gather" if distributed else ""))
+        step_desc = "geot.index_scatter(0, src, index, 'sum', True): index[-1].item() + alloc + tile kernel + fix-up kernel"
+        metric = METRIC
     else:
-        def step():
-            return geot.index_scatter(0, src, index, "sum", True)
+        nodes_all, feat = int(CFG5_NODES * args.scale), CFG5_FEAT
+        nnz, rows = int(CFG5_EDGES * args.scale) // 8, nodes_all // 8
+        index = powerlaw_index(nnz, rows, seed=13 + rank, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(14 + rank)
+        src_index = torch.randint(0, nodes_all, (nnz,), device=dev, generator=gen)
+        gen.manual_seed(15)                                                # src is REPLICATED: same seed on every rank
+        src = torch.rand(nodes_all, feat, device=dev, generator=gen)
+        uniq = int(torch.unique(src_index).numel())
+        alg = nnz * 16 + uniq * 4 * feat + rows * 4 * feat                 # compulsory bytes
+        key_offset = rank * (rows - 1)
+        if distributed:
+            def step():
+                return sharding.sharded_gather_scatter(src_index, index, src, key_offset=key_offset, timing=timing)[0]
+        else:
+            def step():
+                return geot.gather_scatter(src_index, index, src)
+        kernel = "seg_tile_kernel<float, 4, true, 0, false, 0, 3, 8>"
+        workload = (f"gather_scatter, papers100M-scale synthetic, feat={feat}: per GPU {nnz} edges -> {rows} dst rows, "
+                    f"src {nodes_all} x {feat} fp32 replicated (BASELINE.json configs[4]; 8 ranks = the full 1.6 B edges)")
+        step_desc = "geot.gather_scatter(src_index, dst_index, src)" + (" via sharding.sharded_gather_scatter" if distributed else "")
+        metric = "aggregated edges/sec, gather_scatter feat=128, edge-sharded, src replicated"
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -157,18 +313,22 @@ def main():
     for _ in range(args.warmup):
         out = step()
     sync_all()
+    timing.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    exchange_ms = None
+    if timing.get("exchange_events"):
+        exchange_ms = sum(a.elapsed_time(b) for a, b in timing["exchange_events"]) / len(timing["exchange_events"])
+    timing = None
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    edges_per_s = world * NNZ * args.steps / elapsed
-    alg = algorithmic_bytes(NNZ, FEAT, KEYS)
+    edges_per_s = world * nnz * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: HIP events around the tile kernel, K more steps -------
     hip.profile_enable(True)
@@ -183,36 +343,44 @@ def main():
     achieved = alg / (main_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
+    if args.workload == "cfg2" and os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
-    # kernel-only pace of the whole call (tile + fix-up), without the operator's host-side work
     if rank == 0:
         res = {
-            "metric": METRIC, "value": edges_per_s, "unit": "edges/s", "n_gpus": world,
+            "metric": metric, "value": edges_per_s, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64 "
-                                   "(BASELINE.json configs[1])" + (" per GPU, boundary rows exchanged by RCCL all_gather" if distributed else ""),
-                       "nnz_per_gpu": NNZ, "rows_per_gpu": KEYS, "feat": FEAT, "index_dtype": "int64",
-                       "step": "geot.index_scatter(0, src, index, 'sum', True): index[-1].item() + alloc + tile kernel + fix-up kernel"},
+            "config": {"workload": workload, "nnz_per_gpu": nnz, "rows_per_gpu": rows, "feat": feat,
+                       "index_dtype": "int64", "step": step_desc},
             "hbm_gbps_whole_call": world * alg * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>", "kernel_ms": main_ms,
+                         "kernel": kernel, "kernel_ms": main_ms,
                          "fixup_kernel_ms": fix_ms, "algorithmic_bytes_per_launch": alg,
-                         "frac_tile_plus_fixup": alg / ((main_ms + fix_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                         "frac_tile_plus_fixup": alg / ((main_ms + fix_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBPS},
         }
-        if not distributed and not args.no_cpu_baseline:
+        if distributed:
+            res["boundary_exchange_ms"] = exchange_ms      # rank 0: all_gather of first-row partials + owner adds
+            res["dist_backend"] = backend
+        if not distributed and args.workload == "cfg2" and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(index, src)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed", "error": repr(e)}
+        if not distributed and args.workload == "cfg2" and not args.no_secondary:
+            del index, src, out
+            torch.cuda.empty_cache()
+            try:
+                res["secondary"] = secondary(dev, scale=args.scale)
+            except Exception as e:
+                res["secondary"] = {"error": repr(e)}
         print(json.dumps(res))
     if distributed:
         dist.barrier()

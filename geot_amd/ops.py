@@ -110,9 +110,13 @@ def _remember_rows(key, rows: int) -> None:
 
 
 def _begin_row_readback(index: torch.Tensor):
-    slot = getattr(_tls, "slot", None)
-    if slot is None:
-        slot = _tls.slot = (torch.empty(1, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+    slots = getattr(_tls, "slots", None)
+    if slots is None:
+        slots = _tls.slots = {}
+    dev = index.device.index if index.device.index is not None else torch.cuda.current_device()
+    slot = slots.get(dev)              # one (pinned word, event) per DEVICE: an event is bound to the device
+    if slot is None:                   # of its first record
+        slot = slots[dev] = (torch.empty(1, dtype=torch.int64).pin_memory(), torch.cuda.Event())
     host, event = slot
     host.copy_(index[-1:], non_blocking=True)
     event.record(torch.cuda.current_stream(index.device))
@@ -150,82 +154,84 @@ def _with_row_rule(index: torch.Tensor, launch):
     return out
 
 
-# ---- sorted=False: row rule and sortedness from ONE read-back -----------------------------------------
-# The reference's own test and benchmark call index_scatter(..., sorted=False) with an index they have just
-# sorted (test/test_index_scatter.py:11-14, benchmark/bench_index_scatter.py:32); its unsorted kernel then
-# flushes every run with atomics.  The row rule forces a device->host read of index[-1] on that call anyway,
-# so `geot_index_probe` also counts the descents of the index in the same pass and the same 16-byte
-# read-back tells the host whether the atomic-free kernels may serve the call (same sums; narrow rows run
-# up to 4x faster than through atomics).  An index with descents takes the atomic path exactly as before.
-# GEOT_PROBE_SORTED=0 disables the routing (rows still come from the probe).
-_PROBE_SORTED = os.environ.get("GEOT_PROBE_SORTED", "1") != "0"
-_probe_seen: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+# ---- what is known about an index tensor: ascending or not (+ its sorted form) ---------------------------
+# The atomic-free kernels need an ascending index.  The reference's "sorted" kernels flush every run with
+# atomicAdd (csrc/cuda/index_scatter_kernel.cuh:180,197), so they still add up correctly when a caller's
+# `sorted=True` promise is wrong; here a wrong promise must not return wrong rows either.  Every index tensor
+# is therefore PROBED ONCE (geot_index_probe: one pass, 8 B per edge, together with the row-rule read-back)
+# and the answer is remembered for that exact content: (storage identity, offset, length, version counter),
+# with a weak reference to the storage so that a recycled address can never alias a dead tensor.  This is the
+# trust autograd itself places in the version counter (saved-tensor checks); edits made behind it through
+# `.data` are not seen.  GEOT_TRUST_VERSION=0 probes on every call instead.
+#   ascending           -> atomic-free kernels (whatever `sorted` said: the reference's own test and benchmark
+#                          pass sorted=False with a sorted index, test/test_index_scatter.py:11-14)
+#   descents, any op    -> the index is sorted once (stable; kept with the facts) and the gather-mode kernels
+#                          run on (sorted keys, permutation): deterministic, any reduction, any dtype;
+#                          fp32/fp64 sums may instead take the atomic flush where that measured faster
+#                          (GEOT_UNSORTED=atomic|sort forces one).
+_TRUST_VERSION = os.environ.get("GEOT_TRUST_VERSION", "1") != "0"
+_UNSORTED_MODE = os.environ.get("GEOT_UNSORTED", "auto")
+_FACTS_MAX = 16
+_SORTED_KEEP = 4                       # facts that may hold a sorted copy (2 x int64[nnz] each)
 
 
-def _begin_probe(index: torch.Tensor):
-    hip._require_gpu(index)                                  # CPU tensors: the package's "no CPU fallback" error
-    slots = getattr(_tls, "probe", None)
-    if slots is None:
-        slots = _tls.probe = {}
-    dev = index.device.index if index.device.index is not None else torch.cuda.current_device()
-    slot = slots.get(dev)
-    if slot is None:
-        slot = slots[dev] = (torch.empty(2, dtype=torch.int64).pin_memory(),
-                             torch.empty(2, dtype=torch.int64, device=index.device), torch.cuda.Event())
-    host, devbuf, event = slot
-    hip.index_probe_out(index, devbuf)
-    host.copy_(devbuf, non_blocking=True)
-    event.record(torch.cuda.current_stream(index.device))
-    return slot
+class _IndexFacts:
+    __slots__ = ("weak", "rows", "ascending", "keys", "perm")
+
+    def __init__(self, weak, rows, ascending):
+        self.weak, self.rows, self.ascending, self.keys, self.perm = weak, rows, ascending, None, None
 
 
-def _end_probe(slot):
-    host, _, event = slot
-    event.synchronize()
-    return int(host[0]) + 1, (int(host[1]) == 0 and _PROBE_SORTED)
+_facts: "collections.OrderedDict[tuple, _IndexFacts]" = collections.OrderedDict()
 
 
-def _with_probe(index: torch.Tensor, launch, atomics_can_serve: bool):
-    """Run ``launch(rows, ascending) -> Tensor`` for a call that did not promise a sorted index.
-    atomics_can_serve: the atomic path implements this call (fp32/fp64 sum) - then a small, launch-bound
-    problem skips the probe (its kernels cost the same either way; the probe would add ~15 us of host time)."""
-    if index.numel() == 0:
-        return launch(_last_index_plus_one(index), False)   # raises IndexError like the reference
-    if index.numel() < _SPECULATE_MIN_EDGES:
-        if atomics_can_serve:
-            return launch(_last_index_plus_one(index), False)
-        hip._require_gpu(index)                              # one blocking 16-byte read, no bookkeeping
-        last, descents = hip.index_probe_out(index, torch.empty(2, dtype=torch.int64, device=index.device)).tolist()
-        return launch(last + 1, descents == 0 and _PROBE_SORTED)
-    key = _rows_key(index) if _SPECULATE else None
-    guess = _probe_seen.get(key) if key is not None else None
-    slot = _begin_probe(index)
-    if guess is None:
-        seen = _end_probe(slot)
-    else:
-        out = launch(*guess)                                 # overlaps the probe and its read-back
-        seen = _end_probe(slot)
-        if seen == guess:
-            return out
+def _content_key(index: torch.Tensor):
+    try:
+        version = index._version
+    except RuntimeError:               # inference tensors keep no version counter: never remembered
+        return None
+    return (index.untyped_storage()._cdata, index.storage_offset(), index.numel(), version)
+
+
+def _index_facts(index: torch.Tensor) -> _IndexFacts:
+    """Facts about a contiguous 1-D int64 device index; probes (one blocking 16-byte read) on first sight."""
+    key = _content_key(index) if _TRUST_VERSION else None
     if key is not None:
-        _probe_seen[key] = seen
-        _probe_seen.move_to_end(key)
-        while len(_probe_seen) > _ROWS_SEEN_MAX:
-            _probe_seen.popitem(last=False)
-    return launch(*seen)
+        f = _facts.get(key)
+        if f is not None and not f.weak.expired():
+            _facts.move_to_end(key)
+            return f
+    if index.numel() == 0:
+        _last_index_plus_one(index)    # raises IndexError like the reference's index[-1]
+    hip._require_gpu(index)
+    last, descents = hip.index_probe_out(index, torch.empty(2, dtype=torch.int64, device=index.device)).tolist()
+    from torch.multiprocessing.reductions import StorageWeakRef
+    f = _IndexFacts(StorageWeakRef(index.untyped_storage()) if key is not None else None, last + 1, descents == 0)
+    if key is not None:
+        _facts[key] = f
+        while len(_facts) > _FACTS_MAX:
+            _facts.popitem(last=False)
+    return f
 
 
-# GEOT_CHECK_SORTED=1: validate the "ascending index" precondition of the sorted kernels on every call
-# (one extra pass over the index + a host sync - a debugging aid, off by default).  The reference's sorted
-# kernels flush with atomics, so they still add up correctly on an unsorted index as long as index[-1] is
-# the maximum; the atomic-free kernels here do not.
-_CHECK_SORTED = os.environ.get("GEOT_CHECK_SORTED", "0") == "1"
+def _sorted_form(index: torch.Tensor, facts: _IndexFacts):
+    """(keys ascending, perm) of an index with descents; kept with its facts (a few entries at most)."""
+    if facts.keys is None:
+        keys, perm = torch.sort(index, stable=True)
+        if facts.weak is None:
+            return keys, perm
+        facts.keys, facts.perm = keys, perm
+        holders = [f for f in _facts.values() if f.keys is not None]
+        for old in holders[:-_SORTED_KEEP]:
+            old.keys = old.perm = None
+    return facts.keys, facts.perm
 
 
-def _assert_sorted(index: torch.Tensor, name: str) -> None:
-    if _CHECK_SORTED and index.numel() > 1 and not bool((index[1:] >= index[:-1]).all()):
-        raise RuntimeError(f"{name} is not sorted in ascending order (required when sorted=True; "
-                           "pass sorted=False to geot.index_scatter for an unsorted index)")
+def _sort_pays(feat: int, dtype: torch.dtype, kind: str) -> bool:
+    """Unsorted fp32/fp64 sum: sorted-gather path or atomic flush?  (rule measured on MI355X)"""
+    if _UNSORTED_MODE in ("sort", "atomic"):
+        return _UNSORTED_MODE == "sort"
+    return True
 
 
 def _reject_cpu(name: str):
@@ -252,43 +258,63 @@ def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce:
     moved = src if dim == 0 else src.movedim(dim, 0)
     moved = moved.contiguous()
     index = index.contiguous()
-    if sorted:
-        _assert_sorted(index, "index")
+    hip._dtype_code(moved, "index_scatter_sorted" if sorted else "index_scatter_unsorted")
+    facts = _index_facts(index)          # `sorted` is a promise the reference never checks; neither flag is trusted
+    tail = list(moved.shape[1:])
 
-    def launch(rows: int, ascending: bool = True) -> torch.Tensor:
-        if kind != "sum" and not ascending:
-            raise NotImplementedError(
-                f"index_scatter: reduce='{reduce}' needs an ascending index (an unsorted index supports 'sum')")
-        out_shape = list(moved.shape)
-        out_shape[0] = rows
-        out = torch.empty(out_shape, dtype=src.dtype, device=src.device)
-        return hip.index_scatter_out(index, moved, out, sorted=ascending, reduce=kind)
-
-    if sorted:
+    if facts.ascending:
+        def launch(rows: int) -> torch.Tensor:
+            out = torch.empty([rows] + tail, dtype=src.dtype, device=src.device)
+            return hip.index_scatter_out(index, moved, out, sorted=True, reduce=kind)
         out = _with_row_rule(index, launch)
+    elif (kind == "sum" and src.dtype in (torch.float32, torch.float64)
+          and not _sort_pays(moved[0].numel() if moved.shape[0] else 1, src.dtype, kind)):
+        out = torch.empty([facts.rows] + tail, dtype=src.dtype, device=src.device)
+        hip.index_scatter_out(index, moved, out, sorted=False)         # pre-reduced runs + float atomics
     else:
-        out = _with_probe(index, launch, kind == "sum" and src.dtype in (torch.float32, torch.float64))
+        # descents: reduce over (sorted keys, permutation) with the gather-mode kernels - src[perm[e]] is read in
+        # key order; deterministic, every reduction and dtype.  Rows stay index[-1]+1 (the reference's rule even
+        # for an unsorted index, csrc/index_scatter.cpp:30); keys beyond are ignored by the kernels.
+        keys, perm = _sorted_form(index, facts)
+        flat = moved.reshape(moved.shape[0], -1)
+        out = torch.empty([facts.rows] + tail, dtype=src.dtype, device=src.device)
+        hip.gather_reduce_out(perm, keys, None, flat, out.view(facts.rows, -1), kind)
     return out if dim == 0 else out.movedim(0, dim)
 
 
 def _check_gather(src_index, dst_index, src, ndim: int) -> None:
     if not (src_index.dim() == dst_index.dim() == 1):
         raise RuntimeError("src_index and dst_index must be 1 dimensional")
-    _assert_sorted(dst_index, "dst_index")
     if src.dim() != ndim:
         raise RuntimeError(f"src must be {ndim} dimensional")
     if src_index.size(0) != dst_index.size(0):
         raise RuntimeError("src_index and dst_index must have the same length")
 
 
+def _dst_ordered(src_index, dst_index, weight=None, weight_edge_dim: int = 0):
+    """Edges in ascending dst order: the tensors as given when dst_index is ascending (the precondition of the
+    reference, unchecked there; checked once per index content here), else their stable sort by destination.
+    Returns (src_index, dst_index, weight, rows_if_known)."""
+    facts = _index_facts(dst_index)
+    if facts.ascending:
+        return src_index, dst_index, weight, None
+    keys, perm = _sorted_form(dst_index, facts)
+    if weight is not None:
+        weight = weight.index_select(weight_edge_dim, perm).contiguous()
+    return src_index[perm], keys, weight, facts.rows
+
+
 def _gather_scatter_gpu(src_index, dst_index, src, rows: Optional[int] = None) -> torch.Tensor:
     _check_gather(src_index, dst_index, src, 2)
     src_index, dst_index, src = src_index.contiguous(), dst_index.contiguous(), src.contiguous()
+    src_index, dst_index, _, known = _dst_ordered(src_index, dst_index)
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
         return hip.gather_scatter_out(src_index, dst_index, src, out)
 
+    if rows is None and known is not None:
+        rows = known
     return launch(rows) if rows is not None else _with_row_rule(dst_index, launch)
 
 
@@ -298,11 +324,14 @@ def _gather_weight_scatter_gpu(src_index, dst_index, weight, src, rows: Optional
         raise RuntimeError("weight must be 1 dimensional with one value per edge")
     src_index, dst_index = src_index.contiguous(), dst_index.contiguous()
     weight, src = weight.contiguous(), src.contiguous()
+    src_index, dst_index, weight, known = _dst_ordered(src_index, dst_index, weight)
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
         return hip.gather_weight_scatter_out(src_index, dst_index, weight, src, out)
 
+    if rows is None and known is not None:
+        rows = known
     return launch(rows) if rows is not None else _with_row_rule(dst_index, launch)
 
 
@@ -331,12 +360,13 @@ def _mh_spmm_gpu(src_index, dst_index, weight, src, reduce: str) -> torch.Tensor
         raise RuntimeError("Invalid weight size")
     src_index, dst_index = src_index.contiguous(), dst_index.contiguous()
     weight, src = weight.contiguous(), src.contiguous()
+    src_index, dst_index, weight, known = _dst_ordered(src_index, dst_index, weight, 1 if head_major else 0)
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
         return hip.mh_spmm_out(src_index, dst_index, weight, src, out, head_major)
 
-    return _with_row_rule(dst_index, launch)
+    return launch(known) if known is not None else _with_row_rule(dst_index, launch)
 
 
 def _csr_gws_gpu(indptr, indices, weight, src) -> torch.Tensor:
@@ -478,11 +508,14 @@ def _transpose_edges_gpu(src_index, dst_index):
             key = None
     if key is not None and key in _transposed:
         _transposed.move_to_end(key)
-        return _transposed[key]
+        return _transposed[key][0]
     _, perm = torch.sort(src_index, stable=True)
     res = (perm, src_index[perm], dst_index[perm])
     if key is not None:
-        _transposed[key] = res
+        # The entry keeps the two key tensors alive: while it lives the caching allocator cannot hand their
+        # addresses to a NEW edge list of the same size (which would also start at _version 0 and hit this
+        # key with a stale permutation - dynamic kNN graphs, fixed-count edge dropout, negative sampling).
+        _transposed[key] = (res, src_index, dst_index)
         while len(_transposed) > _TRANSPOSED_MAX:
             _transposed.popitem(last=False)
     return res
@@ -564,12 +597,13 @@ def _gather_reduce_gpu(src_index, dst_index, weight, src, reduce):
     kind = _aggr_kind(reduce)
     src_index, dst_index, src = src_index.contiguous(), dst_index.contiguous(), src.contiguous()
     weight = None if weight is None else weight.contiguous()
+    src_index, dst_index, weight, known = _dst_ordered(src_index, dst_index, weight)
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
         return hip.gather_reduce_out(src_index, dst_index, weight, src, out, kind)
 
-    return _with_row_rule(dst_index, launch)
+    return launch(known) if known is not None else _with_row_rule(dst_index, launch)
 
 
 _lib_def.impl("gather_reduce", _gather_reduce_gpu, "CUDA")
@@ -668,8 +702,8 @@ def _mh_spmm_rows_gpu(src_index, dst_index, weight, src, rows):
     if weight.dim() != 2 or weight.size(0) != src_index.size(0) or weight.size(1) != src.size(1):
         raise RuntimeError("Invalid weight size")
     out = torch.empty((int(rows), src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
-    return hip.mh_spmm_out(src_index.contiguous(), dst_index.contiguous(), weight.contiguous(), src.contiguous(),
-                           out, False)
+    src_index, dst_index, weight, _ = _dst_ordered(src_index.contiguous(), dst_index.contiguous(), weight.contiguous())
+    return hip.mh_spmm_out(src_index, dst_index, weight, src.contiguous(), out, False)
 
 
 _lib_def.impl("gather_scatter_rows", lambda si, di, s, rows: _gather_scatter_gpu(si, di, s, rows=int(rows)), "CUDA")

@@ -10,8 +10,10 @@ Two ways to cut:
   * ``segment_aligned_cuts``  snaps every cut to a segment start -> no data-path collective;
   * ``equal_edge_cuts``       exact edge balance -> a segment may straddle a cut; each rank's
     partial first row is then exchanged with ONE small collective (all_gather of W rows of F
-    values + 2 keys - latency-bound, microseconds over xGMI) and added by the owner in rank order
+    values - latency-bound, microseconds over xGMI) and added by the owner in rank order
     (deterministic).  A hub that spans several ranks is handled by the same pass.
+Which case applies is decided per call from every rank's end keys (a 16-byte-per-rank all_gather that runs
+underneath the local kernels), so the host never waits for the reduction and the GPU never idles on the host.
 
 ``local_op(index_local, src_local, rows) -> [rows, F]`` is the per-rank reduction; by default the
 HIP operator.  Tests inject a CPU function to exercise the exchange logic under gloo.
@@ -53,15 +55,19 @@ def _default_local_op(index_local: torch.Tensor, src_local: torch.Tensor, rows: 
 
 # (first_key, last_key) of THIS rank's shard, remembered per index identity: GNN edge lists are static, so
 # the local row count is almost always the same as last time.  It is only a GUESS for launching the local
-# kernels early: the true keys are read back underneath them and verified before anything is sent.
+# kernels early: the true keys of every rank arrive underneath them and are verified before any row is sent.
 _ends_seen: dict = {}
 _tls = __import__("threading").local()
 
 
-def _pinned_slot():
-    slot = getattr(_tls, "slot", None)
+def _pinned_slot(dev: torch.device, world: int):
+    slots = getattr(_tls, "slots", None)
+    if slots is None:
+        slots = _tls.slots = {}
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), world)
+    slot = slots.get(key)             # per device: a CUDA event is bound to the device of its first record
     if slot is None:
-        slot = _tls.slot = (torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        slot = slots[key] = (torch.empty(2 * world, dtype=torch.int64).pin_memory(), torch.cuda.Event())
     return slot
 
 
@@ -73,41 +79,37 @@ def _ident(index: torch.Tensor, world: int, rank: int, key_offset):
     return (index.device.type, index.device.index, index.data_ptr(), index.numel(), version, world, rank, key_offset)
 
 
-def _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange):
-    """Ownership rules given every rank's (first_key, last_key): returns (rows, first_row)."""
+def boundary_plan(firsts: List[int], lasts: List[int], rank: int) -> dict:
+    """Ownership rules, decided on the HOST from every rank's (first_key, last_key).  Every rank computes the same
+    table, so all ranks agree on whether a row exchange is needed at all.
+
+    rank r owns dst rows (last_key_{r-1}, last_key_r].  `joins` = the following ranks whose first-row partial
+    belongs to my last row (a hub may span several ranks); `owns_first` = my first row is mine (the previous
+    rank does not end on the same key); `gap` = empty keys between the previous rank's last key and my first."""
+    world = len(firsts)
     first_key, last_key = firsts[rank], lasts[rank]
     owns_first = rank == 0 or lasts[rank - 1] != first_key
-    if not exchange and not owns_first:
-        raise RuntimeError("exchange=False but a segment straddles the cut between ranks "
-                           f"{rank - 1} and {rank}")
-    if exchange:
-        # add the first-row partials of the following ranks that continue my last key, in rank order
-        r2 = rank + 1
-        tail = None
-        while r2 < world and firsts[r2] == last_key:
-            part = allrows[r2].view(feat_shape)          # float64 record: exact transport of the fp32 / 16-bit row
-            tail = part if tail is None else tail + part
-            if lasts[r2] != last_key:
-                break  # that rank has further keys: the run ends inside it
-            r2 += 1
-        if tail is not None:
-            local[-1].add_(tail)  # in place (one kernel): `local` is this call's own buffer
-    # my rows: (last_key_{rank-1}, last_key]; drop a first row owned by a lower rank,
-    # prepend zero rows for the empty keys between the previous rank's last key and my first key
+    joins = []
+    r2 = rank + 1
+    while r2 < world and firsts[r2] == last_key:
+        joins.append(r2)
+        if lasts[r2] != last_key:
+            break                      # that rank has further keys: the run ends inside it
+        r2 += 1
+    if not owns_first and first_key == last_key:
+        joins = []                     # my whole shard lies inside a run owned by a lower rank: it adds my row
     prev_last = lasts[rank - 1] if rank > 0 else -1
-    if not owns_first:
-        return local[1:], first_key + 1
-    gap = first_key - (prev_last + 1)
-    if gap > 0:
-        local = torch.cat([local.new_zeros((gap,) + feat_shape), local])
-    return local, prev_last + 1
+    any_shared = any(lasts[r - 1] == firsts[r] for r in range(1, world))
+    return {"owns_first": owns_first, "joins": joins, "gap": (first_key - (prev_last + 1)) if owns_first else 0,
+            "first_row": (prev_last + 1) if owns_first else first_key + 1, "any_shared": any_shared}
 
 
 def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
                           group: Optional[dist.ProcessGroup] = None,
                           local_op: Optional[Callable] = None,
                           exchange: bool = True,
-                          key_offset: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+                          key_offset: Optional[int] = None,
+                          timing: Optional[dict] = None) -> Tuple[torch.Tensor, int]:
     """Row-sharded index_scatter over the ranks of ``group``.
 
     ``index_shard`` / ``src_shard`` are this rank's contiguous slice of the globally dst-sorted
@@ -116,21 +118,22 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     its first row.  Concatenating the ranks' ``out_rows`` in rank order gives exactly
     ``index_scatter(0, src, index)`` of the unsharded problem.
 
-    ``exchange=False`` asserts the cuts are segment-aligned (no key is shared by two ranks) and
-    skips the row exchange.
+    ``exchange=False`` asserts the cuts are segment-aligned (no key is shared by two ranks).
 
     ``key_offset``: the shard's index is already rank-local and its first key is 0
     (global key = local key + key_offset); saves the pass that re-bases the keys.
 
-    Host synchronisation without stalling the GPU, and without ever issuing a second collective
-    (every rank always makes exactly ONE all_gather per call, so ranks cannot fall out of step):
-      1. this rank's end keys are remembered per index identity; the local kernels are launched for the
-         remembered row count while the D2H copy of the real end keys completes underneath; a mismatch
-         relaunches the LOCAL kernels only - nothing has been sent yet;
-      2. the all_gather carries every rank's exact keys and first-row partial; one small D2H copy brings
-         the keys to the host (the only other host sync of the call);
-      3. the ownership step (add the following ranks' partials to my last row, drop / pad the first row)
-         is decided from those exact keys and queued behind everything else.
+    Protocol (the host never waits for the local reduction, the GPU never waits for the host):
+      1. KEYS FIRST: an all_gather of every rank's (first_key, last_key) - 16 bytes per rank, independent of the
+         reduction - is queued in front of the local kernels and copied to the host underneath them;
+      2. the local kernels are launched for the REMEMBERED row count of this index tensor while those keys are
+         in flight; when they arrive the guess is verified (a mismatch relaunches the local kernels only);
+      3. every rank now knows every boundary: if no key is shared by two ranks (segment-aligned cuts) the call
+         is done - no data-path collective at all; otherwise ONE all_gather of the ranks' first-row partials
+         (W x F values, native precision) follows the local kernels on the stream, and the owner adds the
+         partials that belong to its last row in rank order (deterministic) - all queued, no host wait.
+    Every rank issues the same collectives in the same order whatever its local verification says.
+    ``timing``: optional dict; receives hipEvent pairs around the exchange ("exchange_events").
     """
     local_op = local_op or _default_local_op
     world = dist.get_world_size(group)
@@ -140,8 +143,10 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     feat_shape = tuple(src_shard.shape[1:])
     F = int(src_shard[0].numel())
     dev = src_shard.device
+    on_gpu = dev.type == "cuda"
     ident = _ident(index_shard, world, rank, key_offset)
     guess = _ends_seen.get(ident) if ident is not None else None
+    off = int(key_offset or 0)
 
     def run_local(lo, hi):
         if key_offset is None:
@@ -149,74 +154,79 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         out = local_op(index_shard, src_shard, hi + 1)
         return out[lo:] if lo else out
 
-    # ---- 1. local reduction, rows [first_key, last_key] ------------------------------------------------
     ends_dev = index_shard[::max(index_shard.numel() - 1, 1)][:2]     # [first, last] as one strided view, no kernel
     if ends_dev.numel() == 1:
         ends_dev = ends_dev.expand(2)
-    if guess is None:
-        ends = ends_dev.cpu()                                       # first call: D2H sync, as index[-1].item()
-        lo, hi = int(ends[0]), int(ends[1])
-        local = run_local(lo, hi)
+
+    # ---- 1. keys of every rank (tiny collective, queued before the local kernels) -------------------------
+    if world > 1:
+        # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or test ranks sharing
+        # one GPU) stages the few bytes through the host
+        via_host = on_gpu and dist.get_backend(group) == "gloo"
+        mine = (ends_dev + off) if off else ends_dev.contiguous()
+        send = mine.cpu() if via_host else mine
+        allkeys = torch.empty(2 * world, dtype=torch.int64, device=send.device)
+        dist.all_gather_into_tensor(allkeys, send, group=group)
     else:
-        lo, hi = guess["local_ends"]
-        if dev.type == "cuda":
-            host, ev = _pinned_slot()
-            host.copy_(ends_dev, non_blocking=True)
-            ev.record(torch.cuda.current_stream(dev))
-            local = run_local(lo, hi)                               # queued behind the copy
-            ev.synchronize()
-            true_ends = (int(host[0]), int(host[1]))
-        else:                                                       # host tensors: nothing to overlap
-            true_ends = (int(ends_dev[0]), int(ends_dev[1]))
-            local = run_local(*true_ends)
-        if true_ends != (lo, hi):                                   # index changed under the same identity
-            if dev.type == "cuda":                                  # (the HIP kernels ignore out-of-range keys)
-                local = run_local(*true_ends)
-            lo, hi = true_ends
-            guess = None
-    first_key, last_key = (key_offset or 0) + lo, (key_offset or 0) + hi
-    head = local[0]
+        via_host = False
+        allkeys = (ends_dev + off) if off else ends_dev
+    waiter = None
+    if on_gpu and not via_host:
+        host, waiter = _pinned_slot(dev, world)
+        host.copy_(allkeys, non_blocking=True)
+        waiter.record(torch.cuda.current_stream(dev))
+    else:
+        host = allkeys
 
-    if world == 1:
-        if ident is not None:
-            _ends_seen[ident] = {"local_ends": (lo, hi)}
-        if first_key > 0:
-            local = torch.cat([local.new_zeros((first_key,) + feat_shape), local])
-        return local, 0
-
-    # ---- 2. the one collective: [first_key, last_key, first_row(F)] of every rank ------------------------
-    # built from device tensors only (no scalar host->device writes on the step path): two small kernels
-    # write the record, the collective moves it, one small D2H copy brings every rank's keys to the host
-    n_rec = 2 + (F if exchange else 0)
-    rec = torch.empty(n_rec, dtype=torch.float64, device=dev)
-    torch.add(ends_dev, int(key_offset or 0), out=rec[:2])          # keys < 2^53: exact in float64
-    if exchange:
-        rec[2:].copy_(head.reshape(-1))
-    # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or two test
-    # ranks sharing one GPU) stages the few hundred bytes through the host
-    via_host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
-    send = rec.cpu() if via_host else rec
-    recv = torch.empty(world * n_rec, dtype=torch.float64, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv_host = recv.cpu().view(world, n_rec)                       # host sync: everything above is queued
-    firsts = [int(v) for v in recv_host[:, 0]]
-    lasts = [int(v) for v in recv_host[:, 1]]
-    allrows = recv.to(dev).view(world, n_rec)[:, 2:] if exchange else None
-
-    # ---- 3. ownership: at most two more small kernels, queued behind the local reduction -----------------
-    # (they run while the host is already preparing the next call)
+    # ---- 2. local reduction, rows [first_key, last_key], launched on the remembered keys ------------------
+    local = run_local(*guess) if (guess is not None and on_gpu) else None   # host tensors: nothing to overlap
+    if waiter is not None:
+        waiter.synchronize()                                        # the keys landed while the kernels run
+    keys = host.tolist()
+    firsts, lasts = keys[0::2], keys[1::2]
+    lo, hi = firsts[rank] - off, lasts[rank] - off
+    if local is None or guess != (lo, hi):                          # first call, or the index changed under the same identity
+        local = run_local(lo, hi)                                   # (the HIP kernels ignore out-of-range keys)
     if ident is not None:
-        _ends_seen[ident] = {"local_ends": (lo, hi)}
+        _ends_seen[ident] = (lo, hi)
         if len(_ends_seen) > 64:
             _ends_seen.pop(next(iter(_ends_seen)))
-    return _apply_boundaries(local, head, allrows, firsts, lasts, rank, world, feat_shape, exchange)
+
+    plan = boundary_plan(firsts, lasts, rank)
+    if not exchange and plan["any_shared"]:
+        r = next(r for r in range(1, world) if lasts[r - 1] == firsts[r])
+        raise RuntimeError(f"exchange=False but a segment straddles the cut between ranks {r - 1} and {r}")
+
+    # ---- 3. first-row partials, only when some key is shared (all ranks agree: they all hold all keys) -----
+    if plan["any_shared"]:
+        ev = None
+        if timing is not None and on_gpu:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(dev))
+        xdtype = torch.float64 if local.dtype == torch.float64 else torch.float32   # exact for fp32 / 16-bit rows
+        rec = local[0].reshape(-1).to(xdtype)
+        send = rec.cpu() if via_host else rec
+        recv = torch.empty(world * F, dtype=xdtype, device=send.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        allrows = (recv.to(dev) if via_host else recv).view(world, F)
+        for r2 in plan["joins"]:                                    # rank order: deterministic
+            local[-1].add_(allrows[r2].view(feat_shape))            # in place: `local` is this call's own buffer
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(dev))
+            timing.setdefault("exchange_events", []).append(ev)
+
+    if not plan["owns_first"]:
+        return local[1:], plan["first_row"]
+    if plan["gap"] > 0:                                             # empty keys in front of my first key (rare)
+        local = torch.cat([local.new_zeros((plan["gap"],) + feat_shape), local])
+    return local, plan["first_row"]
 
 
 def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch.Tensor,
                            src: torch.Tensor, weight_shard: Optional[torch.Tensor] = None,
                            group: Optional[dist.ProcessGroup] = None,
                            local_op: Optional[Callable] = None, exchange: bool = True,
-                           key_offset: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+                           key_offset: Optional[int] = None, timing: Optional[dict] = None) -> Tuple[torch.Tensor, int]:
     """Row-sharded gather_scatter / gather_weight_scatter (BASELINE.json configs[4]).
 
     The edge list (src_index, dst_index[, weight]) is sharded by contiguous dst-sorted edge ranges
@@ -240,7 +250,7 @@ def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch
     # the per-edge operand is only used for its feature shape: hand over one row of src
     proto = src[:1].expand(dst_index_shard.numel(), *src.shape[1:])
     return sharded_index_scatter(dst_index_shard, proto, group=group, local_op=as_index_scatter,
-                                 exchange=exchange, key_offset=key_offset)
+                                 exchange=exchange, key_offset=key_offset, timing=timing)
 
 
 def shard_edges(index: torch.Tensor, src: torch.Tensor, world: int, rank: int, aligned: bool = False):

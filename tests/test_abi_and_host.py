@@ -113,15 +113,28 @@ def test_argument_checks_carry_the_reference_texts():
         ops._index_scatter_gpu(0, idx[:0], src[:0], "sum", True)
 
 
-def test_optional_sortedness_check(monkeypatch):
-    monkeypatch.setattr(ops, "_CHECK_SORTED", True)
-    src = torch.rand(4, 2)
-    with pytest.raises(RuntimeError, match="index is not sorted in ascending order"):
-        ops._index_scatter_gpu(0, torch.tensor([0, 2, 1, 2]), src, "sum", True)
-    with pytest.raises(RuntimeError, match="dst_index is not sorted"):
-        ops._gather_scatter_gpu(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 2, 1, 2]), src)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):      # sorted=False skips the check and reaches the doorway
-        ops._index_scatter_gpu(0, torch.tensor([0, 2, 1, 2]), src, "sum", False)
+def test_index_facts_are_keyed_on_content_identity():
+    """The remembered facts of an index (ascending? rows, sorted form) are keyed on storage identity + offset +
+    length + version counter and guarded by a weak reference to the storage: a new tensor can never alias a
+    dead one, an in-place edit invalidates the entry, a view of the same memory shares it."""
+    a = torch.arange(10)
+    k0 = ops._content_key(a)
+    assert ops._content_key(a[:]) == k0 and ops._content_key(a.view(10)) == k0       # same memory, same facts
+    assert ops._content_key(a[1:]) != k0
+    a.add_(1)
+    assert ops._content_key(a) != k0                                                  # version counter moved
+    from torch.multiprocessing.reductions import StorageWeakRef
+    w = StorageWeakRef(a.untyped_storage())
+    assert not w.expired()
+    del a
+    assert w.expired()                                                                # a recycled address cannot alias
+    with torch.inference_mode():
+        assert ops._content_key(torch.arange(3)) is None                              # no version counter: never kept
+    # CPU tensors never reach the probe: the doorway refuses them
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops._index_scatter_gpu(0, torch.tensor([0, 2, 1, 2]), torch.rand(4, 2), "sum", True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops._gather_scatter_gpu(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 2, 1, 2]), torch.rand(4, 2))
 
 
 def test_cpu_tensors_fail_loudly_no_fallback():

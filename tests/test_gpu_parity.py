@@ -252,20 +252,23 @@ def test_sorted_false_is_routed_by_the_probe(geot, oracle, monkeypatch):
             a = geot.index_scatter(0, dev(src), dev(index), red, sorted=True)
             for _ in range(2):                                        # second call takes the speculated order
                 b = geot.index_scatter(0, dev(src), dev(index), red, sorted=False)
-                if red == "sum" and nnz < ops._SPECULATE_MIN_EDGES:   # launch-bound fp32 sum: atomic path, no probe
-                    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
-                else:
-                    assert torch.equal(a, b), (nnz, red)
+                assert torch.equal(a, b), (nnz, red)                  # ascending: the same atomic-free kernels
         shuffled = index.copy()
         shuffled[:-1] = rng.permutation(shuffled[:-1])
         descents = int((shuffled[:-1] > shuffled[1:]).sum())
         probe = hip.index_probe_out(dev(shuffled), torch.empty(2, dtype=torch.int64, device="cuda")).cpu()
         assert probe.tolist() == [K - 1, descents] and descents > 0
         check_index_scatter(geot, oracle, shuffled, src, sorted=False, what=f"probe-routed unsorted {nnz}")
-        with pytest.raises(NotImplementedError, match="needs an ascending index"):
-            geot.index_scatter(0, dev(src), dev(shuffled), "mean", sorted=False)
-        # same tensor object, content changed in place between calls: the speculated (rows, ascending) pair
-        # must be re-verified, never trusted
+        for red in ("mean", "max"):           # any reduction on an index with descents: sorted-gather path
+            got = geot.index_scatter(0, dev(src), dev(shuffled), red, sorted=False).cpu().numpy()
+            order = np.argsort(shuffled, kind="stable")
+            want = oracle.index_scatter_3pass(shuffled[order], src[order], reduce=red, rows=K)
+            if red == "max":
+                assert np.array_equal(got, want)
+            else:
+                np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+        # same tensor object, content changed in place between calls (copy_ moves the version counter):
+        # the remembered facts must not be reused
         t = dev(index)
         first = geot.index_scatter(0, dev(src), t, "sum", sorted=False)
         t.copy_(dev(shuffled))
@@ -273,11 +276,12 @@ def test_sorted_false_is_routed_by_the_probe(geot, oracle, monkeypatch):
         want = oracle.index_scatter(shuffled, src, acc64=True)
         np.testing.assert_allclose(second.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
         assert first.shape == second.shape
-    monkeypatch.setattr(ops, "_PROBE_SORTED", False)                  # GEOT_PROBE_SORTED=0: atomic path as before
-    index = np.sort(rng.integers(0, 50, 4000)).astype(np.int64)
-    index[-1] = 49
-    src = rng.random((4000, 8), dtype=np.float32)
-    check_index_scatter(geot, oracle, index, src, sorted=False, what="probe routing off")
+    for mode in ("atomic", "sort"):                                   # GEOT_UNSORTED forces either unsorted path
+        monkeypatch.setattr(ops, "_UNSORTED_MODE", mode)
+        index = rng.integers(0, 50, 4000).astype(np.int64)
+        index[-1] = 49
+        src = rng.random((4000, 8), dtype=np.float32)
+        check_index_scatter(geot, oracle, index, src, sorted=False, what=f"unsorted mode {mode}")
 
 
 def test_unsorted_index_with_sorted_false(geot, oracle):

@@ -1,0 +1,318 @@
+"""Round-2 parity cases (`-m gpu`): the holes VERDICT.md (round 1) named.
+
+* BASELINE.json configs[3]'s SHAPE (mh_spmm, H=4 x F=64 = 1-KiB rows) at >= 1 M edges against the oracle;
+* gather mode with a src table beyond 2^31 elements (byte offsets past 8 GB);
+* full-size properties of configs[2] (gws, 124 M edges, F=128) and of one GPU's shard of configs[4]
+  (gather_scatter, 202 M edges, 57 GB src): checksum of checksums (linearity), sampled segments against
+  float64 torch reductions, determinism, exact zeros - the style of test_cfg2_full_size_properties;
+* gather_weight_scatter against rocSPARSE's CSR SpMM result on >= 10 M edges (the north star's comparator);
+* a wrong `sorted=True` promise / an unsorted dst_index never returns wrong rows; the unsorted path is
+  bit-reproducible; the transposed-edge cache cannot alias a dead edge list.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, powerlaw_index
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def geot():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import geot_amd
+    return geot_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def device_powerlaw(nnz, keys, seed):
+    sys.path.insert(0, ROOT)
+    from bench import powerlaw_index as gen
+    return gen(nnz, keys, seed, torch.device("cuda"))
+
+
+def close_to_oracle(got, hi, mag, what):
+    got = got.detach().cpu().numpy()
+    assert got.shape == hi.shape, (what, got.shape, hi.shape)
+    bound = RTOL * mag + 1e-30
+    err = np.abs(got.astype(np.float64) - hi.astype(np.float64))
+    assert np.all(err <= bound), f"{what}: max err/bound = {np.max(err / bound):.3g}"
+    assert np.all(got[mag == 0] == 0), what
+
+
+def test_mh_spmm_cfg4_shape_against_oracle(geot, oracle):
+    """H=4 x F=64 (1-KiB rows, 64 lanes per row, head = f0 / 64), 1.2 M power-law edges, both weight layouts."""
+    rng = np.random.default_rng(404)
+    nodes, nnz, H, F = 20_000, 1_200_000, 4, 64
+    di = powerlaw_index(nnz, nodes, 41)
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    w = rng.random((nnz, H), dtype=np.float32)
+    x = rng.random((nodes, H, F), dtype=np.float32)
+    hi = oracle.mh_spmm(si, di, w, x, acc64=True)
+    a = geot.mh_spmm(dev(si), dev(di), dev(w), dev(x))
+    b = geot.mh_spmm(dev(si), dev(di), dev(np.ascontiguousarray(w.T)), dev(x))
+    close_to_oracle(a, hi, hi, "mh [nnz,H]")
+    close_to_oracle(b, hi, hi, "mh [H,nnz]")
+    assert torch.equal(a, geot.mh_spmm(dev(si), dev(di), dev(w), dev(x)))          # deterministic
+    # heads must not mix: zero one head's weights -> exactly that head's slice is zero
+    w0 = w.copy()
+    w0[:, 2] = 0
+    c = geot.mh_spmm(dev(si), dev(di), dev(w0), dev(x))
+    assert c[:, 2].abs().sum().item() == 0 and torch.equal(c[:, 1], a[:, 1]) and torch.equal(c[:, 3], a[:, 3])
+
+
+def test_gather_src_table_beyond_2_31_elements(geot):
+    """5 M x 512 fp32 = 2.56e9 elements (10.2 GB): gathered-row byte offsets exceed 2^32 and element offsets 2^31."""
+    nodes, F, nnz, rows = 5_000_000, 512, 3_000_000, 200_000
+    torch.manual_seed(5)
+    x = torch.rand(nodes, F, device="cuda")
+    di = device_powerlaw(nnz, rows, 51)
+    si = torch.randint(0, nodes, (nnz,), device="cuda")
+    si[: nnz // 2] = torch.randint(nodes - 400_000, nodes, (nnz // 2,), device="cuda")   # rows above 2^31 elements
+    w = torch.rand(nnz, device="cuda")
+    out = geot.gather_weight_scatter(si, di, w, x)
+    assert out.shape == (rows, F)
+    counts = torch.bincount(di, minlength=rows)
+    offs = torch.cumsum(counts, 0) - counts
+    pick = [int(counts.argmax()), 0, rows - 1] + torch.randint(0, rows, (60,)).tolist()
+    high = 0
+    for k in pick:
+        e = slice(int(offs[k]), int(offs[k] + counts[k]))
+        seg = (x[si[e]].double() * w[e].double()[:, None]).sum(0)
+        assert torch.allclose(out[k].double(), seg, rtol=1e-5, atol=1e-6), k
+        high += int((si[e] * F > 2**31).sum())
+    assert high > 0
+    assert out[counts == 0].abs().sum().item() == 0
+    # checksum of checksums: sum over dst rows == sum over nodes of (total weight into the node) * its row
+    cw = torch.zeros(nodes, dtype=torch.float64, device="cuda").index_add_(0, si, w.double())
+    want = torch.zeros(F, dtype=torch.float64, device="cuda")
+    for lo in range(0, nodes, 1_000_000):
+        want += cw[lo:lo + 1_000_000] @ x[lo:lo + 1_000_000].double()
+    assert torch.allclose(out.double().sum(0), want, rtol=1e-7)
+    gs = geot.gather_scatter(si, di, x)
+    k = pick[0]
+    assert torch.allclose(gs[k].double(), x[si[int(offs[k]): int(offs[k] + counts[k])]].double().sum(0), rtol=1e-5)
+
+
+def _gather_properties(geot, si, di, w, x, rows, samples=150):
+    out = geot.gather_scatter(si, di, x) if w is None else geot.gather_weight_scatter(si, di, w, x)
+    assert out.shape == (rows, x.shape[1])
+    again = geot.gather_scatter(si, di, x) if w is None else geot.gather_weight_scatter(si, di, w, x)
+    assert torch.equal(out, again)                                             # deterministic, no atomics
+    del again
+    counts = torch.bincount(di, minlength=rows)
+    assert out[counts == 0].abs().sum().item() == 0 and int((counts == 0).sum()) > 0
+    offs = torch.cumsum(counts, 0) - counts
+    pick = [int(counts.argmax()), 0, rows - 1, rows // 2] + torch.randint(0, rows, (samples,)).tolist()
+    for k in pick:
+        e = slice(int(offs[k]), int(offs[k] + counts[k]))
+        msg = x[si[e]].double()
+        if w is not None:
+            msg = msg * w[e].double()[:, None]
+        assert torch.allclose(out[k].double(), msg.sum(0), rtol=1e-5, atol=1e-6), k
+    # linearity: column sums of the result == (per-node total weight) @ x
+    nodes = x.shape[0]
+    ones = torch.ones(1, dtype=torch.float64, device="cuda").expand(si.numel()) if w is None else w.double()
+    cw = torch.zeros(nodes, dtype=torch.float64, device="cuda").index_add_(0, si, ones)
+    want = torch.zeros(x.shape[1], dtype=torch.float64, device="cuda")
+    step = 4_000_000
+    for lo in range(0, nodes, step):
+        want += cw[lo:lo + step] @ x[lo:lo + step].double()
+    got = torch.zeros_like(want)
+    for lo in range(0, rows, step):
+        got += out[lo:lo + step].double().sum(0)
+    assert torch.allclose(got, want, rtol=1e-8), (got - want).abs().max()
+    return out
+
+
+def test_cfg3_full_size_properties(geot):
+    """BASELINE.json configs[2] at full size: gws, 2.45 M nodes, 123.7 M edges, F=128."""
+    nodes, nnz, F = 2_449_029, 123_718_280, 128
+    di = device_powerlaw(nnz, nodes, 7)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    w = torch.rand(nnz, device="cuda", generator=g)
+    x = torch.rand(nodes, F, device="cuda", generator=g)
+    _gather_properties(geot, si, di, w, x, nodes)
+
+
+def test_cfg5_one_gpu_shard_full_size_properties(geot):
+    """One GPU's shard of BASELINE.json configs[4]: 202 M edges -> 13.9 M rows, all 111 M source rows (56.9 GB)."""
+    nodes_all, F = 111_059_956, 128
+    nnz, rows = 1_615_685_872 // 8, nodes_all // 8
+    di = device_powerlaw(nnz, rows, 13)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(14)
+    si = torch.randint(0, nodes_all, (nnz,), device="cuda", generator=g)
+    x = torch.rand(nodes_all, F, device="cuda", generator=g)
+    _gather_properties(geot, si, di, None, x, rows, samples=60)
+    del x
+    torch.cuda.empty_cache()
+
+
+def test_gws_matches_rocsparse_csr_spmm(geot):
+    """>= 10 M edges: the result of rocSPARSE's CSR SpMM (its nnz-split algorithm) on the same matrix."""
+    sys.path.insert(0, ROOT)
+    from tools import rocsparse
+    nodes, nnz, F = 400_000, 12_000_000, 128
+    di = device_powerlaw(nnz, nodes, 71)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(72)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    w = torch.rand(nnz, device="cuda", generator=g)
+    x = torch.rand(nodes, F, device="cuda", generator=g)
+    out = geot.gather_weight_scatter(si, di, w, x)
+    rowptr, col = rocsparse.csr_from_sorted_coo(di, si, nodes)
+    y = torch.empty(nodes, F, device="cuda")
+    op = rocsparse.CsrSpMM(nodes, nodes, rowptr, col, w, x, y)
+    assert op.prepare("csr_nnz_split")
+    op.run()
+    torch.cuda.synchronize()
+    assert out.shape == y.shape
+    scale = out.abs().max()
+    assert ((out - y).abs().max() / scale).item() < 2e-5
+    assert torch.allclose(out, y, rtol=1e-4, atol=1e-4 * float(scale))
+
+
+def test_wrong_sorted_promise_still_sums_correctly(geot, oracle):
+    """The reference's sorted kernels flush with atomicAdd, so sorted=True on a not-quite-sorted index still adds
+    up (csrc/cuda/index_scatter_kernel.cuh:180,197).  Here the index is probed once per content: descents are
+    routed to the sorted-gather path (or the atomic flush) - never to the atomic-free kernels."""
+    from geot_amd import ops
+    rng = np.random.default_rng(88)
+    nnz, K, F = 300_000, 9000, 32
+    index = np.sort(rng.integers(0, K, nnz)).astype(np.int64)
+    index[-1] = K - 1
+    swap = rng.integers(0, nnz - 1, 50)
+    index[swap], index[swap + 1] = index[swap + 1].copy(), index[swap].copy()      # a few local descents
+    index[-1] = K - 1
+    assert (index[:-1] > index[1:]).sum() > 0
+    src = rng.random((nnz, F), dtype=np.float32)
+    hi = oracle.index_scatter(np.sort(index, kind="stable"), src[np.argsort(index, kind="stable")], rows=K, acc64=True)
+    t_index, t_src = dev(index), dev(src)
+    a = geot.index_scatter(0, t_src, t_index, "sum", sorted=True)                     # wrong promise
+    close_to_oracle(a, hi, hi, "sorted=True on an index with descents")
+    for _ in range(3):                                                                # remembered facts; bit-reproducible
+        assert torch.equal(geot.index_scatter(0, t_src, t_index, "sum", sorted=True), a)
+    assert torch.equal(geot.index_scatter(0, t_src, t_index, "sum", sorted=False), a)
+    mx = geot.index_scatter(0, t_src, t_index, "max", sorted=True)
+    want = torch.zeros(K, F, device="cuda").scatter_reduce(0, t_index[:, None].expand(-1, F), t_src, "amax", include_self=False)
+    assert torch.equal(mx, want)
+    # gather ops with an unsorted dst_index
+    nodes = K
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    w = rng.random(nnz, dtype=np.float32)
+    x = rng.random((nodes, F), dtype=np.float32)
+    order = np.argsort(index, kind="stable")
+    hi = oracle.gather_weight_scatter(si[order], index[order], w[order], x, rows=K, acc64=True)
+    close_to_oracle(geot.gather_weight_scatter(dev(si), t_index, dev(w), dev(x)), hi, hi, "gws unsorted dst")
+    hi = oracle.gather_scatter(si[order], index[order], x, rows=K, acc64=True)
+    close_to_oracle(geot.gather_scatter(dev(si), t_index, dev(x)), hi, hi, "gs unsorted dst")
+    H = 4
+    wh = rng.random((nnz, H), dtype=np.float32)
+    x3 = x.reshape(nodes, H, F // H)
+    hi = oracle.mh_spmm(si[order], index[order], wh[order], x3, rows=K, acc64=True)
+    close_to_oracle(geot.mh_spmm(dev(si), t_index, dev(wh), dev(x3)), hi, hi, "mh unsorted dst")
+    close_to_oracle(geot.mh_spmm(dev(si), t_index, dev(np.ascontiguousarray(wh.T)), dev(x3)), hi, hi, "mh^T unsorted dst")
+    assert len(ops._facts) <= ops._FACTS_MAX
+
+
+@pytest.mark.parametrize("F", [32, 64, 128])
+def test_unsorted_path_is_bit_reproducible(geot, oracle, F):
+    """sorted=False on a shuffled index: (stable sort once, gather-mode kernels) -> run-to-run bit-equal; the atomic
+    flush (GEOT_UNSORTED=atomic) is only close."""
+    from geot_amd import hip
+    rng = np.random.default_rng(90 + F)
+    nnz, K = 1_000_000, 100_000
+    index = rng.integers(0, K, nnz).astype(np.int64)
+    index[-1] = K - 1
+    src = rng.standard_normal((nnz, F)).astype(np.float32)
+    t_index, t_src = dev(index), dev(src)
+    a = geot.index_scatter(0, t_src, t_index, "sum", sorted=False)
+    for _ in range(3):
+        assert torch.equal(geot.index_scatter(0, t_src, t_index, "sum", sorted=False), a)
+    order = np.argsort(index, kind="stable")
+    hi = oracle.index_scatter(index[order], src[order], rows=K, acc64=True)
+    mag = oracle.index_scatter(index[order], np.abs(src[order]), rows=K, acc64=True)
+    close_to_oracle(a, hi, mag, "unsorted, sorted-gather path")
+    c = hip.index_scatter_out(t_index, t_src, torch.empty_like(a), sorted=False)      # float atomics
+    close_to_oracle(c, hi, mag, "unsorted, atomic flush")
+
+
+def test_transposed_edge_cache_cannot_alias_a_dead_edge_list(geot):
+    """an edge list that is freed and re-created with the same size lands on the same address
+    with _version 0.  The cache entry keeps its key tensors alive, so that cannot happen while it lives."""
+    torch.manual_seed(11)
+    n, nnz, F = 500, 20_000, 16
+    g = torch.rand(n, F, device="cuda")
+    x0 = torch.rand(n, F, device="cuda")
+    w0 = torch.rand(nnz, device="cuda")
+    seen = set()
+    for it in range(6):
+        di = torch.sort(torch.randint(0, n, (nnz,), device="cuda")).values
+        di[-1] = n - 1
+        si = torch.randint(0, n, (nnz,), device="cuda")                # fresh tensors every step (dynamic graph)
+        seen.add((si.data_ptr(), di.data_ptr()))
+        x1, w1 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        x2, w2 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        geot.gather_weight_scatter(si, di, w1, x1).backward(g)
+        torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w2[:, None]).backward(g)
+        assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4), it
+        assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-4), it
+        del si, di
+    # same for the facts of an index: free + re-create at the same address with different content
+    for it in range(4):
+        idx = torch.sort(torch.randint(0, 50 + 10 * it, (5000,), device="cuda")).values
+        if it % 2:
+            idx = idx.flip(0).contiguous()
+            idx[-1] = idx.max()
+        src = torch.rand(5000, 8, device="cuda")
+        out = geot.index_scatter(0, src, idx, "sum", sorted=True)
+        ref = torch.zeros(int(idx[-1]) + 1, 8, device="cuda").index_add_(0, idx, src)
+        assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-5, atol=1e-5), it
+        del idx
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun: the parent (no GPU call) spawns the ranks as children and relays
+    rank 0's line.  The ranks share this box's one GPU over a gloo rendezvous (GEOT_DIST_BACKEND=gloo)."""
+    import json
+    import subprocess
+    env = dict(os.environ, GEOT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    for extra in ([], ["--workload", "cfg5", "--scale", "0.01"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"] + extra,
+                           env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:] + p.stdout[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 1e8 and r["unit"] == "edges/s"
+        assert r["boundary_exchange_ms"] is not None and r["boundary_exchange_ms"] > 0
+        assert 0 < r["roofline"]["frac"] < 1
+
+
+def test_bench_secondary_object_small_scale():
+    """The `secondary` object (gws vs rocSPARSE, mh_spmm) at 2 % scale: keys and sanity of the numbers."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.02",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    sec = r["secondary"]
+    assert "error" not in sec, sec
+    g = sec["gws_cfg3"]
+    assert g["kernel_ms"] > 0 and 0 < g["roofline"]["frac"] < 1 and g["rocsparse_best_ms"] > 0, g
+    assert g["max_rel_diff_vs_rocsparse"] < 2e-5 and g["rocsparse_best_algorithm"] in ("csr_nnz_split", "csr_merge_path", "csr_row_split", "default")
+    m = sec["mh_spmm_cfg4"]
+    assert m["kernel_ms"] > 0 and 0 < m["roofline"]["frac"] < 1

@@ -2,6 +2,8 @@
 # One profiling session for profiles/rNN (run on the MI355X box: `gpurun -- bash tools/profile_round.sh`).
 # Separate rocprofv3 passes, as the micro-arch guide prescribes: kernel trace + stats, then one --pmc
 # counter per pass (never combined with a trace domain), plus the copy-kernel calibration of the counters.
+# bench.py's default run covers the headline kernel AND the `secondary` workloads (gws cfg3, mh_spmm cfg4,
+# rocSPARSE beside them), so every pass sees the gather-mode kernels too.
 # Everything lands in gpurun_out/prof_round/; tools/derive_traffic.py turns it into profiles/.
 set -u
 cd "$(dirname "$0")/.."
@@ -11,7 +13,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 python3 bench.py --steps 100 --warmup 10 > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline \
     > "$OUT/bench_under_kernel_trace.json" 2> "$OUT/kt.err"
-for c in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
+for c in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline \
       > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err"
 done

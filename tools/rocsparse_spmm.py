@@ -9,7 +9,6 @@ stage excluded from the timing (it is per-matrix work, like our cached structure
     python tools/rocsparse_spmm.py [--scale 1.0] [--feat 128] [--local]
 """
 import argparse
-import ctypes
 import os
 import sys
 
@@ -19,24 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import powerlaw_index  # noqa: E402
 from geot_amd import hip  # noqa: E402
-
-OP_NONE, BASE0, I32, F32R, ROW = 111, 0, 2, 151, 0
-ALGS = {"default": 0, "csr (row split, shared mem)": 1, "csr_row_split (shfl)": 4, "csr_nnz_split/merge": 5,
-        "csr_merge_path": 9}
-STAGE_BUF, STAGE_PRE, STAGE_COMPUTE = 1, 2, 3
-
-
-def timeit(fn, iters):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters
+from tools import rocsparse  # noqa: E402
 
 
 def main():
@@ -58,54 +40,19 @@ def main():
     w = torch.rand(nnz, device=dev)
     x = torch.rand(nodes, F, device=dev)
     out = torch.empty(nodes, F, device=dev)
-    t_geot = timeit(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), args.iters)
+    t_geot = rocsparse.device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), args.iters)
     print(f"graph: {nodes} nodes, {nnz} edges, F={F}, {'local' if args.local else 'uniform-random'} sources")
     print(f"geot gather_weight_scatter (int64 COO, dst-sorted): {t_geot:.3f} ms  {nnz / t_geot / 1e6:.2f} Gedge/s")
-
-    rowptr = torch.zeros(nodes + 1, dtype=torch.int32, device=dev)
-    rowptr[1:] = torch.cumsum(torch.bincount(di, minlength=nodes), 0).int()
-    col = si.int()
-    L = ctypes.CDLL("librocsparse.so")
-    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
-    handle = vp()
-    assert L.rocsparse_create_handle(ctypes.byref(handle)) == 0
-    L.rocsparse_set_stream(handle, vp(torch.cuda.current_stream().cuda_stream))
-    A, B, C = vp(), vp(), vp()
-    L.rocsparse_create_csr_descr.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, vp, ci, ci, ci, ci]
-    assert L.rocsparse_create_csr_descr(ctypes.byref(A), nodes, nodes, nnz, rowptr.data_ptr(), col.data_ptr(),
-                                        w.data_ptr(), I32, I32, BASE0, F32R) == 0
-    L.rocsparse_create_dnmat_descr.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, ci, ci]
-    y = torch.empty(nodes, F, device=dev)
-    assert L.rocsparse_create_dnmat_descr(ctypes.byref(B), nodes, F, F, x.data_ptr(), F32R, ROW) == 0
-    assert L.rocsparse_create_dnmat_descr(ctypes.byref(C), nodes, F, F, y.data_ptr(), F32R, ROW) == 0
-    alpha, beta = ctypes.c_float(1.0), ctypes.c_float(0.0)
-    L.rocsparse_spmm.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ctypes.POINTER(ctypes.c_size_t), vp]
-    ref = None
-    for name, alg in ALGS.items():
-        size = ctypes.c_size_t(0)
-        rc = L.rocsparse_spmm(handle, OP_NONE, OP_NONE, ctypes.byref(alpha), A, B, ctypes.byref(beta), C, F32R, alg,
-                              STAGE_BUF, ctypes.byref(size), None)
-        if rc != 0:
-            print(f"rocsparse_spmm alg {name}: buffer_size stage returned status {rc} (not supported for this layout)")
+    best, table, y = rocsparse.best_csr_spmm(di, si, w, x, nodes, iters=args.iters, algs=tuple(rocsparse.ALGS))
+    hip.gather_weight_scatter_out(si, di, w, x, out)
+    err = ((y - out).abs().max() / out.abs().max()).item()
+    for r in table:
+        if r["ms"] is None:
+            print(f"rocsparse_spmm CSR alg={r['algorithm']:16s}: {r['note']}")
             continue
-        buf = torch.empty(max(size.value, 16), dtype=torch.uint8, device=dev)
-        rc = L.rocsparse_spmm(handle, OP_NONE, OP_NONE, ctypes.byref(alpha), A, B, ctypes.byref(beta), C, F32R, alg,
-                              STAGE_PRE, ctypes.byref(size), buf.data_ptr())
-        if rc != 0:
-            print(f"rocsparse_spmm alg {name}: preprocess returned status {rc}")
-            continue
-
-        def run():
-            r = L.rocsparse_spmm(handle, OP_NONE, OP_NONE, ctypes.byref(alpha), A, B, ctypes.byref(beta), C, F32R, alg,
-                                 STAGE_COMPUTE, ctypes.byref(size), buf.data_ptr())
-            assert r == 0, r
-        run()
-        torch.cuda.synchronize()
-        hip.gather_weight_scatter_out(si, di, w, x, out)
-        err = ((y - out).abs().max() / out.abs().max()).item()
-        t = timeit(run, args.iters)
-        print(f"rocsparse_spmm CSR alg={name:30s}: {t:8.3f} ms  {nnz / t / 1e6:6.2f} Gedge/s   geot is {t / t_geot:5.2f}x faster   "
-              f"(max rel diff {err:.1e}, buffer {size.value / 1e6:.0f} MB)")
+        print(f"rocsparse_spmm CSR alg={r['algorithm']:16s}: {r['ms']:8.3f} ms  {nnz / r['ms'] / 1e6:6.2f} Gedge/s   geot is "
+              f"{r['ms'] / t_geot:5.2f}x faster   (preprocess buffer {r['preprocess_buffer_bytes'] / 1e6:.0f} MB, int32 indices)")
+    print(f"best: {best['algorithm']}; max rel diff of its result vs geot: {err:.1e}")
 
 
 if __name__ == "__main__":
