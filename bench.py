@@ -338,6 +338,7 @@ def main():
     torch.cuda.synchronize(dev)
     prof = hip.profile_read()
     hip.profile_enable(False)
+    box = hip.profile_box(src if args.workload == "cfg2" else src[: 20_000_000])   # this box's own read ceiling, now
     main_ms = prof["main_ms"] / max(prof["calls"], 1)
     fix_ms = prof["fixup_ms"] / max(prof["calls"], 1)
     achieved = alg / (main_ms * 1e-3) / 1e9
@@ -363,7 +364,9 @@ def main():
                          "kernel": kernel, "kernel_ms": main_ms,
                          "fixup_kernel_ms": fix_ms, "algorithmic_bytes_per_launch": alg,
                          "frac_tile_plus_fixup": alg / ((main_ms + fix_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBPS},
+                         "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBPS,
+                         "box_read_ceiling_gbps": box["read_ceiling_gbps"], "box_sclk_mhz": box["sclk_mhz"],
+                         "frac_of_box_read_ceiling": achieved / box["read_ceiling_gbps"]},
         }
         if distributed:
             res["boundary_exchange_ms"] = exchange_ms      # rank 0: all_gather of first-row partials + owner adds

@@ -28,7 +28,7 @@ SYMBOLS = [
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
-    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_tune", "geot_set_option",
+    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
     L.geot_profile_enable.restype = None
     L.geot_profile_reset.restype = None
     L.geot_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(c_i64)]
+    L.geot_profile_box.argtypes = [c_vp, c_sz, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_vp]
     L.geot_tune.argtypes = [c_int, c_int, c_int, c_int]
     L.geot_tune.restype = None
     if L.geot_abi_version() != ABI_VERSION:

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         }
       }
     }
-    const int cslot_id = (i == 0 && k == kprev_tile) ? 0 : ((at_end && k == knext_tile) ? 1 : -1);
+    const int cslot_id = (i == 0 && k == kprev_tile) ? 0 : ((at_end && k == knext_tile && k != kNoKey) ? 1 : -1); // (padding is no run)
     if constexpr (MEAN) {
       if (cslot_id >= 0 && c == 0 && blockIdx.y == 0) p.ccnt[tile * 2 + cslot_id] = csum;
     }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void narrow_tile_epilogue(const SegParams &p, const i
     }
     if (!active) continue;
     if (i == 0 && key == kprev_tile) carry[(tile * 2) * F + lane] = sum;
-    else if (at_end && key == knext_tile) carry[(tile * 2 + 1) * F + lane] = sum;
+    else if (at_end && key == knext_tile && key != kNoKey) carry[(tile * 2 + 1) * F + lane] = sum;
     else if ((uint64_t)key < (uint64_t)K) dst[key * F + lane] = sum;
   }
 }
@@ -1361,6 +1361,36 @@ __global__ __launch_bounds__(kThreads) void coo_sorted_to_csr_kernel(const int64
   }
 }
 
+// ---- measurement hooks (geot_profile_box): what THIS box can stream right now -------------------------------
+// pure non-temporal 16-B-per-lane grid-stride read (the read ceiling the tile kernel's traffic is priced
+// against), and the shader clock seen by a busy wave (s_memtime ticks per s_memrealtime tick x 100 MHz)
+__global__ __launch_bounds__(kThreads) void box_read_kernel(const float *__restrict__ a, float *sink, size_t n4) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const f4_t *p = reinterpret_cast<const f4_t *>(a);
+  f4_t s = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) { // 4 loads in flight per lane
+    const f4_t v0 = __builtin_nontemporal_load(p + i), v1 = __builtin_nontemporal_load(p + i + stride);
+    const f4_t v2 = __builtin_nontemporal_load(p + i + 2 * stride), v3 = __builtin_nontemporal_load(p + i + 3 * stride);
+    s += v0 + v1 + v2 + v3;
+  }
+  for (; i < n4; i += stride) s += __builtin_nontemporal_load(p + i);
+  if (s[0] + s[1] + s[2] + s[3] == 123.456f) sink[0] = s[0];
+}
+
+__global__ void box_clock_kernel(unsigned long long *out, int spins) {
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  float x = (float)threadIdx.x;
+  for (int i = 0; i < spins; ++i) x = x * 1.0001f + 0.5f;
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+    out[2] = (unsigned long long)x;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -2111,6 +2141,37 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
   if (fixup_ms) *fixup_ms = g_prof.fix_ms;
   if (aux_ms) *aux_ms = g_prof.aux_ms;
   if (calls) *calls = g_prof.calls;
+  return GEOT_OK;
+}
+
+int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps, double *sclk_mhz, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!buf || bytes < (1u << 20) || iters < 1) return fail(GEOT_EINVAL, "profile_box: needs a device buffer of >= 1 MiB");
+  unsigned long long *d = nullptr;
+  HIP_TRY(hipMalloc(&d, 64));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int it = 0; it < iters + 1; ++it) {
+    HIP_TRY(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(box_read_kernel, dim3(256 * 16), dim3(kThreads), 0, st, static_cast<const float *>(buf),
+                       reinterpret_cast<float *>(d), bytes / 16);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (it > 0 && ms < best) best = ms; // first pass warms up
+  }
+  if (read_gbps) *read_gbps = (double)(bytes / 16 * 16) / (best * 1e-3) / 1e9;
+  hipLaunchKernelGGL(box_clock_kernel, dim3(1), dim3(64), 0, st, d, 200000);
+  unsigned long long h[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (sclk_mhz) *sclk_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0; // s_memrealtime ticks at 100 MHz
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  HIP_TRY(hipFree(d));
   return GEOT_OK;
 }
 

@@ -12,8 +12,11 @@
 // Build (Makefile target `shim`): g++ -shared -fPIC torch_shim.cpp -I<torch>/include -I/opt/rocm/include
 //        -D__HIP_PLATFORM_AMD__ -L<repo>/geot_amd -lgeot_hip -ltorch -ltorch_cpu -lc10 -lc10_hip
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
+
+#include <map>
 
 #include "geot_hip.h"
 
@@ -33,13 +36,22 @@ void *current_stream(const at::Tensor &t) {
   return c10::hip::getCurrentHIPStream(t.device().index()).stream();
 }
 
-// one zero-initialised workspace per device, grown on demand (the ABI wants the control words zero once)
+// one zero-initialised workspace per (device, stream), grown on demand: the ABI allows a workspace to be
+// used by one stream at a time (control words and carries live in it) and wants the control words zero once
 at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
-  static thread_local std::vector<at::Tensor> ws(64);
-  auto &w = ws[like.device().index() < 0 ? 0 : like.device().index()];
+  static thread_local std::map<std::pair<int, void *>, at::Tensor> ws;
+  auto &w = ws[{(int)like.device().index(), current_stream(like)}];
   if (!w.defined() || (size_t)w.numel() < bytes)
     w = at::zeros({(int64_t)std::max<size_t>(bytes, 1 << 20)}, like.options().dtype(at::kByte));
   return w;
+}
+
+// the library launches on the HIP current device: make it the tensors' device for the duration of the call
+#define GEOT_DEVICE_GUARD(t) const c10::hip::HIPGuard geot_device_guard_((t).device())
+
+void check_weight(const at::Tensor &weight, const at::Tensor &src) {
+  TORCH_CHECK(weight.scalar_type() == src.scalar_type(), "expected weight of dtype ", toString(src.scalar_type()),
+              " but found ", toString(weight.scalar_type()));
 }
 
 int reduce_code(c10::string_view reduce) { // csrc/reduceutils.h:5-22
@@ -56,6 +68,7 @@ int64_t rows_from_last(const at::Tensor &index) { return index[-1].item<int64_t>
 at::Tensor index_scatter_impl(const int64_t dim, at::Tensor index, at::Tensor src, const c10::string_view reduce,
                               const bool sorted) {
   TORCH_CHECK(dim >= 0 && dim < src.dim(), "dim must be non-negative and less than input dimensions");
+  GEOT_DEVICE_GUARD(src);
   TORCH_CHECK(index.dim() == 1, "index must be 1 dimensional");
   TORCH_CHECK(src.size(dim) == index.size(0), "index length must be equal to src dimension size");
   const int red = reduce_code(reduce);
@@ -100,6 +113,7 @@ void check_gather(const at::Tensor &si, const at::Tensor &di, const at::Tensor &
 
 at::Tensor gather_scatter_impl(at::Tensor si, at::Tensor di, at::Tensor src) {
   check_gather(si, di, src, 2);
+  GEOT_DEVICE_GUARD(src);
   const int64_t rows = rows_from_last(di), nnz = di.numel(), feat = src.size(1);
   si = si.contiguous(); di = di.contiguous(); src = src.contiguous();
   at::Tensor out = at::empty({rows, feat}, src.options());
@@ -113,6 +127,8 @@ at::Tensor gather_scatter_impl(at::Tensor si, at::Tensor di, at::Tensor src) {
 
 at::Tensor gather_weight_scatter_impl(at::Tensor si, at::Tensor di, at::Tensor weight, at::Tensor src) {
   check_gather(si, di, src, 2);
+  check_weight(weight, src);
+  GEOT_DEVICE_GUARD(src);
   const int64_t rows = rows_from_last(di), nnz = di.numel(), feat = src.size(1);
   si = si.contiguous(); di = di.contiguous(); src = src.contiguous(); weight = weight.contiguous();
   at::Tensor out = at::empty({rows, feat}, src.options());
@@ -126,6 +142,7 @@ at::Tensor gather_weight_scatter_impl(at::Tensor si, at::Tensor di, at::Tensor w
 }
 
 at::Tensor sddmm_coo_impl(at::Tensor si, at::Tensor di, at::Tensor m1, at::Tensor m2) {
+  GEOT_DEVICE_GUARD(m1);
   // the reference's Python wrapper hands over int32 indices (geot/gather_weight_scatter.py:10-11)
   si = si.to(at::kLong).contiguous(); di = di.to(at::kLong).contiguous();
   m1 = m1.contiguous(); m2 = m2.contiguous();
@@ -137,6 +154,8 @@ at::Tensor sddmm_coo_impl(at::Tensor si, at::Tensor di, at::Tensor m1, at::Tenso
 }
 
 at::Tensor csr_gws_impl(at::Tensor indptr, at::Tensor indices, at::Tensor weight, at::Tensor src) {
+  check_weight(weight, src);
+  GEOT_DEVICE_GUARD(src);
   indptr = indptr.to(at::kLong).contiguous(); indices = indices.to(at::kLong).contiguous();
   weight = weight.contiguous(); src = src.contiguous();
   const int64_t rows = indptr.size(0), nnz = indices.size(0), feat = src.size(1); // csrc/csr_gws.cpp:29-31
@@ -152,6 +171,8 @@ at::Tensor csr_gws_impl(at::Tensor indptr, at::Tensor indices, at::Tensor weight
 
 at::Tensor mh_spmm_impl(at::Tensor si, at::Tensor di, at::Tensor weight, at::Tensor src, const c10::string_view reduce) {
   check_gather(si, di, src, 3);
+  check_weight(weight, src);
+  GEOT_DEVICE_GUARD(src);
   TORCH_CHECK(reduce_code(reduce) == GEOT_REDUCE_SUM, "mh_spmm: only 'sum' is implemented");
   const int64_t nnz = si.size(0), rows = rows_from_last(di);
   int layout;

@@ -293,6 +293,17 @@ def profile_read() -> dict:
     return {"main_ms": a.value, "fixup_ms": b.value, "aux_ms": c.value, "calls": n.value}
 
 
+def profile_box(buf: torch.Tensor, iters: int = 5) -> dict:
+    """Read ceiling (pure nt 16-B-per-lane read of `buf`) and shader clock of THIS box, now."""
+    dev = _require_gpu(buf)
+    g, c = ctypes.c_double(), ctypes.c_double()
+    with _on_device(dev):
+        rc = _lib.load().geot_profile_box(buf.data_ptr(), buf.numel() * buf.element_size(), iters, ctypes.byref(g),
+                                          ctypes.byref(c), _stream_handle(dev))
+    _lib.check(rc, "geot_profile_box")
+    return {"read_ceiling_gbps": g.value, "sclk_mhz": c.value}
+
+
 def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2: int = -1) -> None:
     _lib.load().geot_tune(edges_per_group, vec, nontemporal, lpr_log2)
     _ws_bytes.clear()  # the tile shape, hence the workspace need, follows the plan

@@ -17,9 +17,11 @@ with these guarantees the reference's pass does not give:
 * the fused node keeps the row count of the ``index_add`` it replaces (``dst.shape[0]``) through the
   ``geot::*_rows`` ops; the reference rewrites to ``csr_gws(coo_to_csr(row), ...)`` whose output has
   ``max(row) + 2`` rows (SURVEY.md quirk Q9);
-* the fused kernels need ``row`` (the index_add index) ascending.  PyG-style ``edge_index`` sorted by
-  destination satisfies it; pass ``sort_edges=True`` to have the pass insert a stable sort of the edge
-  list (and of the weights) in front of the fused op instead of assuming it.
+* ``index_add`` is order-independent, the atomic-free kernels want ``row`` (the index_add index) ascending.
+  PyG-style ``edge_index`` sorted by destination satisfies it and runs at full speed; any other order is
+  still CORRECT: the ``geot::*_rows`` ops probe ``row`` once per content (geot_amd/ops.py ``_index_facts``)
+  and reduce over its stable sort when it has descents.  ``sort_edges=True`` makes the pass insert that sort
+  into the graph instead (useful when the exported program is to run somewhere the cache does not live).
 """
 from __future__ import annotations
 

@@ -172,6 +172,12 @@ void geot_profile_reset(void);
 /* main = tile kernel, fixup = carry/gap kernel, aux = memsets; *_calls = launches counted */
 int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls);
 
+/* What this box can do right now (bench.py reports it next to the roofline: devices of the pool differ by a few
+ * per cent): best-of-`iters` bandwidth of a pure non-temporal 16-B-per-lane read of `buf` (device memory, `bytes`
+ * long), and the shader clock a busy wave sees (MHz; s_memtime ticks per 100 MHz s_memrealtime tick).
+ * Synchronous; allocates a few bytes; not capturable. */
+int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps, double *sclk_mhz, void *stream);
+
 /* Tuning knobs for experiments: edges per lane-group sub-chunk (0 = auto), forced vector
  * width in elements (0 = auto), non-temporal policy (-1 = auto; bit 0 = row loads, bit 1 = dst
  * stores), lanes per row log2 (-1 = auto). */

@@ -668,11 +668,19 @@ def test_16bit_storage_fp32_accumulate(geot, oracle, dtype):
         out = geot.gather_weight_scatter(dev(si), dev(idx), w.cuda(), x.cuda()).float().cpu().numpy()
         assert np.all(np.abs(out - hi) <= ulp * np.abs(hi) + 2e-5 * mag + 1e-6), ("gws", nnz, F)
     # sorted=False: the probe finds this index ascending -> the same atomic-free kernels (16-bit storage is fine);
-    # an index with descents needs float atomics, which exist for float32/float64 only
-    assert torch.equal(geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=False),
-                       geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=True))
-    with pytest.raises(RuntimeError, match="float32/float64"):
-        geot.index_scatter(0, s32.cuda(), dev(idx[::-1].copy()), "sum", sorted=False)
+    # an index with descents is reduced over its stable sort (no 16-bit float atomics needed): same multiset of
+    # addends per row, fp32 accumulation, one rounding
+    fwd = geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=True)
+    assert torch.equal(geot.index_scatter(0, s32.cuda(), dev(idx), "sum", sorted=False), fwd)
+    rev_idx = idx[::-1].copy()
+    rev_idx[-1] = idx[-1]                                                 # the row rule reads index[-1]
+    rev_src = torch.from_numpy(s32.float().numpy()[::-1].copy()).to(dtype)
+    rev_src[-1] = s32[-1]
+    out = geot.index_scatter(0, rev_src.cuda(), dev(rev_idx), "sum", sorted=False)
+    order = np.argsort(rev_idx, kind="stable")
+    hi = oracle.index_scatter(rev_idx[order], rev_src.float().numpy()[order], rows=int(idx[-1]) + 1, acc64=True)
+    mag = oracle.index_scatter(rev_idx[order], np.abs(rev_src.float().numpy()[order]), rows=int(idx[-1]) + 1, acc64=True)
+    assert out.dtype == dtype and np.all(np.abs(out.float().cpu().numpy() - hi) <= ulp * np.abs(hi) + 2e-5 * mag + 1e-6)
 
 
 def test_calls_are_hipgraph_capturable(geot, oracle):

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-2 GPU session driver: `gpurun --timeout 3300 -- bash tools/gpu_session.sh [steps...]`
+# Each step writes its log under gpurun_out/r02/ and is bounded by its own timeout.
+set -u
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=gpurun_out/r02
+mkdir -p $O
+steps="${@:-tests bench kexp unsorted soak}"
+for s in $steps; do
+  echo "=== $s $(date +%T)"
+  case $s in
+    tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
+    tests2)   timeout 1500 python3 -m pytest tests/test_gpu_round2.py -m gpu -x -q > $O/pytest_round2.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_round2.log ;;
+    bench)    timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?"; cat $O/bench.json; tail -3 $O/bench.err ;;
+    kexp)     hipcc -O3 --offload-arch=gfx950 tools/kexp2.hip -o tools/kexp2 2>&1 | tail -3
+              timeout 600 ./tools/kexp2 slab > $O/kexp2_slab.txt 2>&1; echo "rc=$?"; cat $O/kexp2_slab.txt
+              timeout 300 ./tools/kexp2 slab 2449029 512 123718280 > $O/kexp2_slab_cfg3.txt 2>&1; echo "rc=$?"; cat $O/kexp2_slab_cfg3.txt
+              timeout 300 ./tools/kexp2 mfma > $O/kexp2_mfma.txt 2>&1; echo "rc=$?"; cat $O/kexp2_mfma.txt ;;
+    unsorted) timeout 600 python3 tools/bench_unsorted.py > $O/bench_unsorted.csv 2>&1; echo "rc=$?"; cat $O/bench_unsorted.csv ;;
+    soak)     for seed in 21 22 23 24; do
+                timeout 500 python3 tools/soak_fuzz.py --iters 150 --seed $seed --ops gws,gs,gws,gs,is > $O/soak_gather_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -3 $O/soak_gather_seed$seed.log
+              done ;;
+    profile)  bash tools/profile_round.sh > $O/profile_round.log 2>&1; echo "rc=$?"; tail -30 $O/profile_round.log ;;
+    small)    timeout 300 python3 tools/bench_small.py > $O/bench_small.txt 2>&1; echo "rc=$?"; cat $O/bench_small.txt ;;
+    *)        echo "unknown step $s" ;;
+  esac
+done

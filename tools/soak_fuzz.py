@@ -44,9 +44,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ops", default="is,is,is_unsorted_flag,gws,gs", help="comma list to draw the op from")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    covered = {}
     for it in range(a.iters):
         nnz = int(rng.choice([70_000, 300_000, 1_000_000, int(rng.integers(50_000, 3_000_000))]))
         F = int(rng.choice([1, 2, 4, 5, 8, 16, 31, 32, 64, 100, 128]))
@@ -65,7 +67,8 @@ def main():
         hip.set_option("narrow", narrow)
         hip.tune(cg, 0, -1, -1)
         red = str(rng.choice(["sum", "sum", "mean", "max", "min"]))
-        op = str(rng.choice(["is", "is", "is_unsorted_flag", "gws", "gs"]))
+        op = str(rng.choice(a.ops.split(",")))
+        covered[(op, red)] = covered.get((op, red), 0) + 1
         tag = f"it={it} op={op} nnz={nnz} F={F} keys={index[-1] + 1} red={red} hub={hub} narrow={narrow} cg={cg}"
         src = rng.standard_normal((nnz, F)).astype(np.float32)
         if op.startswith("is"):
@@ -111,6 +114,7 @@ def main():
         if it % 20 == 0:
             print("ok", tag, flush=True)
     hip.set_option("hub", -1); hip.set_option("narrow", 1); hip.tune(0, 0, -1, -1)
+    print("covered (op, reduce): " + ", ".join(f"{o}/{r}={n}" for (o, r), n in sorted(covered.items())))
     print(f"SOAK PASSED ({a.iters} cases, seed {a.seed})")
 
 
