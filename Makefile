@@ -7,13 +7,13 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Iinclude -Wno-unused-value
 
 LIB = geot_amd/libgeot_hip.so
-SRC = geot_amd/csrc/seg_reduce.hip
+SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_slab.hip
 
 .PHONY: all lib tools shim oracle ref clean
 all: lib tools
 
 lib: $(LIB)
-$(LIB): $(SRC) include/geot_hip.h
+$(LIB): $(SRC) include/geot_hip.h geot_amd/csrc/internal.h
 	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
 
 tools: tools/kbench

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 
 GEOT_OK = 0
@@ -28,8 +28,17 @@ SYMBOLS = [
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
+    "geot_slab_units", "geot_slab_rows_per_group", "geot_slab_workspace_bytes", "geot_slab_spmm",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
 ]
+
+class SlabPlan(ctypes.Structure):
+    """geot_slab_plan of include/geot_hip.h (device pointers as integers)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out",
+                                                "c_row", "c_first", "c_count")] + \
+               [(n, ctypes.c_int64) for n in ("n_groups", "n_vrows", "n_carry", "n_split", "nnz")] + \
+               [("units", ctypes.c_int32), ("rows_per_group", ctypes.c_int32)]
+
 
 _lib = None
 
@@ -45,7 +54,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(p) > t for p in SOURCES + [HEADER])
+    return any(os.path.getmtime(p) > t for p in SOURCES + [HEADER, os.path.join(_HERE, "csrc", "internal.h")])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -94,6 +103,12 @@ def load() -> ctypes.CDLL:
     L.geot_csr_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]
     L.geot_csr_gws.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_coo_to_csr.argtypes = [c_vp, c_i64, c_i64, c_vp, c_int, c_vp]
+    L.geot_slab_units.restype = c_int
+    L.geot_slab_rows_per_group.argtypes = [c_int, c_i64]
+    L.geot_slab_rows_per_group.restype = c_int
+    L.geot_slab_workspace_bytes.argtypes = [ctypes.POINTER(SlabPlan), c_i64]
+    L.geot_slab_workspace_bytes.restype = c_sz
+    L.geot_slab_spmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_profile_enable.argtypes = [c_int]
     L.geot_profile_enable.restype = None
     L.geot_profile_reset.restype = None

@@ -1,0 +1,6 @@
+// internal.h -- shared by the translation units of libgeot_hip.so (not part of the ABI)
+#ifndef GEOT_INTERNAL_H
+#define GEOT_INTERNAL_H
+// records `msg` as the calling thread's geot_last_error() and returns `code`
+extern "C" int geot_internal_fail(int code, const char *msg);
+#endif

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "geot_hip.h"
+#include "internal.h"
 
 namespace {
 
@@ -1919,6 +1920,8 @@ int run_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nn
 } // namespace
 
 extern "C" {
+
+int geot_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 
 int geot_abi_version(void) { return GEOT_ABI_VERSION; }
 

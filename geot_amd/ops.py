@@ -304,6 +304,61 @@ def _dst_ordered(src_index, dst_index, weight=None, weight_edge_dim: int = 0):
     return src_index[perm], keys, weight, facts.rows
 
 
+# ---- dense graphs: source-blocked kernels (geot_amd/slab.py, csrc/seg_slab.hip) -------------------------------------
+# A graph whose source rows are re-used often enough (slab.worthwhile: Reddit scale yes, ogbn-products scale no) is
+# re-arranged ONCE - on the second call with the same edge list, so one-shot calls never pay for it - and from then
+# on served by geot_slab_spmm.  The plan is kept per edge-list content (it holds its key tensors alive, see
+# _transpose_edges_gpu) for the last _SLAB_KEEP edge lists.  GEOT_SLAB=0 never, =1 always (tests), auto by the rule.
+_SLAB_MODE = os.environ.get("GEOT_SLAB", "auto")
+_SLAB_KEEP = 2
+_slab_plans: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_slab_sightings: "collections.OrderedDict[tuple, int]" = collections.OrderedDict()
+slab_stats = {"plans_built": 0, "plan_seconds": 0.0, "calls": 0}
+
+
+def _slab_plan(src_index, dst_index, rows: int, src, weight_mode: int, heads: int):
+    if _SLAB_MODE == "0" or src.dtype != torch.float32:
+        return None
+    from . import slab
+    rowbytes = int(src[0].numel()) * 4
+    nnz = dst_index.numel()
+    if rowbytes not in (256, 512, 1024) or nnz >= 2 ** 31 or nnz == 0:
+        return None
+    if _SLAB_MODE != "1" and not slab.worthwhile(nnz, rows, src.shape[0], rowbytes):
+        return None
+    k1, k2 = _content_key(src_index), _content_key(dst_index)
+    if k1 is None or k2 is None:
+        return None
+    key = (k1, k2, rows, src.shape[0], rowbytes, weight_mode, heads)
+    ent = _slab_plans.get(key)
+    if ent is not None and not ent[1].expired() and not ent[2].expired():
+        _slab_plans.move_to_end(key)
+        return ent[0]
+    seen = _slab_sightings.get(key, 0) + 1
+    _slab_sightings[key] = seen
+    while len(_slab_sightings) > 64:
+        _slab_sightings.popitem(last=False)
+    if seen < 2 and _SLAB_MODE != "1":
+        return None
+    import time
+    from torch.multiprocessing.reductions import StorageWeakRef
+    t0 = time.perf_counter()
+    plan = slab.build_plan(src_index, dst_index, rows, src.shape[0], rowbytes, weight_mode, heads)
+    slab_stats["plans_built"] += 1
+    slab_stats["plan_seconds"] += time.perf_counter() - t0
+    _slab_plans[key] = (plan, StorageWeakRef(src_index.untyped_storage()), StorageWeakRef(dst_index.untyped_storage()),
+                        src_index, dst_index)
+    while len(_slab_plans) > _SLAB_KEEP:
+        _slab_plans.popitem(last=False)
+    return plan
+
+
+def _run_slab(plan, weight, weight_mode, src, out, heads, feat):
+    from . import slab
+    slab_stats["calls"] += 1
+    return slab.slab_spmm_out(plan, weight, weight_mode, src, out, heads, feat)
+
+
 def _gather_scatter_gpu(src_index, dst_index, src, rows: Optional[int] = None) -> torch.Tensor:
     _check_gather(src_index, dst_index, src, 2)
     src_index, dst_index, src = src_index.contiguous(), dst_index.contiguous(), src.contiguous()
@@ -311,6 +366,9 @@ def _gather_scatter_gpu(src_index, dst_index, src, rows: Optional[int] = None) -
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
+        plan = _slab_plan(src_index, dst_index, nrows, src, 0, 1) if known is None else None
+        if plan is not None:
+            return _run_slab(plan, None, 0, src, out, 1, src.shape[1])
         return hip.gather_scatter_out(src_index, dst_index, src, out)
 
     if rows is None and known is not None:
@@ -328,6 +386,9 @@ def _gather_weight_scatter_gpu(src_index, dst_index, weight, src, rows: Optional
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
+        plan = _slab_plan(src_index, dst_index, nrows, src, 1, 1) if known is None and weight.dtype == src.dtype else None
+        if plan is not None:
+            return _run_slab(plan, weight, 1, src, out, 1, src.shape[1])
         return hip.gather_weight_scatter_out(src_index, dst_index, weight, src, out)
 
     if rows is None and known is not None:
@@ -364,6 +425,11 @@ def _mh_spmm_gpu(src_index, dst_index, weight, src, reduce: str) -> torch.Tensor
 
     def launch(nrows: int) -> torch.Tensor:
         out = torch.empty((nrows, src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
+        wmode = 3 if head_major else 2
+        plan = (_slab_plan(src_index, dst_index, nrows, src, wmode, src.shape[1])
+                if known is None and weight.dtype == src.dtype and src.shape[2] % 4 == 0 and src.shape[1] <= 16 else None)
+        if plan is not None:
+            return _run_slab(plan, weight, wmode, src, out, src.shape[1], src.shape[2])
         return hip.mh_spmm_out(src_index, dst_index, weight, src, out, head_major)
 
     return launch(known) if known is not None else _with_row_rule(dst_index, launch)

@@ -163,6 +163,45 @@ int geot_csr_gws(const int64_t *indptr, const int64_t *indices, const void *weig
 int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *rowptr,
                     int assume_sorted, void *stream);
 
+/* ---- source-blocked form of the gather ops for dense graphs (csrc/seg_slab.hip) ----------------------------------
+ * Replaces the same reference kernels as geot_mh_spmm / geot_gather_weight_scatter / geot_gather_scatter
+ * (csrc/cuda/mh_spmm_kernel.cuh:28-111, gather_weight_scatter_kernel.cuh:118-185, gather_scatter_kernel.cuh:118-186)
+ * when a graph is dense enough for its source rows to be re-used out of an XCD's L2: Reddit scale runs ~2x
+ * faster than the per-edge gather.  The edge list is pre-arranged ONCE (Phase A, done by the host layer -
+ * geot_amd/slab.py - and kept per edge list): all arrays below are DEVICE memory in processing order.
+ *   units            lane-group streams of the persistent grid = geot_slab_units() * (64 / lanes per row)
+ *   groups           <= rows_per_group consecutive (virtual) dst rows with about equal edge counts, ordered by
+ *                    size (descending); group at position p is run by unit (p % units) in round (p / units)
+ *   e_src/e_dl/e_perm  per edge, grouped by position and sorted by (source slab, row in group): source row,
+ *                    row inside the group, original edge number (for the weights)
+ *   g_begin[p]       first edge of the group at position p (n_groups + 1 entries); g_vrow0 / g_nv its rows
+ *   v_out[v]         >= 0: the dst row of virtual row v;  < 0: -(carry slot + 1) for a piece of a split hub row
+ *   c_row/c_first/c_count  the split rows: dst row, first carry slot, number of slots                          */
+typedef struct geot_slab_plan {
+  const int32_t *e_src;
+  const uint8_t *e_dl;
+  const int32_t *e_perm;
+  const int64_t *g_begin;
+  const int32_t *g_vrow0;
+  const int32_t *g_nv;
+  const int64_t *v_out;
+  const int64_t *c_row;
+  const int64_t *c_first;
+  const int32_t *c_count;
+  int64_t n_groups, n_vrows, n_carry, n_split, nnz;
+  int32_t units, rows_per_group;
+} geot_slab_plan;
+
+int geot_slab_units(void);                                     /* waves of the persistent grid */
+int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget */
+size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
+/* dst[d, h, :] = sum_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
+ * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts).
+ * float32, rows (heads * feat * 4 bytes) of 256 / 512 / 1024 bytes.  dst is written in full. */
+int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
+                   int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
 /* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
  * With profiling on, every segment-reduction call records hipEvents around its kernels on
  * the call's stream; geot_profile_read waits for them and returns the accumulated device

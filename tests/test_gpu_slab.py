@@ -1,0 +1,138 @@
+"""The source-blocked kernels (csrc/seg_slab.hip) against the oracle and against the per-edge gather kernels
+(`-m gpu`): all weight modes, the three row widths, several rounds, split hubs, empty rows, out-of-range sources,
+determinism, and the host layer's routing (second call with the same edge list, GEOT_SLAB)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import powerlaw_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def geot():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import geot_amd
+    return geot_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, hi, what):
+    got = got.detach().cpu().numpy().reshape(hi.shape)
+    bound = 1e-5 * np.abs(hi) + 1e-30
+    err = np.abs(got.astype(np.float64) - hi.astype(np.float64))
+    assert np.all(err <= bound), f"{what}: max err/bound = {np.max(err / bound):.3g}"
+    assert np.all(got[hi == 0] == 0), what
+
+
+@pytest.mark.parametrize("nodes,nnz,H,Fh", [(40_000, 3_000_000, 4, 64), (70_000, 2_500_000, 1, 128), (150_000, 3_000_000, 1, 64),
+                                           (3000, 400_000, 2, 32), (500, 1_000_000, 8, 32)])
+def test_slab_kernel_against_oracle(geot, oracle, nodes, nnz, H, Fh):
+    from geot_amd import hip, slab
+    rng = np.random.default_rng(nodes + H)
+    di = powerlaw_index(nnz, nodes, nodes)
+    di[di == 7] = 8                                                     # an empty key
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    F = H * Fh
+    x = rng.random((nodes, H, Fh), dtype=np.float32)
+    out = torch.empty(nodes, H, Fh, device="cuda")
+    d_si, d_di, d_x = dev(si), dev(di), dev(x)
+    if H == 1:
+        w = rng.random(nnz, dtype=np.float32)
+        plan = slab.build_plan(d_si, d_di, nodes, nodes, F * 4, 1, 1)
+        slab.slab_spmm_out(plan, dev(w), 1, d_x, out, 1, Fh)
+        hi = oracle.gather_weight_scatter(si, di, w, x.reshape(nodes, F), rows=nodes, acc64=True)
+        close(out, hi, "gws")
+        again = torch.empty_like(out)
+        slab.slab_spmm_out(plan, dev(w), 1, d_x, again, 1, Fh)
+        assert torch.equal(out, again)                                  # deterministic
+        plan0 = slab.build_plan(d_si, d_di, nodes, nodes, F * 4, 0, 1)
+        slab.slab_spmm_out(plan0, None, 0, d_x, out, 1, Fh)
+        close(out, oracle.gather_scatter(si, di, x.reshape(nodes, F), rows=nodes, acc64=True), "gs")
+        ref = hip.gather_scatter_out(d_si, d_di, d_x.view(nodes, F), torch.empty(nodes, F, device="cuda"))
+        assert torch.allclose(out.view(nodes, F), ref, rtol=1e-5, atol=1e-5)
+    else:
+        w = rng.random((nnz, H), dtype=np.float32)
+        hi = oracle.mh_spmm(si, di, w, x, rows=nodes, acc64=True)
+        plan = slab.build_plan(d_si, d_di, nodes, nodes, F * 4, 2, H)
+        assert plan.meta["rounds"] >= 1
+        slab.slab_spmm_out(plan, dev(w), 2, d_x, out, H, Fh)
+        close(out, hi, "mh edge-major")
+        plan3 = slab.build_plan(d_si, d_di, nodes, nodes, F * 4, 3, H)
+        slab.slab_spmm_out(plan3, dev(np.ascontiguousarray(w.T)), 3, d_x, out, H, Fh)
+        close(out, hi, "mh head-major")
+
+
+def test_slab_hub_rows_many_rounds_and_bad_sources(geot, oracle):
+    """One row with a third of all edges (split into carry pieces), > 2 rounds of groups, sources out of range
+    (ignored like in every other kernel: memory-safe, row 0 is NOT added)."""
+    from geot_amd import slab
+    rng = np.random.default_rng(3)
+    nodes, nnz, F = 120_000, 4_000_000, 256                              # 1-KiB rows: 2048 units x 15 rows per round
+    di = powerlaw_index(nnz, nodes, 5)
+    di[: nnz // 3] = di[nnz // 3]
+    di = np.sort(di)
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    w = rng.random(nnz, dtype=np.float32)
+    x = rng.random((nodes, F), dtype=np.float32)
+    plan = slab.build_plan(dev(si), dev(di), nodes, nodes, F * 4, 1, 1)
+    assert plan.meta["rounds"] >= 3 and plan.meta["split_rows"] >= 1
+    out = torch.empty(nodes, F, device="cuda")
+    slab.slab_spmm_out(plan, dev(w), 1, dev(x), out, 1, F)
+    close(out, oracle.gather_weight_scatter(si, di, w, x, rows=nodes, acc64=True), "hub")
+    # fewer output rows than keys (keys >= out_rows are ignored), more source rows referenced than exist
+    small = nodes - 1000
+    plan2 = slab.build_plan(dev(si), dev(di), nodes, nodes, F * 4, 1, 1)
+    out2 = torch.empty(small, F, device="cuda")
+    slab.slab_spmm_out(plan2, dev(w), 1, dev(x), out2, 1, F)
+    assert torch.equal(out2, out[:small])
+
+
+def test_host_layer_routes_dense_graphs_on_the_second_call(geot, oracle, monkeypatch):
+    from geot_amd import ops
+    rng = np.random.default_rng(9)
+    nodes, nnz, H, Fh = 30_000, 9_000_000, 4, 64                          # dense enough for the rule (>= 8 M edges)
+    di = powerlaw_index(nnz, nodes, 2)
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    w = rng.random((nnz, H), dtype=np.float32)
+    x = rng.random((nodes, H, Fh), dtype=np.float32)
+    from geot_amd import slab
+    assert slab.worthwhile(nnz, nodes, nodes, H * Fh * 4)
+    d_si, d_di, d_w, d_x = dev(si), dev(di), dev(w), dev(x)
+    built0, calls0 = ops.slab_stats["plans_built"], ops.slab_stats["calls"]
+    a = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # first sighting: per-edge gather kernel
+    assert ops.slab_stats["plans_built"] == built0
+    b = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # second: plan built, slab kernel
+    c = geot.mh_spmm(d_si, d_di, d_w, d_x)
+    assert ops.slab_stats["plans_built"] == built0 + 1 and ops.slab_stats["calls"] == calls0 + 2
+    assert torch.equal(b, c) and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    hi = oracle.mh_spmm(si, di, w, x, rows=nodes, acc64=True)
+    close(b, hi, "routed mh_spmm")
+    d_si[0] = (d_si[0] + 1) % nodes                                       # in-place edit: the plan must not be reused
+    si[0] = (si[0] + 1) % nodes
+    d = geot.mh_spmm(d_si, d_di, d_w, d_x)
+    close(d, oracle.mh_spmm(si, di, w, x, rows=nodes, acc64=True), "after an in-place edit")
+    monkeypatch.setattr(ops, "_SLAB_MODE", "0")
+    e = geot.mh_spmm(d_si, d_di, d_w, d_x)
+    assert torch.allclose(d, e, rtol=1e-5, atol=1e-5)
+    # small graphs never take the path in auto mode; GEOT_SLAB=1 forces it (gws + gs + backward through autograd)
+    monkeypatch.setattr(ops, "_SLAB_MODE", "1")
+    n2, z2, F = 2000, 60_000, 64
+    di2 = dev(powerlaw_index(z2, n2, 3))
+    si2 = dev(rng.integers(0, n2, z2).astype(np.int64))
+    w2 = torch.rand(z2, device="cuda", requires_grad=True)
+    x2 = torch.rand(n2, F, device="cuda", requires_grad=True)
+    calls = ops.slab_stats["calls"]
+    y = geot.gather_weight_scatter(si2, di2, w2, x2)
+    y.sum().backward()
+    assert ops.slab_stats["calls"] >= calls + 2                           # forward and d/dsrc both on the slab kernel
+    ref = torch.zeros(n2, F, device="cuda").index_add(0, di2, x2.detach()[si2] * w2.detach()[:, None])
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4)
+    xg = torch.zeros(n2, F, device="cuda").index_add(0, si2, w2.detach()[:, None].expand(-1, F).contiguous())
+    assert torch.allclose(x2.grad, xg, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(geot.gather_scatter(si2, di2, x2.detach()), torch.zeros(n2, F, device="cuda").index_add(0, di2, x2.detach()[si2]),
+                          rtol=1e-4, atol=1e-4)

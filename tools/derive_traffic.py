@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_round")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 COPY_BYTES = 2_684_354_560            # tools/kbench copy: 160 Mi float4 elements
@@ -36,11 +36,12 @@ def mean(v):
     return sum(v) / len(v) if v else 0.0
 
 
+HEADLINE = "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum"):
     p = os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv")
     shutil.copy(p, os.path.join(dst, f"pmc_{c}.csv"))
-    out[c] = {"tile": counters(p, "seg_tile_kernel"), "fixup": counters(p, "seg_fixup_kernel")}
+    out[c] = {"tile": counters(p, HEADLINE), "fixup": counters(p, "seg_fixup_kernel")}
 cal = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     p = os.path.join(src, f"cal_{c}", "cal_counter_collection.csv")
@@ -59,14 +60,14 @@ alg = 10_000_000 * (4 * 64 + 8) + 1_000_000 * 4 * 64
 kernel = None
 with open(os.path.join(src, "kt", "bench_kernel_stats.csv")) as f:
     for r in csv.DictReader(f):
-        if "seg_tile_kernel" in r["Name"]:
+        if HEADLINE in r["Name"]:
             kernel = {"name": r["Name"].split("::")[-2].split("(")[0] if "::" in r["Name"] else r["Name"],
                       "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                       "max_ns": float(r["MaxNs"])}
         if "seg_fixup_kernel" in r["Name"]:
             fix_ns = float(r["AverageNs"])
 res = {
-    "kernel": "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>",
+    "kernel": HEADLINE,
     "workload": "BASELINE.json configs[1]: index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64",
     "hbm_bytes_per_launch": int(fetch + write),
     "fetch_bytes_per_launch": int(fetch),
@@ -91,3 +92,67 @@ res = {
 }
 json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
+
+
+# ---- the gather-mode kernels of bench.py's `secondary` workloads (cfg3 gws, cfg4 mh_spmm) and rocSPARSE beside them:
+#      kernel-trace time, fabric-side bytes (FETCH_SIZE x2 - 16-B-per-lane row reads, same shape as the calibration
+#      copy - + WRITE_SIZE), L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS)), against SURVEY 8(d)'s compulsory bytes
+def per_kernel(path):
+    d = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            d.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: mean(v) for k, v in d.items()}
+
+
+pm = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"):
+    p = os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"pmc_{c}.csv"))
+        pm[c] = per_kernel(p)
+kt = {}
+with open(os.path.join(src, "kt", "bench_kernel_stats.csv")) as f:
+    for r in csv.DictReader(f):
+        kt[r["Name"]] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6}
+sec = {}
+try:
+    sec = json.load(open(os.path.join(src, "bench_under_kernel_trace.json"))).get("secondary", {})
+except Exception:
+    pass
+want = {"gws_cfg3 (gather_weight_scatter, 124 M edges, F=128)": ("seg_tile_kernel<float, 4, true, 1,", "gws_cfg3"),
+        "mh_spmm_cfg4 [nnz,H] (115 M edges, H=4 F=64)": ("seg_tile_kernel<float, 4, true, 2,", "mh_spmm_cfg4"),
+        "mh_spmm_cfg4 [H,nnz]": ("seg_tile_kernel<float, 4, true, 3,", "mh_spmm_cfg4"),
+        "mh_spmm_cfg4 source-blocked (seg_slab_kernel<2>)": ("seg_slab_kernel<2>", "mh_spmm_cfg4"),
+        "rocSPARSE csr_nnz_split on the cfg3 matrix": ("csrmmnt_nnz_split_main_kernel", "gws_cfg3"),
+        "rocSPARSE csr_merge_path on the cfg3 matrix": ("csrmmnt_merge_path_main_kernel", "gws_cfg3"),
+        "rocSPARSE csr_row_split on the cfg3 matrix": ("csrmmnt_row_split", "gws_cfg3")}
+gather = {}
+for label, (pat, seckey) in want.items():
+    name = next((k for k in kt if pat in k), None)
+    if name is None:
+        continue
+    g = {"kernel": name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], **kt[name]}
+    fetch = next((v for k, v in pm.get("FETCH_SIZE", {}).items() if pat in k), None)
+    write = next((v for k, v in pm.get("WRITE_SIZE", {}).items() if pat in k), None)
+    hit = next((v for k, v in pm.get("TCC_HIT_sum", {}).items() if pat in k), None)
+    miss = next((v for k, v in pm.get("TCC_MISS_sum", {}).items() if pat in k), None)
+    atom = next((v for k, v in pm.get("TCC_EA0_ATOMIC_sum", {}).items() if pat in k), None)
+    if fetch is not None and write is not None:
+        g["fabric_bytes_per_launch"] = int(fetch * 2048 + write * 1024)
+        g["FETCH_SIZE_KB_raw"], g["WRITE_SIZE_KB_raw"] = fetch, write
+    if hit is not None and miss is not None and hit + miss > 0:
+        g["l2_hit_rate"] = hit / (hit + miss)
+    if atom is not None:
+        g["TCC_EA0_ATOMIC_sum"] = atom
+    comp = sec.get(seckey, {}).get("compulsory_bytes")
+    if comp:
+        g["compulsory_bytes"] = comp
+        g["frac_of_8TBps_on_compulsory_bytes"] = comp / (g["average_ms"] * 1e-3) / 8e12
+        if "fabric_bytes_per_launch" in g:
+            g["traffic_over_compulsory"] = g["fabric_bytes_per_launch"] / comp
+    gather[label] = g
+json.dump({"method": "same rocprofv3 session as traffic.json (tools/profile_round.sh): --kernel-trace --stats for the times, one "
+                     "--pmc counter per pass for the bytes; FETCH_SIZE doubled (gfx950, 16-B-per-lane reads)",
+           "kernels": gather}, open(os.path.join(dst, "gather_kernels.json"), "w"), indent=1)
+print(json.dumps(gather, indent=1))

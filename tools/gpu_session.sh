@@ -22,6 +22,8 @@ for s in $steps; do
                 timeout 500 python3 tools/soak_fuzz.py --iters 150 --seed $seed --ops gws,gs,gws,gs,is > $O/soak_gather_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -3 $O/soak_gather_seed$seed.log
               done ;;
     profile)  bash tools/profile_round.sh > $O/profile_round.log 2>&1; echo "rc=$?"; tail -30 $O/profile_round.log ;;
+    slab)     timeout 900 python3 -m pytest tests/test_gpu_slab.py -m gpu -x -q > $O/pytest_slab.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_slab.log
+              timeout 900 python3 tools/bench_slab.py > $O/bench_slab.txt 2>&1; echo "rc=$?"; cat $O/bench_slab.txt ;;
     small)    timeout 300 python3 tools/bench_small.py > $O/bench_small.txt 2>&1; echo "rc=$?"; cat $O/bench_small.txt ;;
     *)        echo "unknown step $s" ;;
   esac
