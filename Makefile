@@ -21,14 +21,14 @@ tools/kbench: tools/kbench.cpp $(LIB) include/geot_hip.h
 	$(HIPCC) -O2 --offload-arch=$(ARCH) -std=c++17 -Iinclude tools/kbench.cpp -Lgeot_amd -lgeot_hip \
 	  -Wl,-rpath,'$$ORIGIN/../geot_amd' -o $@
 
-# optional PyTorch dispatcher plugin over the C ABI (path A): geot_amd/_C.so
+# the PyTorch dispatcher plugin over the C ABI (the host side of the drop-in): geot_amd/_C.so
 TORCH_DIR := $(shell python3 -c "import os,torch;print(os.path.dirname(torch.__file__))")
 CXXABI    := $(shell python3 -c "import torch;print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")
 shim: geot_amd/_C.so
-geot_amd/_C.so: geot_amd/csrc/torch_shim.cpp $(LIB) include/geot_hip.h
+geot_amd/_C.so: geot_amd/csrc/torch_ops.cpp $(LIB) include/geot_hip.h
 	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=$(CXXABI) \
 	  -Iinclude -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
-	  geot_amd/csrc/torch_shim.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -lc10 -lc10_hip \
+	  geot_amd/csrc/torch_ops.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
 	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
 
 oracle:

@@ -16,6 +16,8 @@ LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
+PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
+PLUGIN_SOURCE = os.path.join(_HERE, "csrc", "torch_ops.cpp")
 
 GEOT_OK = 0
 GEOT_F32, GEOT_F64, GEOT_F16, GEOT_BF16 = 0, 1, 2, 3
@@ -37,7 +39,8 @@ class SlabPlan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out",
                                                 "c_row", "c_first", "c_count")] + \
                [(n, ctypes.c_int64) for n in ("n_groups", "n_vrows", "n_carry", "n_split", "nnz")] + \
-               [("units", ctypes.c_int32), ("rows_per_group", ctypes.c_int32)]
+               [("units", ctypes.c_int32), ("rows_per_group", ctypes.c_int32), ("slab_shift", ctypes.c_int32),
+                ("n_slabs", ctypes.c_int32)]
 
 
 _lib = None
@@ -66,6 +69,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     return LIB_PATH
+
+
+def plugin_needs_build() -> bool:
+    if not os.path.exists(PLUGIN_PATH):
+        return True
+    t = os.path.getmtime(PLUGIN_PATH)
+    return any(os.path.getmtime(p) > t for p in (PLUGIN_SOURCE, HEADER))
+
+
+def build_plugin(force: bool = False, verbose: bool = False) -> str:
+    """g++ build of geot_amd/_C.so against the installed torch (no GPU needed; ~30 s).  Same recipe as `make shim`."""
+    if force or plugin_needs_build():
+        import torch
+        tdir = os.path.dirname(torch.__file__)
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+               f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", os.path.join(_ROOT, "include"),
+               "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+               "-I", "/opt/rocm/include", PLUGIN_SOURCE, "-o", PLUGIN_PATH, "-L", _HERE, "-lgeot_hip",
+               "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+               "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{os.path.join(tdir, 'lib')}"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return PLUGIN_PATH
 
 
 def load() -> ctypes.CDLL:

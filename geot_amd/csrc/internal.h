@@ -3,4 +3,6 @@
 #define GEOT_INTERNAL_H
 // records `msg` as the calling thread's geot_last_error() and returns `code`
 extern "C" int geot_internal_fail(int code, const char *msg);
+// experiment knobs of seg_slab.hip, forwarded by geot_set_option
+extern "C" void geot_internal_slab_option(const char *name, int value);
 #endif

@@ -2185,6 +2185,7 @@ void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "lane_e") g_lane_e = value;
   if (name && std::string(name) == "xcd") g_xcd = value;
   if (name && std::string(name) == "nt_keys") g_nt_keys = value;
+  geot_internal_slab_option(name, value);
 }
 
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {

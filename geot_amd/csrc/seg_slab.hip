@@ -16,8 +16,8 @@
 //     edges slab by slab.  All units start together and do the same amount of work per slab, so without any
 //     synchronisation the whole chip sweeps the source table in step: each slab is fetched from HBM / Infinity
 //     Cache once per XCD and round, every further read hits in L2.  Runs of equal (slab, row) are summed in
-//     registers and added to the LDS row with ds_add_f32 (no return, no stall; one unit owns its rows: the order
-//     of additions is fixed -> deterministic).  At the end of the round the rows are stored to dst with plain
+//     registers; when the row changes the open row is written back to LDS and the next one read (one unit owns
+//     its rows: the order of additions is fixed -> deterministic).  At the end of the round the rows are stored to dst with plain
 //     coalesced stores; virtual rows of a split hub go to a carry buffer.
 //   * Phase C (seg_slab_combine_kernel): the few split rows are summed from their carry slots in order.
 //
@@ -46,24 +46,44 @@ struct SlabParams {
   uint32_t rowbytes;
   int lpr_log2;
   int rounds;
+  // loose per-XCD lockstep (see slab_sync): progress words of the waves of each XCD, slab size as a shift
+  int *prog;            // [8][kProgSlots] current step of every registered wave (0x7f7f7f7f = not running)
+  int *prog_cnt;        // [8] slot allocator (starts at 0x7f7f7f7f)
+  int slab_shift;       // slab = source row >> slab_shift
+  int n_slabs;
+  int window;           // a wave may be at most `window` slabs ahead of the slowest wave of its XCD; < 0: no sync
 };
+constexpr int kProgSlots = 512;
+constexpr int kProgIdle = 0x7f7f7f7f;
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
-template <int WMODE>
+// WAVE_ROW: rows of 1 KiB - the whole wave is one unit, edge fields are read with v_readlane (scalar row bases)
+//
+// Per chunk of `lpr` edges of a unit (one edge per lane of the unit: source row, row in group, original edge id):
+//   * the NEXT chunk's fields are loaded at the top, its weights (which need the edge ids) after the first batch
+//     of rows, and staged into the other half of a double-buffered LDS array at the end - nothing the row loop
+//     needs is ever waited for;
+//   * rows are gathered kU at a time; the fields of the batch (row number, row in group, weight) are fetched
+//     BEFORE the loads are issued; the accumulate loop's only LDS traffic is one 16-byte write + read per lane when
+//     the row changes (the open row is kept in registers).
+template <int WMODE, bool WAVE_ROW>
 __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lpr = 1 << p.lpr_log2;
-  const int G = 64 >> p.lpr_log2;           // units per wave
-  const int sub = lane >> p.lpr_log2, c = lane & (lpr - 1);
+  const int lpr = WAVE_ROW ? 64 : (1 << p.lpr_log2);
+  const int G = 64 / lpr;                     // units per wave
+  const int sub = WAVE_ROW ? 0 : (lane >> p.lpr_log2), c = lane & (lpr - 1);
   const int R = P.rows_per_group;
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : p.H);
-  // LDS: accumulators [4 waves][G units][R rows][lpr lanes] float4 = 4 * R KiB, then the staged weights
-  f4_t *accL = reinterpret_cast<f4_t *>(smem) + ((size_t)(wave * G + sub) * R) * lpr;
-  float *wL = reinterpret_cast<float *>(smem + (size_t)4 * R * 1024) + (size_t)(wave * G + sub) * lpr * (hw > 0 ? hw : 1);
+  // LDS: accumulators [4 waves][G units][R rows][lpr lanes] float4 = 4 * R KiB, then the staged
+  // weights [4 waves][2 buffers][64 edge slots][hw]
+  float *accS = reinterpret_cast<float *>(smem) + ((size_t)(wave * G + sub) * R) * 4 * lpr;
+  float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 1024) + (size_t)wave * 2 * 64 * (hw > 0 ? hw : 1) +
+                 (size_t)sub * lpr * (hw > 0 ? hw : 1);
+  const int wbuf_stride = 64 * (hw > 0 ? hw : 1);
   const int64_t unit = ((int64_t)blockIdx.x * 4 + wave) * G + sub;
   const int64_t units = P.units;
   const char *src = static_cast<const char *>(p.src);
@@ -71,86 +91,173 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   float *dst = static_cast<float *>(p.dst);
   const int h = WMODE >= 2 ? (c * 4) / p.Fh : 0;
   const uint32_t rb = p.rowbytes;
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+
+  // ---- loose lockstep inside an XCD -------------------------------------------------------------------------------
+  // The natural lockstep (same start, same work) drifts like a random walk: with ~6000 edges per group the waves of an
+  // XCD spread over ~+-3 % of the table (+-6 MB at 238 MB) - more than the 4 MiB L2.  So every wave publishes the step
+  // (round * slabs + slab) it is working on in a per-XCD array and does not START a slab more than `window` slabs
+  // ahead of the slowest registered wave of its XCD.  Only leaders ever wait, the slowest wave never does, a wave
+  // that is not resident is not registered, and every wait is bounded: no deadlock by construction.  Same-XCD
+  // visibility: plain stores go through to the XCD's L2, the polls bypass L1 (nt loads).
+  int my_slot = -1;
+  int *xprog = nullptr;
+  if (p.window >= 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;        // HW_REG_XCC_ID[3:0]
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  int published = -1;
+  auto slab_sync = [&](int step) {            // wave-uniform
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    for (int tries = 0; tries < 2048; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      if (m + p.window >= step) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+  };
+
+  // a unit's accumulator rows are touched by that unit's lanes only, each lane its own 16 bytes: plain LDS
+  // read / write (ds_read_b128 / ds_write_b128), no atomics (LDS float atomics measured ~30x slower per byte)
+  f4_t *accV = reinterpret_cast<f4_t *>(accS);
 
   for (int r = 0; r < p.rounds; ++r) {
     // serpentine over the size-sorted groups: no unit is always handed the larger group of its round
     const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
-    const bool has = pos < P.n_groups && unit < units;
+    const bool has = pos < P.n_groups;
     const int64_t e0 = has ? P.g_begin[pos] : 0;
     const int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
     const int nv = has ? P.g_nv[pos] : 0;
-    for (int l = 0; l < R; ++l) accL[(size_t)l * lpr + c] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < R; ++l) accV[(size_t)l * lpr + c] = f4_t{0.f, 0.f, 0.f, 0.f};
     int maxlen = len;
-    for (int o = 32; o >= lpr && o > 0; o >>= 1) {   // max over the wave's units (wave-uniform loop bound)
-      const int other = __shfl_xor(maxlen, o, 64);
-      maxlen = other > maxlen ? other : maxlen;
+    if constexpr (!WAVE_ROW) {
+      for (int o = 32; o >= lpr; o >>= 1) {         // max over the wave's units (wave-uniform loop bound)
+        const int other = __shfl_xor(maxlen, o, 64);
+        maxlen = other > maxlen ? other : maxlen;
+      }
     }
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
     int cur = 255;                                   // no open row
-    for (int off = 0; off < maxlen; off += lpr) {
-      const bool valid = off + c < len;
-      const int64_t ei = e0 + off + c;
-      const int my_src = valid ? P.e_src[ei] : 0;
-      const int my_dl = valid ? (int)P.e_dl[ei] : 255;
+
+    // fields of the first chunk, its weights into buffer 0
+    int my_src = 0, my_dl = 255;
+    {
+      const bool valid = c < len;
+      my_src = valid ? P.e_src[e0 + c] : 0;
+      my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
       if constexpr (WMODE != 0) {
-        const int64_t pe = valid ? (int64_t)P.e_perm[ei] : 0;
-        if constexpr (WMODE == 1) wL[c] = valid ? weight[pe] : 0.f;
+        const int64_t pe = valid ? (int64_t)P.e_perm[e0 + c] : 0;
+        if constexpr (WMODE == 1) wbase[c] = valid ? weight[pe] : 0.f;
         if constexpr (WMODE == 2) {
-          if (p.H == 4) {
-            const f4_t t = valid ? *reinterpret_cast<const f4_t *>(weight + pe * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f4_t *>(wL + c * 4) = t;
-          } else {
-            for (int q = 0; q < p.H; ++q) wL[c * hw + q] = valid ? weight[pe * p.H + q] : 0.f;
-          }
+          if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + c * 4) = valid ? *reinterpret_cast<const f4_t *>(weight + pe * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+          else for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? weight[pe * p.H + q] : 0.f;
         }
-        if constexpr (WMODE == 3) {
-          for (int q = 0; q < p.H; ++q) wL[c * hw + q] = valid ? weight[(int64_t)q * P.nnz + pe] : 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();             // LDS is in order per wave: the reads below see these writes
+        if constexpr (WMODE == 3)
+          for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? weight[(int64_t)q * P.nnz + pe] : 0.f;
+        __builtin_amdgcn_wave_barrier();
       }
-      int n_here = len - off;                        // edges of this unit in the chunk (<= 0: none)
+    }
+
+    int k = 0;
+    for (int off = 0; off < maxlen; off += lpr, ++k) {
+      const float *wcur = wbase + (k & 1) * wbuf_stride;
+      float *wnext = wbase + ((k + 1) & 1) * wbuf_stride;
+      // next chunk's fields: in flight underneath this chunk's rows
+      const bool nvalid = off + lpr + c < len;
+      const int64_t ne = e0 + off + lpr + c;
+      const int n_src = nvalid ? P.e_src[ne] : 0;
+      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      int64_t n_pe = 0;
+      if constexpr (WMODE != 0) n_pe = nvalid ? (int64_t)P.e_perm[ne] : 0;
+      f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
+      float wn1 = 0.f;
+
+      const int n_here = len - off;                  // edges of this unit in the chunk (<= 0: none)
       int n_max = maxlen - off;
       n_max = n_max < lpr ? n_max : lpr;
       for (int b = 0; b < n_max; b += kU) {
+        if (p.window >= 0) {                         // which slab does this batch start in (the wave's first unit decides)
+          const int first_row = __builtin_amdgcn_readlane(my_src, b);
+          const int has_edge = __builtin_amdgcn_readfirstlane(n_here) > b;
+          if (has_edge) slab_sync(r * p.n_slabs + (first_row >> p.slab_shift));
+        }
         f4_t v[kU];
+        int dls[kU];
+        float ws[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          int row = __shfl(my_src, b + u, lpr);      // (b+u) < lpr always: lpr >= 16 >= kU and b + kU <= lpr
-          if (b + u >= n_here || (unsigned)row >= (unsigned)p.src_rows) row = 0;
+          const bool ok = b + u < n_here;
+          int row;
+          if constexpr (WAVE_ROW) {
+            row = __builtin_amdgcn_readlane(my_src, b + u);
+            dls[u] = ok ? __builtin_amdgcn_readlane(my_dl, b + u) : 255;
+          } else {
+            row = __shfl(my_src, b + u, lpr);
+            dls[u] = ok ? __shfl(my_dl, b + u, lpr) : 255;
+          }
+          if (!ok || (uint32_t)row >= src_rows) row = 0;
+          if constexpr (WMODE != 0) ws[u] = ok ? wcur[(b + u) * hw + h] : 0.f;
           v[u] = *reinterpret_cast<const f4_t *>(src + (int64_t)row * rb + c * 16);
         }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const int dl = b + u < n_here ? __shfl(my_dl, b + u, lpr) : 255;
-          if (dl != cur) {
-            if (cur != 255) {
-              float *a = reinterpret_cast<float *>(accL + (size_t)cur * lpr + c);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) __hip_atomic_fetch_add(a + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (WMODE != 0) {
+          if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
+            if constexpr (WMODE == 1) wn1 = nvalid ? weight[n_pe] : 0.f;
+            if constexpr (WMODE == 2) {
+              if (p.H == 4) { if (nvalid) wn4 = *reinterpret_cast<const f4_t *>(weight + n_pe * 4); }
             }
-            cur = dl;
-            acc = f4_t{0.f, 0.f, 0.f, 0.f};
-          }
-          if constexpr (WMODE == 0) acc += v[u];
-          else {
-            const float w = b + u < n_here ? wL[(b + u) * hw + h] : 0.f;
-            acc += v[u] * w;
           }
         }
-      }
-      if constexpr (WMODE != 0) __builtin_amdgcn_wave_barrier(); // weights of this chunk are consumed
-    }
-    if (cur != 255) {
-      float *a = reinterpret_cast<float *>(accL + (size_t)cur * lpr + c);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) __hip_atomic_fetch_add(a + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int u = 0; u < kU; ++u) {
+          if (dls[u] != cur) {                       // the open row goes back to LDS, the new one comes out of it
+            if (cur != 255) accV[(size_t)cur * lpr + c] = acc;
+            cur = dls[u];
+            acc = cur != 255 ? accV[(size_t)cur * lpr + c] : f4_t{0.f, 0.f, 0.f, 0.f};
+          }
+          if constexpr (WMODE == 0) acc += v[u];
+          else acc += v[u] * ws[u];
+        }
+      }
+      // stage the next chunk
+      if constexpr (WMODE != 0) {
+        if constexpr (WMODE == 1) wnext[c] = wn1;
+        if constexpr (WMODE == 2) {
+          if (p.H == 4) *reinterpret_cast<f4_t *>(wnext + c * 4) = wn4;
+          else for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? weight[n_pe * p.H + q] : 0.f;
+        }
+        if constexpr (WMODE == 3)
+          for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+      }
+      my_src = n_src;
+      my_dl = n_dl;
+    }
+    if (cur != 255) accV[(size_t)cur * lpr + c] = acc;
+    if (p.window >= 0 && my_slot >= 0) {             // done with this round: never hold the others back
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
     }
     // the group's rows: dst for whole rows, the carry buffer for the pieces of a split hub
     if (has) {
       const int64_t v0 = P.g_vrow0[pos];
       for (int l = 0; l < nv; ++l) {
         const int64_t t = P.v_out[v0 + l];
-        const f4_t row = accL[(size_t)l * lpr + c];
+        const f4_t row = accV[(size_t)l * lpr + c];
         if (t >= 0) {
           if (t < p.K) *reinterpret_cast<f4_t *>(dst + t * p.F + c * 4) = row;
         } else {
@@ -159,6 +266,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       }
     }
   }
+  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row)
@@ -181,11 +289,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p
 
 extern "C" {
 
+constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
+int g_slab_window = 1;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
+
 int geot_slab_units(void) { return 256 * 2 * 4; } // waves of the persistent grid: 256 CUs x 2 workgroups x 4
 
 static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads) {
   const size_t hw = weight_mode <= 1 ? 1 : (size_t)heads;
-  return (size_t)4 * rows_per_group * 1024 + (size_t)4 * 64 * hw * sizeof(float);
+  return (size_t)4 * rows_per_group * 1024 + (size_t)4 * 2 * 64 * hw * sizeof(float); // + double-buffered weights
 }
 
 // two workgroups per CU inside the classic 64 KB per workgroup: R KiB of accumulators per wave + the staged weights
@@ -197,7 +308,7 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) {
 
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total) {
   if (!plan) return 0;
-  return (size_t)(plan->n_carry > 0 ? plan->n_carry : 1) * (size_t)feat_total * sizeof(float) + 256;
+  return (size_t)(plan->n_carry > 0 ? plan->n_carry : 1) * (size_t)feat_total * sizeof(float) + 256 + kSyncBytes;
 }
 
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
@@ -229,7 +340,13 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.weight = weight;
   p.src = src;
   p.dst = dst;
-  p.carry = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256); // (the first 256 bytes are the tile kernels' control words)
+  // workspace: [256 B control words of the tile kernels | progress words + slot counters | carry rows]
+  p.prog = reinterpret_cast<int *>(static_cast<char *>(workspace) + 256);
+  p.prog_cnt = p.prog + 8 * kProgSlots;
+  p.carry = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + kSyncBytes);
+  p.slab_shift = plan->slab_shift;
+  p.n_slabs = plan->n_slabs;
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? g_slab_window : -1;
   p.src_rows = src_rows;
   p.K = out_rows;
   p.F = F;
@@ -241,16 +358,25 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 
   hipError_t e = hipMemsetAsync(dst, 0, (size_t)out_rows * (size_t)rowbytes, st); // rows without edges
   if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
+  if (p.window >= 0) {
+    e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);                              // every word = kProgIdle
+    if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
+  }
   if (plan->n_groups > 0) {
     const size_t lds = slab_lds_bytes(plan->rows_per_group, weight_mode, heads);
     if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group)");
     const dim3 grid(256 * 2), blk(kThreads);
+    const bool wave_row = lpr_log2 == 6;
+#define GEOT_SLAB_LAUNCH(W)                                                                             \
+  if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<W, true>), grid, blk, lds, st, p);                  \
+  else hipLaunchKernelGGL((seg_slab_kernel<W, false>), grid, blk, lds, st, p)
     switch (weight_mode) {
-    case 0: hipLaunchKernelGGL(seg_slab_kernel<0>, grid, blk, lds, st, p); break;
-    case 1: hipLaunchKernelGGL(seg_slab_kernel<1>, grid, blk, lds, st, p); break;
-    case 2: hipLaunchKernelGGL(seg_slab_kernel<2>, grid, blk, lds, st, p); break;
-    default: hipLaunchKernelGGL(seg_slab_kernel<3>, grid, blk, lds, st, p); break;
+    case 0: GEOT_SLAB_LAUNCH(0); break;
+    case 1: GEOT_SLAB_LAUNCH(1); break;
+    case 2: GEOT_SLAB_LAUNCH(2); break;
+    default: GEOT_SLAB_LAUNCH(3); break;
     }
+#undef GEOT_SLAB_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
     if (plan->n_split > 0) {
@@ -262,6 +388,10 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     }
   }
   return GEOT_OK;
+}
+
+void geot_internal_slab_option(const char *name, int value) {
+  if (name && std::string(name) == "slab_window") g_slab_window = value;
 }
 
 } // extern "C"

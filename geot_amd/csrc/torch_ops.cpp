@@ -1,0 +1,825 @@
+// torch_ops.cpp -- the geot::* dispatcher operators (geot_amd/_C.so), the HOST side of the drop-in.
+//
+// The reference's host side is a PyTorch C++ plugin: csrc/index_scatter.cpp:26-56, csrc/gather_scatter.cpp:13-34,
+// csrc/gather_weight_scatter.cpp:11-49, csrc/mh_spmm.cpp:10-23, csrc/csr_gws.cpp:11-60 register the schemas in
+// namespace `geot` and call the device entry points of csrc/cuda/header_cuda.h.  This file is that plugin for
+// MI355X: the same schema strings, checks and error texts, over the C ABI of libgeot_hip.so (include/geot_hip.h).
+// geot_amd/ops.py loads it (torch.ops.load_library, like geot/__init__.py:12-19) and only adds the fake-tensor
+// rules and the autograd formulas, as the reference's Python files do.
+//
+// What the host layer does beyond forwarding pointers:
+//   * row rule rows = index[-1] + 1 (csrc/index_scatter.cpp:30): read back on EVERY call, but the kernels are
+//     launched for the row count remembered for that index tensor while the 8-byte copy is in flight, and the
+//     count is verified afterwards (a mismatch relaunches); GEOT_SPECULATE_ROWS=0 restores the blocking order;
+//   * facts of an index (ascending? row count, stable sort), probed once per CONTENT - storage identity, offset,
+//     length, version counter, guarded by a weak reference to the storage: the atomic-free kernels are only ever
+//     given an ascending index, whatever `sorted` promised; an index with descents is reduced over its sort;
+//   * dense graphs are re-arranged once for the source-blocked kernel (csrc/seg_slab.hip) on their second call;
+//   * one workspace per (device, stream), a device guard, the current stream.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/library.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "geot_hip.h"
+
+namespace {
+
+// ---- options (environment at load time, geot::_host_option at run time) -------------------------------------------
+struct Options {
+  int speculate_rows = 1;    // GEOT_SPECULATE_ROWS
+  int trust_version = 1;     // GEOT_TRUST_VERSION
+  int unsorted_mode = 0;     // GEOT_UNSORTED: 0 auto (sort), 1 sort, 2 atomic
+  int slab_mode = 0;         // GEOT_SLAB: -1 never, 0 auto, 1 always
+  int transpose_cache = 4;   // GEOT_TRANSPOSE_CACHE (entries)
+  int slab_keep = 2;
+  Options() {
+    if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
+    if (const char *e = std::getenv("GEOT_TRUST_VERSION")) trust_version = std::strcmp(e, "0") != 0;
+    if (const char *e = std::getenv("GEOT_UNSORTED")) unsorted_mode = !std::strcmp(e, "atomic") ? 2 : (!std::strcmp(e, "sort") ? 1 : 0);
+    if (const char *e = std::getenv("GEOT_SLAB")) slab_mode = !std::strcmp(e, "0") ? -1 : (!std::strcmp(e, "1") ? 1 : 0);
+    if (const char *e = std::getenv("GEOT_TRANSPOSE_CACHE")) transpose_cache = std::atoi(e);
+  }
+};
+Options g_opt;
+struct Stats {
+  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0;
+};
+Stats g_stats;
+std::mutex g_mu; // guards the caches below (facts, transposed edge lists, slab plans)
+
+// ---- small helpers -------------------------------------------------------------------------------------------------------
+int dtype_code(const at::Tensor &t, const char *op) {
+  switch (t.scalar_type()) {
+  case at::kFloat: return GEOT_F32;
+  case at::kDouble: return GEOT_F64;
+  case at::kHalf: return GEOT_F16;
+  case at::kBFloat16: return GEOT_BF16;
+  default: TORCH_CHECK(false, "\"", op, "\" not implemented for '", toString(t.scalar_type()), "'");
+  }
+}
+
+int reduce_code(c10::string_view reduce, bool pyg_add = false) { // csrc/reduceutils.h:5-22 (+ PyG's 'add' for the gather ops)
+  if (reduce == "max" || reduce == "amax") return GEOT_REDUCE_MAX;
+  if (reduce == "mean") return GEOT_REDUCE_MEAN;
+  if (reduce == "min" || reduce == "amin") return GEOT_REDUCE_MIN;
+  if (reduce == "sum" || (pyg_add && reduce == "add")) return GEOT_REDUCE_SUM;
+  if (reduce == "prod") return GEOT_REDUCE_PROD;
+  TORCH_CHECK(false, "reduce argument must be either sum, prod, mean, amax or amin, got ", reduce);
+}
+
+void require_gpu(const char *op, std::initializer_list<const at::Tensor *> ts) {
+  const at::Tensor *first = nullptr;
+  for (const at::Tensor *t : ts) {
+    if (!t || !t->defined()) continue;
+    TORCH_CHECK(t->is_cuda(), "geot::", op, ": CPU tensors are not supported by geot_amd (MI355X-only package, no CPU "
+                "fallback).  Move the tensors to the GPU.");
+    if (!first) first = t;
+    TORCH_CHECK(t->device() == first->device(), "all tensors must be on the same device");
+  }
+}
+
+void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+#define GEOT_DEVICE_GUARD(t) const c10::hip::HIPGuard geot_device_guard_((t).device())
+#define GEOT_CALL(expr)                                                                                                 \
+  do {                                                                                                                  \
+    const int rc_ = (expr);                                                                                             \
+    TORCH_CHECK(rc_ == GEOT_OK, #expr, " failed (code ", rc_, "): ", geot_last_error());                                \
+  } while (0)
+
+const int64_t *index_ptr(const at::Tensor &t) { return t.data_ptr<int64_t>(); } // "expected scalar type Long but found ..."
+
+// one zero-initialised workspace per (device, stream), grown on demand (the ABI: one stream at a time per workspace)
+at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
+  static thread_local std::map<std::pair<int, void *>, at::Tensor> ws;
+  auto &w = ws[{(int)like.device().index(), stream_of(like)}];
+  if (!w.defined() || (size_t)w.numel() < bytes)
+    w = at::zeros({(int64_t)std::max<size_t>(bytes, 1 << 20)}, like.options().dtype(at::kByte));
+  return w;
+}
+
+// ---- pinned read-back slot per (thread, device) -------------------------------------------------------------------------
+struct Slot {
+  int64_t *host = nullptr;
+  hipEvent_t ev = nullptr;
+};
+Slot &slot_for(int device) {
+  static thread_local std::map<int, Slot> slots;
+  Slot &s = slots[device];
+  if (!s.host) {
+    TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), 4 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
+                "hipHostMalloc failed");
+    TORCH_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+  }
+  return s;
+}
+
+// ---- facts of an index tensor, keyed on its content identity ---------------------------------------------------------------
+struct ContentKey {
+  const void *storage;
+  int64_t offset, numel;
+  uint32_t version;
+  bool operator==(const ContentKey &o) const {
+    return storage == o.storage && offset == o.offset && numel == o.numel && version == o.version;
+  }
+};
+bool content_key(const at::Tensor &t, ContentKey *k) {
+  if (t.is_inference() || !t.has_storage()) return false; // inference tensors keep no version counter: never remembered
+  k->storage = t.storage().unsafeGetStorageImpl();
+  k->offset = t.storage_offset();
+  k->numel = t.numel();
+  k->version = t._version();
+  return true;
+}
+struct Facts {
+  ContentKey key;
+  c10::weak_intrusive_ptr<c10::StorageImpl> weak;
+  int64_t rows;
+  bool ascending;
+  at::Tensor keys, perm; // stable sort of an index with descents (a few entries keep theirs)
+};
+std::list<Facts> g_facts; // most recent first, <= 16 entries
+constexpr size_t kFactsMax = 16, kSortedKeep = 4;
+
+struct FactsView {
+  int64_t rows;
+  bool ascending;
+  bool cached;
+};
+
+void probe_index(const at::Tensor &index, int64_t *last, int64_t *descents) {
+  TORCH_CHECK_INDEX(index.numel() > 0, "index -1 is out of bounds for dimension 0 with size 0");
+  at::Tensor dev = at::empty({2}, index.options());
+  void *st = stream_of(index);
+  GEOT_CALL(geot_index_probe(index_ptr(index), index.numel(), dev.data_ptr<int64_t>(), st));
+  Slot &s = slot_for(index.device().index());
+  TORCH_CHECK(hipMemcpyAsync(s.host, dev.data_ptr<int64_t>(), 16, hipMemcpyDeviceToHost, static_cast<hipStream_t>(st)) == hipSuccess, "hipMemcpyAsync failed");
+  TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(st)) == hipSuccess, "hipStreamSynchronize failed");
+  *last = s.host[0];
+  *descents = s.host[1];
+}
+
+// index: contiguous, 1-D, int64, on the GPU, non-empty checked inside
+FactsView index_facts(const at::Tensor &index) {
+  ContentKey k;
+  const bool keyed = g_opt.trust_version && content_key(index, &k);
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_facts.begin(); it != g_facts.end(); ++it)
+      if (it->key == k && !it->weak.expired()) {
+        g_facts.splice(g_facts.begin(), g_facts, it);
+        return {it->rows, it->ascending, true};
+      }
+  }
+  int64_t last = 0, descents = 0;
+  probe_index(index, &last, &descents);
+  std::lock_guard<std::mutex> lk(g_mu);
+  ++g_stats.probes;
+  if (keyed) {
+    g_facts.push_front(Facts{k, index.storage().getWeakStorageImpl(), last + 1, descents == 0, {}, {}});
+    while (g_facts.size() > kFactsMax) g_facts.pop_back();
+  }
+  return {last + 1, descents == 0, false};
+}
+
+void remember_rows(const at::Tensor &index, int64_t rows) {
+  ContentKey k;
+  if (!content_key(index, &k)) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &f : g_facts)
+    if (f.key == k) f.rows = rows;
+}
+
+// (keys ascending, perm) of an index with descents
+std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
+  ContentKey k;
+  const bool keyed = g_opt.trust_version && content_key(index, &k);
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &f : g_facts)
+      if (f.key == k && !f.weak.expired() && f.keys.defined()) return {f.keys, f.perm};
+  }
+  auto sorted = at::sort(index, /*stable=*/true, /*dim=*/0, /*descending=*/false);
+  std::lock_guard<std::mutex> lk(g_mu);
+  ++g_stats.sorts;
+  if (keyed) {
+    size_t holders = 0;
+    for (auto &f : g_facts) {
+      if (f.key == k) {
+        f.keys = std::get<0>(sorted);
+        f.perm = std::get<1>(sorted);
+      }
+      if (f.keys.defined() && ++holders > kSortedKeep) f.keys = f.perm = at::Tensor();
+    }
+  }
+  return {std::get<0>(sorted), std::get<1>(sorted)};
+}
+
+// ---- the row rule without stalling the GPU ---------------------------------------------------------------------------------
+// launch(rows) allocates the output for `rows` rows and enqueues the kernels.  `guess` comes from the facts.
+template <typename Launch> at::Tensor with_row_rule(const at::Tensor &index, int64_t guess, bool guess_is_fresh, Launch launch) {
+  if (guess_is_fresh) return launch(guess); // this very call has just read index[-1] (the probe)
+  void *st = stream_of(index);
+  Slot &s = slot_for(index.device().index());
+  const int64_t *last = index_ptr(index) + (index.numel() - 1);
+  TORCH_CHECK(hipMemcpyAsync(s.host, last, 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(st)) == hipSuccess, "hipMemcpyAsync failed");
+  if (!g_opt.speculate_rows) {
+    TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(st)) == hipSuccess, "hipStreamSynchronize failed");
+    const int64_t rows = s.host[0] + 1;
+    if (rows != guess) remember_rows(index, rows);
+    return launch(rows);
+  }
+  TORCH_CHECK(hipEventRecord(s.ev, static_cast<hipStream_t>(st)) == hipSuccess, "hipEventRecord failed");
+  at::Tensor out = launch(guess); // queued behind the copy: the copy completes while the kernels run
+  TORCH_CHECK(hipEventSynchronize(s.ev) == hipSuccess, "hipEventSynchronize failed");
+  const int64_t rows = s.host[0] + 1;
+  if (rows != guess) { // the content changed under the same identity and version (a write through .data)
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      ++g_stats.row_mismatches;
+    }
+    remember_rows(index, rows);
+    out = launch(rows);
+  }
+  return out;
+}
+
+// ---- dense graphs: source-blocked kernel (csrc/seg_slab.hip), Phase A -------------------------------------------------------
+struct SlabPlanHolder {
+  std::vector<at::Tensor> keep; // the device arrays the struct points into
+  geot_slab_plan plan;
+  int64_t rounds, budget, cap, slabs, slab_rows;
+};
+
+bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes) {
+  if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024) || nnz >= ((int64_t)1 << 31) || nnz < 8000000 || out_rows < 1 ||
+      src_rows >= ((int64_t)1 << 31))
+    return false;
+  const int64_t units = (int64_t)geot_slab_units() * (1024 / rowbytes);
+  const int64_t rounds = std::max<int64_t>(1, (out_rows + 15 * units - 1) / (15 * units));
+  return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= 4.0;
+}
+
+// dst_index ascending.  Device scans / one stable sort, plus one host loop over the virtual rows.
+std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at::Tensor &dst_index, int64_t out_rows, int64_t src_rows,
+                                           int64_t rowbytes, int weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group,
+                                           int64_t units_override) {
+  auto H = std::make_shared<SlabPlanHolder>();
+  const int64_t nnz = dst_index.numel();
+  const int64_t lanes = rowbytes / 16;
+  const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units() * (64 / lanes);
+  const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group(weight_mode, heads);
+  const auto lopt = dst_index.options();
+  at::Tensor counts = at::bincount(dst_index, {}, out_rows).slice(0, 0, out_rows);
+  at::Tensor rowptr = at::cumsum(counts, 0) - counts;
+  const int64_t nonempty = counts.gt(0).sum().item<int64_t>();
+  const int64_t rounds0 = std::max<int64_t>(1, (nonempty + R * units - 1) / (R * units));
+  const int64_t budget = std::max<int64_t>(256, (nnz + rounds0 * units - 1) / (rounds0 * units));
+  const int64_t cap = std::max<int64_t>(64, budget / 2);
+  at::Tensor nv_row = at::div(counts + (cap - 1), cap, "floor");
+  at::Tensor vstart = at::cumsum(nv_row, 0) - nv_row;
+  const int64_t V = nv_row.sum().item<int64_t>();
+  at::Tensor v_row = at::repeat_interleave(nv_row, c10::optional<int64_t>(V)); // dst row of every virtual row
+  at::Tensor v_piece = at::arange(V, lopt) - vstart.index_select(0, v_row);
+  at::Tensor v_cnt = at::clamp_max(counts.index_select(0, v_row) - v_piece * cap, cap);
+  // groups: greedy over consecutive virtual rows, <= R rows and <= budget edges
+  at::Tensor v_cnt_h = v_cnt.cpu();
+  const int64_t *vc = v_cnt_h.data_ptr<int64_t>();
+  std::vector<int64_t> starts, gedges;
+  for (int64_t i = 0; i < V;) {
+    int64_t j = i, e = 0;
+    while (j < V && j - i < R && (j == i || e + vc[j] <= budget)) e += vc[j++];
+    starts.push_back(i);
+    gedges.push_back(e);
+    i = j;
+  }
+  const int64_t G = (int64_t)starts.size();
+  std::vector<int64_t> order(G), pos_of_group(G), g_begin(G + 1, 0), g_nv_sorted(G), g_v0_sorted(G), nv_of_group(G);
+  for (int64_t g = 0; g < G; ++g) {
+    order[g] = g;
+    nv_of_group[g] = (g + 1 < G ? starts[g + 1] : V) - starts[g];
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return gedges[a] > gedges[b]; });
+  for (int64_t p = 0; p < G; ++p) {
+    pos_of_group[order[p]] = p;
+    g_begin[p + 1] = g_begin[p] + gedges[order[p]];
+    g_nv_sorted[p] = nv_of_group[order[p]];
+    g_v0_sorted[p] = starts[order[p]];
+  }
+  auto to_dev = [&](const std::vector<int64_t> &v, at::ScalarType dt) {
+    at::Tensor t = at::empty({(int64_t)std::max<size_t>(v.size(), 1)}, at::TensorOptions().dtype(at::kLong));
+    if (!v.empty()) std::memcpy(t.data_ptr<int64_t>(), v.data(), v.size() * sizeof(int64_t));
+    else t.zero_();
+    return t.to(dst_index.device(), dt);
+  };
+  at::Tensor nv_of_group_t = to_dev(nv_of_group, at::kLong);
+  at::Tensor group_of_vrow = G > 0 ? at::repeat_interleave(nv_of_group_t.slice(0, 0, G), c10::optional<int64_t>(V)) : at::empty({0}, lopt);
+  at::Tensor start_of_group = to_dev(starts, at::kLong);
+  at::Tensor pos_t = to_dev(pos_of_group, at::kLong);
+  // per edge: virtual row, group position, slab, row in group -> one stable sort
+  at::Tensor e_id = at::arange(nnz, lopt);
+  at::Tensor vrow_e = vstart.index_select(0, dst_index) + at::div(e_id - rowptr.index_select(0, dst_index), cap, "floor");
+  e_id = at::Tensor();
+  at::Tensor gid_e = group_of_vrow.index_select(0, vrow_e);
+  at::Tensor dl_e = vrow_e - start_of_group.index_select(0, gid_e);
+  vrow_e = at::Tensor();
+  int64_t slab_shift = 0;                       // slabs of 2^k source rows (the kernel finds an edge's slab with a shift)
+  while (((int64_t)2 << slab_shift) * rowbytes <= slab_bytes) ++slab_shift;
+  const int64_t slab_rows = (int64_t)1 << slab_shift;
+  const int64_t n_slabs = std::max<int64_t>(1, (src_rows + slab_rows - 1) / slab_rows);
+  at::Tensor key = (pos_t.index_select(0, gid_e) * n_slabs + at::div(src_index, slab_rows, "floor").clamp_(0, n_slabs - 1)) * R + dl_e;
+  gid_e = at::Tensor();
+  at::Tensor perm = std::get<1>(at::sort(key, /*stable=*/true, 0, false));
+  key = at::Tensor();
+  at::Tensor e_src = src_index.index_select(0, perm).to(at::kInt);
+  at::Tensor e_dl = dl_e.index_select(0, perm).to(at::kByte);
+  at::Tensor e_perm = perm.to(at::kInt);
+  perm = dl_e = at::Tensor();
+  // outputs of the virtual rows: the dst row, or a carry slot for the pieces of a split row
+  at::Tensor split_v = nv_row.index_select(0, v_row).gt(1);
+  at::Tensor carry_slot = at::cumsum(split_v.to(at::kLong), 0) - 1;
+  at::Tensor v_out = at::where(split_v, -(carry_slot + 1), v_row).contiguous();
+  at::Tensor split_rows = at::nonzero(nv_row.gt(1)).flatten().contiguous();
+  at::Tensor c_count = nv_row.index_select(0, split_rows).to(at::kInt).contiguous();
+  at::Tensor c_first = split_rows.numel() ? carry_slot.index_select(0, vstart.index_select(0, split_rows)).contiguous() : split_rows;
+  const int64_t n_carry = V > 0 ? split_v.sum().item<int64_t>() : 0;
+  auto nonempty_t = [&](at::Tensor t) { return t.numel() ? t : at::zeros({1}, t.options()); };
+  at::Tensor g_begin_t = to_dev(g_begin, at::kLong), g_v0_t = to_dev(g_v0_sorted, at::kInt), g_nv_t = to_dev(g_nv_sorted, at::kInt);
+  H->keep = {nonempty_t(e_src), nonempty_t(e_dl), nonempty_t(e_perm), g_begin_t, g_v0_t, g_nv_t, nonempty_t(v_out),
+             nonempty_t(split_rows), nonempty_t(c_first), nonempty_t(c_count)};
+  geot_slab_plan &P = H->plan;
+  P.e_src = H->keep[0].data_ptr<int32_t>();
+  P.e_dl = H->keep[1].data_ptr<uint8_t>();
+  P.e_perm = H->keep[2].data_ptr<int32_t>();
+  P.g_begin = H->keep[3].data_ptr<int64_t>();
+  P.g_vrow0 = H->keep[4].data_ptr<int32_t>();
+  P.g_nv = H->keep[5].data_ptr<int32_t>();
+  P.v_out = H->keep[6].data_ptr<int64_t>();
+  P.c_row = H->keep[7].data_ptr<int64_t>();
+  P.c_first = H->keep[8].data_ptr<int64_t>();
+  P.c_count = H->keep[9].data_ptr<int32_t>();
+  P.n_groups = G;
+  P.n_vrows = V;
+  P.n_carry = n_carry;
+  P.n_split = split_rows.numel();
+  P.nnz = nnz;
+  P.units = (int32_t)units;
+  P.rows_per_group = (int32_t)R;
+  P.slab_shift = (int32_t)slab_shift;
+  P.n_slabs = (int32_t)std::min<int64_t>(n_slabs, INT32_MAX);
+  H->rounds = (G + units - 1) / units;
+  H->budget = budget;
+  H->cap = cap;
+  H->slabs = n_slabs;
+  H->slab_rows = slab_rows;
+  return H;
+}
+
+constexpr int64_t kSlabBytes = 2 << 20; // measured (profiles/r02/bench_slab.txt)
+
+struct SlabEntry {
+  ContentKey k1, k2;
+  int64_t rows, src_rows, rowbytes, heads;
+  int wmode;
+  c10::weak_intrusive_ptr<c10::StorageImpl> w1, w2;
+  at::Tensor si, di; // keep the key tensors alive: their addresses cannot be recycled while the entry lives
+  std::shared_ptr<SlabPlanHolder> plan;
+};
+std::list<SlabEntry> g_slab;
+std::list<std::pair<ContentKey, ContentKey>> g_sightings; // edge lists seen once (no tensors held)
+
+std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Tensor &di, int64_t rows, const at::Tensor &src,
+                                              int wmode, int64_t heads) {
+  if (g_opt.slab_mode < 0 || src.scalar_type() != at::kFloat || rows < 1) return nullptr;
+  const int64_t rowbytes = (src.numel() / std::max<int64_t>(src.size(0), 1)) * 4, nnz = di.numel();
+  if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024) || nnz == 0 || nnz >= ((int64_t)1 << 31)) return nullptr;
+  if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes)) return nullptr;
+  ContentKey k1, k2;
+  if (!content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_slab.begin(); it != g_slab.end(); ++it)
+      if (it->k1 == k1 && it->k2 == k2 && it->rows == rows && it->src_rows == src.size(0) && it->rowbytes == rowbytes &&
+          it->wmode == wmode && it->heads == heads && !it->w1.expired() && !it->w2.expired()) {
+        g_slab.splice(g_slab.begin(), g_slab, it);
+        return g_slab.front().plan;
+      }
+    if (g_opt.slab_mode != 1) { // first sighting of this edge list: only remember it - a one-shot call never pays for Phase A
+      bool seen = false;
+      for (auto &sg : g_sightings) seen |= (sg.first == k1 && sg.second == k2);
+      if (!seen) {
+        g_sightings.emplace_back(k1, k2);
+        if (g_sightings.size() > 64) g_sightings.pop_front();
+        return nullptr;
+      }
+    }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  auto plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, kSlabBytes, 0, 0);
+  const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  std::lock_guard<std::mutex> lk(g_mu);
+  ++g_stats.plans_built;
+  g_stats.plan_us += us;
+  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, si.storage().getWeakStorageImpl(),
+                              di.storage().getWeakStorageImpl(), si, di, plan});
+  while ((int)g_slab.size() > g_opt.slab_keep) g_slab.pop_back();
+  return plan;
+}
+
+void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat) {
+  auto &ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
+  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), GEOT_F32,
+                           ws.data_ptr(), ws.numel(), stream_of(src)));
+  std::lock_guard<std::mutex> lk(g_mu);
+  ++g_stats.slab_calls;
+}
+
+// ---- index_scatter -------------------------------------------------------------------------------------------------------------
+at::Tensor index_scatter_op(const int64_t dim, const at::Tensor &index_in, const at::Tensor &src, const c10::string_view reduce,
+                            const bool sorted) {
+  // checks of index_scatter_cuda (csrc/cuda/index_scatter_cuda.cu:90-94), same texts
+  TORCH_CHECK(dim >= 0 && dim < src.dim(), "dim must be non-negative and less than input dimensions");
+  TORCH_CHECK(index_in.dim() == 1, "index must be 1 dimensional");
+  TORCH_CHECK(src.size(dim) == index_in.size(0), "index length must be equal to src dimension size");
+  const int red = reduce_code(reduce);
+  TORCH_CHECK_INDEX(index_in.numel() > 0, "index -1 is out of bounds for dimension 0 with size 0"); // index[-1] of the reference
+  require_gpu("index_scatter", {&index_in, &src});
+  const int dt = dtype_code(src, sorted ? "index_scatter_sorted" : "index_scatter_unsorted");
+  GEOT_DEVICE_GUARD(src);
+  at::Tensor moved = (dim == 0 ? src : src.movedim(dim, 0)).contiguous();
+  at::Tensor index = index_in.contiguous();
+  index_ptr(index);
+  const int64_t nnz = index.numel(), feat = moved.numel() / nnz;
+  const FactsView f = index_facts(index); // `sorted` is a promise the reference never checks; neither flag is trusted
+  auto shape = moved.sizes().vec();
+  at::Tensor out;
+  if (f.ascending) {
+    out = with_row_rule(index, f.rows, !f.cached, [&](int64_t rows) {
+      shape[0] = rows;
+      at::Tensor o = at::empty(shape, moved.options());
+      auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, rows, dt));
+      if (red == GEOT_REDUCE_SUM)
+        GEOT_CALL(geot_index_scatter(index_ptr(index), moved.data_ptr(), o.data_ptr(), nnz, feat, rows, dt, 1, ws.data_ptr(), ws.numel(), stream_of(src)));
+      else
+        GEOT_CALL(geot_index_scatter_reduce(index_ptr(index), moved.data_ptr(), o.data_ptr(), nnz, feat, rows, dt, red, ws.data_ptr(), ws.numel(), stream_of(src)));
+      return o;
+    });
+  } else {
+    shape[0] = f.rows;
+    out = at::empty(shape, moved.options());
+    auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, f.rows, dt));
+    if (g_opt.unsorted_mode == 2 && red == GEOT_REDUCE_SUM && (dt == GEOT_F32 || dt == GEOT_F64)) {
+      // pre-reduced runs + float atomics into a zeroed dst (what the reference does for every flush)
+      GEOT_CALL(geot_index_scatter(index_ptr(index), moved.data_ptr(), out.data_ptr(), nnz, feat, f.rows, dt, 0, ws.data_ptr(), ws.numel(), stream_of(src)));
+    } else {
+      // reduce over (sorted keys, permutation) with the gather-mode kernels: deterministic, any reduction and dtype;
+      // rows stay index[-1]+1 (the reference's rule even for an unsorted index), keys beyond are ignored
+      auto kp = sorted_form(index);
+      GEOT_CALL(geot_gather_reduce(index_ptr(kp.second), index_ptr(kp.first), nullptr, moved.data_ptr(), out.data_ptr(), nnz, feat, nnz, f.rows,
+                                   dt, red, ws.data_ptr(), ws.numel(), stream_of(src)));
+    }
+  }
+  return dim == 0 ? out : out.movedim(0, dim);
+}
+
+// ---- gather ops -------------------------------------------------------------------------------------------------------------------
+void check_gather(const at::Tensor &si, const at::Tensor &di, const at::Tensor &src, int64_t ndim) {
+  TORCH_CHECK(si.dim() == 1 && di.dim() == 1, "src_index and dst_index must be 1 dimensional");
+  TORCH_CHECK(src.dim() == ndim, "src must be ", ndim, " dimensional");
+  TORCH_CHECK(si.size(0) == di.size(0), "src_index and dst_index must have the same length");
+}
+
+struct Edges {
+  at::Tensor si, di, w;
+  int64_t rows;       // index[-1] + 1 as remembered / probed
+  bool fresh;         // rows was read in this very call
+  bool permuted;      // di had descents: (si, di, w) are the stable sort by destination
+};
+
+// edges in ascending dst order: as given when dst_index is ascending (the reference's unchecked precondition, checked
+// once per content here), else their stable sort by destination
+Edges dst_ordered(const at::Tensor &si_in, const at::Tensor &di_in, const c10::optional<at::Tensor> &w_in, int64_t w_edge_dim) {
+  Edges e;
+  e.si = si_in.contiguous();
+  e.di = di_in.contiguous();
+  index_ptr(e.si);
+  index_ptr(e.di);
+  if (w_in.has_value() && w_in->defined()) e.w = w_in->contiguous();
+  TORCH_CHECK_INDEX(e.di.numel() > 0, "index -1 is out of bounds for dimension 0 with size 0");
+  const FactsView f = index_facts(e.di);
+  e.rows = f.rows;
+  e.fresh = !f.cached;
+  e.permuted = !f.ascending;
+  if (e.permuted) {
+    auto kp = sorted_form(e.di);
+    e.si = e.si.index_select(0, kp.second);
+    if (e.w.defined()) e.w = e.w.index_select(w_edge_dim, kp.second).contiguous();
+    e.di = kp.first;
+  }
+  return e;
+}
+
+// reduce: GEOT_REDUCE_*; weight optional; rows < 0 -> the row rule
+at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor &di, const c10::optional<at::Tensor> &weight,
+                         const at::Tensor &src, int red, int64_t rows_given) {
+  check_gather(si, di, src, 2);
+  const bool has_w = weight.has_value() && weight->defined();
+  if (has_w) TORCH_CHECK(weight->dim() == 1 && weight->size(0) == di.size(0), "weight must be 1 dimensional with one value per edge");
+  require_gpu(op, {&si, &di, &src, has_w ? &*weight : nullptr});
+  const int dt = dtype_code(src, has_w ? "gather_weight_scatter_sorted" : "gather_scatter_sorted");
+  if (has_w) TORCH_CHECK(weight->scalar_type() == src.scalar_type(), "expected weight of dtype ", toString(src.scalar_type()), " but found ",
+                         toString(weight->scalar_type()));
+  GEOT_DEVICE_GUARD(src);
+  at::Tensor x = src.contiguous();
+  Edges e = dst_ordered(si, di, weight, 0);
+  const int64_t nnz = e.di.numel(), feat = x.size(1);
+  auto launch = [&](int64_t rows) {
+    at::Tensor o = at::empty({rows, feat}, x.options());
+    if (red == GEOT_REDUCE_SUM && !e.permuted) {
+      if (auto plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1)) {
+        run_slab(*plan, has_w ? e.w.data_ptr() : nullptr, has_w ? 1 : 0, x, o, 1, feat);
+        return o;
+      }
+    }
+    auto &ws = workspace(x, geot_workspace_bytes(nnz, feat, rows, dt));
+    if (red == GEOT_REDUCE_SUM && has_w)
+      GEOT_CALL(geot_gather_weight_scatter(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows,
+                                           dt, ws.data_ptr(), ws.numel(), stream_of(x)));
+    else if (red == GEOT_REDUCE_SUM)
+      GEOT_CALL(geot_gather_scatter(index_ptr(e.si), index_ptr(e.di), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows, dt, ws.data_ptr(),
+                                    ws.numel(), stream_of(x)));
+    else
+      GEOT_CALL(geot_gather_reduce(index_ptr(e.si), index_ptr(e.di), has_w ? e.w.data_ptr() : nullptr, x.data_ptr(), o.data_ptr(), nnz, feat,
+                                   x.size(0), rows, dt, red, ws.data_ptr(), ws.numel(), stream_of(x)));
+    return o;
+  };
+  if (rows_given >= 0) return launch(rows_given);
+  if (e.permuted) return launch(e.rows);
+  return with_row_rule(e.di, e.rows, e.fresh, launch);
+}
+
+at::Tensor gather_scatter_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &src) {
+  return gather_common("gather_scatter", si, di, c10::nullopt, src, GEOT_REDUCE_SUM, -1);
+}
+at::Tensor gather_weight_scatter_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight, const at::Tensor &src) {
+  return gather_common("gather_weight_scatter", si, di, weight, src, GEOT_REDUCE_SUM, -1);
+}
+at::Tensor gather_scatter_rows_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &src, int64_t rows) {
+  TORCH_CHECK(rows >= 0, "rows must be non-negative");
+  return gather_common("gather_scatter_rows", si, di, c10::nullopt, src, GEOT_REDUCE_SUM, rows);
+}
+at::Tensor gather_weight_scatter_rows_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight, const at::Tensor &src,
+                                         int64_t rows) {
+  TORCH_CHECK(rows >= 0, "rows must be non-negative");
+  return gather_common("gather_weight_scatter_rows", si, di, weight, src, GEOT_REDUCE_SUM, rows);
+}
+// PyG call sites forward their `aggr` as the trailing reduce of the gather ops (models/conv/spmm.py:5-14)
+at::Tensor gather_reduce_op(const at::Tensor &si, const at::Tensor &di, const c10::optional<at::Tensor> &weight, const at::Tensor &src,
+                            const c10::string_view reduce) {
+  return gather_common("gather_reduce", si, di, weight, src, reduce_code(reduce, /*pyg_add=*/true), -1);
+}
+
+at::Tensor mh_spmm_common(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight, const at::Tensor &src, int64_t rows_given,
+                          bool edge_major_only) {
+  check_gather(si, di, src, 3);
+  const int64_t nnz = si.size(0);
+  // layout pick of csrc/cuda/wrapper/mh_spmm_base.h:38-49 ([nnz, H] first, then [H, nnz])
+  int layout;
+  if (weight.dim() == 2 && weight.size(0) == nnz && weight.size(1) == src.size(1)) layout = GEOT_W_EDGE_MAJOR;
+  else if (!edge_major_only && weight.dim() == 2 && weight.size(1) == nnz && weight.size(0) == src.size(1)) layout = GEOT_W_HEAD_MAJOR;
+  else TORCH_CHECK(false, "Invalid weight size"); // csrc/cuda/wrapper/mh_spmm_base.h:49
+  require_gpu("mh_spmm", {&si, &di, &weight, &src});
+  const int dt = dtype_code(src, "mh_spmm_sorted");
+  TORCH_CHECK(weight.scalar_type() == src.scalar_type(), "expected weight of dtype ", toString(src.scalar_type()), " but found ",
+              toString(weight.scalar_type()));
+  GEOT_DEVICE_GUARD(src);
+  at::Tensor x = src.contiguous();
+  Edges e = dst_ordered(si, di, weight, layout == GEOT_W_HEAD_MAJOR ? 1 : 0);
+  const int64_t heads = x.size(1), feat = x.size(2);
+  auto launch = [&](int64_t rows) {
+    at::Tensor o = at::empty({rows, heads, feat}, x.options());
+    if (!e.permuted && feat % 4 == 0 && heads <= 16) {
+      const int wmode = layout == GEOT_W_HEAD_MAJOR ? 3 : 2;
+      if (auto plan = slab_plan_for(e.si, e.di, rows, x, wmode, heads)) {
+        run_slab(*plan, e.w.data_ptr(), wmode, x, o, heads, feat);
+        return o;
+      }
+    }
+    auto &ws = workspace(x, geot_mh_workspace_bytes(nnz, heads, feat, rows, dt));
+    GEOT_CALL(geot_mh_spmm(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, heads, feat, x.size(0), rows, layout,
+                           dt, ws.data_ptr(), ws.numel(), stream_of(x)));
+    return o;
+  };
+  if (rows_given >= 0) return launch(rows_given);
+  if (e.permuted) return launch(e.rows);
+  return with_row_rule(e.di, e.rows, e.fresh, launch);
+}
+
+at::Tensor mh_spmm_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight, const at::Tensor &src, const c10::string_view reduce) {
+  check_gather(si, di, src, 3);
+  TORCH_CHECK_NOT_IMPLEMENTED(reduce_code(reduce) == GEOT_REDUCE_SUM, "mh_spmm: reduce='", reduce,
+                              "' is not implemented on the HIP path (only 'sum').  Note the reference's GPU kernels ignore `reduce` and always sum.");
+  return mh_spmm_common(si, di, weight, src, -1, false);
+}
+at::Tensor mh_spmm_rows_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight, const at::Tensor &src, int64_t rows) {
+  TORCH_CHECK(rows >= 0, "rows must be non-negative");
+  return mh_spmm_common(si, di, weight, src, rows, true);
+}
+
+at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const at::Tensor &m1_in, const at::Tensor &m2_in) {
+  TORCH_CHECK(m1_in.dim() == 2 && m2_in.dim() == 2 && m1_in.size(1) == m2_in.size(1),
+              "mat_1 and mat_2 must be 2 dimensional with the same feature dimension");
+  require_gpu("sddmm_coo_impl", {&si_in, &di_in, &m1_in, &m2_in});
+  GEOT_DEVICE_GUARD(m1_in);
+  // the reference's Python wrapper hands over int32 indices (geot/gather_weight_scatter.py:10-11): both widths accepted
+  at::Tensor si = si_in.to(at::kLong).contiguous(), di = di_in.to(at::kLong).contiguous();
+  at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
+  at::Tensor out = at::empty({di.size(0)}, m1.options());
+  GEOT_CALL(geot_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), out.data_ptr(), di.size(0), m1.size(1), m1.size(0),
+                           m2.size(0), dtype_code(m1, "sddmm_coo"), stream_of(m1)));
+  return out;
+}
+
+// csrc/csr_gws.cpp:24-35: any integer dtype for indptr / indices; indptr.size(0) output rows (the last one always zero)
+at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in, const at::Tensor &weight_in, const at::Tensor &src_in) {
+  TORCH_CHECK(indptr_in.dim() == 1 && indices_in.dim() == 1, "indptr and indices must be 1 dimensional");
+  TORCH_CHECK(src_in.dim() == 2, "src must be 2 dimensional");
+  TORCH_CHECK(weight_in.dim() == 1 && weight_in.size(0) == indices_in.size(0), "weight must be 1 dimensional with one value per nonzero");
+  require_gpu("csr_gws_impl", {&indptr_in, &indices_in, &weight_in, &src_in});
+  TORCH_CHECK(weight_in.scalar_type() == src_in.scalar_type(), "expected weight of dtype ", toString(src_in.scalar_type()), " but found ",
+              toString(weight_in.scalar_type()));
+  GEOT_DEVICE_GUARD(src_in);
+  at::Tensor indptr = indptr_in.to(at::kLong).contiguous(), indices = indices_in.to(at::kLong).contiguous();
+  at::Tensor weight = weight_in.contiguous(), src = src_in.contiguous();
+  const int64_t rows = indptr.size(0), nnz = indices.size(0), feat = src.size(1);
+  at::Tensor out = at::empty({rows, feat}, src.options());
+  const int dt = dtype_code(src, "csr_gws");
+  auto &ws = workspace(src, geot_csr_workspace_bytes(nnz, feat, rows, dt));
+  GEOT_CALL(geot_csr_gws(index_ptr(indptr), index_ptr(indices), weight.data_ptr(), src.data_ptr(), out.data_ptr(), rows - 1, nnz, feat, src.size(0),
+                         rows, dt, ws.data_ptr(), ws.numel(), stream_of(src)));
+  return out;
+}
+
+// backward of index_scatter: d/dsrc[e] = grad[index[e]] (the reference ships gather_eb_sorted_kernel,
+// csrc/cuda/index_scatter_kernel.cuh:266-315, but never wires it to an op)
+at::Tensor gather_rows_op(const at::Tensor &index_in, const at::Tensor &src_in) {
+  TORCH_CHECK(index_in.dim() == 1 && src_in.dim() >= 1, "gather_rows: index must be 1 dimensional");
+  require_gpu("gather_rows", {&index_in, &src_in});
+  GEOT_DEVICE_GUARD(src_in);
+  at::Tensor index = index_in.contiguous(), src = src_in.contiguous();
+  auto shape = src.sizes().vec();
+  shape[0] = index.size(0);
+  at::Tensor out = at::empty(shape, src.options());
+  const int64_t feat = src.numel() / std::max<int64_t>(src.size(0), 1);
+  GEOT_CALL(geot_gather_rows(index_ptr(index), src.data_ptr(), out.data_ptr(), index.size(0), feat, src.size(0), dtype_code(src, "gather_rows"),
+                             stream_of(src)));
+  return out;
+}
+
+// The backward of the gather ops needs the edge list sorted by SOURCE (the transposed graph).  The reference re-sorts on
+// every backward call (geot/gather_scatter.py:30-33); graphs are static, so it is kept per edge-list content.  The entry
+// keeps its key tensors alive: a freed edge list's address can never be handed to a new one while the entry lives.
+struct TransposedEntry {
+  ContentKey k1, k2;
+  at::Tensor si, di, perm, si_sorted, di_perm;
+};
+std::list<TransposedEntry> g_transposed;
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tensor &si, const at::Tensor &di) {
+  require_gpu("transpose_edges", {&si, &di});
+  GEOT_DEVICE_GUARD(si);
+  ContentKey k1, k2;
+  const bool keyed = g_opt.transpose_cache > 0 && content_key(si, &k1) && content_key(di, &k2);
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_transposed.begin(); it != g_transposed.end(); ++it)
+      if (it->k1 == k1 && it->k2 == k2) {
+        g_transposed.splice(g_transposed.begin(), g_transposed, it);
+        return {it->perm, it->si_sorted, it->di_perm};
+      }
+  }
+  auto sorted = at::sort(si, /*stable=*/true, 0, false);
+  at::Tensor perm = std::get<1>(sorted), di_perm = di.index_select(0, perm);
+  std::lock_guard<std::mutex> lk(g_mu);
+  ++g_stats.transposes;
+  if (keyed) {
+    g_transposed.push_front(TransposedEntry{k1, k2, si, di, perm, std::get<0>(sorted), di_perm});
+    while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
+  }
+  return {perm, std::get<0>(sorted), di_perm};
+}
+
+// ---- introspection for tests / tools ------------------------------------------------------------------------------------------
+int64_t host_option_op(c10::string_view name, int64_t value) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int *p = nullptr;
+  if (name == "speculate_rows") p = &g_opt.speculate_rows;
+  else if (name == "trust_version") p = &g_opt.trust_version;
+  else if (name == "unsorted_mode") p = &g_opt.unsorted_mode;
+  else if (name == "slab_mode") p = &g_opt.slab_mode;
+  else if (name == "transpose_cache") p = &g_opt.transpose_cache;
+  else if (name == "slab_keep") p = &g_opt.slab_keep;
+  else if (name == "clear_caches") {
+    g_facts.clear();
+    g_transposed.clear();
+    g_slab.clear();
+    g_sightings.clear();
+    return 0;
+  }
+  TORCH_CHECK(p, "unknown host option ", name);
+  const int old = *p;
+  if (value != INT64_MIN) *p = (int)value;
+  if (name == "transpose_cache")
+    while ((int)g_transposed.size() > std::max(g_opt.transpose_cache, 0)) g_transposed.pop_back();
+  return old;
+}
+
+std::vector<int64_t> host_stats_op() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
+          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size()};
+}
+
+// Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).
+// Returns [e_src, e_dl, e_perm, g_begin, g_vrow0, g_nv, v_out, c_row, c_first, c_count, scalars(int64[12])]
+std::vector<at::Tensor> slab_plan_op(const at::Tensor &si, const at::Tensor &di, int64_t rows, int64_t src_rows, int64_t rowbytes,
+                                     int64_t weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group, int64_t units) {
+  TORCH_CHECK(si.dim() == 1 && di.dim() == 1 && si.numel() == di.numel(), "slab_plan: 1-D edge lists of equal length");
+  auto H = slab_build(si.contiguous(), di.contiguous(), rows, src_rows, rowbytes, (int)weight_mode, heads,
+                      slab_bytes > 0 ? slab_bytes : kSlabBytes, rows_per_group, units);
+  std::vector<at::Tensor> out = H->keep;
+  at::Tensor sc = at::empty({13}, at::TensorOptions().dtype(at::kLong));
+  int64_t *s = sc.data_ptr<int64_t>();
+  s[0] = H->plan.n_groups; s[1] = H->plan.n_vrows; s[2] = H->plan.n_carry; s[3] = H->plan.n_split; s[4] = H->plan.nnz;
+  s[5] = H->plan.units; s[6] = H->plan.rows_per_group; s[7] = H->rounds; s[8] = H->budget; s[9] = H->cap; s[10] = H->slabs; s[11] = H->slab_rows; s[12] = H->plan.slab_shift;
+  out.push_back(sc);
+  return out;
+}
+
+bool slab_worthwhile_op(int64_t nnz, int64_t rows, int64_t src_rows, int64_t rowbytes) { return slab_worthwhile(nnz, rows, src_rows, rowbytes); }
+
+} // namespace
+
+// Schema strings: csrc/index_scatter.cpp:43-47, gather_scatter.cpp:16-17, gather_weight_scatter.cpp:12-16, csr_gws.cpp:12-13;
+// mh_spmm is a catch-all def in the reference (csrc/mh_spmm.cpp:23), named here.  geot::gather_scatter /
+// gather_weight_scatter / csr_gws are Python custom ops in the reference (geot/gather_scatter.py:7,
+// gather_weight_scatter.py:15, csr_gws.py:25) with the same schemas; defining them here saves a Python hop per call,
+// their fake and autograd rules are registered from Python exactly where the reference has them.
+TORCH_LIBRARY_FRAGMENT(geot, m) {
+  m.def("index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor");
+  m.def("gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor");
+  m.def("gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor");
+  m.def("sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor");
+  m.def("csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src) -> Tensor");
+  m.def("mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor");
+  m.def("gather_scatter(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor");
+  m.def("gather_weight_scatter(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor");
+  m.def("csr_gws(Tensor csrptr, Tensor csrind, Tensor weight, Tensor src) -> Tensor");
+  m.def("gather_reduce(Tensor src_index, Tensor dst_index, Tensor? weight, Tensor src, str reduce) -> Tensor");
+  m.def("gather_scatter_rows(Tensor src_index, Tensor dst_index, Tensor src, SymInt rows) -> Tensor");
+  m.def("gather_weight_scatter_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");
+  m.def("mh_spmm_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");
+  m.def("gather_rows(Tensor index, Tensor src) -> Tensor");
+  m.def("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)");
+  m.def("_host_option(str name, int value) -> int", host_option_op);
+  m.def("_host_stats() -> int[]", host_stats_op);
+  m.def("_slab_plan(Tensor src_index, Tensor dst_index, int rows, int src_rows, int rowbytes, int weight_mode, int heads, int slab_bytes, "
+        "int rows_per_group, int units) -> Tensor[]", slab_plan_op);
+  m.def("_slab_worthwhile(int nnz, int rows, int src_rows, int rowbytes) -> bool", slab_worthwhile_op);
+}
+
+// One implementation per op for both device keys: the argument checks (reference texts) come first, then CPU tensors are
+// refused - this package is the MI355X path and has no CPU fallback.
+#define GEOT_IMPLS(m)                                                                \
+  m.impl("index_scatter", index_scatter_op);                                         \
+  m.impl("gather_scatter_impl", gather_scatter_op);                                  \
+  m.impl("gather_weight_scatter_impl", gather_weight_scatter_op);                    \
+  m.impl("sddmm_coo_impl", sddmm_coo_op);                                            \
+  m.impl("csr_gws_impl", csr_gws_op);                                                \
+  m.impl("mh_spmm", mh_spmm_op);                                                     \
+  m.impl("gather_scatter", gather_scatter_op);                                       \
+  m.impl("gather_weight_scatter", gather_weight_scatter_op);                         \
+  m.impl("csr_gws", csr_gws_op);                                                     \
+  m.impl("gather_reduce", gather_reduce_op);                                         \
+  m.impl("gather_scatter_rows", gather_scatter_rows_op);                             \
+  m.impl("gather_weight_scatter_rows", gather_weight_scatter_rows_op);               \
+  m.impl("mh_spmm_rows", mh_spmm_rows_op);                                           \
+  m.impl("gather_rows", gather_rows_op);                                             \
+  m.impl("transpose_edges", transpose_edges_op)
+
+TORCH_LIBRARY_IMPL(geot, CUDA, m) { GEOT_IMPLS(m); }
+TORCH_LIBRARY_IMPL(geot, CPU, m) { GEOT_IMPLS(m); }

@@ -1,56 +1,57 @@
-"""The geot.* operator surface on top of the HIP library -- same names, argument order, shape rule
-and error texts as the reference, so PyG / torch_scatter style call sites are drop-in.
+"""The geot.* operator surface -- same names, argument order, shape rule and error texts as the reference, so
+PyG / torch_scatter style call sites are drop-in.
 
-What this file mirrors (paths relative to the reference tree):
+Layering, as in the reference (paths relative to its tree):
 
-* Python wrappers      geot/index_scatter.py:5-8, geot/gather_scatter.py:3-39,
-                       geot/gather_weight_scatter.py:4-51, geot/mh_spmm.py:4-12
-* dispatcher shims     csrc/index_scatter.cpp:11-56, csrc/gather_scatter.cpp:13-34,
-                       csrc/gather_weight_scatter.cpp:11-49, csrc/mh_spmm.cpp:10-23
-* argument checks      csrc/cuda/index_scatter_cuda.cu:86-105, gather_scatter_cuda.cu:15-28,
-                       gather_weight_scatter_cuda.cu:22-39, mh_spmm_cuda.cu:20-38,
-                       csrc/reduceutils.h:5-22, csrc/cuda/wrapper/mh_spmm_base.h:38-49
+* dispatcher ops + host logic    geot_amd/csrc/torch_ops.cpp -> geot_amd/_C.so, loaded here with
+                                 torch.ops.load_library like geot/__init__.py:12-19 loads the reference's `_C`
+                                 (csrc/index_scatter.cpp:11-56, csrc/gather_scatter.cpp:13-34,
+                                 csrc/gather_weight_scatter.cpp:11-49, csrc/mh_spmm.cpp:10-23, csrc/csr_gws.cpp:11-60);
+* this file                      what the reference keeps in Python: the public functions (geot/index_scatter.py:5-8,
+                                 geot/gather_scatter.py:3-39, geot/gather_weight_scatter.py:4-51, geot/mh_spmm.py:4-12,
+                                 geot/csr_gws.py:3-37), the fake-tensor rules and the autograd formulas.
 
-Ops registered in the torch dispatcher namespace ``geot`` (device key CUDA -- which is what a
-ROCm build of PyTorch calls the GPU):
+Ops in the dispatcher namespace ``geot`` (device key CUDA -- which is what a ROCm build of PyTorch calls the GPU):
     geot::index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor
     geot::gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor
     geot::gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor
     geot::sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor
     geot::mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor
-plus the Python-defined custom ops geot::gather_scatter / geot::gather_weight_scatter with
-register_fake and register_autograd exactly where the reference has them.
+    geot::csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src) -> Tensor
+    geot::gather_scatter / geot::gather_weight_scatter / geot::csr_gws      (the differentiable ops)
 
 Deliberate differences (all documented in DESIGN.md):
-* the output row count still comes from ``index[-1] + 1``, read back from the device and checked on
-  every call (part of the reference contract), but the read-back overlaps the kernels (see
-  ``_with_row_rule``) and the output is ``torch.empty``: the sorted kernels write every row exactly
-  once, so the reference's ``torch::zeros`` pass is not needed;
-* ``reduce``: index_scatter implements sum / mean / min(amin) / max(amax) / prod with the semantics of
-  the reference's CPU path (csrc/cpu/index_scatter_cpu.cpp:124-134); the reference's GPU kernels
-  parse the argument but always add (csrc/cuda/index_scatter_cuda.cu:68-72).  The gather ops only
-  have 'sum' (as in the reference) and raise for anything else;
-* ``dim != 0`` is honoured (the reference validates ``dim`` but always reduces along dim 0,
-  csrc/cuda/index_scatter_cuda.cu:9-11);
+* the output row count still comes from ``index[-1] + 1``, read back from the device and checked on every call
+  (part of the reference contract), but the read-back overlaps the kernels and the output is ``torch.empty``: the
+  sorted kernels write every row exactly once, so the reference's ``torch::zeros`` pass is not needed;
+* ``sorted`` is a promise the reference never checks (its "sorted" kernels flush with atomics and survive a wrong
+  one): here every index is probed once per content and an index with descents is reduced over its stable sort -
+  deterministic, every reduction and dtype; the gather ops accept an unsorted ``dst_index`` the same way;
+* ``reduce``: sum / mean / min(amin) / max(amax) / prod with the semantics of the reference's CPU path
+  (csrc/cpu/index_scatter_cpu.cpp:124-134); the reference's GPU kernels parse the argument but always add;
+* ``dim != 0`` is honoured (the reference validates ``dim`` but always reduces along dim 0);
 * CPU tensors raise: this package is the MI355X path and has no CPU fallback.
 """
 from __future__ import annotations
 
-import collections
 import os
-import threading
 from typing import Optional
 
 import torch
 
-from . import hip
+from . import _lib, hip
+
+if not os.path.exists(_lib.PLUGIN_PATH):
+    raise ImportError(f"Could not find module '_C' in {os.path.dirname(_lib.PLUGIN_PATH)}: build it with `make shim` (or "
+                      "`python -c 'import __graft_entry__ as g; g.build()'`).  geot_amd has no fallback path.")
+torch.ops.load_library(_lib.PLUGIN_PATH)
 
 _REDUCE_ENUM = {"max": "max", "amax": "max", "mean": "mean", "min": "min", "amin": "min",
                 "sum": "sum", "prod": "prod"}
 
 
 def get_reduction_enum(reduce: str) -> str:
-    """csrc/reduceutils.h:5-22 -- same accepted spellings, same error text."""
+    """csrc/reduceutils.h:5-22 -- same accepted spellings, same error text (the C++ host layer has the same table)."""
     if reduce in _REDUCE_ENUM:
         return _REDUCE_ENUM[reduce]
     raise RuntimeError(
@@ -63,415 +64,39 @@ def _aggr_kind(reduce: str) -> str:
     return "sum" if reduce == "add" else get_reduction_enum(reduce)
 
 
-def _only_sum(reduce: str, op: str) -> None:
-    kind = get_reduction_enum(reduce)
-    if kind != "sum":
-        raise NotImplementedError(
-            f"{op}: reduce='{reduce}' is not implemented on the HIP path (only 'sum'). "
-            "Note the reference's GPU kernels ignore `reduce` and always sum.")
+# ---- host-layer switches and counters (geot_amd/csrc/torch_ops.cpp) -----------------------------------------------
+_KEEP = -(2 ** 63)
+_UNSORTED = {"auto": 0, "sort": 1, "atomic": 2}
+_SLAB = {"never": -1, "auto": 0, "always": 1}
 
 
-def _last_index_plus_one(index: torch.Tensor) -> int:
-    # csrc/index_scatter.cpp:30 -- index[-1].item<int64_t>(): a device->host copy + stream sync
-    return int(index[-1].item()) + 1
+def set_option(name: str, value) -> int:
+    """speculate_rows (0|1), trust_version (0|1), unsorted_mode ('auto'|'sort'|'atomic'), slab_mode
+    ('never'|'auto'|'always'), transpose_cache (entries), slab_keep (plans).  Returns the previous value."""
+    if name == "unsorted_mode" and isinstance(value, str):
+        value = _UNSORTED[value]
+    if name == "slab_mode" and isinstance(value, str):
+        value = _SLAB[value]
+    return int(torch.ops.geot._host_option(name, int(value)))
 
 
-# ---- the row rule without stalling the GPU ---------------------------------------------------------
-# The reference reads index[-1] back to the host BEFORE it can allocate the output, so the GPU idles
-# for a D2H round trip + the host's launch path on every call.  GNN graphs are static across layers
-# and epochs, so the row count of a given index tensor almost never changes.  We therefore keep the
-# last row count seen for (data_ptr, numel, version) of the index tensor and
-#   1. enqueue the D2H copy of index[-1] (async, pinned buffer) on the current stream,
-#   2. allocate the output for the REMEMBERED row count and enqueue the kernels,
-#   3. wait for the copy (it completes while the kernels run) and VERIFY the row count;
-#      on a mismatch the output is dropped and the op re-runs with the right size.
-# Nothing is skipped: the read-back, the check, the allocation and the kernels all happen on every
-# call and the result is always sized by index[-1]+1; only their order lets them overlap.
-# GEOT_SPECULATE_ROWS=0 restores the strictly sequential order of the reference.
-_SPECULATE = os.environ.get("GEOT_SPECULATE_ROWS", "1") != "0"
-_rows_seen: "collections.OrderedDict[tuple, int]" = collections.OrderedDict()
-_ROWS_SEEN_MAX = 64
-_tls = threading.local()
+def get_option(name: str) -> int:
+    return int(torch.ops.geot._host_option(name, _KEEP))
 
 
-def _rows_key(index: torch.Tensor):
-    try:
-        version = index._version
-    except RuntimeError:      # inference tensors keep no version counter: do not speculate on them
-        return None
-    return (index.device.index, index.data_ptr(), index.numel(), version)
+def clear_caches() -> None:
+    """Drop the remembered index facts, transposed edge lists and slab plans."""
+    torch.ops.geot._host_option("clear_caches", 0)
 
 
-def _remember_rows(key, rows: int) -> None:
-    _rows_seen[key] = rows
-    _rows_seen.move_to_end(key)
-    while len(_rows_seen) > _ROWS_SEEN_MAX:
-        _rows_seen.popitem(last=False)
-
-
-def _begin_row_readback(index: torch.Tensor):
-    slots = getattr(_tls, "slots", None)
-    if slots is None:
-        slots = _tls.slots = {}
-    dev = index.device.index if index.device.index is not None else torch.cuda.current_device()
-    slot = slots.get(dev)              # one (pinned word, event) per DEVICE: an event is bound to the device
-    if slot is None:                   # of its first record
-        slot = slots[dev] = (torch.empty(1, dtype=torch.int64).pin_memory(), torch.cuda.Event())
-    host, event = slot
-    host.copy_(index[-1:], non_blocking=True)
-    event.record(torch.cuda.current_stream(index.device))
-    return slot
-
-
-def _end_row_readback(slot) -> int:
-    host, event = slot
-    event.synchronize()
-    return int(host[0]) + 1
-
-
-_SPECULATE_MIN_EDGES = 200_000   # below this the kernels are shorter than the bookkeeping that hides the read-back
-
-
-def _with_row_rule(index: torch.Tensor, launch):
-    """Run ``launch(rows) -> Tensor`` under the reference's row rule rows = index[-1] + 1."""
-    if index.numel() == 0:
-        return launch(_last_index_plus_one(index))          # raises IndexError like the reference
-    if index.numel() < _SPECULATE_MIN_EDGES:
-        return launch(_last_index_plus_one(index))          # small problem: the plain blocking read is cheaper
-    key = _rows_key(index)
-    guess = _rows_seen.get(key) if (_SPECULATE and key is not None) else None
-    if guess is None:
-        rows = _last_index_plus_one(index)
-        if key is not None:
-            _remember_rows(key, rows)
-        return launch(rows)
-    slot = _begin_row_readback(index)
-    out = launch(guess)
-    rows = _end_row_readback(slot)
-    if rows != guess:                                        # the index changed under the same identity
-        _remember_rows(key, rows)
-        out = launch(rows)
-    return out
-
-
-# ---- what is known about an index tensor: ascending or not (+ its sorted form) ---------------------------
-# The atomic-free kernels need an ascending index.  The reference's "sorted" kernels flush every run with
-# atomicAdd (csrc/cuda/index_scatter_kernel.cuh:180,197), so they still add up correctly when a caller's
-# `sorted=True` promise is wrong; here a wrong promise must not return wrong rows either.  Every index tensor
-# is therefore PROBED ONCE (geot_index_probe: one pass, 8 B per edge, together with the row-rule read-back)
-# and the answer is remembered for that exact content: (storage identity, offset, length, version counter),
-# with a weak reference to the storage so that a recycled address can never alias a dead tensor.  This is the
-# trust autograd itself places in the version counter (saved-tensor checks); edits made behind it through
-# `.data` are not seen.  GEOT_TRUST_VERSION=0 probes on every call instead.
-#   ascending           -> atomic-free kernels (whatever `sorted` said: the reference's own test and benchmark
-#                          pass sorted=False with a sorted index, test/test_index_scatter.py:11-14)
-#   descents, any op    -> the index is sorted once (stable; kept with the facts) and the gather-mode kernels
-#                          run on (sorted keys, permutation): deterministic, any reduction, any dtype;
-#                          fp32/fp64 sums may instead take the atomic flush where that measured faster
-#                          (GEOT_UNSORTED=atomic|sort forces one).
-_TRUST_VERSION = os.environ.get("GEOT_TRUST_VERSION", "1") != "0"
-_UNSORTED_MODE = os.environ.get("GEOT_UNSORTED", "auto")
-_FACTS_MAX = 16
-_SORTED_KEEP = 4                       # facts that may hold a sorted copy (2 x int64[nnz] each)
-
-
-class _IndexFacts:
-    __slots__ = ("weak", "rows", "ascending", "keys", "perm")
-
-    def __init__(self, weak, rows, ascending):
-        self.weak, self.rows, self.ascending, self.keys, self.perm = weak, rows, ascending, None, None
-
-
-_facts: "collections.OrderedDict[tuple, _IndexFacts]" = collections.OrderedDict()
-
-
-def _content_key(index: torch.Tensor):
-    try:
-        version = index._version
-    except RuntimeError:               # inference tensors keep no version counter: never remembered
-        return None
-    return (index.untyped_storage()._cdata, index.storage_offset(), index.numel(), version)
-
-
-def _index_facts(index: torch.Tensor) -> _IndexFacts:
-    """Facts about a contiguous 1-D int64 device index; probes (one blocking 16-byte read) on first sight."""
-    key = _content_key(index) if _TRUST_VERSION else None
-    if key is not None:
-        f = _facts.get(key)
-        if f is not None and not f.weak.expired():
-            _facts.move_to_end(key)
-            return f
-    if index.numel() == 0:
-        _last_index_plus_one(index)    # raises IndexError like the reference's index[-1]
-    hip._require_gpu(index)
-    last, descents = hip.index_probe_out(index, torch.empty(2, dtype=torch.int64, device=index.device)).tolist()
-    from torch.multiprocessing.reductions import StorageWeakRef
-    f = _IndexFacts(StorageWeakRef(index.untyped_storage()) if key is not None else None, last + 1, descents == 0)
-    if key is not None:
-        _facts[key] = f
-        while len(_facts) > _FACTS_MAX:
-            _facts.popitem(last=False)
-    return f
-
-
-def _sorted_form(index: torch.Tensor, facts: _IndexFacts):
-    """(keys ascending, perm) of an index with descents; kept with its facts (a few entries at most)."""
-    if facts.keys is None:
-        keys, perm = torch.sort(index, stable=True)
-        if facts.weak is None:
-            return keys, perm
-        facts.keys, facts.perm = keys, perm
-        holders = [f for f in _facts.values() if f.keys is not None]
-        for old in holders[:-_SORTED_KEEP]:
-            old.keys = old.perm = None
-    return facts.keys, facts.perm
-
-
-def _sort_pays(feat: int, dtype: torch.dtype, kind: str) -> bool:
-    """Unsorted fp32/fp64 sum: sorted-gather path or atomic flush?  (rule measured on MI355X)"""
-    if _UNSORTED_MODE in ("sort", "atomic"):
-        return _UNSORTED_MODE == "sort"
-    return True
-
-
-def _reject_cpu(name: str):
-    def impl(*args, **kwargs):
-        raise RuntimeError(
-            f"geot::{name}: CPU tensors are not supported by geot_amd (MI355X-only package, no CPU "
-            "fallback).  Move the tensors to the GPU.")
-    return impl
+def stats() -> dict:
+    names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans")
+    return dict(zip(names, torch.ops.geot._host_stats()))
 
 
 # --------------------------------------------------------------------------------------------------
-# dispatcher-level implementations (the reference's *_cuda_impl functions)
+# fake-tensor rules (geot/gather_scatter.py:12-18 etc.: [dynamic rows, F])
 # --------------------------------------------------------------------------------------------------
-def _index_scatter_gpu(dim: int, index: torch.Tensor, src: torch.Tensor, reduce: str,
-                       sorted: bool) -> torch.Tensor:
-    # checks of index_scatter_cuda (csrc/cuda/index_scatter_cuda.cu:90-94), same texts
-    if not (0 <= dim < src.dim()):
-        raise RuntimeError("dim must be non-negative and less than input dimensions")
-    if index.dim() != 1:
-        raise RuntimeError("index must be 1 dimensional")
-    if src.size(dim) != index.size(0):
-        raise RuntimeError("index length must be equal to src dimension size")
-    kind = get_reduction_enum(reduce)
-    moved = src if dim == 0 else src.movedim(dim, 0)
-    moved = moved.contiguous()
-    index = index.contiguous()
-    hip._dtype_code(moved, "index_scatter_sorted" if sorted else "index_scatter_unsorted")
-    facts = _index_facts(index)          # `sorted` is a promise the reference never checks; neither flag is trusted
-    tail = list(moved.shape[1:])
-
-    if facts.ascending:
-        def launch(rows: int) -> torch.Tensor:
-            out = torch.empty([rows] + tail, dtype=src.dtype, device=src.device)
-            return hip.index_scatter_out(index, moved, out, sorted=True, reduce=kind)
-        out = _with_row_rule(index, launch)
-    elif (kind == "sum" and src.dtype in (torch.float32, torch.float64)
-          and not _sort_pays(moved[0].numel() if moved.shape[0] else 1, src.dtype, kind)):
-        out = torch.empty([facts.rows] + tail, dtype=src.dtype, device=src.device)
-        hip.index_scatter_out(index, moved, out, sorted=False)         # pre-reduced runs + float atomics
-    else:
-        # descents: reduce over (sorted keys, permutation) with the gather-mode kernels - src[perm[e]] is read in
-        # key order; deterministic, every reduction and dtype.  Rows stay index[-1]+1 (the reference's rule even
-        # for an unsorted index, csrc/index_scatter.cpp:30); keys beyond are ignored by the kernels.
-        keys, perm = _sorted_form(index, facts)
-        flat = moved.reshape(moved.shape[0], -1)
-        out = torch.empty([facts.rows] + tail, dtype=src.dtype, device=src.device)
-        hip.gather_reduce_out(perm, keys, None, flat, out.view(facts.rows, -1), kind)
-    return out if dim == 0 else out.movedim(0, dim)
-
-
-def _check_gather(src_index, dst_index, src, ndim: int) -> None:
-    if not (src_index.dim() == dst_index.dim() == 1):
-        raise RuntimeError("src_index and dst_index must be 1 dimensional")
-    if src.dim() != ndim:
-        raise RuntimeError(f"src must be {ndim} dimensional")
-    if src_index.size(0) != dst_index.size(0):
-        raise RuntimeError("src_index and dst_index must have the same length")
-
-
-def _dst_ordered(src_index, dst_index, weight=None, weight_edge_dim: int = 0):
-    """Edges in ascending dst order: the tensors as given when dst_index is ascending (the precondition of the
-    reference, unchecked there; checked once per index content here), else their stable sort by destination.
-    Returns (src_index, dst_index, weight, rows_if_known)."""
-    facts = _index_facts(dst_index)
-    if facts.ascending:
-        return src_index, dst_index, weight, None
-    keys, perm = _sorted_form(dst_index, facts)
-    if weight is not None:
-        weight = weight.index_select(weight_edge_dim, perm).contiguous()
-    return src_index[perm], keys, weight, facts.rows
-
-
-# ---- dense graphs: source-blocked kernels (geot_amd/slab.py, csrc/seg_slab.hip) -------------------------------------
-# A graph whose source rows are re-used often enough (slab.worthwhile: Reddit scale yes, ogbn-products scale no) is
-# re-arranged ONCE - on the second call with the same edge list, so one-shot calls never pay for it - and from then
-# on served by geot_slab_spmm.  The plan is kept per edge-list content (it holds its key tensors alive, see
-# _transpose_edges_gpu) for the last _SLAB_KEEP edge lists.  GEOT_SLAB=0 never, =1 always (tests), auto by the rule.
-_SLAB_MODE = os.environ.get("GEOT_SLAB", "auto")
-_SLAB_KEEP = 2
-_slab_plans: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
-_slab_sightings: "collections.OrderedDict[tuple, int]" = collections.OrderedDict()
-slab_stats = {"plans_built": 0, "plan_seconds": 0.0, "calls": 0}
-
-
-def _slab_plan(src_index, dst_index, rows: int, src, weight_mode: int, heads: int):
-    if _SLAB_MODE == "0" or src.dtype != torch.float32:
-        return None
-    from . import slab
-    rowbytes = int(src[0].numel()) * 4
-    nnz = dst_index.numel()
-    if rowbytes not in (256, 512, 1024) or nnz >= 2 ** 31 or nnz == 0:
-        return None
-    if _SLAB_MODE != "1" and not slab.worthwhile(nnz, rows, src.shape[0], rowbytes):
-        return None
-    k1, k2 = _content_key(src_index), _content_key(dst_index)
-    if k1 is None or k2 is None:
-        return None
-    key = (k1, k2, rows, src.shape[0], rowbytes, weight_mode, heads)
-    ent = _slab_plans.get(key)
-    if ent is not None and not ent[1].expired() and not ent[2].expired():
-        _slab_plans.move_to_end(key)
-        return ent[0]
-    seen = _slab_sightings.get(key, 0) + 1
-    _slab_sightings[key] = seen
-    while len(_slab_sightings) > 64:
-        _slab_sightings.popitem(last=False)
-    if seen < 2 and _SLAB_MODE != "1":
-        return None
-    import time
-    from torch.multiprocessing.reductions import StorageWeakRef
-    t0 = time.perf_counter()
-    plan = slab.build_plan(src_index, dst_index, rows, src.shape[0], rowbytes, weight_mode, heads)
-    slab_stats["plans_built"] += 1
-    slab_stats["plan_seconds"] += time.perf_counter() - t0
-    _slab_plans[key] = (plan, StorageWeakRef(src_index.untyped_storage()), StorageWeakRef(dst_index.untyped_storage()),
-                        src_index, dst_index)
-    while len(_slab_plans) > _SLAB_KEEP:
-        _slab_plans.popitem(last=False)
-    return plan
-
-
-def _run_slab(plan, weight, weight_mode, src, out, heads, feat):
-    from . import slab
-    slab_stats["calls"] += 1
-    return slab.slab_spmm_out(plan, weight, weight_mode, src, out, heads, feat)
-
-
-def _gather_scatter_gpu(src_index, dst_index, src, rows: Optional[int] = None) -> torch.Tensor:
-    _check_gather(src_index, dst_index, src, 2)
-    src_index, dst_index, src = src_index.contiguous(), dst_index.contiguous(), src.contiguous()
-    src_index, dst_index, _, known = _dst_ordered(src_index, dst_index)
-
-    def launch(nrows: int) -> torch.Tensor:
-        out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
-        plan = _slab_plan(src_index, dst_index, nrows, src, 0, 1) if known is None else None
-        if plan is not None:
-            return _run_slab(plan, None, 0, src, out, 1, src.shape[1])
-        return hip.gather_scatter_out(src_index, dst_index, src, out)
-
-    if rows is None and known is not None:
-        rows = known
-    return launch(rows) if rows is not None else _with_row_rule(dst_index, launch)
-
-
-def _gather_weight_scatter_gpu(src_index, dst_index, weight, src, rows: Optional[int] = None) -> torch.Tensor:
-    _check_gather(src_index, dst_index, src, 2)
-    if weight.dim() != 1 or weight.size(0) != dst_index.size(0):
-        raise RuntimeError("weight must be 1 dimensional with one value per edge")
-    src_index, dst_index = src_index.contiguous(), dst_index.contiguous()
-    weight, src = weight.contiguous(), src.contiguous()
-    src_index, dst_index, weight, known = _dst_ordered(src_index, dst_index, weight)
-
-    def launch(nrows: int) -> torch.Tensor:
-        out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
-        plan = _slab_plan(src_index, dst_index, nrows, src, 1, 1) if known is None and weight.dtype == src.dtype else None
-        if plan is not None:
-            return _run_slab(plan, weight, 1, src, out, 1, src.shape[1])
-        return hip.gather_weight_scatter_out(src_index, dst_index, weight, src, out)
-
-    if rows is None and known is not None:
-        rows = known
-    return launch(rows) if rows is not None else _with_row_rule(dst_index, launch)
-
-
-def _sddmm_coo_gpu(src_index, dst_index, mat_1, mat_2) -> torch.Tensor:
-    # the reference casts the indices to int32 first (geot/gather_weight_scatter.py:10-11);
-    # both widths are accepted here, the kernel reads int64
-    if mat_1.dim() != 2 or mat_2.dim() != 2 or mat_1.shape[1] != mat_2.shape[1]:
-        raise RuntimeError("mat_1 and mat_2 must be 2 dimensional with the same feature dimension")
-    out = torch.empty((dst_index.size(0),), dtype=mat_1.dtype, device=mat_1.device)
-    return hip.sddmm_coo_out(src_index.to(torch.int64).contiguous(), dst_index.to(torch.int64).contiguous(),
-                             mat_1.contiguous(), mat_2.contiguous(), out)
-
-
-def _mh_spmm_gpu(src_index, dst_index, weight, src, reduce: str) -> torch.Tensor:
-    _check_gather(src_index, dst_index, src, 3)
-    _only_sum(reduce, "mh_spmm")
-    nnz = src_index.size(0)
-    # layout pick of csrc/cuda/wrapper/mh_spmm_base.h:38-49 ([nnz, H] first, then [H, nnz])
-    if weight.dim() != 2:
-        raise RuntimeError("Invalid weight size")
-    if weight.size(0) == nnz and weight.size(1) == src.size(1):
-        head_major = False
-    elif weight.size(1) == nnz and weight.size(0) == src.size(1):
-        head_major = True
-    else:
-        raise RuntimeError("Invalid weight size")
-    src_index, dst_index = src_index.contiguous(), dst_index.contiguous()
-    weight, src = weight.contiguous(), src.contiguous()
-    src_index, dst_index, weight, known = _dst_ordered(src_index, dst_index, weight, 1 if head_major else 0)
-
-    def launch(nrows: int) -> torch.Tensor:
-        out = torch.empty((nrows, src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
-        wmode = 3 if head_major else 2
-        plan = (_slab_plan(src_index, dst_index, nrows, src, wmode, src.shape[1])
-                if known is None and weight.dtype == src.dtype and src.shape[2] % 4 == 0 and src.shape[1] <= 16 else None)
-        if plan is not None:
-            return _run_slab(plan, weight, wmode, src, out, src.shape[1], src.shape[2])
-        return hip.mh_spmm_out(src_index, dst_index, weight, src, out, head_major)
-
-    return launch(known) if known is not None else _with_row_rule(dst_index, launch)
-
-
-def _csr_gws_gpu(indptr, indices, weight, src) -> torch.Tensor:
-    """csrc/csr_gws.cpp:24-35: any integer dtype for indptr/indices (the reference casts to int32, the
-    kernel here reads int64); the output has indptr.size(0) rows as in the reference (the last row is
-    always zero - SURVEY.md quirk Q9, kept so the op is a drop-in; see csr_gws(..., rows=) below)."""
-    if indptr.dim() != 1 or indices.dim() != 1:
-        raise RuntimeError("indptr and indices must be 1 dimensional")
-    if src.dim() != 2:
-        raise RuntimeError("src must be 2 dimensional")
-    if weight.dim() != 1 or weight.size(0) != indices.size(0):
-        raise RuntimeError("weight must be 1 dimensional with one value per nonzero")
-    out = torch.empty((indptr.size(0), src.shape[1]), dtype=src.dtype, device=src.device)
-    return hip.csr_gws_out(indptr.to(torch.int64).contiguous(), indices.to(torch.int64).contiguous(),
-                           weight.contiguous(), src.contiguous(), out)
-
-
-# --------------------------------------------------------------------------------------------------
-# schema registration (csrc/*.cpp TORCH_LIBRARY_FRAGMENT / TORCH_LIBRARY_IMPL)
-# --------------------------------------------------------------------------------------------------
-_lib_def = torch.library.Library("geot", "FRAGMENT")
-_lib_def.define("index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor")
-_lib_def.define("gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor")
-_lib_def.define("gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor")
-_lib_def.define("sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor")
-_lib_def.define("mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor")
-
-_lib_def.define("csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src) -> Tensor")
-_lib_def.impl("csr_gws_impl", _csr_gws_gpu, "CUDA")
-_lib_def.impl("index_scatter", _index_scatter_gpu, "CUDA")
-_lib_def.impl("gather_scatter_impl", lambda si, di, s: _gather_scatter_gpu(si, di, s), "CUDA")
-_lib_def.impl("gather_weight_scatter_impl", lambda si, di, w, s: _gather_weight_scatter_gpu(si, di, w, s), "CUDA")
-_lib_def.impl("sddmm_coo_impl", _sddmm_coo_gpu, "CUDA")
-_lib_def.impl("mh_spmm", _mh_spmm_gpu, "CUDA")
-for _name in ("index_scatter", "gather_scatter_impl", "gather_weight_scatter_impl", "sddmm_coo_impl", "mh_spmm",
-              "csr_gws_impl"):
-    _lib_def.impl(_name, _reject_cpu(_name), "CPU")
-
-
 def _fake_rows(src_like: torch.Tensor, tail_shape) -> torch.Tensor:
     ctx = torch.library.get_ctx()
     rows = ctx.new_dynamic_size()
@@ -496,6 +121,21 @@ def _(src_index, dst_index, weight, src):
     return _fake_rows(src, [src.shape[1]])
 
 
+@torch.library.register_fake("geot::gather_scatter")
+def _(src_index, dst_index, src):
+    return _fake_rows(src, [src.shape[1]])
+
+
+@torch.library.register_fake("geot::gather_weight_scatter")
+def _(src_index, dst_index, weight, src):
+    return _fake_rows(src, [src.shape[1]])
+
+
+@torch.library.register_fake("geot::gather_reduce")
+def _(src_index, dst_index, weight, src, reduce):
+    return _fake_rows(src, [src.shape[1]])
+
+
 @torch.library.register_fake("geot::sddmm_coo_impl")
 def _(src_index, dst_index, mat_1, mat_2):
     return mat_1.new_empty([dst_index.shape[0]])
@@ -506,9 +146,120 @@ def _(indptr, indices, weight, src):
     return src.new_empty([indptr.shape[0], src.shape[1]])
 
 
+@torch.library.register_fake("geot::csr_gws")
+def _(csrptr, csrind, weight, src):
+    ctx = torch.library.get_ctx()
+    return src.new_empty([ctx.new_dynamic_size(), src.shape[1]])
+
+
 @torch.library.register_fake("geot::mh_spmm")
 def _(src_index, dst_index, weight, src, reduce):
     return _fake_rows(src, [src.shape[1], src.shape[2]])
+
+
+@torch.library.register_fake("geot::gather_scatter_rows")
+def _(src_index, dst_index, src, rows):
+    return src.new_empty([rows, src.shape[1]])
+
+
+@torch.library.register_fake("geot::gather_weight_scatter_rows")
+def _(src_index, dst_index, weight, src, rows):
+    return src.new_empty([rows, src.shape[1]])
+
+
+@torch.library.register_fake("geot::mh_spmm_rows")
+def _(src_index, dst_index, weight, src, rows):
+    return src.new_empty([rows, src.shape[1], src.shape[2]])
+
+
+@torch.library.register_fake("geot::gather_rows")
+def _(index, src):
+    return src.new_empty([index.shape[0], *src.shape[1:]])
+
+
+@torch.library.register_fake("geot::transpose_edges")
+def _(src_index, dst_index):
+    return src_index.new_empty(src_index.shape), src_index.new_empty(src_index.shape), dst_index.new_empty(dst_index.shape)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd (geot/gather_scatter.py:21-39, geot/gather_weight_scatter.py:31-51)
+# --------------------------------------------------------------------------------------------------
+def _sorted_by_source(src_index, dst_index):
+    """(perm, edges' sources ascending, their destinations): the transposed edge list.  The reference re-sorts on every
+    backward call (geot/gather_scatter.py:30-33); the host layer keeps it per edge-list content (an opaque dispatcher
+    op, so torch.compile / AOT autograd never trace into the cache)."""
+    return torch.ops.geot.transpose_edges(src_index, dst_index)
+
+
+def _gs_setup_context(ctx, inputs, output):
+    src_index, dst_index, src = inputs[:3]
+    ctx.save_for_backward(src_index, dst_index)
+    ctx.src_rows = src.shape[0]
+
+
+def _gs_backward(ctx, grad):
+    """d/dsrc of gather_scatter = the same op on the transposed edge list (geot/gather_scatter.py:26-39).
+
+    Unlike the reference the result has src.shape[0] rows even when the last source node has no
+    out-edge (the reference returns max(src_index)+1 rows and autograd then rejects the shape).
+    """
+    src_index, dst_index = ctx.saved_tensors
+    grad = grad.contiguous()
+    _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+    g = torch.ops.geot.gather_scatter_rows(src_index_bwd, dst_index_bwd, grad, ctx.src_rows)
+    return None, None, g
+
+
+def _gws_setup_context(ctx, inputs, output):
+    src_index, dst_index, weight, src = inputs[:4]
+    ctx.save_for_backward(src_index, dst_index, weight, src)
+
+
+def _gws_backward(ctx, grad):
+    """geot/gather_weight_scatter.py:36-51.
+
+    d/dsrc   = gws on the transposed (source-sorted) edge list, as in the reference.
+    d/dweight[e] = <grad[dst_index[e]], src[src_index[e]]> in ORIGINAL edge order.  The reference
+    calls sddmm on the re-sorted lists with grad/src swapped, which returns the values in
+    source-sorted order and against the wrong rows (SURVEY.md section 8b, verified against dense
+    autograd); this is the mathematically correct gradient.
+    """
+    src_index, dst_index, weight, src = ctx.saved_tensors
+    grad = grad.contiguous()
+    perm, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+    src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight[perm], grad,
+                                                         src.shape[0])
+    weight_grad = torch.ops.geot.sddmm_coo_impl(src_index, dst_index, grad, src)
+    return None, None, weight_grad, src_grad
+
+
+torch.library.register_autograd("geot::gather_scatter", _gs_backward, setup_context=_gs_setup_context)
+torch.library.register_autograd("geot::gather_weight_scatter", _gws_backward, setup_context=_gws_setup_context)
+torch.library.register_autograd("geot::gather_scatter_rows", lambda ctx, grad: (*_gs_backward(ctx, grad), None),
+                                setup_context=_gs_setup_context)
+torch.library.register_autograd("geot::gather_weight_scatter_rows", lambda ctx, grad: (*_gws_backward(ctx, grad), None),
+                                setup_context=_gws_setup_context)
+
+
+def _is_setup(ctx, inputs, output):
+    dim, index, src, reduce, _sorted = inputs
+    ctx.save_for_backward(index)
+    ctx.dim, ctx.reduce = dim, reduce
+
+
+def _is_backward(ctx, grad):
+    """d/dsrc[e] = grad[index[e]]: the row gather the reference ships as gather_eb_sorted_kernel
+    (csrc/cuda/index_scatter_kernel.cuh:266-315) but never wires to an op.  sum only, as in the reference."""
+    if get_reduction_enum(ctx.reduce) != "sum":
+        raise NotImplementedError(f"index_scatter: backward is implemented for reduce='sum' only (got '{ctx.reduce}')")
+    (index,) = ctx.saved_tensors
+    g = grad if ctx.dim == 0 else grad.movedim(ctx.dim, 0)
+    out = torch.ops.geot.gather_rows(index, g.contiguous())
+    return None, None, (out if ctx.dim == 0 else out.movedim(0, ctx.dim)), None, None
+
+
+torch.library.register_autograd("geot::index_scatter", _is_backward, setup_context=_is_setup)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -539,148 +290,6 @@ def sddmm_coo_impl(src_index: torch.Tensor, dst_index: torch.Tensor, mat_1: torc
     return torch.ops.geot.sddmm_coo_impl(src_index, dst_index, mat_1, mat_2)
 
 
-@torch.library.custom_op("geot::gather_scatter", mutates_args=())
-def _gather_scatter_op(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
-    return gather_scatter_impl(src_index, dst_index, src)
-
-
-@torch.library.register_fake("geot::gather_scatter")
-def _(src_index, dst_index, src):
-    return _fake_rows(src, [src.shape[1]])
-
-
-def _gs_setup_context(ctx, inputs, output):
-    src_index, dst_index, src = inputs
-    ctx.save_for_backward(src_index, dst_index)
-    ctx.src_rows = src.shape[0]
-
-
-# The backward needs the edge list sorted by SOURCE (the transposed graph).  The reference re-sorts on
-# every backward call (geot/gather_scatter.py:30-33); GNN graphs are static, so the permutation is kept
-# per (src_index, dst_index) identity+version.  It lives behind an opaque dispatcher op so that
-# torch.compile / AOT autograd never trace into the cache.
-_lib_def.define("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)")
-_transposed: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
-_TRANSPOSED_MAX = int(os.environ.get("GEOT_TRANSPOSE_CACHE", "4"))   # entries; each holds 3 int64 tensors of nnz
-
-
-def _transpose_edges_gpu(src_index, dst_index):
-    key = None
-    if _TRANSPOSED_MAX > 0:
-        try:
-            key = (src_index.device.index, src_index.data_ptr(), dst_index.data_ptr(), src_index.numel(),
-                   src_index._version, dst_index._version)
-        except RuntimeError:          # inference tensors: no version counter
-            key = None
-    if key is not None and key in _transposed:
-        _transposed.move_to_end(key)
-        return _transposed[key][0]
-    _, perm = torch.sort(src_index, stable=True)
-    res = (perm, src_index[perm], dst_index[perm])
-    if key is not None:
-        # The entry keeps the two key tensors alive: while it lives the caching allocator cannot hand their
-        # addresses to a NEW edge list of the same size (which would also start at _version 0 and hit this
-        # key with a stale permutation - dynamic kNN graphs, fixed-count edge dropout, negative sampling).
-        _transposed[key] = (res, src_index, dst_index)
-        while len(_transposed) > _TRANSPOSED_MAX:
-            _transposed.popitem(last=False)
-    return res
-
-
-_lib_def.impl("transpose_edges", _transpose_edges_gpu, "CUDA")
-_lib_def.impl("transpose_edges", _reject_cpu("transpose_edges"), "CPU")
-
-
-@torch.library.register_fake("geot::transpose_edges")
-def _(src_index, dst_index):
-    return src_index.new_empty(src_index.shape), src_index.new_empty(src_index.shape), dst_index.new_empty(dst_index.shape)
-
-
-def _sorted_by_source(src_index, dst_index):
-    """(perm, edges' sources ascending, their destinations): the transposed edge list."""
-    return torch.ops.geot.transpose_edges(src_index, dst_index)
-
-
-def _gs_backward(ctx, grad):
-    """d/dsrc of gather_scatter = the same op on the transposed edge list (geot/gather_scatter.py:26-39).
-
-    Unlike the reference the result has src.shape[0] rows even when the last source node has no
-    out-edge (the reference returns max(src_index)+1 rows and autograd then rejects the shape).
-    """
-    src_index, dst_index = ctx.saved_tensors
-    grad = grad.contiguous()
-    _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
-    # through the dispatcher (opaque to torch.compile / AOT autograd), with the row count made explicit
-    g = torch.ops.geot.gather_scatter_rows(src_index_bwd, dst_index_bwd, grad, ctx.src_rows)
-    return None, None, g
-
-
-torch.library.register_autograd("geot::gather_scatter", _gs_backward, setup_context=_gs_setup_context)
-
-
-@torch.library.custom_op("geot::gather_weight_scatter", mutates_args=())
-def _gather_weight_scatter_op(src_index: torch.Tensor, dst_index: torch.Tensor, weight: torch.Tensor,
-                              src: torch.Tensor) -> torch.Tensor:
-    return gather_weight_scatter_impl(src_index, dst_index, weight, src)
-
-
-@torch.library.register_fake("geot::gather_weight_scatter")
-def _(src_index, dst_index, weight, src):
-    return _fake_rows(src, [src.shape[1]])
-
-
-def _gws_setup_context(ctx, inputs, output):
-    src_index, dst_index, weight, src = inputs
-    ctx.save_for_backward(src_index, dst_index, weight, src)
-
-
-def _gws_backward(ctx, grad):
-    """geot/gather_weight_scatter.py:36-51.
-
-    d/dsrc   = gws on the transposed (source-sorted) edge list, as in the reference.
-    d/dweight[e] = <grad[dst_index[e]], src[src_index[e]]> in ORIGINAL edge order.  The reference
-    calls sddmm on the re-sorted lists with grad/src swapped, which returns the values in
-    source-sorted order and against the wrong rows (SURVEY.md section 8b, verified against dense
-    autograd); this is the mathematically correct gradient.
-    """
-    src_index, dst_index, weight, src = ctx.saved_tensors
-    grad = grad.contiguous()
-    perm, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
-    src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight[perm], grad,
-                                                         src.shape[0])
-    weight_grad = torch.ops.geot.sddmm_coo_impl(src_index, dst_index, grad, src)
-    return None, None, weight_grad, src_grad
-
-
-torch.library.register_autograd("geot::gather_weight_scatter", _gws_backward, setup_context=_gws_setup_context)
-
-
-_lib_def.define("gather_reduce(Tensor src_index, Tensor dst_index, Tensor? weight, Tensor src, str reduce) -> Tensor")
-
-
-def _gather_reduce_gpu(src_index, dst_index, weight, src, reduce):
-    _check_gather(src_index, dst_index, src, 2)
-    kind = _aggr_kind(reduce)
-    src_index, dst_index, src = src_index.contiguous(), dst_index.contiguous(), src.contiguous()
-    weight = None if weight is None else weight.contiguous()
-    src_index, dst_index, weight, known = _dst_ordered(src_index, dst_index, weight)
-
-    def launch(nrows: int) -> torch.Tensor:
-        out = torch.empty((nrows, src.shape[1]), dtype=src.dtype, device=src.device)
-        return hip.gather_reduce_out(src_index, dst_index, weight, src, out, kind)
-
-    return launch(known) if known is not None else _with_row_rule(dst_index, launch)
-
-
-_lib_def.impl("gather_reduce", _gather_reduce_gpu, "CUDA")
-_lib_def.impl("gather_reduce", _reject_cpu("gather_reduce"), "CPU")
-
-
-@torch.library.register_fake("geot::gather_reduce")
-def _(src_index, dst_index, weight, src, reduce):
-    return _fake_rows(src, [src.shape[1]])
-
-
 def gather_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.Tensor,
                    reduce: str = "sum") -> torch.Tensor:
     """dst[dst_index[e]] += src[src_index[e]], dst_index ascending (geot/gather_scatter.py:7-9).
@@ -690,7 +299,7 @@ def gather_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.
     reference; 'mean' / 'min' / 'max' / 'prod' aggregate the messages of every row (forward only).
     """
     if _aggr_kind(reduce) == "sum":
-        return _gather_scatter_op(src_index, dst_index, src)
+        return torch.ops.geot.gather_scatter(src_index, dst_index, src)
     return torch.ops.geot.gather_reduce(src_index, dst_index, None, src, reduce)
 
 
@@ -699,7 +308,7 @@ def gather_weight_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, weig
     """dst[dst_index[e]] += weight[e] * src[src_index[e]] (geot/gather_weight_scatter.py:15-18); ``reduce`` as in
     :func:`gather_scatter` (models/conv/spmm.py:10-14)."""
     if _aggr_kind(reduce) == "sum":
-        return _gather_weight_scatter_op(src_index, dst_index, weight, src)
+        return torch.ops.geot.gather_weight_scatter(src_index, dst_index, weight, src)
     return torch.ops.geot.gather_reduce(src_index, dst_index, weight, src, reduce)
 
 
@@ -723,17 +332,10 @@ def csr_gws_impl(csrptr: torch.Tensor, csrind: torch.Tensor, weight: torch.Tenso
     return torch.ops.geot.csr_gws_impl(csrptr, csrind, weight, src)
 
 
-@torch.library.custom_op("geot::csr_gws", mutates_args=())
 def csr_gws(csrptr: torch.Tensor, csrind: torch.Tensor, weight: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """CSR weighted SpMM: out[r] = sum_e weight[e] * src[csrind[e]] over the row's nonzeros
     (geot/csr_gws.py:25-28).  Output rows = csrptr.size(0) as in the reference."""
-    return csr_gws_impl(csrptr, csrind, weight, src)
-
-
-@torch.library.register_fake("geot::csr_gws")
-def _(csrptr, csrind, weight, src):
-    ctx = torch.library.get_ctx()
-    return src.new_empty([ctx.new_dynamic_size(), src.shape[1]])
+    return torch.ops.geot.csr_gws(csrptr, csrind, weight, src)
 
 
 @torch.library.custom_op("geot::coo_to_csr", mutates_args=())
@@ -751,109 +353,3 @@ def coo_to_csr(coo_row: torch.Tensor) -> torch.Tensor:
 def _(coo_row):
     ctx = torch.library.get_ctx()
     return coo_row.new_empty([ctx.new_dynamic_size()], dtype=torch.int32)
-
-
-# --------------------------------------------------------------------------------------------------
-# Row-count-explicit variants used by the FX rewrite (geot_amd/match_replace.py): the rewritten graph
-# must keep the shape of the index_add it replaces (dst.shape[0] rows), which the `index[-1]+1` rule
-# cannot promise.  Static output shape => no dynamic-size fake tensor, no D2H read-back at all.
-# --------------------------------------------------------------------------------------------------
-_lib_def.define("gather_scatter_rows(Tensor src_index, Tensor dst_index, Tensor src, SymInt rows) -> Tensor")
-_lib_def.define("gather_weight_scatter_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor")
-_lib_def.define("mh_spmm_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor")
-
-
-def _mh_spmm_rows_gpu(src_index, dst_index, weight, src, rows):
-    _check_gather(src_index, dst_index, src, 3)
-    if weight.dim() != 2 or weight.size(0) != src_index.size(0) or weight.size(1) != src.size(1):
-        raise RuntimeError("Invalid weight size")
-    out = torch.empty((int(rows), src.shape[1], src.shape[2]), dtype=src.dtype, device=src.device)
-    src_index, dst_index, weight, _ = _dst_ordered(src_index.contiguous(), dst_index.contiguous(), weight.contiguous())
-    return hip.mh_spmm_out(src_index, dst_index, weight, src.contiguous(), out, False)
-
-
-_lib_def.impl("gather_scatter_rows", lambda si, di, s, rows: _gather_scatter_gpu(si, di, s, rows=int(rows)), "CUDA")
-_lib_def.impl("gather_weight_scatter_rows",
-              lambda si, di, w, s, rows: _gather_weight_scatter_gpu(si, di, w, s, rows=int(rows)), "CUDA")
-_lib_def.impl("mh_spmm_rows", _mh_spmm_rows_gpu, "CUDA")
-for _name in ("gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm_rows"):
-    _lib_def.impl(_name, _reject_cpu(_name), "CPU")
-
-
-@torch.library.register_fake("geot::gather_scatter_rows")
-def _(src_index, dst_index, src, rows):
-    return src.new_empty([rows, src.shape[1]])
-
-
-@torch.library.register_fake("geot::gather_weight_scatter_rows")
-def _(src_index, dst_index, weight, src, rows):
-    return src.new_empty([rows, src.shape[1]])
-
-
-@torch.library.register_fake("geot::mh_spmm_rows")
-def _(src_index, dst_index, weight, src, rows):
-    return src.new_empty([rows, src.shape[1], src.shape[2]])
-
-
-def _gs_rows_setup(ctx, inputs, output):
-    src_index, dst_index, src, _rows = inputs
-    ctx.save_for_backward(src_index, dst_index)
-    ctx.src_rows = src.shape[0]
-
-
-def _gs_rows_backward(ctx, grad):
-    return (*_gs_backward(ctx, grad), None)
-
-
-def _gws_rows_setup(ctx, inputs, output):
-    src_index, dst_index, weight, src, _rows = inputs
-    ctx.save_for_backward(src_index, dst_index, weight, src)
-
-
-def _gws_rows_backward(ctx, grad):
-    return (*_gws_backward(ctx, grad), None)
-
-
-torch.library.register_autograd("geot::gather_scatter_rows", _gs_rows_backward, setup_context=_gs_rows_setup)
-torch.library.register_autograd("geot::gather_weight_scatter_rows", _gws_rows_backward, setup_context=_gws_rows_setup)
-
-
-# --------------------------------------------------------------------------------------------------
-# backward of index_scatter: d/dsrc[e] = grad[index[e]] - the row gather the
-# reference ships as gather_eb_sorted_kernel (csrc/cuda/index_scatter_kernel.cuh:266-315) but never wires
-# to an op.  sum only (mean / min / max / prod have no backward here, as in the reference).
-# --------------------------------------------------------------------------------------------------
-_lib_def.define("gather_rows(Tensor index, Tensor src) -> Tensor")
-
-
-def _gather_rows_gpu(index, src):
-    src = src.contiguous()
-    out = torch.empty((index.size(0),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-    return hip.gather_rows_out(index.contiguous(), src, out)
-
-
-_lib_def.impl("gather_rows", _gather_rows_gpu, "CUDA")
-_lib_def.impl("gather_rows", _reject_cpu("gather_rows"), "CPU")
-
-
-@torch.library.register_fake("geot::gather_rows")
-def _(index, src):
-    return src.new_empty([index.shape[0], *src.shape[1:]])
-
-
-def _is_setup(ctx, inputs, output):
-    dim, index, src, reduce, _sorted = inputs
-    ctx.save_for_backward(index)
-    ctx.dim, ctx.reduce = dim, reduce
-
-
-def _is_backward(ctx, grad):
-    if get_reduction_enum(ctx.reduce) != "sum":
-        raise NotImplementedError(f"index_scatter: backward is implemented for reduce='sum' only (got '{ctx.reduce}')")
-    (index,) = ctx.saved_tensors
-    g = grad if ctx.dim == 0 else grad.movedim(ctx.dim, 0)
-    out = torch.ops.geot.gather_rows(index, g.contiguous())
-    return None, None, (out if ctx.dim == 0 else out.movedim(0, ctx.dim)), None, None
-
-
-torch.library.register_autograd("geot::index_scatter", _is_backward, setup_context=_is_setup)

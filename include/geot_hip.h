@@ -190,6 +190,7 @@ typedef struct geot_slab_plan {
   const int32_t *c_count;
   int64_t n_groups, n_vrows, n_carry, n_split, nnz;
   int32_t units, rows_per_group;
+  int32_t slab_shift, n_slabs; /* the plan's slabs: source row >> slab_shift, n_slabs of them (0 / 0: unknown -> no pacing) */
 } geot_slab_plan;
 
 int geot_slab_units(void);                                     /* waves of the persistent grid */

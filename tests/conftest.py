@@ -27,6 +27,8 @@ def _ensure_native_builds():
     spec.loader.exec_module(mod)
     if mod.needs_build():
         mod.build()
+    if mod.plugin_needs_build():
+        mod.build_plugin()
 
 
 _ensure_native_builds()

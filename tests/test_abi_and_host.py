@@ -86,55 +86,59 @@ def test_reduce_parsing_matches_reduceutils():
 
 
 def test_argument_checks_carry_the_reference_texts():
+    """The C++ host layer (geot_amd/csrc/torch_ops.cpp) runs the reference's argument checks before it looks at the
+    device, so they can be exercised with CPU tensors here."""
+    G = torch.ops.geot
     src = torch.rand(6, 4)
     idx = torch.tensor([0, 0, 1, 1, 2, 2])
     with pytest.raises(RuntimeError, match="dim must be non-negative and less than input dimensions"):
-        ops._index_scatter_gpu(2, idx, src, "sum", True)
+        G.index_scatter(2, idx, src, "sum", True)
     with pytest.raises(RuntimeError, match="dim must be non-negative and less than input dimensions"):
-        ops._index_scatter_gpu(-1, idx, src, "sum", True)
+        G.index_scatter(-1, idx, src, "sum", True)
     with pytest.raises(RuntimeError, match="index must be 1 dimensional"):
-        ops._index_scatter_gpu(0, idx.view(2, 3), src, "sum", True)
+        G.index_scatter(0, idx.view(2, 3), src, "sum", True)
     with pytest.raises(RuntimeError, match="index length must be equal to src dimension size"):
-        ops._index_scatter_gpu(0, idx[:5], src, "sum", True)
-    with pytest.raises(RuntimeError, match="reduce argument must be either"):
-        ops._index_scatter_gpu(0, idx, src, "bogus", True)
+        G.index_scatter(0, idx[:5], src, "sum", True)
+    with pytest.raises(RuntimeError, match="reduce argument must be either sum, prod, mean, amax or amin, got bogus"):
+        G.index_scatter(0, idx, src, "bogus", True)
     with pytest.raises(NotImplementedError, match="only 'sum'"):
-        ops._only_sum("mean", "mh_spmm")
+        G.mh_spmm(idx, idx, torch.rand(6, 2), src.view(6, 2, 2), "mean")
     assert ops._aggr_kind("add") == "sum" and ops._aggr_kind("amax") == "max"
+    with pytest.raises(RuntimeError, match="reduce argument must be either"):
+        G.gather_reduce(idx, idx, None, src, "median")
     with pytest.raises(RuntimeError, match="src_index and dst_index must be 1 dimensional"):
-        ops._gather_scatter_gpu(idx.view(2, 3), idx, src)
+        G.gather_scatter_impl(idx.view(2, 3), idx, src)
     with pytest.raises(RuntimeError, match="src must be 2 dimensional"):
-        ops._gather_scatter_gpu(idx, idx, src.view(6, 2, 2))
+        G.gather_scatter_impl(idx, idx, src.view(6, 2, 2))
     with pytest.raises(RuntimeError, match="src must be 3 dimensional"):
-        ops._mh_spmm_gpu(idx, idx, torch.rand(6, 2), src, "sum")
+        G.mh_spmm(idx, idx, torch.rand(6, 2), src, "sum")
     with pytest.raises(RuntimeError, match="Invalid weight size"):
-        ops._mh_spmm_gpu(idx, idx, torch.rand(5, 2), src.view(6, 2, 2), "sum")
+        G.mh_spmm(idx, idx, torch.rand(5, 2), src.view(6, 2, 2), "sum")
+    with pytest.raises(RuntimeError, match="weight must be 1 dimensional with one value per edge"):
+        G.gather_weight_scatter_impl(idx, idx, torch.rand(5), src)
     with pytest.raises(IndexError):                       # index[-1] of an empty index, as in the reference
-        ops._index_scatter_gpu(0, idx[:0], src[:0], "sum", True)
+        G.index_scatter(0, idx[:0], src[:0], "sum", True)
 
 
-def test_index_facts_are_keyed_on_content_identity():
-    """The remembered facts of an index (ascending? rows, sorted form) are keyed on storage identity + offset +
-    length + version counter and guarded by a weak reference to the storage: a new tensor can never alias a
-    dead one, an in-place edit invalidates the entry, a view of the same memory shares it."""
-    a = torch.arange(10)
-    k0 = ops._content_key(a)
-    assert ops._content_key(a[:]) == k0 and ops._content_key(a.view(10)) == k0       # same memory, same facts
-    assert ops._content_key(a[1:]) != k0
-    a.add_(1)
-    assert ops._content_key(a) != k0                                                  # version counter moved
-    from torch.multiprocessing.reductions import StorageWeakRef
-    w = StorageWeakRef(a.untyped_storage())
-    assert not w.expired()
-    del a
-    assert w.expired()                                                                # a recycled address cannot alias
-    with torch.inference_mode():
-        assert ops._content_key(torch.arange(3)) is None                              # no version counter: never kept
-    # CPU tensors never reach the probe: the doorway refuses them
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        ops._index_scatter_gpu(0, torch.tensor([0, 2, 1, 2]), torch.rand(4, 2), "sum", True)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        ops._gather_scatter_gpu(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 2, 1, 2]), torch.rand(4, 2))
+def test_host_options_and_counters():
+    """The host layer's switches (env at load, set_option at run time) and counters."""
+    st = ops.stats()
+    assert set(st) >= {"probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "facts"}
+    old = ops.set_option("unsorted_mode", "atomic")
+    assert ops.get_option("unsorted_mode") == 2 and ops.set_option("unsorted_mode", old) == 2
+    old = ops.set_option("slab_mode", "always")
+    assert ops.get_option("slab_mode") == 1
+    ops.set_option("slab_mode", old)
+    assert ops.get_option("speculate_rows") in (0, 1) and ops.get_option("trust_version") in (0, 1)
+    with pytest.raises(RuntimeError, match="unknown host option"):
+        ops.set_option("nope", 1)
+    ops.clear_caches()
+    assert ops.stats()["facts"] == 0
+    # CPU tensors never reach the probe: the doorway refuses them after the argument checks
+    with pytest.raises(RuntimeError, match="CPU tensors are not supported"):
+        torch.ops.geot.index_scatter(0, torch.tensor([0, 2, 1, 2]), torch.rand(4, 2), "sum", True)
+    with pytest.raises(RuntimeError, match="CPU tensors are not supported"):
+        torch.ops.geot.gather_scatter(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 2, 1, 2]), torch.rand(4, 2))
 
 
 def test_cpu_tensors_fail_loudly_no_fallback():

@@ -277,11 +277,14 @@ def test_sorted_false_is_routed_by_the_probe(geot, oracle, monkeypatch):
         np.testing.assert_allclose(second.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
         assert first.shape == second.shape
     for mode in ("atomic", "sort"):                                   # GEOT_UNSORTED forces either unsorted path
-        monkeypatch.setattr(ops, "_UNSORTED_MODE", mode)
-        index = rng.integers(0, 50, 4000).astype(np.int64)
-        index[-1] = 49
-        src = rng.random((4000, 8), dtype=np.float32)
-        check_index_scatter(geot, oracle, index, src, sorted=False, what=f"unsorted mode {mode}")
+        old = ops.set_option("unsorted_mode", mode)
+        try:
+            index = rng.integers(0, 50, 4000).astype(np.int64)
+            index[-1] = 49
+            src = rng.random((4000, 8), dtype=np.float32)
+            check_index_scatter(geot, oracle, index, src, sorted=False, what=f"unsorted mode {mode}")
+        finally:
+            ops.set_option("unsorted_mode", old)
 
 
 def test_unsorted_index_with_sorted_false(geot, oracle):
@@ -506,7 +509,8 @@ def test_row_rule_is_verified_on_every_call(geot, oracle, monkeypatch):
     """The row count remembered for an index tensor is only a guess: index[-1] is read back and checked
     on every call.  `.data` writes change the content without bumping the version counter."""
     from geot_amd import ops
-    monkeypatch.setattr(ops, "_SPECULATE_MIN_EDGES", 0)       # exercise the speculative path on a small problem
+    assert ops.get_option("speculate_rows") == 1              # the host layer speculates at every size
+    mism = ops.stats()["row_mismatches"]
     rng = np.random.default_rng(21)
     index_h = sorted_index(rng, 4000, 300)
     src_h = rng.random((4000, 32), dtype=np.float32)
@@ -533,6 +537,13 @@ def test_row_rule_is_verified_on_every_call(geot, oracle, monkeypatch):
     for last in (299, 320, 299):
         index.data[-1] = last
         assert geot.gather_scatter(si, index, src[:300].contiguous()).shape[0] == last + 1
+    assert ops.stats()["row_mismatches"] >= mism + 4          # every silent edit was caught by the read-back
+    old = ops.set_option("speculate_rows", 0)                 # GEOT_SPECULATE_ROWS=0: the reference's blocking order
+    try:
+        index.data[-1] = 310
+        assert geot.index_scatter(0, src, index).shape[0] == 311
+    finally:
+        ops.set_option("speculate_rows", old)
 
 
 @pytest.mark.parametrize("reduce", ["mean", "min", "amin", "max", "amax", "prod", "sum"])

@@ -103,12 +103,12 @@ def test_host_layer_routes_dense_graphs_on_the_second_call(geot, oracle, monkeyp
     from geot_amd import slab
     assert slab.worthwhile(nnz, nodes, nodes, H * Fh * 4)
     d_si, d_di, d_w, d_x = dev(si), dev(di), dev(w), dev(x)
-    built0, calls0 = ops.slab_stats["plans_built"], ops.slab_stats["calls"]
+    built0, calls0 = ops.stats()["plans_built"], ops.stats()["slab_calls"]
     a = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # first sighting: per-edge gather kernel
-    assert ops.slab_stats["plans_built"] == built0
+    assert ops.stats()["plans_built"] == built0
     b = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # second: plan built, slab kernel
     c = geot.mh_spmm(d_si, d_di, d_w, d_x)
-    assert ops.slab_stats["plans_built"] == built0 + 1 and ops.slab_stats["calls"] == calls0 + 2
+    assert ops.stats()["plans_built"] == built0 + 1 and ops.stats()["slab_calls"] == calls0 + 2
     assert torch.equal(b, c) and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
     hi = oracle.mh_spmm(si, di, w, x, rows=nodes, acc64=True)
     close(b, hi, "routed mh_spmm")
@@ -116,23 +116,27 @@ def test_host_layer_routes_dense_graphs_on_the_second_call(geot, oracle, monkeyp
     si[0] = (si[0] + 1) % nodes
     d = geot.mh_spmm(d_si, d_di, d_w, d_x)
     close(d, oracle.mh_spmm(si, di, w, x, rows=nodes, acc64=True), "after an in-place edit")
-    monkeypatch.setattr(ops, "_SLAB_MODE", "0")
+    mode0 = ops.set_option("slab_mode", "never")
     e = geot.mh_spmm(d_si, d_di, d_w, d_x)
     assert torch.allclose(d, e, rtol=1e-5, atol=1e-5)
     # small graphs never take the path in auto mode; GEOT_SLAB=1 forces it (gws + gs + backward through autograd)
-    monkeypatch.setattr(ops, "_SLAB_MODE", "1")
+    ops.set_option("slab_mode", "always")
+    monkeypatch.setattr(ops, "_restore_slab_mode", mode0, raising=False)
     n2, z2, F = 2000, 60_000, 64
     di2 = dev(powerlaw_index(z2, n2, 3))
     si2 = dev(rng.integers(0, n2, z2).astype(np.int64))
     w2 = torch.rand(z2, device="cuda", requires_grad=True)
     x2 = torch.rand(n2, F, device="cuda", requires_grad=True)
-    calls = ops.slab_stats["calls"]
-    y = geot.gather_weight_scatter(si2, di2, w2, x2)
-    y.sum().backward()
-    assert ops.slab_stats["calls"] >= calls + 2                           # forward and d/dsrc both on the slab kernel
+    calls = ops.stats()["slab_calls"]
+    try:
+        y = geot.gather_weight_scatter(si2, di2, w2, x2)
+        y.sum().backward()
+        gs = geot.gather_scatter(si2, di2, x2.detach())
+    finally:
+        ops.set_option("slab_mode", mode0)
+    assert ops.stats()["slab_calls"] >= calls + 3                         # forward, d/dsrc and gather_scatter on the slab kernel
     ref = torch.zeros(n2, F, device="cuda").index_add(0, di2, x2.detach()[si2] * w2.detach()[:, None])
     assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4)
     xg = torch.zeros(n2, F, device="cuda").index_add(0, si2, w2.detach()[:, None].expand(-1, F).contiguous())
     assert torch.allclose(x2.grad, xg, rtol=1e-4, atol=1e-4)
-    assert torch.allclose(geot.gather_scatter(si2, di2, x2.detach()), torch.zeros(n2, F, device="cuda").index_add(0, di2, x2.detach()[si2]),
-                          rtol=1e-4, atol=1e-4)
+    assert torch.allclose(gs, torch.zeros(n2, F, device="cuda").index_add(0, di2, x2.detach()[si2]), rtol=1e-4, atol=1e-4)

@@ -1,6 +1,6 @@
-"""The optional C++ dispatcher plugin geot_amd/_C.so (INTEGRATION.md path A): loaded with
-torch.ops.load_library in a FRESH process (it registers the same schemas geot_amd/ops.py registers from
-Python, so the two must not meet) and driven the way the reference's Python wrappers drive `_C`."""
+"""The C++ dispatcher plugin geot_amd/_C.so (csrc/torch_ops.cpp) on its own: loaded with torch.ops.load_library in
+a FRESH process - no geot_amd Python at all - and driven the way the reference's Python wrappers drive their `_C`
+(INTEGRATION.md path A: the reference's unmodified geot/*.py on top of this plugin)."""
 import os
 import subprocess
 import sys
@@ -74,10 +74,10 @@ def test_cpp_dispatcher_plugin_over_the_c_abi():
 
 
 def test_shim_source_declares_the_reference_schemas():
-    text = open(os.path.join(ROOT, "geot_amd", "csrc", "torch_shim.cpp")).read()
+    text = open(os.path.join(ROOT, "geot_amd", "csrc", "torch_ops.cpp")).read()
     for frag in ("index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted)",
                  "gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src)",
                  "gather_weight_scatter_impl(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src)",
                  "sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2)",
-                 "csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src)", 'm.def("mh_spmm"'):
+                 "csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src)", 'm.def("mh_spmm('):
         assert frag in text

@@ -115,11 +115,9 @@ def main():
         wg.grad = None
 
     t_cached = timeit(train_step, 3)
-    keep = gops._TRANSPOSED_MAX
-    gops._TRANSPOSED_MAX = 0
-    gops._transposed.clear()
+    keep = gops.set_option("transpose_cache", 0)
     t_resort = timeit(train_step, 3)
-    gops._TRANSPOSED_MAX = keep
+    gops.set_option("transpose_cache", keep)
     print(f"cfg3 gws fwd+bwd (autograd): {t_cached:.2f} ms with the cached transposed edge list, {t_resort:.2f} ms re-sorting every call")
     del xg, wg
     # backward pieces (row f1): SDDMM (d/dweight of gws) and the row gather (backward of index_scatter)

@@ -50,11 +50,18 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             plan = slab.build_plan(si, di, nodes, nodes, H * Fh * 4, wmode, H, slab_bytes=int(slab_mib * (1 << 20)))
+            torch.cuda.synchronize()
             t_plan = time.perf_counter() - t0
-            t = device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 3, warmup=1)
+            times = {}
+            for window in (-1, 0, 1, 2, 4):
+                hip.set_option("slab_window", window)
+                times[window] = device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 3, warmup=1)
+            hip.set_option("slab_window", 1)
             base()
             err = ((out - ref).abs().max() / ref.abs().max()).item()
-            print(f"   slab {slab_mib} MiB: {t:.3f} ms ({t_base / t:.2f}x)  phase A {t_plan * 1e3:.0f} ms  plan {plan.nbytes() / 1e6:.0f} MB  "
+            best = min(times.values())
+            print(f"   slab {slab_mib} MiB: window(-1=free,0,1,2,4) " + " ".join(f"{times[k]:.3f}" for k in (-1, 0, 1, 2, 4)) +
+                  f" ms  best {t_base / best:.2f}x  phase A {t_plan * 1e3:.0f} ms  plan {plan.nbytes() / 1e6:.0f} MB  "
                   f"max rel diff {err:.1e}  {plan.meta}", flush=True)
             del plan
         del di, si, x, out, ref, w

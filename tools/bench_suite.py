@@ -7,8 +7,10 @@ synchronize at the end - host overhead included).
 No network here, so each dataset of the reference's list (benchmark/bench_index_scatter.py:91,
 benchmark/utils.py:17-46) is replaced by a synthetic graph with its published node / edge counts
 (+ self loops, as utils.py:49 adds them), power-law destination degrees, uniform sources.  torch_scatter /
-torch_sparse (PyG) are not installed in this image: their columns are left out; `triton_pr` / `triton_sr` /
-`torch_compile` are the reference's comparator launchers served by this engine (geot_amd/comparators.py).
+torch_sparse (PyG) are not installed in this image and there is no Triton: their columns are left out.  The columns
+`geot_via_launch_*` are THIS engine called through the reference's comparator launcher surface
+(geot.triton.launch_* -> geot_amd/comparators.py): they measure that call path (accumulate into `output`), they are
+NOT a comparison against Triton kernels.
 
     python tools/bench_suite.py [--out-dir gpurun_out] [--iters 100] [--quick]
 """
@@ -82,8 +84,9 @@ def main():
     f1 = open(os.path.join(a.out_dir, "benchop_index_scatter.csv"), "w")
     f2 = open(os.path.join(a.out_dir, "benchop_spmm.csv"), "w")
     f1.write("dataset,feature_size,torch_scatter_reduce,torch_index_reduce,index_scatter_reduce,"
-             "index_scatter_sorted,triton_pr,triton_sr\n")
-    f2.write("dataset,feature_size,gather_weight_scatter,pytorch_spmm,triton_pr,triton_sr,torch_compile\n")
+             "index_scatter_sorted,geot_via_launch_parallel_reduction,geot_via_launch_serial_reduction\n")
+    f2.write("dataset,feature_size,gather_weight_scatter,pytorch_spmm,geot_via_launch_pr_spmm,geot_via_launch_sr_spmm,"
+             "geot_via_launch_torch_compile_spmm\n")
     for name in names:
         nodes, dst, col = synth(name, dev)
         nnz = dst.numel()
