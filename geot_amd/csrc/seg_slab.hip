@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p
 extern "C" {
 
 constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
-int g_slab_window = 1;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
+int g_slab_window = 2;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
 
 int geot_slab_units(void) { return 256 * 2 * 4; } // waves of the persistent grid: 256 CUs x 2 workgroups x 4
 

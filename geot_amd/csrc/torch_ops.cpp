@@ -17,8 +17,8 @@
 //   * dense graphs are re-arranged once for the source-blocked kernel (csrc/seg_slab.hip) on their second call;
 //   * one workspace per (device, stream), a device guard, the current stream.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
 #include <torch/library.h>
 
@@ -92,9 +92,10 @@ void require_gpu(const char *op, std::initializer_list<const at::Tensor *> ts) {
   }
 }
 
-void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// (a ROCm build of PyTorch calls the GPU "cuda": the guard / stream types that accept that device type)
+void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
-#define GEOT_DEVICE_GUARD(t) const c10::hip::HIPGuard geot_device_guard_((t).device())
+#define GEOT_DEVICE_GUARD(t) const c10::hip::HIPGuardMasqueradingAsCUDA geot_device_guard_((t).device())
 #define GEOT_CALL(expr)                                                                                                 \
   do {                                                                                                                  \
     const int rc_ = (expr);                                                                                             \
