@@ -111,10 +111,12 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     if (slot >= 0 && slot < kProgSlots) my_slot = slot;
   }
   int published = -1;
+  int known_min = -1;                         // a lower bound of the slowest wave's step (steps only grow)
   auto slab_sync = [&](int step) {            // wave-uniform
     if (my_slot < 0 || step <= published) return;
     published = step;
     if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return; // the last poll already allows this step: no memory round trip
     for (int tries = 0; tries < 2048; ++tries) {
       int m = kProgIdle;
 #pragma unroll
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         const int other = __shfl_xor(m, o, 64);
         m = other < m ? other : m;
       }
+      known_min = m;
       if (m + p.window >= step) break;
       __builtin_amdgcn_s_sleep(16);
     }
@@ -292,7 +295,9 @@ extern "C" {
 constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
 int g_slab_window = 2;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
 
-int geot_slab_units(void) { return 256 * 2 * 4; } // waves of the persistent grid: 256 CUs x 2 workgroups x 4
+int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
+
+int geot_slab_units(void) { return 256 * g_slab_blocks * 4; } // waves of the persistent grid: 256 CUs x workgroups x 4
 
 static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads) {
   const size_t hw = weight_mode <= 1 ? 1 : (size_t)heads;
@@ -302,7 +307,8 @@ static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads)
 // two workgroups per CU inside the classic 64 KB per workgroup: R KiB of accumulators per wave + the staged weights
 int geot_slab_rows_per_group(int weight_mode, int64_t heads) {
   int r = 16;
-  while (r > 1 && slab_lds_bytes(r, weight_mode, heads) > 64 * 1024) --r;
+  const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (size_t)(156 * 1024) / g_slab_blocks / 1024 * 1024;
+  while (r > 1 && slab_lds_bytes(r, weight_mode, heads) > budget) --r;
   return r;
 }
 
@@ -328,7 +334,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: rows of 256, 512 or 1024 bytes only");
   if ((4 * feat) % 16 != 0 && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of 4");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
-  if (plan->units != geot_slab_units() * (64 >> lpr_log2)) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: plan was built for a different unit count");
+  const int64_t waves = plan->units / (64 >> lpr_log2);
+  if (plan->units % (64 >> lpr_log2) != 0 || waves % (4 * 256) != 0 || waves < 4 * 256 || waves > 4 * 256 * 4)
+    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: the plan's unit count is not 256 CUs x (1..4 workgroups) x 4 waves");
   if (plan->rows_per_group < 1 || plan->rows_per_group > 32) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group 1..32");
   if (heads > 16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: at most 16 heads");
   const size_t need = geot_slab_workspace_bytes(plan, F);
@@ -346,7 +354,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.carry = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + kSyncBytes);
   p.slab_shift = plan->slab_shift;
   p.n_slabs = plan->n_slabs;
-  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? g_slab_window : -1;
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (lpr_log2 == 6 ? 2 : 1) : g_slab_window) : -1;
   p.src_rows = src_rows;
   p.K = out_rows;
   p.F = F;
@@ -365,7 +373,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (plan->n_groups > 0) {
     const size_t lds = slab_lds_bytes(plan->rows_per_group, weight_mode, heads);
     if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group)");
-    const dim3 grid(256 * 2), blk(kThreads);
+    const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
     const bool wave_row = lpr_log2 == 6;
 #define GEOT_SLAB_LAUNCH(W)                                                                             \
   if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<W, true>), grid, blk, lds, st, p);                  \
@@ -392,6 +400,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 
 void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_window") g_slab_window = value;
+  if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 
 } // extern "C"

@@ -271,7 +271,8 @@ bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t ro
       src_rows >= ((int64_t)1 << 31))
     return false;
   const int64_t units = (int64_t)geot_slab_units() * (1024 / rowbytes);
-  const int64_t rounds = std::max<int64_t>(1, (out_rows + 15 * units - 1) / (15 * units));
+  const int64_t rpg = geot_slab_rows_per_group(1, 1);
+  const int64_t rounds = std::max<int64_t>(1, (out_rows + rpg * units - 1) / (rpg * units));
   return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= 4.0;
 }
 

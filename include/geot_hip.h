@@ -225,7 +225,9 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
 /* named switches: "unroll" = 0 | 8 | 16 row loads in flight per lane (fp32 index_scatter, 0 = rule);
  * "narrow" = 1 | 0 lane-per-edge kernel for fp32 rows of <= 7 elements; "xcd" = 1 | 0 XCD-contiguous tile
  * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
- * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always) */
+ * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
+ * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
+ * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free) */
 void geot_set_option(const char *name, int value);
 
 #ifdef __cplusplus
