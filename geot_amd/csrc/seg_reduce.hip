@@ -29,6 +29,7 @@
 //   * empty keys are zero-filled by whoever sees the key jump: dst needs no memset pass.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
@@ -1397,15 +1398,18 @@ __global__ void box_clock_kernel(unsigned long long *out, int spins) {
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_err;
 
+// Experiment knobs (geot_tune / geot_set_option): process-wide, relaxed atomics - a call reads each of them once or
+// twice while it plans; flipping one while calls are in flight on other threads changes which (equally correct)
+// kernel shape those calls pick, nothing else.
 struct Tune {
-  int cg = 0, vec = 0, nt = -1, lpr_log2 = -1;
+  std::atomic<int> cg{0}, vec{0}, nt{-1}, lpr_log2{-1};
 };
 Tune g_tune;
-int g_unroll = 0; // 0 = rule, 8 / 16 = forced
-int g_xcd = 1;    // XCD-aware tile mapping for the gather modes
-int g_nt_keys = 0; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
-int g_hub = -1;   // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
-int g_narrow = 1; // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
+std::atomic<int> g_unroll{0};  // 0 = rule, 8 / 16 = forced
+std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
+std::atomic<int> g_nt_keys{0}; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
+std::atomic<int> g_hub{-1};    // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
+std::atomic<int> g_narrow{1};  // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
 
 struct Prof {
   bool on = false;
@@ -1472,7 +1476,7 @@ inline void layout_workspace(Plan &P, int64_t F, int asize) {
   P.total = P.wflag_off + up256(nw * sizeof(int));
 }
 
-int g_lane_e = 0; // experiment: 4 | 8 forces E of seg_lane_kernel where that instantiation exists (F <= 4)
+std::atomic<int> g_lane_e{0}; // experiment: 4 | 8 forces E of seg_lane_kernel where that instantiation exists (F <= 4)
 inline int lane_seq_edges(int64_t F) { return F <= 4 ? (g_lane_e == 4 ? 4 : 8) : 4; }  // E of seg_lane_kernel<F, E>
 constexpr int scan_steps(int64_t F) { return F <= 2 ? 8 : 4; }      // S of seg_narrow_kernel<F, S>
 
@@ -1707,7 +1711,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // non-temporal policy: the streamed operand of index_scatter is read exactly once -> nt loads
   // (measured +13 % with the store mix of this op) and nt dst stores (a further ~5 %);
   // gathered rows are re-used across edges -> default cache policy there.
-  int nt = g_tune.nt >= 0 ? g_tune.nt : (mode == 0 ? 3 : 0);
+  const int tune_nt = g_tune.nt;
+  int nt = tune_nt >= 0 ? tune_nt : (mode == 0 ? 3 : 0);
 
   Prof::Rec rec{};
   const bool prof = g_prof.on;

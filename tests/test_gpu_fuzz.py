@@ -92,3 +92,83 @@ def test_fuzz_gather_ops(oracle, seed):
         sd = geot.sddmm_coo_impl(t(si), t(di), t(x[: int(di[-1]) + 1 if False else nodes]), t(x))
         ref = oracle.sddmm_coo(si, di, x, x, acc64=True)
         assert np.allclose(sd.cpu().numpy(), ref, rtol=1e-4, atol=1e-4), (seed, nnz, F, "sddmm")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_source_blocked_kernel(oracle, seed):
+    """The same random graphs through the source-blocked path (forced: these graphs are far too small for the density
+    rule): every weight mode, the three row widths, hubs that must be split, gaps, tiny inputs."""
+    import geot_amd as geot
+    from geot_amd import ops
+    rng = np.random.default_rng(3000 + seed)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    old = ops.set_option("slab_mode", "always")
+    try:
+        for _ in range(20):
+            nnz = int(rng.choice([1, 64, 65, 1000, 5000, 30_000, int(rng.integers(1, 60_000))]))
+            di = random_index(rng, nnz)
+            nodes = int(di[-1]) + 1 + int(rng.integers(0, 50))
+            si = rng.integers(0, nodes, nnz).astype(np.int64)
+            H, Fh = [(1, 64), (1, 128), (1, 256), (2, 32), (4, 64), (8, 32), (4, 16), (16, 16)][int(rng.integers(0, 8))]
+            x3 = rng.standard_normal((nodes, H, Fh)).astype(np.float32)
+            calls = ops.stats()["slab_calls"]
+            if H == 1:
+                w = rng.random(nnz, dtype=np.float32)
+                x = x3.reshape(nodes, Fh)
+                hi = oracle.gather_weight_scatter(si, di, w, x, acc64=True)
+                mag = oracle.gather_weight_scatter(si, di, w, np.abs(x), acc64=True)
+                assert close(geot.gather_weight_scatter(t(si), t(di), t(w), t(x)), hi, mag), (seed, nnz, Fh, "gws")
+                hi = oracle.gather_scatter(si, di, x, acc64=True)
+                mag = oracle.gather_scatter(si, di, np.abs(x), acc64=True)
+                assert close(geot.gather_scatter(t(si), t(di), t(x)), hi, mag), (seed, nnz, Fh, "gs")
+                assert ops.stats()["slab_calls"] == calls + 2
+            else:
+                wh = rng.random((nnz, H), dtype=np.float32)
+                hi = oracle.mh_spmm(si, di, wh, x3, acc64=True)
+                mag = oracle.mh_spmm(si, di, wh, np.abs(x3), acc64=True)
+                assert close(geot.mh_spmm(t(si), t(di), t(wh), t(x3)), hi, mag), (seed, nnz, H, Fh)
+                if nnz != H:
+                    assert close(geot.mh_spmm(t(si), t(di), t(np.ascontiguousarray(wh.T)), t(x3)), hi, mag), (seed, nnz, H, Fh, "T")
+                assert ops.stats()["slab_calls"] > calls
+    finally:
+        ops.set_option("slab_mode", old)
+
+
+def test_host_layer_streams_and_inplace_edits(oracle):
+    """The plugin's caches under use a model would make of them: two streams at once (one workspace per stream),
+    in-place edits of the index between calls (version counter moves: facts, sorted form and plans must not be reused),
+    views of one edge_index tensor (they share their storage's facts)."""
+    import geot_amd as geot
+    rng = np.random.default_rng(77)
+    nnz, K, F = 200_000, 5000, 64
+    index = np.sort(rng.integers(0, K, nnz)).astype(np.int64)
+    index[-1] = K - 1
+    src = rng.standard_normal((nnz, F)).astype(np.float32)
+    t_idx, t_src = torch.from_numpy(index).cuda(), torch.from_numpy(src).cuda()
+    hi = oracle.index_scatter(index, src, acc64=True)
+    mag = oracle.index_scatter(index, np.abs(src), acc64=True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(geot.index_scatter(0, t_src, t_idx, "sum", True))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert close(o, hi, mag)
+        assert torch.equal(o, outs[0])
+    # shuffle IN PLACE (version counter moves): must be noticed, and noticed again when sorted back
+    perm = torch.randperm(nnz - 1, device="cuda")
+    t_idx[:-1] = t_idx[:-1][perm]
+    t_src2 = t_src.clone()
+    t_src2[:-1] = t_src[:-1][perm]
+    assert close(geot.index_scatter(0, t_src2, t_idx, "sum", True), hi, mag, tol=2e-5)
+    t_idx.copy_(torch.from_numpy(index).cuda())
+    assert torch.equal(geot.index_scatter(0, t_src, t_idx, "sum", True), outs[0])
+    # a [2, nnz] edge_index: its rows are views of one storage at different offsets
+    edge_index = torch.stack([torch.from_numpy(rng.integers(0, K, nnz)).cuda(), t_idx])
+    x = torch.rand(K, F, device="cuda")
+    a = geot.gather_scatter(edge_index[0], edge_index[1], x)
+    b = geot.gather_scatter(edge_index[0].clone(), edge_index[1].clone(), x)
+    assert torch.equal(a, b)
