@@ -230,6 +230,35 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
   return {std::get<0>(sorted), std::get<1>(sorted)};
 }
 
+// ---- int32 indices (the reference's Python wrappers cast to int32 for sddmm_coo_impl / csr_gws_impl,
+// geot/gather_weight_scatter.py:10-11, geot/csr_gws.py) -> the int64 the kernels read, converted once per content
+struct WidenedEntry {
+  ContentKey key;
+  at::Tensor narrow, wide; // `narrow` is kept alive: its address cannot be recycled while the entry lives
+};
+std::list<WidenedEntry> g_widened;
+
+at::Tensor as_int64(const at::Tensor &t) {
+  if (t.scalar_type() == at::kLong) return t.contiguous();
+  ContentKey k;
+  const bool keyed = g_opt.trust_version && content_key(t, &k);
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_widened.begin(); it != g_widened.end(); ++it)
+      if (it->key == k) {
+        g_widened.splice(g_widened.begin(), g_widened, it);
+        return g_widened.front().wide;
+      }
+  }
+  at::Tensor wide = t.to(at::kLong).contiguous();
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_widened.push_front(WidenedEntry{k, t, wide});
+    while (g_widened.size() > 6) g_widened.pop_back();
+  }
+  return wide;
+}
+
 // ---- the row rule without stalling the GPU ---------------------------------------------------------------------------------
 // launch(rows) allocates the output for `rows` rows and enqueues the kernels.  `guess` comes from the facts.
 template <typename Launch> at::Tensor with_row_rule(const at::Tensor &index, int64_t guess, bool guess_is_fresh, Launch launch) {
@@ -648,7 +677,7 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
   require_gpu("sddmm_coo_impl", {&si_in, &di_in, &m1_in, &m2_in});
   GEOT_DEVICE_GUARD(m1_in);
   // the reference's Python wrapper hands over int32 indices (geot/gather_weight_scatter.py:10-11): both widths accepted
-  at::Tensor si = si_in.to(at::kLong).contiguous(), di = di_in.to(at::kLong).contiguous();
+  at::Tensor si = as_int64(si_in), di = as_int64(di_in);
   at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
   at::Tensor out = at::empty({di.size(0)}, m1.options());
   GEOT_CALL(geot_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), out.data_ptr(), di.size(0), m1.size(1), m1.size(0),
@@ -665,7 +694,7 @@ at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in,
   TORCH_CHECK(weight_in.scalar_type() == src_in.scalar_type(), "expected weight of dtype ", toString(src_in.scalar_type()), " but found ",
               toString(weight_in.scalar_type()));
   GEOT_DEVICE_GUARD(src_in);
-  at::Tensor indptr = indptr_in.to(at::kLong).contiguous(), indices = indices_in.to(at::kLong).contiguous();
+  at::Tensor indptr = as_int64(indptr_in), indices = as_int64(indices_in);
   at::Tensor weight = weight_in.contiguous(), src = src_in.contiguous();
   const int64_t rows = indptr.size(0), nnz = indices.size(0), feat = src.size(1);
   at::Tensor out = at::empty({rows, feat}, src.options());
@@ -740,6 +769,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
     g_transposed.clear();
     g_slab.clear();
     g_sightings.clear();
+    g_widened.clear();
     return 0;
   }
   TORCH_CHECK(p, "unknown host option ", name);

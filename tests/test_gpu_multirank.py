@@ -80,19 +80,37 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)
-send = torch.arange(66, dtype=torch.float64, device=dev)
-recv = torch.empty(66, dtype=torch.float64, device=dev)
+# the two collectives of geot_amd/sharding.py: every rank's (first_key, last_key) as int64, first-row partials as fp32
+keys = torch.tensor([3, 2 ** 40 + 7], dtype=torch.int64, device=dev)
+allkeys = torch.empty(2, dtype=torch.int64, device=dev)
+dist.all_gather_into_tensor(allkeys, keys)
+host = torch.empty(2, dtype=torch.int64).pin_memory()
+host.copy_(allkeys, non_blocking=True)
+send = torch.arange(64, dtype=torch.float32, device=dev)
+recv = torch.empty(64, dtype=torch.float32, device=dev)
 dist.all_gather_into_tensor(recv, send)
+# bench.py: max over ranks of the elapsed time, barrier
 t = torch.tensor([1.5], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()
 torch.cuda.synchronize()
-assert torch.equal(recv, send) and t.item() == 1.5 and dist.get_backend() == "nccl"
+assert host.tolist() == [3, 2 ** 40 + 7] and torch.equal(recv, send) and t.item() == 1.5 and dist.get_backend() == "nccl"
+# and the whole sharded call on a 1-rank RCCL group (no collective is needed at world 1; the code path is the GPU one)
+import sys
+sys.path.insert(0, os.environ["GEOT_ROOT"])
+import geot_amd
+from geot_amd import sharding
+idx = torch.sort(torch.randint(0, 5000, (300000,), device=dev)).values
+src = torch.rand(300000, 64, device=dev)
+for _ in range(3):
+    out, first = sharding.sharded_index_scatter(idx, src)
+ref = geot_amd.index_scatter(0, src, idx)
+assert first == 0 and torch.equal(out, ref)
 dist.destroy_process_group()
 print("RCCL OK")
 '''
     p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GEOT_ROOT=ROOT))
     assert p.returncode == 0 and "RCCL OK" in p.stdout, p.stderr[-2000:]
 
 
