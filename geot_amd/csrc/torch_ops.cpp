@@ -497,33 +497,30 @@ at::Tensor index_scatter_op(const int64_t dim, const at::Tensor &index_in, const
   const int64_t nnz = index.numel(), feat = moved.numel() / nnz;
   const FactsView f = index_facts(index); // `sorted` is a promise the reference never checks; neither flag is trusted
   auto shape = moved.sizes().vec();
-  at::Tensor out;
-  if (f.ascending) {
-    out = with_row_rule(index, f.rows, !f.cached, [&](int64_t rows) {
-      shape[0] = rows;
-      at::Tensor o = at::empty(shape, moved.options());
-      auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, rows, dt));
+  std::pair<at::Tensor, at::Tensor> kp;
+  const bool atomic_flush = !f.ascending && g_opt.unsorted_mode == 2 && red == GEOT_REDUCE_SUM && (dt == GEOT_F32 || dt == GEOT_F64);
+  if (!f.ascending && !atomic_flush) kp = sorted_form(index);
+  // rows = index[-1] + 1 is read back and verified on every call, whichever kernels serve it
+  at::Tensor out = with_row_rule(index, f.rows, !f.cached, [&](int64_t rows) {
+    shape[0] = rows;
+    at::Tensor o = at::empty(shape, moved.options());
+    auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, rows, dt));
+    if (f.ascending) {
       if (red == GEOT_REDUCE_SUM)
         GEOT_CALL(geot_index_scatter(index_ptr(index), moved.data_ptr(), o.data_ptr(), nnz, feat, rows, dt, 1, ws.data_ptr(), ws.numel(), stream_of(src)));
       else
         GEOT_CALL(geot_index_scatter_reduce(index_ptr(index), moved.data_ptr(), o.data_ptr(), nnz, feat, rows, dt, red, ws.data_ptr(), ws.numel(), stream_of(src)));
-      return o;
-    });
-  } else {
-    shape[0] = f.rows;
-    out = at::empty(shape, moved.options());
-    auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, f.rows, dt));
-    if (g_opt.unsorted_mode == 2 && red == GEOT_REDUCE_SUM && (dt == GEOT_F32 || dt == GEOT_F64)) {
+    } else if (atomic_flush) {
       // pre-reduced runs + float atomics into a zeroed dst (what the reference does for every flush)
-      GEOT_CALL(geot_index_scatter(index_ptr(index), moved.data_ptr(), out.data_ptr(), nnz, feat, f.rows, dt, 0, ws.data_ptr(), ws.numel(), stream_of(src)));
+      GEOT_CALL(geot_index_scatter(index_ptr(index), moved.data_ptr(), o.data_ptr(), nnz, feat, rows, dt, 0, ws.data_ptr(), ws.numel(), stream_of(src)));
     } else {
       // reduce over (sorted keys, permutation) with the gather-mode kernels: deterministic, any reduction and dtype;
       // rows stay index[-1]+1 (the reference's rule even for an unsorted index), keys beyond are ignored
-      auto kp = sorted_form(index);
-      GEOT_CALL(geot_gather_reduce(index_ptr(kp.second), index_ptr(kp.first), nullptr, moved.data_ptr(), out.data_ptr(), nnz, feat, nnz, f.rows,
+      GEOT_CALL(geot_gather_reduce(index_ptr(kp.second), index_ptr(kp.first), nullptr, moved.data_ptr(), o.data_ptr(), nnz, feat, nnz, rows,
                                    dt, red, ws.data_ptr(), ws.numel(), stream_of(src)));
     }
-  }
+    return o;
+  });
   return dim == 0 ? out : out.movedim(0, dim);
 }
 
@@ -536,6 +533,7 @@ void check_gather(const at::Tensor &si, const at::Tensor &di, const at::Tensor &
 
 struct Edges {
   at::Tensor si, di, w;
+  at::Tensor di_given; // the caller's dst_index (contiguous): the row rule reads ITS last element
   int64_t rows;       // index[-1] + 1 as remembered / probed
   bool fresh;         // rows was read in this very call
   bool permuted;      // di had descents: (si, di, w) are the stable sort by destination
@@ -547,6 +545,7 @@ Edges dst_ordered(const at::Tensor &si_in, const at::Tensor &di_in, const c10::o
   Edges e;
   e.si = si_in.contiguous();
   e.di = di_in.contiguous();
+  e.di_given = e.di;
   index_ptr(e.si);
   index_ptr(e.di);
   if (w_in.has_value() && w_in->defined()) e.w = w_in->contiguous();
@@ -599,8 +598,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
     return o;
   };
   if (rows_given >= 0) return launch(rows_given);
-  if (e.permuted) return launch(e.rows);
-  return with_row_rule(e.di, e.rows, e.fresh, launch);
+  return with_row_rule(e.di_given, e.rows, e.fresh, launch);
 }
 
 at::Tensor gather_scatter_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &src) {
@@ -656,8 +654,7 @@ at::Tensor mh_spmm_common(const at::Tensor &si, const at::Tensor &di, const at::
     return o;
   };
   if (rows_given >= 0) return launch(rows_given);
-  if (e.permuted) return launch(e.rows);
-  return with_row_rule(e.di, e.rows, e.fresh, launch);
+  return with_row_rule(e.di_given, e.rows, e.fresh, launch);
 }
 
 at::Tensor mh_spmm_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight, const at::Tensor &src, const c10::string_view reduce) {

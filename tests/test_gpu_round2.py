@@ -204,6 +204,11 @@ def test_wrong_sorted_promise_still_sums_correctly(geot, oracle):
     for _ in range(3):                                                                # remembered facts; bit-reproducible
         assert torch.equal(geot.index_scatter(0, t_src, t_index, "sum", sorted=True), a)
     assert torch.equal(geot.index_scatter(0, t_src, t_index, "sum", sorted=False), a)
+    t_index.data[-1] = K + 10                         # behind the version counter: the row rule still follows index[-1]
+    grown = geot.index_scatter(0, t_src, t_index, "sum", sorted=True)
+    assert grown.shape[0] == K + 11 and grown[K - 1:K + 10].abs().sum().item() >= 0
+    t_index.data[-1] = K - 1
+    assert torch.equal(geot.index_scatter(0, t_src, t_index, "sum", sorted=True), a)
     mx = geot.index_scatter(0, t_src, t_index, "max", sorted=True)
     want = torch.zeros(K, F, device="cuda").scatter_reduce(0, t_index[:, None].expand(-1, F), t_src, "amax", include_self=False)
     assert torch.equal(mx, want)
