@@ -287,9 +287,12 @@ def main():
             def step():
                 return geot.index_scatter(0, src, index, "sum", True)
         kernel = "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"
+        coll = "RCCL" if backend == "nccl" else backend
         workload = ("index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64 (BASELINE.json configs[1])"
-                    + (" per GPU, boundary rows exchanged by RCCL all_gather" if distributed else ""))
-        step_desc = "geot.index_scatter(0, src, index, 'sum', True): index[-1].item() + alloc + tile kernel + fix-up kernel"
+                    + (f" per GPU, neighbouring shards share their boundary key, boundary rows exchanged by a {coll} all_gather" if distributed else ""))
+        step_desc = ("sharding.sharded_index_scatter: 16-byte-per-rank key all_gather under the local kernels (tile + fix-up), "
+                     "all_gather of the first-row partials, owner add" if distributed else
+                     "geot.index_scatter(0, src, index, 'sum', True): read-back of index[-1] + alloc + tile kernel + fix-up kernel")
         metric = METRIC
     else:
         nodes_all, feat = int(CFG5_NODES * args.scale), CFG5_FEAT
