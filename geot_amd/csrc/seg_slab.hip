@@ -58,6 +58,26 @@ constexpr int kProgIdle = 0x7f7f7f7f;
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
+// reductions over the messages of a row (codes of include/geot_hip.h, csrc/reducetype.h:3); mean = sum, divided by the
+// row's edge count when the row is written; min / max propagate NaN like ATen (csrc/cpu/index_scatter_cpu.cpp:124-134)
+template <int RED> __device__ __forceinline__ float slab_ident() {
+  if constexpr (RED == GEOT_REDUCE_MAX) return -INFINITY;
+  else if constexpr (RED == GEOT_REDUCE_MIN) return INFINITY;
+  else return 0.f;
+}
+template <int RED> __device__ __forceinline__ float slab_op(float x, float y) {
+  if constexpr (RED == GEOT_REDUCE_MAX) return (y != y) ? y : (x < y ? y : x);
+  else if constexpr (RED == GEOT_REDUCE_MIN) return (y != y) ? y : (y < x ? y : x);
+  else return x + y;
+}
+template <int RED> __device__ __forceinline__ void slab_acc(f4_t &acc, const f4_t &m) {
+  if constexpr (RED == GEOT_REDUCE_SUM || RED == GEOT_REDUCE_MEAN) acc += m;
+  else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = slab_op<RED>(acc[i], m[i]);
+  }
+}
+
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // WAVE_ROW: rows of 1 KiB - the whole wave is one unit, edge fields are read with v_readlane (scalar row bases)
 //
@@ -68,8 +88,9 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 //   * rows are gathered kU at a time; the fields of the batch (row number, row in group, weight) are fetched
 //     BEFORE the loads are issued; the accumulate loop's only LDS traffic is one 16-byte write + read per lane when
 //     the row changes (the open row is kept in registers).
-template <int WMODE, bool WAVE_ROW>
+template <int WMODE, bool WAVE_ROW, int RED>
 __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
+  constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     const int64_t e0 = has ? P.g_begin[pos] : 0;
     const int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
     const int nv = has ? P.g_nv[pos] : 0;
-    for (int l = 0; l < R; ++l) accV[(size_t)l * lpr + c] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < R; ++l) accV[(size_t)l * lpr + c] = f4_t{kIdent, kIdent, kIdent, kIdent};
     int maxlen = len;
     if constexpr (!WAVE_ROW) {
       for (int o = 32; o >= lpr; o >>= 1) {         // max over the wave's units (wave-uniform loop bound)
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         maxlen = other > maxlen ? other : maxlen;
       }
     }
-    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f4_t acc = {kIdent, kIdent, kIdent, kIdent};
     int cur = 255;                                   // no open row
 
     // fields of the first chunk, its weights into buffer 0
@@ -230,10 +251,12 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
           if (dls[u] != cur) {                       // the open row goes back to LDS, the new one comes out of it
             if (cur != 255) accV[(size_t)cur * lpr + c] = acc;
             cur = dls[u];
-            acc = cur != 255 ? accV[(size_t)cur * lpr + c] : f4_t{0.f, 0.f, 0.f, 0.f};
+            acc = cur != 255 ? accV[(size_t)cur * lpr + c] : f4_t{kIdent, kIdent, kIdent, kIdent};
           }
-          if constexpr (WMODE == 0) acc += v[u];
-          else acc += v[u] * ws[u];
+          if (dls[u] != 255) {                       // (padding slots of a short unit carry no edge)
+            if constexpr (WMODE == 0) slab_acc<RED>(acc, v[u]);
+            else slab_acc<RED>(acc, v[u] * ws[u]);
+          }
         }
       }
       // stage the next chunk
@@ -260,7 +283,10 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       const int64_t v0 = P.g_vrow0[pos];
       for (int l = 0; l < nv; ++l) {
         const int64_t t = P.v_out[v0 + l];
-        const f4_t row = accV[(size_t)l * lpr + c];
+        f4_t row = accV[(size_t)l * lpr + c];
+        if constexpr (RED == GEOT_REDUCE_MEAN) {
+          if (t >= 0) row = row / (float)P.v_total[v0 + l];   // pieces of a split row are divided after the combine
+        }
         if (t >= 0) {
           if (t < p.K) *reinterpret_cast<f4_t *>(dst + t * p.F + c * 4) = row;
         } else {
@@ -273,6 +299,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
 }
 
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row)
+template <int RED>
 __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p) {
   const geot_slab_plan &P = p.plan;
   const int lpr = 1 << p.lpr_log2;
@@ -282,8 +309,10 @@ __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p
     const int64_t row = P.c_row[s];
     const int64_t first = P.c_first[s];
     const int n = P.c_count[s];
-    f4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < n; ++i) acc += *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * 4);
+    constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
+    f4_t acc = {kIdent, kIdent, kIdent, kIdent};
+    for (int i = 0; i < n; ++i) slab_acc<RED>(acc, *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * 4));
+    if constexpr (RED == GEOT_REDUCE_MEAN) acc = acc / (float)P.c_total[s];
     if (row >= 0 && row < p.K) *reinterpret_cast<f4_t *>(static_cast<float *>(p.dst) + row * p.F + c * 4) = acc;
   }
 }
@@ -318,12 +347,17 @@ size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total)
 }
 
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
-                   int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, void *workspace,
+                   int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce, void *workspace,
                    size_t workspace_bytes, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!plan || !src || !dst) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: null pointer");
   if (dtype != GEOT_F32) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: float32 only");
   if (heads < 1 || feat < 1 || out_rows < 0) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: bad sizes");
+  if (reduce != GEOT_REDUCE_SUM && reduce != GEOT_REDUCE_MEAN && reduce != GEOT_REDUCE_MAX && reduce != GEOT_REDUCE_MIN)
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: reduce must be sum, mean, max or min");
+  if (reduce != GEOT_REDUCE_SUM && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: multi-head weights reduce with sum only");
+  if (reduce == GEOT_REDUCE_MEAN && (!plan->v_total || (plan->n_split > 0 && !plan->c_total)))
+    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: mean needs the plan's edge counts (v_total, c_total)");
   if (weight_mode < 0 || weight_mode > 3 || (weight_mode != 0 && !weight))
     return geot_internal_fail(GEOT_EINVAL, "slab_spmm: weight_mode 0..3 (and a weight pointer for 1..3)");
   const int64_t F = heads * feat;
@@ -375,22 +409,35 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group)");
     const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
     const bool wave_row = lpr_log2 == 6;
-#define GEOT_SLAB_LAUNCH(W)                                                                             \
-  if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<W, true>), grid, blk, lds, st, p);                  \
-  else hipLaunchKernelGGL((seg_slab_kernel<W, false>), grid, blk, lds, st, p)
+#define GEOT_SLAB_LAUNCH(W, RED_)                                                                             \
+  if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<W, true, RED_>), grid, blk, lds, st, p);                  \
+  else hipLaunchKernelGGL((seg_slab_kernel<W, false, RED_>), grid, blk, lds, st, p)
+#define GEOT_SLAB_RED(W)                                                                                      \
+  switch (reduce) {                                                                                           \
+  case GEOT_REDUCE_MEAN: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_MEAN); break;                                        \
+  case GEOT_REDUCE_MAX: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_MAX); break;                                          \
+  case GEOT_REDUCE_MIN: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_MIN); break;                                          \
+  default: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_SUM); break;                                                       \
+  }
     switch (weight_mode) {
-    case 0: GEOT_SLAB_LAUNCH(0); break;
-    case 1: GEOT_SLAB_LAUNCH(1); break;
-    case 2: GEOT_SLAB_LAUNCH(2); break;
-    default: GEOT_SLAB_LAUNCH(3); break;
+    case 0: GEOT_SLAB_RED(0) break;
+    case 1: GEOT_SLAB_RED(1) break;
+    case 2: GEOT_SLAB_LAUNCH(2, GEOT_REDUCE_SUM); break;
+    default: GEOT_SLAB_LAUNCH(3, GEOT_REDUCE_SUM); break;
     }
+#undef GEOT_SLAB_RED
 #undef GEOT_SLAB_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
     if (plan->n_split > 0) {
       int64_t blocks = (plan->n_split + (kThreads >> lpr_log2) - 1) / (kThreads >> lpr_log2);
       if (blocks > 1024) blocks = 1024;
-      hipLaunchKernelGGL(seg_slab_combine_kernel, dim3((unsigned)blocks), blk, 0, st, p);
+      switch (reduce) {
+      case GEOT_REDUCE_MEAN: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_MEAN>, dim3((unsigned)blocks), blk, 0, st, p); break;
+      case GEOT_REDUCE_MAX: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_MAX>, dim3((unsigned)blocks), blk, 0, st, p); break;
+      case GEOT_REDUCE_MIN: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_MIN>, dim3((unsigned)blocks), blk, 0, st, p); break;
+      default: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_SUM>, dim3((unsigned)blocks), blk, 0, st, p); break;
+      }
       e = hipGetLastError();
       if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
     }

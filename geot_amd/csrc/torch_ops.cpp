@@ -390,8 +390,10 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
   const int64_t n_carry = V > 0 ? split_v.sum().item<int64_t>() : 0;
   auto nonempty_t = [&](at::Tensor t) { return t.numel() ? t : at::zeros({1}, t.options()); };
   at::Tensor g_begin_t = to_dev(g_begin, at::kLong), g_v0_t = to_dev(g_v0_sorted, at::kInt), g_nv_t = to_dev(g_nv_sorted, at::kInt);
+  at::Tensor v_total = counts.index_select(0, v_row).to(at::kInt).contiguous();      // edges of the virtual row's whole dst row
+  at::Tensor c_total = counts.index_select(0, split_rows).contiguous();
   H->keep = {nonempty_t(e_src), nonempty_t(e_dl), nonempty_t(e_perm), g_begin_t, g_v0_t, g_nv_t, nonempty_t(v_out),
-             nonempty_t(split_rows), nonempty_t(c_first), nonempty_t(c_count)};
+             nonempty_t(split_rows), nonempty_t(c_first), nonempty_t(c_count), nonempty_t(v_total), nonempty_t(c_total)};
   geot_slab_plan &P = H->plan;
   P.e_src = H->keep[0].data_ptr<int32_t>();
   P.e_dl = H->keep[1].data_ptr<uint8_t>();
@@ -403,6 +405,8 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
   P.c_row = H->keep[7].data_ptr<int64_t>();
   P.c_first = H->keep[8].data_ptr<int64_t>();
   P.c_count = H->keep[9].data_ptr<int32_t>();
+  P.v_total = H->keep[10].data_ptr<int32_t>();
+  P.c_total = H->keep[11].data_ptr<int64_t>();
   P.n_groups = G;
   P.n_vrows = V;
   P.n_carry = n_carry;
@@ -471,9 +475,10 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   return plan;
 }
 
-void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat) {
+void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
+              int red = GEOT_REDUCE_SUM) {
   auto &ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
-  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), GEOT_F32,
+  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), GEOT_F32, red,
                            ws.data_ptr(), ws.numel(), stream_of(src)));
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.slab_calls;
@@ -579,9 +584,9 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
   const int64_t nnz = e.di.numel(), feat = x.size(1);
   auto launch = [&](int64_t rows) {
     at::Tensor o = at::empty({rows, feat}, x.options());
-    if (red == GEOT_REDUCE_SUM && !e.permuted) {
+    if (red != GEOT_REDUCE_PROD && !e.permuted) {      // dense graphs: sum / mean / max / min on the source-blocked kernel
       if (auto plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1)) {
-        run_slab(*plan, has_w ? e.w.data_ptr() : nullptr, has_w ? 1 : 0, x, o, 1, feat);
+        run_slab(*plan, has_w ? e.w.data_ptr() : nullptr, has_w ? 1 : 0, x, o, 1, feat, red);
         return o;
       }
     }

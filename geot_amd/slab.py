@@ -49,7 +49,7 @@ def worthwhile(nnz: int, out_rows: int, src_rows: int, rowbytes: int) -> bool:
     return bool(torch.ops.geot._slab_worthwhile(nnz, out_rows, src_rows, rowbytes))
 
 
-_FIELDS = ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out", "c_row", "c_first", "c_count")
+_FIELDS = ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out", "c_row", "c_first", "c_count", "v_total", "c_total")
 _SCALARS = ("n_groups", "n_vrows", "n_carry", "n_split", "nnz", "units", "rows_per_group")
 
 
@@ -74,8 +74,9 @@ def build_plan(src_index: torch.Tensor, dst_index: torch.Tensor, out_rows: int, 
 
 
 def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: int, src: torch.Tensor, out: torch.Tensor,
-                  heads: int, feat: int) -> torch.Tensor:
-    """out[d, h, :] = sum_e w(e, h) * src[s[e], h, :] over the plan's edges (pointer-level doorway)."""
+                  heads: int, feat: int, reduce: str = "sum") -> torch.Tensor:
+    """out[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges (pointer-level doorway);
+    reduce: 'sum' | 'mean' | 'max' | 'min' (weight modes 0 / 1)."""
     tensors = [src, out] + ([weight] if weight is not None else [])
     dev = hip._require_gpu(*tensors)
     if src.dtype != torch.float32:
@@ -87,6 +88,6 @@ def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: i
         ws = hip.workspace(dev, nbytes, st)
         rc = L.geot_slab_spmm(ctypes.byref(plan.struct), None if weight is None else weight.data_ptr(), weight_mode,
                               src.data_ptr(), out.data_ptr(), heads, feat, src.shape[0], out.shape[0], _lib.GEOT_F32,
-                              ws.data_ptr(), ws.numel(), st)
+                              hip._REDUCE_CODES[reduce], ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "geot_slab_spmm")
     return out

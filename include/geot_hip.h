@@ -188,6 +188,8 @@ typedef struct geot_slab_plan {
   const int64_t *c_row;
   const int64_t *c_first;
   const int32_t *c_count;
+  const int32_t *v_total; /* per virtual row: edges of its WHOLE dst row (mean); may be NULL for sum / max / min */
+  const int64_t *c_total; /* per split row: its edge count (mean) */
   int64_t n_groups, n_vrows, n_carry, n_split, nnz;
   int32_t units, rows_per_group;
   int32_t slab_shift, n_slabs; /* the plan's slabs: source row >> slab_shift, n_slabs of them (0 / 0: unknown -> no pacing) */
@@ -196,12 +198,14 @@ typedef struct geot_slab_plan {
 int geot_slab_units(void);                                     /* waves of the persistent grid */
 int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget */
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
-/* dst[d, h, :] = sum_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
+/* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
  * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts).
+ * reduce: GEOT_REDUCE_SUM | MEAN | MAX | MIN over the messages of a row (weight modes 0 / 1; the multi-head modes sum) -
+ * the aggregations PyG call sites forward (GraphSAGE mean / max on Reddit-like graphs).
  * float32, rows (heads * feat * 4 bytes) of 256 / 512 / 1024 bytes.  dst is written in full. */
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
-                   int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, void *workspace,
-                   size_t workspace_bytes, void *stream);
+                   int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
  * With profiling on, every segment-reduction call records hipEvents around its kernels on

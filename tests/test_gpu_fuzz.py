@@ -121,7 +121,13 @@ def test_fuzz_source_blocked_kernel(oracle, seed):
                 hi = oracle.gather_scatter(si, di, x, acc64=True)
                 mag = oracle.gather_scatter(si, di, np.abs(x), acc64=True)
                 assert close(geot.gather_scatter(t(si), t(di), t(x)), hi, mag), (seed, nnz, Fh, "gs")
-                assert ops.stats()["slab_calls"] == calls + 2
+                red = str(rng.choice(["mean", "max", "min"]))
+                kind = {"max": "amax", "min": "amin"}.get(red, red)
+                msg = t(x)[t(si)] * t(w)[:, None]
+                ref = torch.zeros(hi.shape[0], Fh, device="cuda").scatter_reduce(0, t(di)[:, None].expand(-1, Fh), msg, kind, include_self=False)
+                got = geot.gather_weight_scatter(t(si), t(di), t(w), t(x), red)
+                assert got.shape == ref.shape and (torch.equal(got, ref) if red != "mean" else torch.allclose(got, ref, rtol=1e-4, atol=1e-5)), (seed, nnz, Fh, red)
+                assert ops.stats()["slab_calls"] == calls + 3
             else:
                 wh = rng.random((nnz, H), dtype=np.float32)
                 hi = oracle.mh_spmm(si, di, wh, x3, acc64=True)

@@ -140,3 +140,52 @@ def test_host_layer_routes_dense_graphs_on_the_second_call(geot, oracle, monkeyp
     xg = torch.zeros(n2, F, device="cuda").index_add(0, si2, w2.detach()[:, None].expand(-1, F).contiguous())
     assert torch.allclose(x2.grad, xg, rtol=1e-4, atol=1e-4)
     assert torch.allclose(gs, torch.zeros(n2, F, device="cuda").index_add(0, di2, x2.detach()[si2]), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("reduce", ["mean", "max", "min", "sum", "add"])
+def test_slab_reductions_match_the_per_edge_kernels(geot, reduce):
+    """GraphSAGE-style mean / max aggregation on a dense graph: the source-blocked kernel (forced here) against
+    torch.scatter_reduce over the materialised messages and against the per-edge kernels; a hub that is split into
+    carry pieces and an empty row included."""
+    from geot_amd import ops
+    rng = np.random.default_rng(21)
+    nodes, nnz, F = 30_000, 2_000_000, 128
+    di_h = powerlaw_index(nnz, nodes, 6)
+    di_h[: nnz // 4] = di_h[nnz // 4]
+    di_h = np.sort(di_h)
+    di_h[di_h == 9] = 10
+    si, di = dev(rng.integers(0, nodes, nnz).astype(np.int64)), dev(di_h)
+    x = dev(rng.standard_normal((nodes, F)).astype(np.float32))
+    w = dev(rng.random(nnz, dtype=np.float32) + 0.5)
+    kind = {"add": "sum", "max": "amax", "min": "amin"}.get(reduce, reduce)
+    for weight in (None, w):
+        msg = x[si] if weight is None else x[si] * weight[:, None]
+        if reduce in ("max", "min"):
+            ref = torch.zeros(nodes, F, device="cuda").scatter_reduce(0, di[:, None].expand(-1, F), msg, kind, include_self=False)
+        else:                                  # float64 reference + the magnitude the fp32 error bound scales with
+            ref = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, di, msg.double())
+            mag = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, di, msg.double().abs())
+            if reduce == "mean":
+                cnt = torch.bincount(di, minlength=nodes).clamp(min=1).double()[:, None]
+                ref, mag = ref / cnt, mag / cnt
+        del msg
+        run = (lambda: geot.gather_scatter(si, di, x, reduce)) if weight is None else (lambda: geot.gather_weight_scatter(si, di, weight, x, reduce))
+        old = ops.set_option("slab_mode", "always")
+        calls = ops.stats()["slab_calls"]
+        try:
+            out = run()
+            again = run()
+        finally:
+            ops.set_option("slab_mode", "never")
+        assert ops.stats()["slab_calls"] == calls + 2
+        try:
+            tile = run()                                                  # the per-edge kernels on the same inputs
+        finally:
+            ops.set_option("slab_mode", old)
+        assert torch.equal(out, again)
+        if reduce in ("max", "min"):
+            assert torch.equal(out, ref) and torch.equal(out, tile)
+        else:
+            bound = 1e-5 * mag + 1e-30
+            assert bool(((out.double() - ref).abs() <= bound).all()) and bool(((tile.double() - ref).abs() <= bound).all())
+        assert out[9].abs().sum().item() == 0                             # the empty row
