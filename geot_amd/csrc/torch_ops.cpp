@@ -687,6 +687,36 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
   return out;
 }
 
+// CSR row pointers -> per-edge row ids, once per indptr content (the COO form is what every kernel consumes; with it a
+// CSR call shares the index facts, the row-count handling and the source-blocked path of the COO ops)
+struct ExpandedEntry {
+  ContentKey key;
+  at::Tensor indptr, dst_index;
+};
+std::list<ExpandedEntry> g_expanded;
+
+at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
+  ContentKey k;
+  const bool keyed = g_opt.trust_version && content_key(indptr, &k);
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_expanded.begin(); it != g_expanded.end(); ++it)
+      if (it->key == k && it->dst_index.numel() == nnz) {
+        g_expanded.splice(g_expanded.begin(), g_expanded, it);
+        return g_expanded.front().dst_index;
+      }
+  }
+  const int64_t nrow = indptr.numel() - 1;
+  at::Tensor counts = (indptr.slice(0, 1, nrow + 1) - indptr.slice(0, 0, nrow)).clamp_min(0);
+  at::Tensor dst_index = at::repeat_interleave(counts, c10::optional<int64_t>(nnz));
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_expanded.push_front(ExpandedEntry{k, indptr, dst_index});
+    while (g_expanded.size() > 4) g_expanded.pop_back();
+  }
+  return dst_index;
+}
+
 // csrc/csr_gws.cpp:24-35: any integer dtype for indptr / indices; indptr.size(0) output rows (the last one always zero)
 at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in, const at::Tensor &weight_in, const at::Tensor &src_in) {
   TORCH_CHECK(indptr_in.dim() == 1 && indices_in.dim() == 1, "indptr and indices must be 1 dimensional");
@@ -697,6 +727,12 @@ at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in,
               toString(weight_in.scalar_type()));
   GEOT_DEVICE_GUARD(src_in);
   at::Tensor indptr = as_int64(indptr_in), indices = as_int64(indices_in);
+  if (g_opt.slab_mode >= 0 && indices.numel() > 0 && indptr.numel() >= 2 && src_in.scalar_type() == at::kFloat) {
+    // a graph dense enough for the source-blocked kernel: go through the COO path (row ids expanded once per indptr)
+    const int64_t rowbytes = src_in.size(1) * 4;
+    if (g_opt.slab_mode == 1 || slab_worthwhile(indices.numel(), indptr.size(0), src_in.size(0), rowbytes))
+      return gather_common("csr_gws_impl", indices, expand_indptr(indptr, indices.numel()), weight_in, src_in, GEOT_REDUCE_SUM, indptr.size(0));
+  }
   at::Tensor weight = weight_in.contiguous(), src = src_in.contiguous();
   const int64_t rows = indptr.size(0), nnz = indices.size(0), feat = src.size(1);
   at::Tensor out = at::empty({rows, feat}, src.options());
@@ -772,6 +808,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
     g_slab.clear();
     g_sightings.clear();
     g_widened.clear();
+    g_expanded.clear();
     return 0;
   }
   TORCH_CHECK(p, "unknown host option ", name);

@@ -53,6 +53,33 @@ def test_csr_gws_hip(oracle, nrow, nnz, F, empty_tail):
 
 
 @pytest.mark.gpu
+def test_csr_gws_dense_graph_takes_the_source_blocked_path(oracle):
+    """A CSR call on a graph the density rule accepts (forced here) goes through the COO path: row ids expanded once per
+    indptr content, then the source-blocked kernel; same rows (indptr.size(0), the last one zero) and values."""
+    import geot_amd as geot
+    from geot_amd import ops
+    rng = np.random.default_rng(11)
+    nrow, nnz, F = 4000, 300_000, 64
+    dst, col, w, src, rowptr = make_csr(rng, nrow, nnz, F, empty_tail=300)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    args = (t(rowptr), t(col), t(w), t(src))
+    base = geot.csr_gws(*args)
+    old = ops.set_option("slab_mode", "always")
+    try:
+        calls = ops.stats()["slab_calls"]
+        out = geot.csr_gws(*args)
+        out32 = geot.csr_gws(args[0].int(), args[1].int(), args[2], args[3])
+        assert ops.stats()["slab_calls"] == calls + 2
+    finally:
+        ops.set_option("slab_mode", old)
+    assert out.shape == (nrow + 1, F) and out[nrow - 300:].abs().sum().item() == 0
+    hi = oracle.csr_gws(rowptr, col, w, src, acc64=True)
+    got = out.cpu().numpy()
+    assert np.all(np.abs(got - hi) <= 1e-5 * np.abs(hi) + 1e-30) and np.all(got[hi == 0] == 0)
+    assert torch.allclose(out, base, rtol=1e-5, atol=1e-6) and torch.equal(out32, out)
+
+
+@pytest.mark.gpu
 def test_coo_to_csr_hip(oracle):
     import geot_amd as geot
     from geot_amd import hip
