@@ -86,6 +86,45 @@ def test_equal_edge_cuts_with_boundary_exchange(name, world):
     np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)
 
 
+def test_eight_ranks_hub_over_many_ranks_and_tiny_shards():
+    """The world size of BASELINE.json configs[4]: a hub that covers ranks 2..5 completely (their whole shard lies inside
+    one run owned by rank 1), then 8 ranks with TWO edges each."""
+    from oracle import api
+    rng = np.random.default_rng(8)
+    hub = np.sort(np.concatenate([rng.integers(0, 5, 700), np.full(5000, 5), rng.integers(6, 40, 1500)])).astype(np.int64)
+    case = dict(index=hub, src=rng.random((len(hub), 4), dtype=np.float32))
+    res = _run(case, 8, aligned=False)
+    full = api.index_scatter(case["index"], case["src"], acc64=True)
+    got = np.concatenate([o for _, _, o in res])
+    assert got.shape == full.shape and sum(o.shape[0] for _, _, o in res) == full.shape[0]
+    np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-5)
+    assert any(o.shape[0] == 0 for _, _, o in res)                      # ranks inside the hub own no row
+    row = 0
+    for _, first_row, out in res:
+        assert first_row == row or out.shape[0] == 0
+        row += out.shape[0]
+    tiny = dict(index=np.array([0, 0, 0, 1, 1, 1, 1, 1, 4, 4, 4, 9, 9, 9, 9, 9], dtype=np.int64),
+                src=rng.random((16, 3), dtype=np.float32))
+    res = _run(tiny, 8, aligned=False)
+    np.testing.assert_allclose(np.concatenate([o for _, _, o in res]), api.index_scatter(tiny["index"], tiny["src"], acc64=True),
+                               rtol=1e-6, atol=1e-6)
+
+
+def test_boundary_plan_table():
+    """The ownership rules on their own (every rank computes the same table from the gathered keys)."""
+    from geot_amd.sharding import boundary_plan
+    firsts, lasts = [0, 5, 5, 5, 9], [5, 5, 5, 7, 12]                    # key 5 runs from rank 0 into rank 3
+    p0, p1, p2, p3, p4 = (boundary_plan(firsts, lasts, r) for r in range(5))
+    assert p0["owns_first"] and p0["joins"] == [1, 2, 3] and p0["first_row"] == 0 and p0["any_shared"]
+    assert not p1["owns_first"] and p1["joins"] == [] and p1["first_row"] == 6
+    assert not p2["owns_first"] and p2["joins"] == []
+    assert not p3["owns_first"] and p3["joins"] == [] and p3["first_row"] == 6
+    assert p4["owns_first"] and p4["gap"] == 1 and p4["first_row"] == 8 and p4["joins"] == []
+    q = [boundary_plan([0, 4, 9], [3, 8, 9], r) for r in range(3)]       # segment-aligned cuts: nothing shared
+    assert not any(x["any_shared"] for x in q) and all(x["owns_first"] and x["joins"] == [] for x in q)
+    assert [x["gap"] for x in q] == [0, 0, 0] and [x["first_row"] for x in q] == [0, 4, 9]
+
+
 @pytest.mark.parametrize("name", ["uniform", "gaps_and_offset"])
 def test_segment_aligned_cuts_need_no_exchange(name):
     from oracle import api
