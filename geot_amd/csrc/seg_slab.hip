@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
             cur = dls[u];
             acc = cur != 255 ? accV[(size_t)cur * lpr + c] : f4_t{kIdent, kIdent, kIdent, kIdent};
           }
-          if (dls[u] != 255) {                       // (padding slots of a short unit carry no edge)
+          // padding slots of a short unit (dl = 255): their sum goes to a row that is never written back, but a
+          // max / min must not see their value at all
+          if ((RED != GEOT_REDUCE_MAX && RED != GEOT_REDUCE_MIN) || dls[u] != 255) {
             if constexpr (WMODE == 0) slab_acc<RED>(acc, v[u]);
             else slab_acc<RED>(acc, v[u] * ws[u]);
           }

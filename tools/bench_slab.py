@@ -46,7 +46,7 @@ def main():
         t_base = device_ms(base, 3, warmup=1)
         print(f"{name}: nodes={nodes} nnz={nnz} rowbytes={H * Fh * 4} worthwhile={slab.worthwhile(nnz, nodes, nodes, H * Fh * 4)}  "
               f"per-edge gather kernel {t_base:.3f} ms", flush=True)
-        for slab_mib, blocks in ((2.0, 3), (2.0, 2)):
+        for slab_mib, blocks in ((2.0, 3), (2.0, 3)):
             hip.set_option("slab_blocks", blocks)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -54,7 +54,7 @@ def main():
             torch.cuda.synchronize()
             t_plan = time.perf_counter() - t0
             times = {}
-            for window in (-1, 1, 2, 3):
+            for window in (-1, 2, -2, 2):
                 hip.set_option("slab_window", window)
                 times[window] = device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 3, warmup=1)
             hip.set_option("slab_window", -2)
@@ -62,7 +62,7 @@ def main():
             base()
             err = ((out - ref).abs().max() / ref.abs().max()).item()
             best = min(times.values())
-            print(f"   slab {slab_mib} MiB, {blocks} workgroups per CU: window(-1=free,1,2,3) " + " ".join(f"{times[k]:.3f}" for k in (-1, 1, 2, 3)) +
+            print(f"   slab {slab_mib} MiB, {blocks} workgroups per CU: window(-1=free,2,rule) " + " ".join(f"{times[k]:.3f}" for k in (-1, 2, -2)) +
                   f" ms  best {t_base / best:.2f}x  phase A {t_plan * 1e3:.0f} ms  plan {plan.nbytes() / 1e6:.0f} MB  "
                   f"max rel diff {err:.1e}  {plan.meta}", flush=True)
             del plan

@@ -123,7 +123,7 @@ except Exception:
 want = {"gws_cfg3 (gather_weight_scatter, 124 M edges, F=128)": ("seg_tile_kernel<float, 4, true, 1,", "gws_cfg3"),
         "mh_spmm_cfg4 [nnz,H] (115 M edges, H=4 F=64)": ("seg_tile_kernel<float, 4, true, 2,", "mh_spmm_cfg4"),
         "mh_spmm_cfg4 [H,nnz]": ("seg_tile_kernel<float, 4, true, 3,", "mh_spmm_cfg4"),
-        "mh_spmm_cfg4 source-blocked (seg_slab_kernel<2, true>)": ("seg_slab_kernel<2, true>", "mh_spmm_cfg4"),
+        "mh_spmm_cfg4 source-blocked (seg_slab_kernel<2, true, sum>)": ("seg_slab_kernel<2, true,", "mh_spmm_cfg4"),
         "rocSPARSE csr_nnz_split on the cfg3 matrix": ("csrmmnt_nnz_split_main_kernel", "gws_cfg3"),
         "rocSPARSE csr_merge_path on the cfg3 matrix": ("csrmmnt_merge_path_main_kernel", "gws_cfg3"),
         "rocSPARSE csr_row_split on the cfg3 matrix": ("csrmmnt_row_split", "gws_cfg3")}
