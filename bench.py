@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["cfg2", "cfg5"], default="cfg2")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink cfg5 / the secondary workloads (tests)")
+    ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the 10 M-edge problem split over the ranks)")
+    ap.add_argument("--cuts", choices=["equal", "aligned"], default="equal",
+                    help="N > 1: equal = neighbouring shards share their boundary key (one small all_gather of partial rows per "
+                         "step); aligned = segment-aligned cuts, no data-path collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     return ap.parse_args()
@@ -274,12 +278,14 @@ def main():
     timing = {}
     if args.workload == "cfg2":
         nnz, rows, feat = NNZ, KEYS, FEAT
-        index = powerlaw_index(nnz, rows, seed=rank, device=dev)          # rank-local keys 0..KEYS-1
+        if args.strong and distributed:
+            nnz, rows = NNZ // world, KEYS // world
+        index = powerlaw_index(nnz, rows, seed=rank, device=dev)          # rank-local keys 0..rows-1
         gen = torch.Generator(device=dev)
         gen.manual_seed(1000 + rank)
         src = torch.rand(nnz, feat, device=dev, generator=gen)
         alg = algorithmic_bytes(nnz, feat, rows)
-        key_offset = rank * (rows - 1)                                     # neighbours share one key
+        key_offset = rank * (rows - 1) if args.cuts == "equal" else rank * rows   # equal: neighbours share one key
         if distributed:
             def step():
                 return sharding.sharded_index_scatter(index, src, key_offset=key_offset, timing=timing)[0]
@@ -305,7 +311,7 @@ def main():
         src = torch.rand(nodes_all, feat, device=dev, generator=gen)
         uniq = int(torch.unique(src_index).numel())
         alg = nnz * 16 + uniq * 4 * feat + rows * 4 * feat                 # compulsory bytes
-        key_offset = rank * (rows - 1)
+        key_offset = rank * (rows - 1) if args.cuts == "equal" else rank * rows
         if distributed:
             def step():
                 return sharding.sharded_gather_scatter(src_index, index, src, key_offset=key_offset, timing=timing)[0]
@@ -369,7 +375,7 @@ def main():
         res = {
             "metric": metric, "value": edges_per_s, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if (args.strong and distributed) else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "nnz_per_gpu": nnz, "rows_per_gpu": rows, "feat": feat,
                        "index_dtype": "int64", "step": step_desc},
@@ -384,7 +390,8 @@ def main():
                          "frac_of_box_read_ceiling": achieved / box["read_ceiling_gbps"]},
         }
         if distributed:
-            res["boundary_exchange_ms"] = exchange_ms      # rank 0: all_gather of first-row partials + owner adds
+            res["boundary_exchange_ms"] = exchange_ms      # rank 0: all_gather of first-row partials + owner adds (None: no key shared)
+            res["cuts"] = args.cuts
             res["dist_backend"] = backend
         if not distributed and args.workload == "cfg2" and not args.no_cpu_baseline:
             try:
