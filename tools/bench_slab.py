@@ -44,9 +44,15 @@ def main():
             w = None
             base = lambda: hip.gather_scatter_out(si, di, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
         t_base = device_ms(base, 3, warmup=1)
+        roc = ""
+        if wmode == 1:      # the comparator of the north star on THIS graph too
+            from tools import rocsparse
+            best, table, y = rocsparse.best_csr_spmm(di, si, w, x.view(nodes, Fh), nodes, iters=3, algs=("csr_nnz_split", "csr_merge_path"))
+            roc = "  | rocSPARSE CSR SpMM on this matrix: " + ", ".join(f"{r['algorithm']} {r['ms']:.3f} ms" for r in table if r['ms'])
+            del y
         print(f"{name}: nodes={nodes} nnz={nnz} rowbytes={H * Fh * 4} worthwhile={slab.worthwhile(nnz, nodes, nodes, H * Fh * 4)}  "
-              f"per-edge gather kernel {t_base:.3f} ms", flush=True)
-        for slab_mib, blocks in ((2.0, 3), (2.0, 3)):
+              f"per-edge gather kernel {t_base:.3f} ms{roc}", flush=True)
+        for slab_mib, blocks in ((2.0, 3),):
             hip.set_option("slab_blocks", blocks)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
