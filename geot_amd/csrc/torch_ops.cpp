@@ -302,7 +302,9 @@ bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t ro
   const int64_t units = (int64_t)geot_slab_units() * (1024 / rowbytes);
   const int64_t rpg = geot_slab_rows_per_group(1, 1);
   const int64_t rounds = std::max<int64_t>(1, (out_rows + rpg * units - 1) / (rpg * units));
-  return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= 4.0;
+  // uses of a source row per XCD and round; measured (profiles/r02/bench_slab_density_rule.txt, 120 M edges): 10 -> 1.50x,
+  // 4.8 -> 1.34x, 2.8 -> 1.22x, 1.6 -> 1.09x, 0.8 -> 0.86x at 512-B rows; 8.8 -> 2.08x, 2.4 -> 1.62x, 1.0 -> 1.13x at 1 KiB
+  return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= 2.0;
 }
 
 // dst_index ascending.  Device scans / one stable sort, plus one host loop over the virtual rows.

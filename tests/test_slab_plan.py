@@ -90,5 +90,9 @@ def test_density_rule():
     assert slab.worthwhile(114_615_892, 232_965, 232_965, 1024)          # BASELINE.json configs[3]: Reddit scale
     assert not slab.worthwhile(123_718_280, 2_449_029, 2_449_029, 512)   # configs[2]: ogbn-products scale
     assert not slab.worthwhile(201_960_734, 13_882_494, 111_059_956, 512)  # configs[4] shard
+    assert slab.worthwhile(120_000_000, 450_000, 450_000, 1024)          # measured 1.62x
+    assert slab.worthwhile(120_000_000, 600_000, 600_000, 512)           # measured 1.22x
+    assert not slab.worthwhile(120_000_000, 800_000, 800_000, 512)       # measured 1.09x: not worth a 1 GB plan
+    assert not slab.worthwhile(100_000_000, 1_000_000, 1_000_000, 512)   # measured 0.86x
     assert not slab.worthwhile(114_615_892, 232_965, 232_965, 1000)      # rows must be 256 / 512 / 1024 bytes
     assert not slab.worthwhile(1_000_000, 2000, 2000, 256)               # small problems stay on the tile kernel

@@ -19,6 +19,7 @@ from geot_amd import hip, slab  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--rule", action="store_true", help="density sweep around the routing threshold (gws F=128, 120 M edges)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     print(hip.build_info())
@@ -26,6 +27,9 @@ def main():
              ("cfg4 graph, gws F=128", int(232_965 * a.scale), int(114_615_892 * a.scale), 1, 128, 1),
              ("cfg4 graph, gs F=64", int(232_965 * a.scale), int(114_615_892 * a.scale), 1, 64, 0),
              ("1M nodes x deg 100, gws F=128", int(1_000_000 * a.scale), int(100_000_000 * a.scale), 1, 128, 1)]
+    if a.rule:
+        cases = [(f"{n // 1000}k nodes x 120M edges, gws F=128", n, 120_000_000, 1, 128, 1) for n in (300_000, 450_000, 600_000, 800_000)] + \
+                [(f"{n // 1000}k nodes x 120M edges, mh H=4 F=64", n, 120_000_000, 4, 64, 2) for n in (450_000, 700_000)]
     for name, nodes, nnz, H, Fh, wmode in cases:
         di = powerlaw_index(nnz, nodes, 11, dev)
         g = torch.Generator(device=dev)
