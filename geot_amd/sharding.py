@@ -71,6 +71,16 @@ def _pinned_slot(dev: torch.device, world: int):
     return slot
 
 
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    streams = getattr(_tls, "side", None)
+    if streams is None:
+        streams = _tls.side = {}
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=dev)
+    return streams[key]
+
+
 def _ident(index: torch.Tensor, world: int, rank: int, key_offset):
     try:
         version = index._version
@@ -125,7 +135,7 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
 
     Protocol (the host never waits for the local reduction, the GPU never waits for the host):
       1. KEYS FIRST: an all_gather of every rank's (first_key, last_key) - 16 bytes per rank, independent of the
-         reduction - is queued in front of the local kernels and copied to the host underneath them;
+         reduction - runs on a side stream beside the local kernels and is copied to the host underneath them;
       2. the local kernels are launched for the REMEMBERED row count of this index tensor while those keys are
          in flight; when they arrive the guess is verified (a mismatch relaunches the local kernels only);
       3. every rank now knows every boundary: if no key is shared by two ranks (segment-aligned cuts) the call
@@ -158,25 +168,31 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     if ends_dev.numel() == 1:
         ends_dev = ends_dev.expand(2)
 
-    # ---- 1. keys of every rank (tiny collective, queued before the local kernels) -------------------------
-    if world > 1:
-        # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or test ranks sharing
-        # one GPU) stages the few bytes through the host
-        via_host = on_gpu and dist.get_backend(group) == "gloo"
-        mine = (ends_dev + off) if off else ends_dev.contiguous()
-        send = mine.cpu() if via_host else mine
-        allkeys = torch.empty(2 * world, dtype=torch.int64, device=send.device)
-        dist.all_gather_into_tensor(allkeys, send, group=group)
-    else:
-        via_host = False
-        allkeys = (ends_dev + off) if off else ends_dev
+    # ---- 1. keys of every rank: a tiny collective on a SIDE stream, so the local kernels do not queue behind it ------
+    # RCCL ("nccl") moves device tensors directly over xGMI; a gloo group (CPU tests, or test ranks sharing
+    # one GPU) stages the few bytes through the host
+    via_host = world > 1 and on_gpu and dist.get_backend(group) == "gloo"
     waiter = None
     if on_gpu and not via_host:
-        host, waiter = _pinned_slot(dev, world)
-        host.copy_(allkeys, non_blocking=True)
-        waiter.record(torch.cuda.current_stream(dev))
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)                                      # the index is ready wherever main is now
+        with torch.cuda.stream(side):                               # (tensors made here live in the side stream's pool)
+            mine = (ends_dev + off) if off else ends_dev.contiguous()
+            if world > 1:
+                allkeys = torch.empty(2 * world, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(allkeys, mine, group=group)
+            else:
+                allkeys = mine
+            host, waiter = _pinned_slot(dev, world)
+            host.copy_(allkeys, non_blocking=True)
+            waiter.record(side)
+    elif world > 1:
+        mine = (ends_dev + off) if off else ends_dev.contiguous()
+        send = mine.cpu() if via_host else mine
+        host = torch.empty(2 * world, dtype=torch.int64, device=send.device)
+        dist.all_gather_into_tensor(host, send, group=group)
     else:
-        host = allkeys
+        host = (ends_dev + off) if off else ends_dev
 
     # ---- 2. local reduction, rows [first_key, last_key], launched on the remembered keys ------------------
     local = run_local(*guess) if (guess is not None and on_gpu) else None   # host tensors: nothing to overlap
