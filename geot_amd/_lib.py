@@ -30,14 +30,14 @@ SYMBOLS = [
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
-    "geot_slab_units", "geot_slab_rows_per_group", "geot_slab_workspace_bytes", "geot_slab_spmm",
+    "geot_slab_units", "geot_slab_rows_per_group", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
 ]
 
 class SlabPlan(ctypes.Structure):
     """geot_slab_plan of include/geot_hip.h (device pointers as integers)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out",
-                                                "c_row", "c_first", "c_count", "v_total", "c_total")] + \
+                                                "c_row", "c_first", "c_count", "v_row", "v_total", "c_total")] + \
                [(n, ctypes.c_int64) for n in ("n_groups", "n_vrows", "n_carry", "n_split", "nnz")] + \
                [("units", ctypes.c_int32), ("rows_per_group", ctypes.c_int32), ("slab_shift", ctypes.c_int32),
                 ("n_slabs", ctypes.c_int32)]
@@ -136,6 +136,7 @@ def load() -> ctypes.CDLL:
     L.geot_slab_workspace_bytes.argtypes = [ctypes.POINTER(SlabPlan), c_i64]
     L.geot_slab_workspace_bytes.restype = c_sz
     L.geot_slab_spmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
+    L.geot_slab_sddmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_profile_enable.argtypes = [c_int]
     L.geot_profile_enable.restype = None
     L.geot_profile_reset.restype = None

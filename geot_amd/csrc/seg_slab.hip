@@ -300,6 +300,165 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
+// SDDMM over the same plan (d/dweight of gather_weight_scatter on a dense graph): out[e] = <m1[dst(e)], m2[src(e)]>.
+// The unit's <= R rows of m1 (the dst side: shared by all edges of a row) sit in LDS where the forward kernel keeps its
+// accumulators; the m2 rows are gathered slab by slab in the same loose lockstep.  The 8 dot products of a batch are
+// reduced across the unit's lanes together (3 halving exchanges + log2(lpr/8) plain ones instead of 8 x log2(lpr)),
+// and written to out[original edge id] by the 8 lanes that end up holding them.
+template <bool WAVE_ROW>
+__global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpr = WAVE_ROW ? 64 : (1 << p.lpr_log2);
+  const int G = 64 / lpr;
+  const int sub = WAVE_ROW ? 0 : (lane >> p.lpr_log2), c = lane & (lpr - 1);
+  const int R = P.rows_per_group;
+  f4_t *rowV = reinterpret_cast<f4_t *>(smem) + ((size_t)(wave * G + sub) * R) * lpr;
+  const int64_t unit = ((int64_t)blockIdx.x * 4 + wave) * G + sub;
+  const int64_t units = P.units;
+  const char *m2 = static_cast<const char *>(p.src);
+  const float *m1 = static_cast<const float *>(p.weight);   // (the dst-side matrix travels in the `weight` slot)
+  float *out = static_cast<float *>(p.dst);
+  const uint32_t rb = p.rowbytes;
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+
+  int my_slot = -1;
+  int *xprog = nullptr;
+  if (p.window >= 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  int published = -1, known_min = -1;
+  auto slab_sync = [&](int step) {
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return;
+    for (int tries = 0; tries < 2048; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      known_min = m;
+      if (m + p.window >= step) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+  };
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    const bool has = pos < P.n_groups;
+    const int64_t e0 = has ? P.g_begin[pos] : 0;
+    const int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    const int nv = has ? P.g_nv[pos] : 0;
+    const int64_t v0 = has ? P.g_vrow0[pos] : 0;
+    for (int l = 0; l < nv; ++l) {                       // the group's m1 rows (pieces of a split hub share their row)
+      const int64_t row = P.v_row[v0 + l];
+      rowV[(size_t)l * lpr + c] = (row >= 0 && row < p.K) ? *reinterpret_cast<const f4_t *>(m1 + row * p.F + c * 4)
+                                                          : f4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    int maxlen = len;
+    if constexpr (!WAVE_ROW) {
+      for (int o = 32; o >= lpr; o >>= 1) {
+        const int other = __shfl_xor(maxlen, o, 64);
+        maxlen = other > maxlen ? other : maxlen;
+      }
+    }
+    int cur = 255;
+    f4_t mrow = {0.f, 0.f, 0.f, 0.f};
+    int my_src = 0, my_dl = 255, my_pe = 0;
+    {
+      const bool valid = c < len;
+      my_src = valid ? P.e_src[e0 + c] : 0;
+      my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
+      my_pe = valid ? P.e_perm[e0 + c] : 0;
+    }
+    for (int off = 0; off < maxlen; off += lpr) {
+      const bool nvalid = off + lpr + c < len;
+      const int64_t ne = e0 + off + lpr + c;
+      const int n_src = nvalid ? P.e_src[ne] : 0;
+      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      const int n_pe = nvalid ? P.e_perm[ne] : 0;
+      const int n_here = len - off;
+      int n_max = maxlen - off;
+      n_max = n_max < lpr ? n_max : lpr;
+      for (int b = 0; b < n_max; b += kU) {
+        if (p.window >= 0) {
+          const int first_row = __builtin_amdgcn_readlane(my_src, b);
+          const int has_edge = __builtin_amdgcn_readfirstlane(n_here) > b;
+          if (has_edge) slab_sync(r * p.n_slabs + (first_row >> p.slab_shift));
+        }
+        f4_t v[kU];
+        int dls[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const bool ok = b + u < n_here;
+          int row;
+          if constexpr (WAVE_ROW) {
+            row = __builtin_amdgcn_readlane(my_src, b + u);
+            dls[u] = ok ? __builtin_amdgcn_readlane(my_dl, b + u) : 255;
+          } else {
+            row = __shfl(my_src, b + u, lpr);
+            dls[u] = ok ? __shfl(my_dl, b + u, lpr) : 255;
+          }
+          if (!ok || (uint32_t)row >= src_rows) { row = 0; dls[u] = 255; }   // no edge / out-of-range source: the dot is 0
+          v[u] = *reinterpret_cast<const f4_t *>(m2 + (int64_t)row * rb + c * 16);
+        }
+        float pd[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (dls[u] != cur) {
+            cur = dls[u];
+            mrow = cur != 255 ? rowV[(size_t)cur * lpr + c] : f4_t{0.f, 0.f, 0.f, 0.f};
+          }
+          pd[u] = v[u][0] * mrow[0] + v[u][1] * mrow[1] + v[u][2] * mrow[2] + v[u][3] * mrow[3];
+        }
+        // 8 values x lpr lanes -> lane l < 8 of the unit holds the total of value 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)
+        const bool b0 = c & 1, b1 = c & 2, b2 = c & 4;
+        float q[4], t2[2], s1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep = b0 ? pd[i + 4] : pd[i], give = b0 ? pd[i] : pd[i + 4];
+          q[i] = keep + __shfl_xor(give, 1, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float keep = b1 ? q[i + 2] : q[i], give = b1 ? q[i] : q[i + 2];
+          t2[i] = keep + __shfl_xor(give, 2, 64);
+        }
+        {
+          const float keep = b2 ? t2[1] : t2[0], give = b2 ? t2[0] : t2[1];
+          s1 = keep + __shfl_xor(give, 4, 64);
+        }
+        for (int o = 8; o < lpr; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const int j = 4 * (c & 1) + 2 * ((c >> 1) & 1) + ((c >> 2) & 1);
+        const int pe = __shfl(my_pe, b + j, lpr);          // original edge id of the batch's j-th edge
+        if (c < 8 && b + j < n_here) out[pe] = s1;
+      }
+      my_src = n_src;
+      my_dl = n_dl;
+      my_pe = n_pe;
+    }
+    if (p.window >= 0 && my_slot >= 0) {
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
+    }
+  }
+  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+}
+
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row)
 template <int RED>
 __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p) {
@@ -444,6 +603,56 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
       if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
     }
   }
+  return GEOT_OK;
+}
+
+int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, int64_t feat, int64_t rows_1,
+                    int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!plan || !mat_1 || !mat_2 || !out) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: null pointer");
+  if (dtype != GEOT_F32) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: float32 only");
+  if (!plan->v_row) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan has no v_row table");
+  const int64_t rowbytes = feat * 4;
+  int lpr_log2 = -1;
+  for (int l = 4; l <= 6; ++l)
+    if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
+  if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: rows of 256, 512 or 1024 bytes only");
+  if ((((uintptr_t)mat_1) | ((uintptr_t)mat_2) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 16-byte aligned operands");
+  const int64_t waves = plan->units / (64 >> lpr_log2);
+  if (plan->units % (64 >> lpr_log2) != 0 || waves % (4 * 256) != 0 || waves < 4 * 256 || waves > 4 * 256 * 4)
+    return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan's unit count is not 256 CUs x (1..4 workgroups) x 4 waves");
+  if (!workspace || workspace_bytes < 256 + kSyncBytes) return geot_internal_fail(GEOT_EWORKSPACE, "slab_sddmm: workspace too small");
+  if (plan->n_groups == 0) return GEOT_OK;
+  SlabParams p;
+  p.plan = *plan;
+  p.weight = mat_1;
+  p.src = mat_2;
+  p.dst = out;
+  p.carry = nullptr;
+  p.src_rows = rows_2;
+  p.K = rows_1;
+  p.F = feat;
+  p.H = 1;
+  p.Fh = (int)feat;
+  p.rowbytes = (uint32_t)rowbytes;
+  p.lpr_log2 = lpr_log2;
+  p.rounds = (int)((plan->n_groups + plan->units - 1) / plan->units);
+  p.prog = reinterpret_cast<int *>(static_cast<char *>(workspace) + 256);
+  p.prog_cnt = p.prog + 8 * kProgSlots;
+  p.slab_shift = plan->slab_shift;
+  p.n_slabs = plan->n_slabs;
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (lpr_log2 == 6 ? 2 : 1) : g_slab_window) : -1;
+  hipError_t e = hipSuccess;
+  if (p.window >= 0) {
+    e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);
+    if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
+  }
+  const size_t lds = (size_t)4 * plan->rows_per_group * 1024;
+  const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
+  if (lpr_log2 == 6) hipLaunchKernelGGL(seg_slab_sddmm_kernel<true>, grid, blk, lds, st, p);
+  else hipLaunchKernelGGL(seg_slab_sddmm_kernel<false>, grid, blk, lds, st, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   return GEOT_OK;
 }
 

@@ -392,10 +392,11 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
   const int64_t n_carry = V > 0 ? split_v.sum().item<int64_t>() : 0;
   auto nonempty_t = [&](at::Tensor t) { return t.numel() ? t : at::zeros({1}, t.options()); };
   at::Tensor g_begin_t = to_dev(g_begin, at::kLong), g_v0_t = to_dev(g_v0_sorted, at::kInt), g_nv_t = to_dev(g_nv_sorted, at::kInt);
+  at::Tensor v_row32 = v_row.to(at::kInt).contiguous();
   at::Tensor v_total = counts.index_select(0, v_row).to(at::kInt).contiguous();      // edges of the virtual row's whole dst row
   at::Tensor c_total = counts.index_select(0, split_rows).contiguous();
   H->keep = {nonempty_t(e_src), nonempty_t(e_dl), nonempty_t(e_perm), g_begin_t, g_v0_t, g_nv_t, nonempty_t(v_out),
-             nonempty_t(split_rows), nonempty_t(c_first), nonempty_t(c_count), nonempty_t(v_total), nonempty_t(c_total)};
+             nonempty_t(split_rows), nonempty_t(c_first), nonempty_t(c_count), nonempty_t(v_row32), nonempty_t(v_total), nonempty_t(c_total)};
   geot_slab_plan &P = H->plan;
   P.e_src = H->keep[0].data_ptr<int32_t>();
   P.e_dl = H->keep[1].data_ptr<uint8_t>();
@@ -407,8 +408,9 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
   P.c_row = H->keep[7].data_ptr<int64_t>();
   P.c_first = H->keep[8].data_ptr<int64_t>();
   P.c_count = H->keep[9].data_ptr<int32_t>();
-  P.v_total = H->keep[10].data_ptr<int32_t>();
-  P.c_total = H->keep[11].data_ptr<int64_t>();
+  P.v_row = H->keep[10].data_ptr<int32_t>();
+  P.v_total = H->keep[11].data_ptr<int32_t>();
+  P.c_total = H->keep[12].data_ptr<int64_t>();
   P.n_groups = G;
   P.n_vrows = V;
   P.n_carry = n_carry;
@@ -687,6 +689,23 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
   at::Tensor si = as_int64(si_in), di = as_int64(di_in);
   at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
   at::Tensor out = at::empty({di.size(0)}, m1.options());
+  if (m1.scalar_type() == at::kFloat && di.numel() > 0 && m1.size(0) < ((int64_t)1 << 31)) {
+    // a dense graph that has (or now earns) a source-blocked plan - the forward gather_weight_scatter's - and an
+    // ascending dst_index (known from the facts): SDDMM over the plan, the gathered m2 rows re-used out of L2
+    const int64_t rowbytes = m1.size(1) * 4;
+    if ((rowbytes == 256 || rowbytes == 512 || rowbytes == 1024) &&
+        (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(di.numel(), m1.size(0), m2.size(0), rowbytes))) &&
+        index_facts(di).ascending) {
+      if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 1, 1)) {
+        auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
+        GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), out.data_ptr(), m1.size(1), m1.size(0), m2.size(0), GEOT_F32,
+                                  ws.data_ptr(), ws.numel(), stream_of(m1)));
+        std::lock_guard<std::mutex> lk(g_mu);
+        ++g_stats.slab_calls;
+        return out;
+      }
+    }
+  }
   GEOT_CALL(geot_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), out.data_ptr(), di.size(0), m1.size(1), m1.size(0),
                            m2.size(0), dtype_code(m1, "sddmm_coo"), stream_of(m1)));
   return out;

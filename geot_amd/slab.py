@@ -49,7 +49,7 @@ def worthwhile(nnz: int, out_rows: int, src_rows: int, rowbytes: int) -> bool:
     return bool(torch.ops.geot._slab_worthwhile(nnz, out_rows, src_rows, rowbytes))
 
 
-_FIELDS = ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out", "c_row", "c_first", "c_count", "v_total", "c_total")
+_FIELDS = ("e_src", "e_dl", "e_perm", "g_begin", "g_vrow0", "g_nv", "v_out", "c_row", "c_first", "c_count", "v_row", "v_total", "c_total")
 _SCALARS = ("n_groups", "n_vrows", "n_carry", "n_split", "nnz", "units", "rows_per_group")
 
 
@@ -90,4 +90,17 @@ def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: i
                               src.data_ptr(), out.data_ptr(), heads, feat, src.shape[0], out.shape[0], _lib.GEOT_F32,
                               hip._REDUCE_CODES[reduce], ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "geot_slab_spmm")
+    return out
+
+
+def slab_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[e] = <mat_1[dst(e)], mat_2[src(e)]> in original edge order over the plan's edges (pointer-level doorway)."""
+    dev = hip._require_gpu(mat_1, mat_2, out)
+    L = _lib.load()
+    with hip._on_device(dev):
+        st = hip._stream_handle(dev)
+        ws = hip.workspace(dev, int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), mat_1.shape[1])), st)
+        rc = L.geot_slab_sddmm(ctypes.byref(plan.struct), mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), mat_1.shape[1],
+                               mat_1.shape[0], mat_2.shape[0], _lib.GEOT_F32, ws.data_ptr(), ws.numel(), st)
+    _lib.check(rc, "geot_slab_sddmm")
     return out

@@ -188,6 +188,7 @@ typedef struct geot_slab_plan {
   const int64_t *c_row;
   const int64_t *c_first;
   const int32_t *c_count;
+  const int32_t *v_row;   /* per virtual row: its dst row (geot_slab_sddmm); may be NULL for geot_slab_spmm */
   const int32_t *v_total; /* per virtual row: edges of its WHOLE dst row (mean); may be NULL for sum / max / min */
   const int64_t *c_total; /* per split row: its edge count (mean) */
   int64_t n_groups, n_vrows, n_carry, n_split, nnz;
@@ -206,6 +207,12 @@ size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total)
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
                    int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce,
                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[e] = < mat_1[dst(e), :], mat_2[src(e), :] > in ORIGINAL edge order over the plan's edges - geot_sddmm_coo
+ * (sddmm_coo_cuda, csrc/cuda/header_cuda.h:28-30) for a graph that has a plan: the backward (d/dweight) of
+ * gather_weight_scatter on a dense graph.  float32, rows of 256 / 512 / 1024 bytes; workspace as geot_slab_spmm. */
+int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, int64_t feat,
+                    int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
  * With profiling on, every segment-reduction call records hipEvents around its kernels on

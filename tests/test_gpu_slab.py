@@ -189,3 +189,55 @@ def test_slab_reductions_match_the_per_edge_kernels(geot, reduce):
             bound = 1e-5 * mag + 1e-30
             assert bool(((out.double() - ref).abs() <= bound).all()) and bool(((tile.double() - ref).abs() <= bound).all())
         assert out[9].abs().sum().item() == 0                             # the empty row
+
+
+@pytest.mark.parametrize("nodes,nnz,F", [(30_000, 2_500_000, 128), (60_000, 2_000_000, 256), (100_000, 2_000_000, 64), (300, 200_000, 128)])
+def test_slab_sddmm_against_oracle_and_the_per_edge_kernel(geot, oracle, nodes, nnz, F):
+    """d/dweight of gather_weight_scatter over the plan: every edge written once, in ORIGINAL edge order; hubs (split
+    rows share their m1 row), out-of-range sources (-> 0), more m2 rows than m1 rows."""
+    from geot_amd import hip, slab
+    rng = np.random.default_rng(nodes)
+    di = powerlaw_index(nnz, nodes, nodes + 1)
+    di[: nnz // 5] = di[nnz // 5]
+    di = np.sort(di)
+    src_rows = nodes + 37
+    si = rng.integers(0, src_rows, nnz).astype(np.int64)
+    m1 = rng.standard_normal((nodes, F)).astype(np.float32)
+    m2 = rng.standard_normal((src_rows, F)).astype(np.float32)
+    plan = slab.build_plan(dev(si), dev(di), nodes, src_rows, F * 4, 1, 1)
+    out = torch.full((nnz,), float("nan"), device="cuda")
+    slab.slab_sddmm_out(plan, dev(m1), dev(m2), out)
+    assert not torch.isnan(out).any()                                     # every edge written
+    ref = oracle.sddmm_coo(si, di, m1, m2, acc64=True)
+    mag = oracle.sddmm_coo(si, di, np.abs(m1), np.abs(m2), acc64=True)
+    got = out.cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30)
+    tile = hip.sddmm_coo_out(dev(si), dev(di), dev(m1), dev(m2), torch.empty(nnz, device="cuda"))
+    assert torch.allclose(out, tile, rtol=1e-4, atol=1e-4)
+    again = torch.empty(nnz, device="cuda")
+    slab.slab_sddmm_out(plan, dev(m1), dev(m2), again)
+    assert torch.equal(out, again)
+
+
+def test_gws_training_step_on_the_source_blocked_path(geot):
+    """forward, d/dsrc (the same op on the transposed edge list) and d/dweight (SDDMM over the forward's plan) all take
+    the source-blocked kernels when the path is on; gradients against dense autograd."""
+    from geot_amd import ops
+    rng = np.random.default_rng(5)
+    n, nnz, F = 5000, 400_000, 128
+    di = dev(powerlaw_index(nnz, n, 9))
+    si = dev(rng.integers(0, n, nnz).astype(np.int64))
+    g = torch.rand(n, F, device="cuda")
+    x0, w0 = torch.rand(n, F, device="cuda"), torch.rand(nnz, device="cuda")
+    old = ops.set_option("slab_mode", "always")
+    try:
+        calls = ops.stats()["slab_calls"]
+        x1, w1 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        geot.gather_weight_scatter(si, di, w1, x1).backward(g)
+        assert ops.stats()["slab_calls"] == calls + 3
+    finally:
+        ops.set_option("slab_mode", old)
+    x2, w2 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w2[:, None]).backward(g)
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-3)
