@@ -127,7 +127,10 @@ def test_fuzz_source_blocked_kernel(oracle, seed):
                 ref = torch.zeros(hi.shape[0], Fh, device="cuda").scatter_reduce(0, t(di)[:, None].expand(-1, Fh), msg, kind, include_self=False)
                 got = geot.gather_weight_scatter(t(si), t(di), t(w), t(x), red)
                 assert got.shape == ref.shape and (torch.equal(got, ref) if red != "mean" else torch.allclose(got, ref, rtol=1e-4, atol=1e-5)), (seed, nnz, Fh, red)
-                assert ops.stats()["slab_calls"] == calls + 3
+                sd = geot.sddmm_coo_impl(t(si), t(di), t(x), t(x))               # SDDMM over the same plan
+                ref = oracle.sddmm_coo(si, di, x, x, acc64=True)
+                assert np.allclose(sd.cpu().numpy(), ref, rtol=1e-4, atol=1e-4), (seed, nnz, Fh, "sddmm")
+                assert ops.stats()["slab_calls"] == calls + 4
             else:
                 wh = rng.random((nnz, H), dtype=np.float32)
                 hi = oracle.mh_spmm(si, di, wh, x3, acc64=True)
