@@ -15,6 +15,8 @@
 //   index_probe_kernel  index[-1] and the number of descents of an index in one pass (row rule + sorted=False).
 //   seg_lds_bin_kernel  unsorted index with an output that fits in LDS: LDS-binned atomics.
 //   sddmm_coo_kernel, gather_rows_kernel, csr_expand_kernel, coo_*_kernel   backward / CSR helpers.
+//   (seg_slab.hip, the other translation unit of the library: seg_slab_kernel / seg_slab_sddmm_kernel, the
+//    source-blocked persistent kernels for dense graphs.)
 //
 // Sorted path in one paragraph:
 //   * edge-balanced tiles: block b owns edges [b*TE, (b+1)*TE) whatever the segment lengths are;
