@@ -52,6 +52,7 @@ struct SlabParams {
   int slab_shift;       // slab = source row >> slab_shift
   int n_slabs;
   int window;           // a wave may be at most `window` slabs ahead of the slowest wave of its XCD; < 0: no sync
+  int w_in_plan_order;  // WMODE 1: weight[] is indexed by plan position (a static weight permuted once), not by edge id
 };
 constexpr int kProgSlots = 512;
 constexpr int kProgIdle = 0x7f7f7f7f;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
       if constexpr (WMODE != 0) {
         const int64_t pe = valid ? (int64_t)P.e_perm[e0 + c] : 0;
-        if constexpr (WMODE == 1) wbase[c] = valid ? weight[pe] : 0.f;
+        if constexpr (WMODE == 1) wbase[c] = valid ? weight[p.w_in_plan_order ? e0 + c : pe] : 0.f;
         if constexpr (WMODE == 2) {
           if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + c * 4) = valid ? *reinterpret_cast<const f4_t *>(weight + pe * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
           else for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? weight[pe * p.H + q] : 0.f;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         }
         if constexpr (WMODE != 0) {
           if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
-            if constexpr (WMODE == 1) wn1 = nvalid ? weight[n_pe] : 0.f;
+            if constexpr (WMODE == 1) wn1 = nvalid ? weight[p.w_in_plan_order ? ne : n_pe] : 0.f;
             if constexpr (WMODE == 2) {
               if (p.H == 4) { if (nvalid) wn4 = *reinterpret_cast<const f4_t *>(weight + n_pe * 4); }
             }
@@ -511,6 +512,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
                    int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce, void *workspace,
                    size_t workspace_bytes, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool w_in_plan_order = weight_mode == 4;   // mode 4 = mode 1 with weight[] already permuted into plan order
+  if (w_in_plan_order) weight_mode = 1;
   if (!plan || !src || !dst) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: null pointer");
   if (dtype != GEOT_F32) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: float32 only");
   if (heads < 1 || feat < 1 || out_rows < 0) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: bad sizes");
@@ -520,7 +523,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (reduce == GEOT_REDUCE_MEAN && (!plan->v_total || (plan->n_split > 0 && !plan->c_total)))
     return geot_internal_fail(GEOT_EINVAL, "slab_spmm: mean needs the plan's edge counts (v_total, c_total)");
   if (weight_mode < 0 || weight_mode > 3 || (weight_mode != 0 && !weight))
-    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: weight_mode 0..3 (and a weight pointer for 1..3)");
+    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: weight_mode 0..4 (and a weight pointer for 1..4)");
   const int64_t F = heads * feat;
   const int64_t rowbytes = F * 4;
   int lpr_log2 = -1;
@@ -550,6 +553,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.slab_shift = plan->slab_shift;
   p.n_slabs = plan->n_slabs;
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (lpr_log2 == 6 ? 2 : 1) : g_slab_window) : -1;
+  p.w_in_plan_order = w_in_plan_order ? 1 : 0;
   p.src_rows = src_rows;
   p.K = out_rows;
   p.F = F;
@@ -629,6 +633,7 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
   p.src = mat_2;
   p.dst = out;
   p.carry = nullptr;
+  p.w_in_plan_order = 0;
   p.src_rows = rows_2;
   p.K = rows_1;
   p.F = feat;

@@ -200,7 +200,9 @@ int geot_slab_units(void);                                     /* waves of the p
 int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget */
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
 /* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
- * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts).
+ * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts),
+ * 4 = 1 with weight[] already permuted into the plan's edge order (weight[i] belongs to e_perm[i]: a static weight,
+ * e.g. a normalised adjacency, permuted once by the caller).
  * reduce: GEOT_REDUCE_SUM | MEAN | MAX | MIN over the messages of a row (weight modes 0 / 1; the multi-head modes sum) -
  * the aggregations PyG call sites forward (GraphSAGE mean / max on Reddit-like graphs).
  * float32, rows (heads * feat * 4 bytes) of 256 / 512 / 1024 bytes.  dst is written in full. */

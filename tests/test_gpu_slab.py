@@ -241,3 +241,28 @@ def test_gws_training_step_on_the_source_blocked_path(geot):
     torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w2[:, None]).backward(g)
     assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_static_weights_are_permuted_once_and_edits_are_seen(geot, oracle):
+    """gather_weight_scatter on the source-blocked path keeps a plan-ordered copy of a weight tensor it sees twice
+    (a normalised adjacency); an in-place edit of the weight (version counter) must not be served from the copy."""
+    from geot_amd import ops
+    rng = np.random.default_rng(31)
+    n, nnz, F = 4000, 300_000, 64
+    di_h, si_h = powerlaw_index(nnz, n, 4), rng.integers(0, n, nnz).astype(np.int64)
+    w_h, x_h = rng.random(nnz, dtype=np.float32), rng.random((n, F), dtype=np.float32)
+    si, di, w, x = dev(si_h), dev(di_h), dev(w_h), dev(x_h)
+    old = ops.set_option("slab_mode", "always")
+    try:
+        outs = [geot.gather_weight_scatter(si, di, w, x) for _ in range(4)]     # 3rd call on: the plan-ordered copy
+        hi = oracle.gather_weight_scatter(si_h, di_h, w_h, x_h, acc64=True)
+        for o in outs:
+            close(o, hi, "static weights")
+            assert torch.equal(o, outs[0])
+        w.mul_(2.0)                                                              # in place: version counter moves
+        close(geot.gather_weight_scatter(si, di, w, x), 2 * hi, "after an in-place edit of the weights")
+        w2 = torch.rand(nnz, device="cuda")                                      # a different tensor every call (attention)
+        ref = torch.zeros(n, F, device="cuda").index_add_(0, di, x[si] * w2[:, None])
+        assert torch.allclose(geot.gather_weight_scatter(si, di, w2, x), ref, rtol=1e-4, atol=1e-4)
+    finally:
+        ops.set_option("slab_mode", old)

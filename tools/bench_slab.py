@@ -27,6 +27,9 @@ def main():
              ("cfg4 graph, gws F=128", int(232_965 * a.scale), int(114_615_892 * a.scale), 1, 128, 1),
              ("cfg4 graph, gs F=64", int(232_965 * a.scale), int(114_615_892 * a.scale), 1, 64, 0),
              ("1M nodes x deg 100, gws F=128", int(1_000_000 * a.scale), int(100_000_000 * a.scale), 1, 128, 1)]
+    if os.environ.get("BENCH_SLAB_NOW"):
+        cases = [("cfg4 graph, gs F=256 (1-KiB rows, no weights)", 232_965, 114_615_892, 1, 256, 0),
+                 ("cfg4 graph, gws F=256 (1-KiB rows, weight[e])", 232_965, 114_615_892, 1, 256, 1)]
     if a.rule:
         cases = [(f"{n // 1000}k nodes x 120M edges, gws F=128", n, 120_000_000, 1, 128, 1) for n in (300_000, 450_000, 600_000, 800_000)] + \
                 [(f"{n // 1000}k nodes x 120M edges, mh H=4 F=64", n, 120_000_000, 4, 64, 2) for n in (450_000, 700_000)]
