@@ -18,8 +18,8 @@ for s in $steps; do
               timeout 300 ./tools/kexp2 slab 2449029 512 123718280 > $O/kexp2_slab_cfg3.txt 2>&1; echo "rc=$?"; cat $O/kexp2_slab_cfg3.txt
               timeout 300 ./tools/kexp2 mfma > $O/kexp2_mfma.txt 2>&1; echo "rc=$?"; cat $O/kexp2_mfma.txt ;;
     unsorted) timeout 600 python3 tools/bench_unsorted.py > $O/bench_unsorted.csv 2>&1; echo "rc=$?"; cat $O/bench_unsorted.csv ;;
-    soak)     for seed in 21 22 23 24; do
-                timeout 500 python3 tools/soak_fuzz.py --iters 150 --seed $seed --ops gws,gs,gws,gs,is > $O/soak_gather_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -3 $O/soak_gather_seed$seed.log
+    soak)     for seed in 31 32 33; do
+                timeout 600 python3 tools/soak_fuzz.py --iters 150 --seed $seed --ops gws,gs,gws,gs,is > $O/soak_final_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -3 $O/soak_final_seed$seed.log
               done ;;
     profile)  bash tools/profile_round.sh > $O/profile_round.log 2>&1; echo "rc=$?"; tail -30 $O/profile_round.log ;;
     slab)     timeout 900 python3 -m pytest tests/test_gpu_slab.py -m gpu -x -q > $O/pytest_slab.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_slab.log

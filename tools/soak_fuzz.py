@@ -63,13 +63,17 @@ def main():
             index = np.minimum(index // (int(index[-1]) // max_rows + 1), max_rows - 1)
         hub, narrow = int(rng.choice([-1, 0, 1])), int(rng.choice([1, 1, 2, 0]))
         cg = int(rng.choice([0, 0, 16, 32, 64]))
+        slab_always = bool(rng.integers(0, 2)) and F in (64, 128, 256)      # the source-blocked kernels on random graphs too
+        geot.ops.set_option("slab_mode", "always" if slab_always else "auto")
         hip.set_option("hub", hub)
         hip.set_option("narrow", narrow)
         hip.tune(cg, 0, -1, -1)
         red = str(rng.choice(["sum", "sum", "mean", "max", "min"]))
         op = str(rng.choice(a.ops.split(",")))
         covered[(op, red)] = covered.get((op, red), 0) + 1
-        tag = f"it={it} op={op} nnz={nnz} F={F} keys={index[-1] + 1} red={red} hub={hub} narrow={narrow} cg={cg}"
+        tag = f"it={it} op={op} nnz={nnz} F={F} keys={index[-1] + 1} red={red} hub={hub} narrow={narrow} cg={cg} slab={slab_always}"
+        if slab_always and not op.startswith("is"):
+            covered[("slab", red)] = covered.get(("slab", red), 0) + 1
         src = rng.standard_normal((nnz, F)).astype(np.float32)
         if op.startswith("is"):
             out = geot.index_scatter(0, t(src), t(index), red, op == "is").cpu().numpy()
@@ -113,7 +117,7 @@ def main():
             sys.exit(1)
         if it % 20 == 0:
             print("ok", tag, flush=True)
-    hip.set_option("hub", -1); hip.set_option("narrow", 1); hip.tune(0, 0, -1, -1)
+    hip.set_option("hub", -1); hip.set_option("narrow", 1); hip.tune(0, 0, -1, -1); geot.ops.set_option("slab_mode", "auto")
     print("covered (op, reduce): " + ", ".join(f"{o}/{r}={n}" for (o, r), n in sorted(covered.items())))
     print(f"SOAK PASSED ({a.iters} cases, seed {a.seed})")
 
