@@ -266,3 +266,35 @@ def test_static_weights_are_permuted_once_and_edits_are_seen(geot, oracle):
         assert torch.allclose(geot.gather_weight_scatter(si, di, w2, x), ref, rtol=1e-4, atol=1e-4)
     finally:
         ops.set_option("slab_mode", old)
+
+
+def test_slab_calls_are_hipgraph_capturable(geot):
+    """geot_slab_spmm / geot_slab_sddmm: two memsets and kernels on the caller's stream, no host sync, no allocation -
+    capture once, replay with new operand values at the same addresses."""
+    from geot_amd import slab
+    rng = np.random.default_rng(13)
+    n, nnz, F = 20_000, 1_500_000, 128
+    di = dev(powerlaw_index(nnz, n, 8))
+    si = dev(rng.integers(0, n, nnz).astype(np.int64))
+    w, x, g_ = torch.rand(nnz, device="cuda"), torch.rand(n, F, device="cuda"), torch.rand(n, F, device="cuda")
+    out, dw = torch.empty(n, F, device="cuda"), torch.empty(nnz, device="cuda")
+    plan = slab.build_plan(si, di, n, n, F * 4, 1, 1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        slab.slab_spmm_out(plan, w, 1, x, out, 1, F)                    # warm-up on the capture stream (workspace)
+        slab.slab_sddmm_out(plan, g_, x, dw)
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            slab.slab_spmm_out(plan, w, 1, x, out, 1, F)
+            slab.slab_sddmm_out(plan, g_, x, dw)
+    for rep in range(3):
+        x.uniform_()
+        w.uniform_()
+        out.fill_(float("nan"))
+        dw.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = torch.zeros_like(out).index_add_(0, di, x[si] * w[:, None])
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-4)
+        assert torch.allclose(dw, (g_[di] * x[si]).sum(1), rtol=1e-4, atol=1e-4)
