@@ -818,6 +818,11 @@ at::Tensor gather_rows_op(const at::Tensor &index_in, const at::Tensor &src_in) 
 struct TransposedEntry {
   ContentKey k1, k2;
   at::Tensor si, di, perm, si_sorted, di_perm;
+  // the per-edge weight in transposed order, kept for the content it was made from (a static weight - a normalised
+  // adjacency that does not require grad - is permuted once, not on every backward call)
+  bool w_valid = false;
+  ContentKey wkey{};
+  at::Tensor w_given, w_perm;
 };
 std::list<TransposedEntry> g_transposed;
 
@@ -843,6 +848,34 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
     while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
   }
   return {perm, std::get<0>(sorted), di_perm};
+}
+
+at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight) {
+  require_gpu("transposed_weight", {&si, &di, &weight});
+  TORCH_CHECK(weight.dim() >= 1 && weight.size(0) == si.size(0), "weight must have one entry per edge");
+  GEOT_DEVICE_GUARD(si);
+  auto tr = transpose_edges_op(si, di);           // (cached) permutation by source
+  const at::Tensor &perm = std::get<0>(tr);
+  ContentKey k1, k2, wk;
+  const bool keyed = g_opt.transpose_cache > 0 && g_opt.trust_version && content_key(si, &k1) && content_key(di, &k2) &&
+                     content_key(weight, &wk) && !weight.requires_grad();
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &e : g_transposed)
+      if (e.k1 == k1 && e.k2 == k2 && e.w_valid && e.wkey == wk) return e.w_perm;
+  }
+  at::Tensor wp = weight.index_select(0, perm);
+  if (keyed) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &e : g_transposed)
+      if (e.k1 == k1 && e.k2 == k2) {
+        e.w_valid = true;
+        e.wkey = wk;
+        e.w_given = weight;
+        e.w_perm = wp;
+      }
+  }
+  return wp;
 }
 
 // ---- introspection for tests / tools ------------------------------------------------------------------------------------------
@@ -919,6 +952,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("mh_spmm_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");
   m.def("gather_rows(Tensor index, Tensor src) -> Tensor");
   m.def("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)");
+  m.def("transposed_weight(Tensor src_index, Tensor dst_index, Tensor weight) -> Tensor");
   m.def("_host_option(str name, int value) -> int", host_option_op);
   m.def("_host_stats() -> int[]", host_stats_op);
   m.def("_slab_plan(Tensor src_index, Tensor dst_index, int rows, int src_rows, int rowbytes, int weight_mode, int heads, int slab_bytes, "
@@ -943,7 +977,8 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.impl("gather_weight_scatter_rows", gather_weight_scatter_rows_op);               \
   m.impl("mh_spmm_rows", mh_spmm_rows_op);                                           \
   m.impl("gather_rows", gather_rows_op);                                             \
-  m.impl("transpose_edges", transpose_edges_op)
+  m.impl("transpose_edges", transpose_edges_op);                                     \
+  m.impl("transposed_weight", transposed_weight_op)
 
 TORCH_LIBRARY_IMPL(geot, CUDA, m) { GEOT_IMPLS(m); }
 TORCH_LIBRARY_IMPL(geot, CPU, m) { GEOT_IMPLS(m); }

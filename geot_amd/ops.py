@@ -177,6 +177,11 @@ def _(index, src):
     return src.new_empty([index.shape[0], *src.shape[1:]])
 
 
+@torch.library.register_fake("geot::transposed_weight")
+def _(src_index, dst_index, weight):
+    return weight.new_empty(weight.shape)
+
+
 @torch.library.register_fake("geot::transpose_edges")
 def _(src_index, dst_index):
     return src_index.new_empty(src_index.shape), src_index.new_empty(src_index.shape), dst_index.new_empty(dst_index.shape)
@@ -227,10 +232,18 @@ def _gws_backward(ctx, grad):
     """
     src_index, dst_index, weight, src = ctx.saved_tensors
     grad = grad.contiguous()
-    perm, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
-    src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight[perm], grad,
-                                                         src.shape[0])
-    weight_grad = torch.ops.geot.sddmm_coo_impl(src_index, dst_index, grad, src)
+    _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+    # the weights in transposed edge order (kept by the host layer while the weight tensor's content is unchanged and
+    # it does not require grad: a normalised adjacency is permuted once, not on every backward call)
+    # (only the gradients autograd asks for: a GCN's normalised adjacency does not require grad - no SDDMM then)
+    need_w, need_src = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+    src_grad = weight_grad = None
+    if need_src:
+        weight_bwd = torch.ops.geot.transposed_weight(src_index, dst_index, weight.detach())
+        src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight_bwd, grad,
+                                                             src.shape[0])
+    if need_w:
+        weight_grad = torch.ops.geot.sddmm_coo_impl(src_index, dst_index, grad, src.detach())
     return None, None, weight_grad, src_grad
 
 

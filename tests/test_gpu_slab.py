@@ -298,3 +298,32 @@ def test_slab_calls_are_hipgraph_capturable(geot):
         ref = torch.zeros_like(out).index_add_(0, di, x[si] * w[:, None])
         assert torch.allclose(out, ref, rtol=1e-5, atol=1e-4)
         assert torch.allclose(dw, (g_[di] * x[si]).sum(1), rtol=1e-4, atol=1e-4)
+
+
+def test_backward_computes_only_what_autograd_asks_for(geot):
+    """A GCN's normalised adjacency does not require grad: no SDDMM; its transposed copy is kept while its content is
+    unchanged.  Gradients against dense autograd in every combination."""
+    from geot_amd import ops
+    rng = np.random.default_rng(41)
+    n, nnz, F = 3000, 120_000, 32
+    di = dev(powerlaw_index(nnz, n, 3))
+    si = dev(rng.integers(0, n, nnz).astype(np.int64))
+    g = torch.rand(n, F, device="cuda")
+    x0, w0 = torch.rand(n, F, device="cuda"), torch.rand(nnz, device="cuda")
+    for wreq, xreq in ((False, True), (True, False), (True, True)):
+        for it in range(3):                                              # repeated calls: the kept transposed weights
+            x1, w1 = x0.clone().requires_grad_(xreq), w0 if not wreq else w0.clone().requires_grad_(True)
+            x2, w2 = x0.clone().requires_grad_(xreq), w0.clone().requires_grad_(wreq)
+            geot.gather_weight_scatter(si, di, w1, x1).backward(g)
+            torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w2[:, None]).backward(g)
+            if xreq:
+                assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
+            else:
+                assert x1.grad is None
+            if wreq:
+                assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-4)
+    w0.mul_(0.5)                                                         # in-place edit of the static weight: seen
+    x1, x2 = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    geot.gather_weight_scatter(si, di, w0, x1).backward(g)
+    torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w0[:, None]).backward(g)
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
