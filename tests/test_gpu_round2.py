@@ -294,15 +294,18 @@ def test_bench_launches_its_own_ranks():
     import subprocess
     env = dict(os.environ, GEOT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    for extra in ([], ["--workload", "cfg5", "--scale", "0.01"], ["--strong", "--cuts", "aligned"]):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"] + extra,
+    for gpus, extra in ((2, []), (2, ["--workload", "cfg5", "--scale", "0.01"]), (2, ["--strong", "--cuts", "aligned"]),
+                        (8, ["--strong"])):                              # the world size of BASELINE.json configs[4]
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "4", "--warmup", "2"] + extra,
                            env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-3000:] + p.stdout[-2000:]
         lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, lines
         r = json.loads(lines[0])
-        assert r["n_gpus"] == 2 and r["value"] > 1e8 and r["unit"] == "edges/s"
-        if "--strong" in extra:                                             # aligned cuts: no data-path collective at all
+        assert r["n_gpus"] == gpus and r["value"] > 1e8 and r["unit"] == "edges/s"
+        if gpus == 8:
+            assert r["scaling"] == "strong" and r["config"]["nnz_per_gpu"] == 1_250_000 and r["boundary_exchange_ms"] > 0
+        elif "--strong" in extra:                                           # aligned cuts: no data-path collective at all
             assert r["scaling"] == "strong" and r["boundary_exchange_ms"] is None and r["config"]["nnz_per_gpu"] == 5_000_000
         else:
             assert r["scaling"] == "weak" and r["boundary_exchange_ms"] is not None and r["boundary_exchange_ms"] > 0
