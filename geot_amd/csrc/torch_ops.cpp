@@ -441,6 +441,7 @@ struct SlabEntry {
   ContentKey k1, k2;
   int64_t rows, src_rows, rowbytes, heads;
   int wmode;
+  int rpg;   // rows per group the plan was built for: the only thing the weight mode / head count changes
   c10::weak_intrusive_ptr<c10::StorageImpl> w1, w2;
   at::Tensor si, di; // keep the key tensors alive: their addresses cannot be recycled while the entry lives
   std::shared_ptr<SlabPlanHolder> plan;
@@ -456,11 +457,12 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes)) return nullptr;
   ContentKey k1, k2;
   if (!content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
+  const int rpg = geot_slab_rows_per_group(wmode, heads);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_slab.begin(); it != g_slab.end(); ++it)
       if (it->k1 == k1 && it->k2 == k2 && it->rows == rows && it->src_rows == src.size(0) && it->rowbytes == rowbytes &&
-          it->wmode == wmode && it->heads == heads && !it->w1.expired() && !it->w2.expired()) {
+          it->rpg == rpg && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R)
         g_slab.splice(g_slab.begin(), g_slab, it);
         return g_slab.front().plan;
       }
@@ -480,7 +482,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.plans_built;
   g_stats.plan_us += us;
-  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, si.storage().getWeakStorageImpl(),
+  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, rpg, si.storage().getWeakStorageImpl(),
                               di.storage().getWeakStorageImpl(), si, di, plan});
   while ((int)g_slab.size() > g_opt.slab_keep) g_slab.pop_back();
   return plan;
