@@ -3,7 +3,7 @@
 These are the `*_cuda(...)` entry points of the reference (csrc/cuda/header_cuda.h:4-30) restated
 for the HIP library: the caller supplies the output tensor and its row count, nothing here
 synchronises with the host, allocates device memory per call (beyond the cached workspace) or
-touches the CPU.  The operator layer (geot_amd/ops.py) adds the reference's shape rule, checks
+touches the CPU.  The operator layer (geot_amd/csrc/torch_ops.cpp + geot_amd/ops.py) adds the reference's shape rule, checks
 and error texts on top.
 """
 from __future__ import annotations
