@@ -41,14 +41,15 @@ namespace {
 // ---- options (environment at load time, geot::_host_option at run time) -------------------------------------------
 struct Options {
   int speculate_rows = 1;    // GEOT_SPECULATE_ROWS
-  int trust_version = 1;     // GEOT_TRUST_VERSION
+  int trust_version = 1;     // GEOT_TRUST_VERSION: 0 probe every call, 1 facts per content + row count read back every call,
+                             //   2 the remembered row count is trusted too (no read-back, no host wait: lowest latency)
   int unsorted_mode = 0;     // GEOT_UNSORTED: 0 auto (sort), 1 sort, 2 atomic
   int slab_mode = 0;         // GEOT_SLAB: -1 never, 0 auto, 1 always
   int transpose_cache = 4;   // GEOT_TRANSPOSE_CACHE (entries)
   int slab_keep = 2;
   Options() {
     if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
-    if (const char *e = std::getenv("GEOT_TRUST_VERSION")) trust_version = std::strcmp(e, "0") != 0;
+    if (const char *e = std::getenv("GEOT_TRUST_VERSION")) trust_version = !std::strcmp(e, "0") ? 0 : (!std::strcmp(e, "2") ? 2 : 1);
     if (const char *e = std::getenv("GEOT_UNSORTED")) unsorted_mode = !std::strcmp(e, "atomic") ? 2 : (!std::strcmp(e, "sort") ? 1 : 0);
     if (const char *e = std::getenv("GEOT_SLAB")) slab_mode = !std::strcmp(e, "0") ? -1 : (!std::strcmp(e, "1") ? 1 : 0);
     if (const char *e = std::getenv("GEOT_TRANSPOSE_CACHE")) transpose_cache = std::atoi(e);
@@ -263,6 +264,7 @@ at::Tensor as_int64(const at::Tensor &t) {
 // launch(rows) allocates the output for `rows` rows and enqueues the kernels.  `guess` comes from the facts.
 template <typename Launch> at::Tensor with_row_rule(const at::Tensor &index, int64_t guess, bool guess_is_fresh, Launch launch) {
   if (guess_is_fresh) return launch(guess); // this very call has just read index[-1] (the probe)
+  if (g_opt.trust_version >= 2) return launch(guess); // opt-in: index[-1] is as trusted as the sortedness (same content key)
   void *st = stream_of(index);
   Slot &s = slot_for(index.device().index());
   const int64_t *last = index_ptr(index) + (index.numel() - 1);

@@ -542,6 +542,15 @@ def test_row_rule_is_verified_on_every_call(geot, oracle, monkeypatch):
         index.data[-1] = last
         assert geot.gather_scatter(si, index, src[:300].contiguous()).shape[0] == last + 1
     assert ops.stats()["row_mismatches"] >= mism + 4          # every silent edit was caught by the read-back
+    old = ops.set_option("trust_version", 2)                  # GEOT_TRUST_VERSION=2: no read-back at all for a known content
+    try:
+        idx2 = index.clone()
+        for _ in range(3):
+            assert geot.index_scatter(0, src, idx2).shape[0] == int(idx2[-1]) + 1
+        idx2[-1] = 400                                            # an in-place edit moves the version counter: seen
+        assert geot.index_scatter(0, src, idx2).shape[0] == 401
+    finally:
+        ops.set_option("trust_version", old)
     old = ops.set_option("speculate_rows", 0)                 # GEOT_SPECULATE_ROWS=0: the reference's blocking order
     try:
         index.data[-1] = 310

@@ -42,7 +42,7 @@ def main():
     dev = torch.device("cuda")
     print(hip.build_info(), file=sys.stderr)
     print("dataset,nodes,edges,feat,index_scatter_sorted_us,index_scatter_sorted_false_us,doorway_no_row_rule_us,torch_index_add_us,"
-          "gather_weight_scatter_us,torch_sparse_mm_us")
+          "gather_weight_scatter_us,torch_sparse_mm_us,index_scatter_trust2_us,gather_weight_scatter_trust2_us")
     for name, (nodes, edges) in DATASETS.items():
         nnz = edges + nodes
         dst = powerlaw_index(nnz, nodes, 3, dev)
@@ -61,6 +61,10 @@ def main():
                  wall_us(lambda: torch.zeros(nodes, F, device=dev).index_add_(0, dst, src), a.iters),
                  wall_us(lambda: geot.gather_weight_scatter(col, dst, val, x), a.iters),
                  wall_us(lambda: torch.sparse.mm(adj, x), max(50, a.iters // 10))]
+            geot.ops.set_option("trust_version", 2)      # opt-in: the remembered row count is not read back
+            t += [wall_us(lambda: geot.index_scatter(0, src, dst, "sum", True), a.iters),
+                  wall_us(lambda: geot.gather_weight_scatter(col, dst, val, x), a.iters)]
+            geot.ops.set_option("trust_version", 1)
             print(f"{name},{nodes},{nnz},{F}," + ",".join(f"{v:.1f}" for v in t), flush=True)
 
 
