@@ -181,3 +181,52 @@ def test_host_layer_streams_and_inplace_edits(oracle):
     a = geot.gather_scatter(edge_index[0], edge_index[1], x)
     b = geot.gather_scatter(edge_index[0].clone(), edge_index[1].clone(), x)
     assert torch.equal(a, b)
+
+
+def test_host_layer_from_several_threads(oracle):
+    """The dispatcher releases the GIL inside the C++ ops: four Python threads, each on its own stream, call the
+    operators concurrently (shared caches behind a mutex, per-thread read-back slots and workspaces)."""
+    import threading
+    import geot_amd as geot
+    rng = np.random.default_rng(99)
+    nnz, K, F = 150_000, 4000, 64
+    index = np.sort(rng.integers(0, K, nnz)).astype(np.int64)
+    index[-1] = K - 1
+    shuffled = index.copy()
+    shuffled[:-1] = rng.permutation(shuffled[:-1])
+    src = rng.standard_normal((nnz, F)).astype(np.float32)
+    si = rng.integers(0, K, nnz).astype(np.int64)
+    w = rng.random(nnz, dtype=np.float32)
+    x = rng.standard_normal((K, F)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    t_index, t_shuf, t_src, t_si, t_w, t_x = t(index), t(shuffled), t(src), t(si), t(w), t(x)
+    want_is = geot.index_scatter(0, t_src, t_index)
+    want_un = geot.index_scatter(0, t_src, t_shuf, "sum", False)
+    want_gws = geot.gather_weight_scatter(t_si, t_index, t_w, t_x)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(seed):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(40):
+                    kind = (seed + it) % 3
+                    if kind == 0:
+                        ok = torch.equal(geot.index_scatter(0, t_src, t_index), want_is)
+                    elif kind == 1:
+                        ok = torch.equal(geot.index_scatter(0, t_src, t_shuf, "sum", False), want_un)
+                    else:
+                        ok = torch.equal(geot.gather_weight_scatter(t_si, t_index, t_w, t_x), want_gws)
+                    if not ok:
+                        errors.append((seed, it, kind))
+                s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
