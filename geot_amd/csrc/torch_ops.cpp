@@ -479,7 +479,16 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
     }
   }
   const auto t0 = std::chrono::steady_clock::now();
-  auto plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, kSlabBytes, 0, 0);
+  std::shared_ptr<SlabPlanHolder> plan;
+  try {
+    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, kSlabBytes, 0, 0);
+  } catch (const c10::Error &) {
+    // Phase A needs ~80 bytes per edge of transient memory and keeps 9: if that does not fit, the per-edge kernels serve
+    // the call (and every later one: the sighting is forgotten, a later call may try again)
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_sightings.remove_if([&](const std::pair<ContentKey, ContentKey> &sg) { return sg.first == k1 && sg.second == k2; });
+    return nullptr;
+  }
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.plans_built;
