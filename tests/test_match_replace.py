@@ -105,6 +105,7 @@ def test_ops_run_under_torch_compile():
 def test_rewritten_model_is_trainable():
     """Gradients through the fused ops of a rewritten graph equal the eager model's."""
     from geot_amd.match_replace import pattern_transform
+    torch._dynamo.reset()          # (this test exports right after the torch.compile test: start from a clean tracer state)
     torch.manual_seed(1)
     model = GCNLike(16, 16).cuda()
     x, ei, w = _inputs(n=1500, nnz=30_000, f=16, device="cuda", seed=7)
