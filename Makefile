@@ -28,7 +28,7 @@ shim: geot_amd/_C.so
 geot_amd/_C.so: geot_amd/csrc/torch_ops.cpp $(LIB) include/geot_hip.h
 	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=$(CXXABI) \
 	  -Iinclude -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
-	  geot_amd/csrc/torch_ops.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
+	  geot_amd/csrc/torch_ops.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -ltorch_hip -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
 	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
 
 oracle:

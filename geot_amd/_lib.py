@@ -87,7 +87,7 @@ def build_plugin(force: bool = False, verbose: bool = False) -> str:
                f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", os.path.join(_ROOT, "include"),
                "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
                "-I", "/opt/rocm/include", PLUGIN_SOURCE, "-o", PLUGIN_PATH, "-L", _HERE, "-lgeot_hip",
-               "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+               "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
                "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{os.path.join(tdir, 'lib')}"]
         if verbose:
             print(" ".join(cmd))

@@ -17,6 +17,7 @@
 //   * dense graphs are re-arranged once for the source-blocked kernel (csrc/seg_slab.hip) on their second call;
 //   * one workspace per (device, stream), a device guard, the current stream.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
@@ -105,6 +106,38 @@ void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqu
 
 const int64_t *index_ptr(const at::Tensor &t) { return t.data_ptr<int64_t>(); } // "expected scalar type Long but found ..."
 
+// ---- cached device artefacts and streams -----------------------------------------------------------------------------------
+// What the caches below keep (the sort of an index, a widened index, a plan, a transposed edge list) was enqueued on the
+// stream that was current when it was made.  A later call on ANOTHER stream must not read it before that work is done,
+// and the caching allocator must not recycle its memory for the producing stream while the consumer still reads it:
+// the entry keeps an event of its production; a consumer on a different stream waits for it and records itself.
+struct Produced {
+  std::shared_ptr<void> ev;
+  void *stream = nullptr;
+  void mark(const at::Tensor &on) {
+    hipEvent_t e = nullptr;
+    TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    ev = std::shared_ptr<void>(e, [](void *p) { (void)hipEventDestroy(static_cast<hipEvent_t>(p)); });
+    stream = stream_of(on);
+    TORCH_CHECK(hipEventRecord(e, static_cast<hipStream_t>(stream)) == hipSuccess, "hipEventRecord failed");
+  }
+  template <typename Each> void consume(const at::Tensor &on, Each each) const {
+    if (!ev) return;
+    const auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(on.device().index());
+    if (cur.stream() == stream) return;
+    TORCH_CHECK(hipStreamWaitEvent(cur.stream(), static_cast<hipEvent_t>(ev.get()), 0) == hipSuccess, "hipStreamWaitEvent failed");
+    each([&](const at::Tensor &t) {
+      if (t.defined() && t.is_cuda()) c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(t.storage().data_ptr(), cur);
+    });
+  }
+  void before_use(const at::Tensor &on, std::initializer_list<const at::Tensor *> ts) const {
+    consume(on, [&](auto rec) { for (const at::Tensor *t : ts) rec(*t); });
+  }
+  void before_use(const at::Tensor &on, const std::vector<at::Tensor> &ts) const {
+    consume(on, [&](auto rec) { for (const at::Tensor &t : ts) rec(t); });
+  }
+};
+
 // one zero-initialised workspace per (device, stream), grown on demand (the ABI: one stream at a time per workspace)
 at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
   static thread_local std::map<std::pair<int, void *>, at::Tensor> ws;
@@ -153,6 +186,7 @@ struct Facts {
   int64_t rows;
   bool ascending;
   at::Tensor keys, perm; // stable sort of an index with descents (a few entries keep theirs)
+  Produced made;         // ... and the event of that sort
 };
 std::list<Facts> g_facts; // most recent first, <= 16 entries
 constexpr size_t kFactsMax = 16, kSortedKeep = 4;
@@ -192,7 +226,7 @@ FactsView index_facts(const at::Tensor &index) {
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.probes;
   if (keyed) {
-    g_facts.push_front(Facts{k, index.storage().getWeakStorageImpl(), last + 1, descents == 0, {}, {}});
+    g_facts.push_front(Facts{k, index.storage().getWeakStorageImpl(), last + 1, descents == 0, {}, {}, {}});
     while (g_facts.size() > kFactsMax) g_facts.pop_back();
   }
   return {last + 1, descents == 0, false};
@@ -213,7 +247,10 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &f : g_facts)
-      if (f.key == k && !f.weak.expired() && f.keys.defined()) return {f.keys, f.perm};
+      if (f.key == k && !f.weak.expired() && f.keys.defined()) {
+        f.made.before_use(index, {&f.keys, &f.perm});
+        return {f.keys, f.perm};
+      }
   }
   auto sorted = at::sort(index, /*stable=*/true, /*dim=*/0, /*descending=*/false);
   std::lock_guard<std::mutex> lk(g_mu);
@@ -224,6 +261,7 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
       if (f.key == k) {
         f.keys = std::get<0>(sorted);
         f.perm = std::get<1>(sorted);
+        f.made.mark(index);
       }
       if (f.keys.defined() && ++holders > kSortedKeep) f.keys = f.perm = at::Tensor();
     }
@@ -236,6 +274,7 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
 struct WidenedEntry {
   ContentKey key;
   at::Tensor narrow, wide; // `narrow` is kept alive: its address cannot be recycled while the entry lives
+  Produced made;
 };
 std::list<WidenedEntry> g_widened;
 
@@ -248,13 +287,15 @@ at::Tensor as_int64(const at::Tensor &t) {
     for (auto it = g_widened.begin(); it != g_widened.end(); ++it)
       if (it->key == k) {
         g_widened.splice(g_widened.begin(), g_widened, it);
+        g_widened.front().made.before_use(t, {&g_widened.front().wide});
         return g_widened.front().wide;
       }
   }
   at::Tensor wide = t.to(at::kLong).contiguous();
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_widened.push_front(WidenedEntry{k, t, wide});
+    g_widened.push_front(WidenedEntry{k, t, wide, {}});
+    g_widened.front().made.mark(t);
     while (g_widened.size() > 6) g_widened.pop_back();
   }
   return wide;
@@ -302,6 +343,7 @@ struct SlabPlanHolder {
   bool w_seen_valid = false;
   ContentKey w_seen{}, w_key{};
   at::Tensor w_given, w_planorder;
+  Produced made, w_made; // events of Phase A / of the weight permutation (consumers on other streams wait for them)
 };
 
 bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes) {
@@ -466,6 +508,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
       if (it->k1 == k1 && it->k2 == k2 && it->rows == rows && it->src_rows == src.size(0) && it->rowbytes == rowbytes &&
           it->rpg == rpg && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R)
         g_slab.splice(g_slab.begin(), g_slab, it);
+        g_slab.front().plan->made.before_use(src, g_slab.front().plan->keep);
         return g_slab.front().plan;
       }
     if (g_opt.slab_mode != 1) { // first sighting of this edge list: only remember it - a one-shot call never pays for Phase A
@@ -490,6 +533,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
     return nullptr;
   }
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  plan->made.mark(src);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.plans_built;
   g_stats.plan_us += us;
@@ -618,8 +662,10 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
           std::lock_guard<std::mutex> lk(plan->wmu);
           if (plan->w_planorder.defined() && plan->w_key == wk) {
             w_planorder = plan->w_planorder;
+            plan->w_made.before_use(x, {&w_planorder});
           } else if (plan->w_seen_valid && plan->w_seen == wk) { // the same weight content again: permute it once
             plan->w_planorder = e.w.index_select(0, plan->keep[2]);
+            plan->w_made.mark(x);
             plan->w_key = wk;
             plan->w_given = e.w;                       // kept alive: its address cannot be recycled under this key
             w_planorder = plan->w_planorder;
@@ -758,6 +804,7 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
 struct ExpandedEntry {
   ContentKey key;
   at::Tensor indptr, dst_index;
+  Produced made;
 };
 std::list<ExpandedEntry> g_expanded;
 
@@ -769,6 +816,7 @@ at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
     for (auto it = g_expanded.begin(); it != g_expanded.end(); ++it)
       if (it->key == k && it->dst_index.numel() == nnz) {
         g_expanded.splice(g_expanded.begin(), g_expanded, it);
+        g_expanded.front().made.before_use(indptr, {&g_expanded.front().dst_index});
         return g_expanded.front().dst_index;
       }
   }
@@ -777,7 +825,8 @@ at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   at::Tensor dst_index = at::repeat_interleave(counts, c10::optional<int64_t>(nnz));
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_expanded.push_front(ExpandedEntry{k, indptr, dst_index});
+    g_expanded.push_front(ExpandedEntry{k, indptr, dst_index, {}});
+    g_expanded.front().made.mark(indptr);
     while (g_expanded.size() > 4) g_expanded.pop_back();
   }
   return dst_index;
@@ -836,6 +885,7 @@ struct TransposedEntry {
   bool w_valid = false;
   ContentKey wkey{};
   at::Tensor w_given, w_perm;
+  Produced made, w_made;
 };
 std::list<TransposedEntry> g_transposed;
 
@@ -849,6 +899,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
     for (auto it = g_transposed.begin(); it != g_transposed.end(); ++it)
       if (it->k1 == k1 && it->k2 == k2) {
         g_transposed.splice(g_transposed.begin(), g_transposed, it);
+        it->made.before_use(si, {&it->perm, &it->si_sorted, &it->di_perm});
         return {it->perm, it->si_sorted, it->di_perm};
       }
   }
@@ -858,6 +909,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
   ++g_stats.transposes;
   if (keyed) {
     g_transposed.push_front(TransposedEntry{k1, k2, si, di, perm, std::get<0>(sorted), di_perm});
+    g_transposed.front().made.mark(si);
     while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
   }
   return {perm, std::get<0>(sorted), di_perm};
@@ -875,7 +927,10 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &e : g_transposed)
-      if (e.k1 == k1 && e.k2 == k2 && e.w_valid && e.wkey == wk) return e.w_perm;
+      if (e.k1 == k1 && e.k2 == k2 && e.w_valid && e.wkey == wk) {
+        e.w_made.before_use(weight, {&e.w_perm});
+        return e.w_perm;
+      }
   }
   at::Tensor wp = weight.index_select(0, perm);
   if (keyed) {
@@ -886,6 +941,7 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
         e.wkey = wk;
         e.w_given = weight;
         e.w_perm = wp;
+        e.w_made.mark(weight);
       }
   }
   return wp;

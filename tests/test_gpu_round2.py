@@ -287,6 +287,78 @@ def test_transposed_edge_cache_cannot_alias_a_dead_edge_list(geot):
         del idx
 
 
+def test_cached_artefacts_are_safe_on_another_stream(geot):
+    """What the host layer caches per index content (the stable sort of an index with descents, the transposed edge
+    list, a widened int32 index, the per-edge row ids of a CSR) is enqueued on the stream of the call that made it.  A
+    second call on ANOTHER stream, issued while that work may still be running, must wait for it (an event per cache
+    entry) - results are checked against float64 references with no synchronisation in between."""
+    torch.manual_seed(5)
+    nnz, K, F = 6_000_000, 200_000, 32
+    index = torch.randint(0, K, (nnz,), device="cuda")
+    index[-1] = K - 1
+    src = torch.rand(nnz, F, device="cuda")
+    ref = torch.zeros(K, F, dtype=torch.float64, device="cuda").index_add_(0, index, src.double())
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    a.wait_stream(torch.cuda.current_stream())
+    b.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(a):
+        out_a = geot.index_scatter(0, src, index, "sum", sorted=False)       # probe, stable sort, reduce - on stream a
+    with torch.cuda.stream(b):
+        out_b = geot.index_scatter(0, src, index, "sum", sorted=False)       # cached sort, consumed on stream b
+    torch.cuda.synchronize()
+    for name, o in (("producer stream", out_a), ("consumer stream", out_b)):
+        assert torch.allclose(o.double(), ref, rtol=1e-5, atol=1e-4), name
+    assert torch.equal(out_a, out_b)
+
+    # transposed edge list + widened int32 indices (the backward pass) made on stream a, used on stream b
+    n, e = 100_000, 4_000_000
+    di = torch.sort(torch.randint(0, n, (e,), device="cuda")).values
+    di[-1] = n - 1
+    si = torch.randint(0, n, (e,), device="cuda")
+    x = torch.rand(n, F, device="cuda")
+    g = torch.rand(n, F, device="cuda")
+    w = torch.rand(e, device="cuda")
+    gx_ref = torch.zeros(n, F, dtype=torch.float64, device="cuda").index_add_(0, si, g.double()[di] * w.double()[:, None])
+    gw_ref = (g.double()[di] * x.double()[si]).sum(1)
+    si32, di32 = si.int(), di.int()
+    torch.cuda.synchronize()
+    grads = []
+    for st in (a, b):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            geot.gather_weight_scatter(si, di, w1, x1).backward(g)
+            dots = torch.ops.geot.sddmm_coo_impl(si32, di32, g, x)             # the reference's wrapper casts to int32
+            grads.append((x1.grad, w1.grad, dots))
+    torch.cuda.synchronize()
+    for gx, gw, dots in grads:
+        assert torch.allclose(gx.double(), gx_ref, rtol=1e-5, atol=1e-4)
+        assert torch.allclose(gw.double(), gw_ref, rtol=1e-5, atol=1e-4)
+        assert torch.allclose(dots.double(), gw_ref, rtol=1e-5, atol=1e-4)
+
+    # the source-blocked plan (Phase A: scans, a sort, host loop) and the weight in plan order: built on a, used on b
+    from geot_amd import ops
+    F2 = 64
+    x2 = torch.rand(n, F2, device="cuda")
+    y_ref = torch.zeros(n, F2, dtype=torch.float64, device="cuda").index_add_(0, di, x2.double()[si] * w.double()[:, None])
+    old = ops.set_option("slab_mode", "always")
+    try:
+        torch.cuda.synchronize()
+        before = ops.stats()["slab_calls"]
+        ys = []
+        for st in (a, b, a, b):
+            with torch.cuda.stream(st):
+                ys.append(geot.gather_weight_scatter(si, di, w, x2))
+        torch.cuda.synchronize()
+        assert ops.stats()["slab_calls"] - before == 4
+        for y in ys:
+            assert torch.allclose(y.double(), y_ref, rtol=1e-5, atol=1e-4)
+            assert torch.equal(y, ys[0])
+    finally:
+        ops.set_option("slab_mode", old)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT torchrun: the parent (no GPU call) spawns the ranks as children and relays
     rank 0's line.  The ranks share this box's one GPU over a gloo rendezvous (GEOT_DIST_BACKEND=gloo)."""
