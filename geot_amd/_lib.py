@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip"),
+           os.path.join(_HERE, "csrc", "seg_sort.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
 PLUGIN_SOURCE = os.path.join(_HERE, "csrc", "torch_ops.cpp")
@@ -29,6 +30,7 @@ SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes", "geot_mh_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
+    "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_rows_per_group", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
@@ -118,6 +120,11 @@ def load() -> ctypes.CDLL:
     L.geot_mh_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_i64, c_int]
     L.geot_workspace_init.argtypes = [c_vp, c_sz, c_vp]
     L.geot_index_probe.argtypes = [c_vp, c_i64, c_vp, c_vp]
+    L.geot_index_probe_range.argtypes = [c_vp, c_i64, c_vp, c_vp]
+    L.geot_sort_supported.argtypes = [c_i64, c_i64, c_i64]
+    L.geot_sort_workspace_bytes.restype = c_sz
+    L.geot_sort_workspace_bytes.argtypes = [c_i64]
+    L.geot_sort_index.argtypes = [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]
     L.geot_index_scatter.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_index_scatter_reduce.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_gather_reduce.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]

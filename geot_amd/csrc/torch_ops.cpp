@@ -185,6 +185,7 @@ struct Facts {
   c10::weak_intrusive_ptr<c10::StorageImpl> weak;
   int64_t rows;
   bool ascending;
+  int64_t kmin, kmax;    // key range (sizes the sort of an index with descents)
   at::Tensor keys, perm; // stable sort of an index with descents (a few entries keep theirs)
   Produced made;         // ... and the event of that sort
 };
@@ -195,18 +196,19 @@ struct FactsView {
   int64_t rows;
   bool ascending;
   bool cached;
+  int64_t kmin, kmax;
 };
 
-void probe_index(const at::Tensor &index, int64_t *last, int64_t *descents) {
+// one pass: {index[-1], descents, min, max}
+void probe_index(const at::Tensor &index, int64_t out4[4]) {
   TORCH_CHECK_INDEX(index.numel() > 0, "index -1 is out of bounds for dimension 0 with size 0");
-  at::Tensor dev = at::empty({2}, index.options());
+  at::Tensor dev = at::empty({4}, index.options());
   void *st = stream_of(index);
-  GEOT_CALL(geot_index_probe(index_ptr(index), index.numel(), dev.data_ptr<int64_t>(), st));
+  GEOT_CALL(geot_index_probe_range(index_ptr(index), index.numel(), dev.data_ptr<int64_t>(), st));
   Slot &s = slot_for(index.device().index());
-  TORCH_CHECK(hipMemcpyAsync(s.host, dev.data_ptr<int64_t>(), 16, hipMemcpyDeviceToHost, static_cast<hipStream_t>(st)) == hipSuccess, "hipMemcpyAsync failed");
+  TORCH_CHECK(hipMemcpyAsync(s.host, dev.data_ptr<int64_t>(), 32, hipMemcpyDeviceToHost, static_cast<hipStream_t>(st)) == hipSuccess, "hipMemcpyAsync failed");
   TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(st)) == hipSuccess, "hipStreamSynchronize failed");
-  *last = s.host[0];
-  *descents = s.host[1];
+  std::memcpy(out4, s.host, 32);
 }
 
 // index: contiguous, 1-D, int64, on the GPU, non-empty checked inside
@@ -218,18 +220,18 @@ FactsView index_facts(const at::Tensor &index) {
     for (auto it = g_facts.begin(); it != g_facts.end(); ++it)
       if (it->key == k && !it->weak.expired()) {
         g_facts.splice(g_facts.begin(), g_facts, it);
-        return {it->rows, it->ascending, true};
+        return {it->rows, it->ascending, true, it->kmin, it->kmax};
       }
   }
-  int64_t last = 0, descents = 0;
-  probe_index(index, &last, &descents);
+  int64_t p[4] = {0, 0, 0, 0};
+  probe_index(index, p);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.probes;
   if (keyed) {
-    g_facts.push_front(Facts{k, index.storage().getWeakStorageImpl(), last + 1, descents == 0, {}, {}, {}});
+    g_facts.push_front(Facts{k, index.storage().getWeakStorageImpl(), p[0] + 1, p[1] == 0, p[2], p[3], {}, {}, {}});
     while (g_facts.size() > kFactsMax) g_facts.pop_back();
   }
-  return {last + 1, descents == 0, false};
+  return {p[0] + 1, p[1] == 0, false, p[2], p[3]};
 }
 
 void remember_rows(const at::Tensor &index, int64_t rows) {
@@ -240,8 +242,26 @@ void remember_rows(const at::Tensor &index, int64_t rows) {
     if (f.key == k) f.rows = rows;
 }
 
+// stable sort by key: keys that fit 32 bits go through geot_sort_index (radix passes over the bits in use only),
+// anything else (negative keys, keys >= 2^32) through ATen's generic sort
+std::pair<at::Tensor, at::Tensor> stable_sort_index(const at::Tensor &index, int64_t kmin, int64_t kmax) {
+  const int64_t nnz = index.numel();
+  if (geot_sort_supported(nnz, kmin, kmax)) {
+    const size_t bytes = geot_sort_workspace_bytes(nnz);
+    if (bytes) {
+      at::Tensor keys = at::empty_like(index), perm = at::empty_like(index);
+      at::Tensor ws = at::empty({(int64_t)bytes}, index.options().dtype(at::kByte));
+      GEOT_CALL(geot_sort_index(index_ptr(index), nnz, kmax, keys.data_ptr<int64_t>(), perm.data_ptr<int64_t>(), ws.data_ptr(), bytes,
+                                stream_of(index)));
+      return {keys, perm};
+    }
+  }
+  auto sorted = at::sort(index, /*stable=*/true, /*dim=*/0, /*descending=*/false);
+  return {std::get<0>(sorted), std::get<1>(sorted)};
+}
+
 // (keys ascending, perm) of an index with descents
-std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
+std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t kmin, int64_t kmax) {
   ContentKey k;
   const bool keyed = g_opt.trust_version && content_key(index, &k);
   if (keyed) {
@@ -252,21 +272,21 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index) {
         return {f.keys, f.perm};
       }
   }
-  auto sorted = at::sort(index, /*stable=*/true, /*dim=*/0, /*descending=*/false);
+  auto sorted = stable_sort_index(index, kmin, kmax);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.sorts;
   if (keyed) {
     size_t holders = 0;
     for (auto &f : g_facts) {
       if (f.key == k) {
-        f.keys = std::get<0>(sorted);
-        f.perm = std::get<1>(sorted);
+        f.keys = sorted.first;
+        f.perm = sorted.second;
         f.made.mark(index);
       }
       if (f.keys.defined() && ++holders > kSortedKeep) f.keys = f.perm = at::Tensor();
     }
   }
-  return {std::get<0>(sorted), std::get<1>(sorted)};
+  return sorted;
 }
 
 // ---- int32 indices (the reference's Python wrappers cast to int32 for sddmm_coo_impl / csr_gws_impl,
@@ -427,7 +447,9 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
   const int64_t n_slabs = std::max<int64_t>(1, (src_rows + slab_rows - 1) / slab_rows);
   at::Tensor key = (pos_t.index_select(0, gid_e) * n_slabs + at::div(src_index, slab_rows, "floor").clamp_(0, n_slabs - 1)) * R + dl_e;
   gid_e = at::Tensor();
-  at::Tensor perm = std::get<1>(at::sort(key, /*stable=*/true, 0, false));
+  // (on the GPU the composite key's range is known: radix passes over its bits only)
+  at::Tensor perm = key.is_cuda() ? stable_sort_index(key, 0, std::max<int64_t>(G, 1) * n_slabs * R).second
+                                  : std::get<1>(at::sort(key, /*stable=*/true, 0, false));
   key = at::Tensor();
   at::Tensor e_src = src_index.index_select(0, perm).to(at::kInt);
   at::Tensor e_dl = dl_e.index_select(0, perm).to(at::kByte);
@@ -572,7 +594,7 @@ at::Tensor index_scatter_op(const int64_t dim, const at::Tensor &index_in, const
   auto shape = moved.sizes().vec();
   std::pair<at::Tensor, at::Tensor> kp;
   const bool atomic_flush = !f.ascending && g_opt.unsorted_mode == 2 && red == GEOT_REDUCE_SUM && (dt == GEOT_F32 || dt == GEOT_F64);
-  if (!f.ascending && !atomic_flush) kp = sorted_form(index);
+  if (!f.ascending && !atomic_flush) kp = sorted_form(index, f.kmin, f.kmax);
   // rows = index[-1] + 1 is read back and verified on every call, whichever kernels serve it
   at::Tensor out = with_row_rule(index, f.rows, !f.cached, [&](int64_t rows) {
     shape[0] = rows;
@@ -628,7 +650,7 @@ Edges dst_ordered(const at::Tensor &si_in, const at::Tensor &di_in, const c10::o
   e.fresh = !f.cached;
   e.permuted = !f.ascending;
   if (e.permuted) {
-    auto kp = sorted_form(e.di);
+    auto kp = sorted_form(e.di, f.kmin, f.kmax);
     e.si = e.si.index_select(0, kp.second);
     if (e.w.defined()) e.w = e.w.index_select(w_edge_dim, kp.second).contiguous();
     e.di = kp.first;
@@ -903,16 +925,20 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
         return {it->perm, it->si_sorted, it->di_perm};
       }
   }
-  auto sorted = at::sort(si, /*stable=*/true, 0, false);
-  at::Tensor perm = std::get<1>(sorted), di_perm = di.index_select(0, perm);
+  at::Tensor sic = si.contiguous();
+  index_ptr(sic);
+  int64_t p[4] = {0, 0, 0, 0};
+  if (sic.numel() > 0) probe_index(sic, p); // the key range sizes the sort
+  auto sorted = sic.numel() > 0 ? stable_sort_index(sic, p[2], p[3]) : std::make_pair(sic, sic);
+  at::Tensor perm = sorted.second, di_perm = di.index_select(0, perm);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.transposes;
   if (keyed) {
-    g_transposed.push_front(TransposedEntry{k1, k2, si, di, perm, std::get<0>(sorted), di_perm});
+    g_transposed.push_front(TransposedEntry{k1, k2, si, di, perm, sorted.first, di_perm});
     g_transposed.front().made.mark(si);
     while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
   }
-  return {perm, std::get<0>(sorted), di_perm};
+  return {perm, sorted.first, di_perm};
 }
 
 at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight) {

@@ -245,6 +245,34 @@ def index_probe_out(index: torch.Tensor, out2: torch.Tensor) -> torch.Tensor:
     return out2
 
 
+def index_probe_range_out(index: torch.Tensor, out4: torch.Tensor) -> torch.Tensor:
+    """out4 (device int64[4]) <- [index[-1], number of descents, min, max]; asynchronous on the current stream."""
+    dev = _require_gpu(index, out4)
+    if out4.dtype != torch.int64 or out4.numel() < 4 or not out4.is_contiguous():
+        raise TypeError("index_probe_range: out4 must be a contiguous int64 tensor of 4 elements")
+    with _on_device(dev):
+        rc = _lib.load().geot_index_probe_range(_index_ptr(index, "index"), index.numel(), out4.data_ptr(), _stream_handle(dev))
+    _lib.check(rc, "geot_index_probe_range")
+    return out4
+
+
+def sort_index(index: torch.Tensor, key_max: int):
+    """(keys ascending, perm) - the stable sort of `index` (keys in [0, key_max], key_max < 2^32) by geot_sort_index."""
+    dev = _require_gpu(index)
+    L = _lib.load()
+    nnz = index.numel()
+    keys, perm = torch.empty_like(index), torch.empty_like(index)
+    with _on_device(dev):
+        nbytes = L.geot_sort_workspace_bytes(nnz)
+        if nbytes == 0:
+            raise RuntimeError("geot_sort_workspace_bytes failed")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=index.device)
+        rc = L.geot_sort_index(_index_ptr(index, "index"), nnz, int(key_max), keys.data_ptr(), perm.data_ptr(), ws.data_ptr(),
+                               ws.numel(), _stream_handle(dev))
+    _lib.check(rc, "geot_sort_index")
+    return keys, perm
+
+
 def csr_gws_out(indptr, indices, weight, src, out) -> torch.Tensor:
     """out[r] = sum_{e in [indptr[r], indptr[r+1])} weight[e] * src[indices[e]]; weight None = ones."""
     tensors = [indptr, indices, src, out] + ([weight] if weight is not None else [])

@@ -143,6 +143,22 @@ int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t n
  * anyway for the row count can route such calls to the atomic-free kernels. */
 int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *stream);
 
+/* The same pass with the key range: out4 = {index[nnz-1], descents, min(index), max(index)}.  The range sizes the sort
+ * of an index with descents (below) and tells an index with negative keys apart. */
+int geot_index_probe_range(const int64_t *index, int64_t nnz, int64_t *out4, void *stream);
+
+/* Stable sort of an index by key - what replaces scatter_reduce_kernel's one atomicAdd per edge
+ * (csrc/cuda/index_scatter_kernel.cuh:204-263; dispatch csrc/cuda/index_scatter_cuda.cu:28-63) for an index with
+ * descents: the host layer reduces over (keys_out, perm_out) with geot_gather_reduce (deterministic, any reduction).
+ *   keys_out[i]  ascending, perm_out[i] = position of that key in `index`, equal keys in their original order.
+ * Keys must lie in [0, key_max], key_max < 2^32, nnz < 2^32 (geot_sort_supported; otherwise the host layer falls back to
+ * a generic 64-bit sort).  Radix passes cover only bit_width(key_max) bits of 32-bit (key, position) pairs.
+ * Workspace: geot_sort_workspace_bytes(nnz) bytes (0 = the query failed), 256-B aligned, no initialisation needed. */
+int geot_sort_supported(int64_t nnz, int64_t key_min, int64_t key_max);
+size_t geot_sort_workspace_bytes(int64_t nnz);
+int geot_sort_index(const int64_t *index, int64_t nnz, int64_t key_max, int64_t *keys_out, int64_t *perm_out, void *ws,
+                    size_t ws_bytes, void *stream);
+
 /* ---- CSR path ("next" row f2 of SURVEY.md section 8) ---------------------------------------
  * geot_csr_gws  <- csr_gws_cuda   csrc/cuda/header_cuda.h:19-21 (impl csrc/cuda/csr_gws_cuda.cu,
  *                                 kernel csrc/cuda/csr_gws_kernel.cuh:12-186)

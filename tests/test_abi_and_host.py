@@ -35,7 +35,10 @@ def test_library_exports_every_declared_symbol():
 def test_library_is_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
-    assert b"gfx942" not in blob and b"sm_80" not in blob     # single target, no dual paths
+    # single offload target, no dual paths (rocPRIM's host-side tuning table names other archs as plain strings;
+    # what counts is the set of code objects bundled in the library)
+    import re
+    assert set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob)) == {b"gfx950"} and b"sm_80" not in blob
 
 
 def test_workspace_bytes_is_monotonic_upper_bound():

@@ -237,6 +237,48 @@ def test_sorted_path_is_deterministic_and_atomic_free(geot):
     assert torch.allclose(a, c, rtol=1e-5, atol=1e-5)
 
 
+def test_sort_index_matches_a_stable_sort_bit_for_bit(geot):
+    """geot_sort_index (32-bit radix passes over the bits in use) against numpy's stable argsort: keys and positions
+    equal exactly - key ranges from one bit to 2^32-1, odd lengths, a misaligned index, ties everywhere; and the range
+    probe (last, descents, min, max) that sizes it.  The host layer's unsorted path reduces over this sort."""
+    from geot_amd import hip
+    rng = np.random.default_rng(2024)
+    cases = [(1, 1), (2, 5), (1000, 1), (1001, 2), (4097, 37), (70_001, 1 << 20), (300_000, 1 << 31),
+             (300_001, (1 << 32) - 1), (2_000_003, 1000), (2_000_000, 1_000_000)]
+    for nnz, top in cases:
+        index = rng.integers(0, top + 1, nnz, dtype=np.int64)
+        index[rng.integers(0, nnz)] = top                                   # the declared maximum is present
+        for off in (0, 1):                                                    # off=1: data pointer 8 mod 16
+            buf = torch.empty(nnz + off, dtype=torch.int64, device="cuda")
+            t = buf[off:]
+            t.copy_(torch.from_numpy(index))
+            probe = hip.index_probe_range_out(t, torch.empty(4, dtype=torch.int64, device="cuda")).cpu().tolist()
+            assert probe == [int(index[-1]), int((index[:-1] > index[1:]).sum()), int(index.min()), int(index.max())], (nnz, top)
+            keys, perm = hip.sort_index(t, int(index.max()))
+            order = np.argsort(index, kind="stable")
+            assert np.array_equal(perm.cpu().numpy(), order), (nnz, top, off)
+            assert np.array_equal(keys.cpu().numpy(), index[order]), (nnz, top, off)
+    L = hip._lib.load()
+    assert L.geot_sort_supported(10, 0, (1 << 32) - 1) == 1
+    assert L.geot_sort_supported(10, -1, 5) == 0 and L.geot_sort_supported(10, 0, 1 << 32) == 0
+
+
+def test_unsorted_index_outside_the_fast_sort_range(geot, oracle):
+    """Keys the 32-bit sort cannot take (a negative key is invalid input and must not be reached silently; keys at or
+    above 2^32 with a small index[-1]) go through the generic sort: rows stay index[-1]+1, keys beyond are ignored."""
+    rng = np.random.default_rng(9)
+    nnz, K, F = 5000, 40, 8
+    index = rng.integers(0, K, nnz).astype(np.int64)
+    index[7] = (1 << 33) + 5                                                  # beyond rows: ignored, as the reference's rule implies
+    index[-1] = K - 1
+    src = rng.random((nnz, F), dtype=np.float32)
+    got = geot.index_scatter(0, dev(src), dev(index), "sum", sorted=False).cpu().numpy()
+    keep = index < K
+    want = np.zeros((K, F), dtype=np.float64)
+    np.add.at(want, index[keep], src[keep].astype(np.float64))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
 def test_sorted_false_is_routed_by_the_probe(geot, oracle, monkeypatch):
     """sorted=False promises nothing: an ascending index is served by the atomic-free kernels (all
     reductions), an index with descents by the atomic path (sum only); both sized by index[-1]+1."""
