@@ -97,7 +97,25 @@ void require_gpu(const char *op, std::initializer_list<const at::Tensor *> ts) {
 // (a ROCm build of PyTorch calls the GPU "cuda": the guard / stream types that accept that device type)
 void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
-#define GEOT_DEVICE_GUARD(t) const c10::hip::HIPGuardMasqueradingAsCUDA geot_device_guard_((t).device())
+// ---- hipGraph capture --------------------------------------------------------------------------------------------------
+// Under stream capture (torch.cuda.graph around a model) nothing may synchronise and nothing enqueued has run yet:
+// an op whose index facts are already known launches with the remembered row count and skips the read-back; nothing
+// produced during the capture enters a cache (its kernels have only been recorded); a plan that is not there is not
+// built.  An index that has never been seen cannot be probed: the call fails with a clear message (run it once first).
+thread_local bool tl_capturing = false;
+struct CaptureScope {
+  bool prev;
+  explicit CaptureScope(const at::Tensor &t) : prev(tl_capturing) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    tl_capturing = t.is_cuda() && hipStreamIsCapturing(static_cast<hipStream_t>(stream_of(t)), &st) == hipSuccess &&
+                   st != hipStreamCaptureStatusNone;
+  }
+  ~CaptureScope() { tl_capturing = prev; }
+};
+
+#define GEOT_DEVICE_GUARD(t)                                                                                            \
+  const c10::hip::HIPGuardMasqueradingAsCUDA geot_device_guard_((t).device());                                         \
+  const CaptureScope geot_capture_scope_(t)
 #define GEOT_CALL(expr)                                                                                                 \
   do {                                                                                                                  \
     const int rc_ = (expr);                                                                                             \
@@ -115,6 +133,7 @@ struct Produced {
   std::shared_ptr<void> ev;
   void *stream = nullptr;
   void mark(const at::Tensor &on) {
+    if (tl_capturing) return; // (nothing made during a capture is cached; see CaptureScope)
     hipEvent_t e = nullptr;
     TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
     ev = std::shared_ptr<void>(e, [](void *p) { (void)hipEventDestroy(static_cast<hipEvent_t>(p)); });
@@ -223,6 +242,8 @@ FactsView index_facts(const at::Tensor &index) {
         return {it->rows, it->ascending, true, it->kmin, it->kmax};
       }
   }
+  TORCH_CHECK(!tl_capturing, "geot: this index tensor has not been seen before (or GEOT_TRUST_VERSION=0), and its row count / "
+              "ordering cannot be read back while the stream is being captured into a graph.  Run the call once before the capture.");
   int64_t p[4] = {0, 0, 0, 0};
   probe_index(index, p);
   std::lock_guard<std::mutex> lk(g_mu);
@@ -275,7 +296,7 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t k
   auto sorted = stable_sort_index(index, kmin, kmax);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.sorts;
-  if (keyed) {
+  if (keyed && !tl_capturing) {
     size_t holders = 0;
     for (auto &f : g_facts) {
       if (f.key == k) {
@@ -312,7 +333,7 @@ at::Tensor as_int64(const at::Tensor &t) {
       }
   }
   at::Tensor wide = t.to(at::kLong).contiguous();
-  if (keyed) {
+  if (keyed && !tl_capturing) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_widened.push_front(WidenedEntry{k, t, wide, {}});
     g_widened.front().made.mark(t);
@@ -326,6 +347,7 @@ at::Tensor as_int64(const at::Tensor &t) {
 template <typename Launch> at::Tensor with_row_rule(const at::Tensor &index, int64_t guess, bool guess_is_fresh, Launch launch) {
   if (guess_is_fresh) return launch(guess); // this very call has just read index[-1] (the probe)
   if (g_opt.trust_version >= 2) return launch(guess); // opt-in: index[-1] is as trusted as the sortedness (same content key)
+  if (tl_capturing) return launch(guess);             // a graph has static shapes: the remembered count is the contract
   void *st = stream_of(index);
   Slot &s = slot_for(index.device().index());
   const int64_t *last = index_ptr(index) + (index.numel() - 1);
@@ -533,6 +555,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
         g_slab.front().plan->made.before_use(src, g_slab.front().plan->keep);
         return g_slab.front().plan;
       }
+    if (tl_capturing) return nullptr; // Phase A synchronises: never inside a capture (the per-edge kernels serve the call)
     if (g_opt.slab_mode != 1) { // first sighting of this edge list: only remember it - a one-shot call never pays for Phase A
       bool seen = false;
       for (auto &sg : g_sightings) seen |= (sg.first == k1 && sg.second == k2);
@@ -685,6 +708,8 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
           if (plan->w_planorder.defined() && plan->w_key == wk) {
             w_planorder = plan->w_planorder;
             plan->w_made.before_use(x, {&w_planorder});
+          } else if (tl_capturing) {
+            // (no new cache content during a capture)
           } else if (plan->w_seen_valid && plan->w_seen == wk) { // the same weight content again: permute it once
             plan->w_planorder = e.w.index_select(0, plan->keep[2]);
             plan->w_made.mark(x);
@@ -805,7 +830,7 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
     const int64_t rowbytes = m1.size(1) * 4;
     if ((rowbytes == 256 || rowbytes == 512 || rowbytes == 1024) &&
         (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(di.numel(), m1.size(0), m2.size(0), rowbytes))) &&
-        index_facts(di).ascending) {
+        (tl_capturing || index_facts(di).ascending)) { // (under capture only an existing plan is used: built on an ascending di)
       if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 1, 1)) {
         auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
         GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), out.data_ptr(), m1.size(1), m1.size(0), m2.size(0), GEOT_F32,
@@ -845,7 +870,7 @@ at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   const int64_t nrow = indptr.numel() - 1;
   at::Tensor counts = (indptr.slice(0, 1, nrow + 1) - indptr.slice(0, 0, nrow)).clamp_min(0);
   at::Tensor dst_index = at::repeat_interleave(counts, c10::optional<int64_t>(nnz));
-  if (keyed) {
+  if (keyed && !tl_capturing) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_expanded.push_front(ExpandedEntry{k, indptr, dst_index, {}});
     g_expanded.front().made.mark(indptr);
@@ -927,13 +952,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
   }
   at::Tensor sic = si.contiguous();
   index_ptr(sic);
-  int64_t p[4] = {0, 0, 0, 0};
-  if (sic.numel() > 0) probe_index(sic, p); // the key range sizes the sort
+  int64_t p[4] = {0, 0, -1, -1};                                         // (min -1: the generic sort)
+  if (sic.numel() > 0 && !tl_capturing) probe_index(sic, p);              // the key range sizes the sort
   auto sorted = sic.numel() > 0 ? stable_sort_index(sic, p[2], p[3]) : std::make_pair(sic, sic);
   at::Tensor perm = sorted.second, di_perm = di.index_select(0, perm);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.transposes;
-  if (keyed) {
+  if (keyed && !tl_capturing) {
     g_transposed.push_front(TransposedEntry{k1, k2, si, di, perm, sorted.first, di_perm});
     g_transposed.front().made.mark(si);
     while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
@@ -959,7 +984,7 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
       }
   }
   at::Tensor wp = weight.index_select(0, perm);
-  if (keyed) {
+  if (keyed && !tl_capturing) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &e : g_transposed)
       if (e.k1 == k1 && e.k2 == k2) {

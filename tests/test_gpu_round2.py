@@ -359,6 +359,74 @@ def test_cached_artefacts_are_safe_on_another_stream(geot):
         ops.set_option("slab_mode", old)
 
 
+def test_dispatched_ops_are_hipgraph_capturable_after_one_eager_call(geot):
+    """torch.cuda.graph around a whole forward pass (what removes the launch-bound host cost of small graphs): after ONE
+    eager call - which probes the index facts - the dispatched operators launch with the remembered row count, do not
+    read index[-1] back, cache nothing they produce during the capture, and replay with new feature values."""
+    from geot_amd import ops
+    torch.manual_seed(21)
+    n, nnz, F, H = 3000, 40_000, 32, 4
+    di = torch.sort(torch.randint(0, n, (nnz,), device="cuda")).values
+    di[-1] = n - 1
+    si = torch.randint(0, n, (nnz,), device="cuda")
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    rowptr[1:] = torch.bincount(di, minlength=n).cumsum(0)
+    unsorted = torch.randint(0, n, (nnz,), device="cuda")
+    unsorted[-1] = n - 1
+    w = torch.rand(nnz, device="cuda")
+    wh = torch.rand(nnz, H, device="cuda")
+    x = torch.rand(n, F, device="cuda")
+    xh = torch.rand(n, H, F // H, device="cuda")
+    e = torch.rand(nnz, F, device="cuda")
+
+    def forward():
+        h = geot.gather_weight_scatter(si, di, w, x)                  # GCN-style aggregation
+        h = geot.gather_scatter(si, di, torch.relu(h))
+        pooled = geot.index_scatter(0, e, di, "sum", sorted=True)     # edge messages -> nodes
+        anyorder = geot.index_scatter(0, e, unsorted, "max", sorted=False)   # index with descents: sort path
+        c = geot.csr_gws(rowptr, si, w, x)
+        m = geot.mh_spmm(si, di, wh, xh)
+        return h, pooled, anyorder, c, m
+
+    def reference():
+        h = torch.zeros(n, F, device="cuda", dtype=torch.float64).index_add_(0, di, x.double()[si] * w.double()[:, None])
+        h = torch.zeros(n, F, device="cuda", dtype=torch.float64).index_add_(0, di, torch.relu(h)[si])
+        pooled = torch.zeros(n, F, device="cuda", dtype=torch.float64).index_add_(0, di, e.double())
+        anyorder = torch.zeros(n, F, device="cuda").scatter_reduce_(0, unsorted[:, None].expand(-1, F), e, "amax", include_self=False)
+        m = torch.zeros(n, H, F // H, device="cuda", dtype=torch.float64).index_add_(0, di, xh.double()[si] * wh.double()[:, :, None])
+        return h, pooled, anyorder, m
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        forward()                                                     # the eager call: facts, workspace
+        s.synchronize()
+        before = ops.stats()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            outs = forward()
+        after = ops.stats()
+    assert after["probes"] == before["probes"] and after["facts"] == before["facts"]       # nothing probed, nothing cached
+    for rep in range(3):
+        x.uniform_()
+        e.uniform_()
+        w.uniform_()
+        g.replay()
+        torch.cuda.synchronize()
+        h, pooled, anyorder, c, m = outs
+        rh, rp, ra, rm = reference()
+        assert torch.allclose(h.double(), rh, rtol=1e-5, atol=1e-4), rep
+        assert torch.allclose(pooled.double(), rp, rtol=1e-5, atol=1e-4), rep
+        assert torch.equal(anyorder, ra), rep
+        assert c.shape == (n + 1, F) and torch.allclose(c[:n].double(), torch.zeros(n, F, device="cuda", dtype=torch.float64).index_add_(
+            0, di, x.double()[si] * w.double()[:, None]), rtol=1e-5, atol=1e-4), rep
+        assert torch.allclose(m.double(), rm, rtol=1e-5, atol=1e-4), rep
+    # eager calls after the capture still see consistent caches
+    with torch.no_grad():
+        h2 = forward()[0]
+    assert torch.allclose(h2, outs[0], rtol=1e-6, atol=1e-6)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT torchrun: the parent (no GPU call) spawns the ranks as children and relays
     rank 0's line.  The ranks share this box's one GPU over a gloo rendezvous (GEOT_DIST_BACKEND=gloo)."""

@@ -3,7 +3,8 @@
 graphs - five of the reference's nine benchmark datasets (benchmark/bench_index_scatter.py:91) - timed the way the
 reference times them (wall clock over back-to-back calls, one synchronize at the end): the operator as dispatched
 (C++ host layer: row rule read-back + allocation + kernels) beside torch.index_add_ / torch.sparse.mm, which are
-handed the row count.  CSV on stdout.
+handed the row count; and the same dispatched operators replayed from a hipGraph (torch.cuda.graph around 20 calls:
+after one eager call they are capturable - what a small-graph model would do around its whole forward pass).  CSV on stdout.
     python tools/bench_small.py [--iters 2000]
 """
 import argparse
@@ -35,6 +36,28 @@ def wall_us(fn, n):
     return (time.perf_counter() - t0) / n * 1e6
 
 
+def graph_us(fn, n, per_graph=20):
+    """per-call time of `fn` replayed from a captured graph of `per_graph` calls"""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        fn()
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(per_graph):
+                fn()
+    reps = max(5, n // per_graph)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (reps * per_graph) * 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=2000)
@@ -42,7 +65,8 @@ def main():
     dev = torch.device("cuda")
     print(hip.build_info(), file=sys.stderr)
     print("dataset,nodes,edges,feat,index_scatter_sorted_us,index_scatter_sorted_false_us,doorway_no_row_rule_us,torch_index_add_us,"
-          "gather_weight_scatter_us,torch_sparse_mm_us,index_scatter_trust2_us,gather_weight_scatter_trust2_us")
+          "gather_weight_scatter_us,torch_sparse_mm_us,index_scatter_trust2_us,gather_weight_scatter_trust2_us,"
+          "index_scatter_graph_replay_us,gather_weight_scatter_graph_replay_us")
     for name, (nodes, edges) in DATASETS.items():
         nnz = edges + nodes
         dst = powerlaw_index(nnz, nodes, 3, dev)
@@ -65,6 +89,8 @@ def main():
             t += [wall_us(lambda: geot.index_scatter(0, src, dst, "sum", True), a.iters),
                   wall_us(lambda: geot.gather_weight_scatter(col, dst, val, x), a.iters)]
             geot.ops.set_option("trust_version", 1)
+            t += [graph_us(lambda: geot.index_scatter(0, src, dst, "sum", True), a.iters),
+                  graph_us(lambda: geot.gather_weight_scatter(col, dst, val, x), a.iters)]
             print(f"{name},{nodes},{nnz},{F}," + ",".join(f"{v:.1f}" for v in t), flush=True)
 
 
