@@ -17,6 +17,8 @@
 //   * dense graphs are re-arranged once for the source-blocked kernel (csrc/seg_slab.hip) on their second call;
 //   * one workspace per (device, stream), a device guard, the current stream.
 #include <ATen/ATen.h>
+#include <ATen/OpMathType.h>
+#include <ATen/Parallel.h>
 #include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -28,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <list>
 #include <map>
 #include <mutex>
@@ -642,6 +645,105 @@ at::Tensor index_scatter_op(const int64_t dim, const at::Tensor &index_in, const
   return dim == 0 ? out : out.movedim(0, dim);
 }
 
+// ---- index_scatter on CPU tensors -------------------------------------------------------------------------------------------
+// The one operator the reference registers for the CPU key as well (csrc/index_scatter.cpp:11-24,53 ->
+// csrc/cpu/index_scatter_cpu.cpp:25-155).  This is that key's kernel for CPU tensors - it is never reached by GPU
+// tensors and is no fallback for them (without libgeot_hip.so the package does not import).  Semantics: the intended
+// ones, dst[index[e]] (op)= src[e] (the reference reads src[index[e]]); per row strictly sequential in edge
+// order with fp32 accumulation for 16-bit storage (index_scatter_cpu.cpp:78-113), rows = index[-1] + 1, rows without
+// edges 0, NaN propagated by max / min as ATen does.  Rows are found without a segment table: every thread of
+// at::parallel_for takes an edge range moved to row boundaries.  An index with descents (the reference refuses:
+// "unsorted index is not supported yet", :151) is reduced over its stable sort, as on the GPU.
+template <typename T, int RED> void cpu_reduce_rows(const int64_t *index, const T *src, const int64_t *perm, T *out, int64_t nnz, int64_t feat) {
+  using acc_t = at::opmath_type<T>;
+  const int64_t grain = std::max<int64_t>(1, 32768 / std::max<int64_t>(feat, 1));
+  at::parallel_for(0, nnz, grain, [&](int64_t b, int64_t e) {
+    while (b > 0 && b < nnz && index[b] == index[b - 1]) ++b;         // both ends move forward to the next row start:
+    while (e > 0 && e < nnz && index[e] == index[e - 1]) ++e;         // neighbouring ranges meet at the same edge
+    std::vector<acc_t> acc((size_t)feat);
+    for (int64_t i = b; i < e;) {
+      const int64_t row = index[i];
+      int64_t j = i;
+      const acc_t identity = RED == GEOT_REDUCE_PROD ? acc_t(1) : RED == GEOT_REDUCE_MAX ? -std::numeric_limits<acc_t>::infinity()
+                             : RED == GEOT_REDUCE_MIN ? std::numeric_limits<acc_t>::infinity() : acc_t(0);
+      std::fill(acc.begin(), acc.end(), identity);
+      for (; j < nnz && index[j] == row; ++j) {
+        const T *x = src + (perm ? perm[j] : j) * feat;
+        for (int64_t k = 0; k < feat; ++k) {
+          const acc_t v = static_cast<acc_t>(x[k]);
+          if (RED == GEOT_REDUCE_SUM || RED == GEOT_REDUCE_MEAN) acc[k] += v;
+          else if (RED == GEOT_REDUCE_PROD) acc[k] *= v;
+          else if (RED == GEOT_REDUCE_MAX) acc[k] = (v != v) ? v : (acc[k] < v ? v : acc[k]);
+          else acc[k] = (v != v) ? v : (v < acc[k] ? v : acc[k]);
+        }
+      }
+      T *o = out + row * feat;
+      const acc_t count = static_cast<acc_t>(j - i);
+      for (int64_t k = 0; k < feat; ++k) o[k] = static_cast<T>(RED == GEOT_REDUCE_MEAN ? acc[k] / count : acc[k]);
+      i = j;
+    }
+  });
+}
+
+template <typename T>
+void cpu_reduce_dispatch(int red, const int64_t *index, const T *src, const int64_t *perm, T *out, int64_t nnz, int64_t feat) {
+  switch (red) {
+  case GEOT_REDUCE_SUM: return cpu_reduce_rows<T, GEOT_REDUCE_SUM>(index, src, perm, out, nnz, feat);
+  case GEOT_REDUCE_MEAN: return cpu_reduce_rows<T, GEOT_REDUCE_MEAN>(index, src, perm, out, nnz, feat);
+  case GEOT_REDUCE_MAX: return cpu_reduce_rows<T, GEOT_REDUCE_MAX>(index, src, perm, out, nnz, feat);
+  case GEOT_REDUCE_MIN: return cpu_reduce_rows<T, GEOT_REDUCE_MIN>(index, src, perm, out, nnz, feat);
+  default: return cpu_reduce_rows<T, GEOT_REDUCE_PROD>(index, src, perm, out, nnz, feat);
+  }
+}
+
+at::Tensor index_scatter_cpu_op(const int64_t dim, const at::Tensor &index_in, const at::Tensor &src, const c10::string_view reduce,
+                                const bool /*sorted: a hint, checked below*/) {
+  TORCH_CHECK(dim >= 0 && dim < src.dim(), "dim must be non-negative and less than input dimensions");
+  TORCH_CHECK(index_in.dim() == 1, "index must be 1 dimensional");
+  TORCH_CHECK(src.size(dim) == index_in.size(0), "index length must be equal to src dimension size");
+  const int red = reduce_code(reduce);
+  TORCH_CHECK_INDEX(index_in.numel() > 0, "index -1 is out of bounds for dimension 0 with size 0");
+  TORCH_CHECK(index_in.device().is_cpu() && src.device().is_cpu(), "all tensors must be on the same device");
+  at::Tensor moved = (dim == 0 ? src : src.movedim(dim, 0)).contiguous();
+  at::Tensor index = index_in.contiguous();
+  const int64_t *ip = index_ptr(index);
+  const int64_t nnz = index.numel(), feat = moved.numel() / nnz;
+  const int64_t rows = ip[nnz - 1] + 1; // csrc/index_scatter.cpp:15
+  TORCH_CHECK_INDEX(rows >= 0, "index out of range");
+  bool ascending = ip[0] >= 0;
+  for (int64_t i = 0; i + 1 < nnz && ascending; ++i) ascending = ip[i] <= ip[i + 1];
+  at::Tensor keys = index, perm;
+  if (!ascending) { // stable sort; rows stay index[-1] + 1, keys outside [0, rows) are ignored
+    auto sorted = at::sort(index, /*stable=*/true, 0, false);
+    at::Tensor k = std::get<0>(sorted), p = std::get<1>(sorted);
+    at::Tensor keep = at::nonzero(k.ge(0).logical_and(k.lt(rows))).flatten();
+    keys = k.index_select(0, keep).contiguous();
+    perm = p.index_select(0, keep).contiguous();
+  }
+  auto shape = moved.sizes().vec();
+  shape[0] = rows;
+  at::Tensor out = at::zeros(shape, moved.options());
+  const int64_t n = keys.numel();
+  const int64_t *pp = perm.defined() ? perm.data_ptr<int64_t>() : nullptr;
+  if (n > 0 && feat > 0) {
+    switch (moved.scalar_type()) {
+    case at::kFloat: cpu_reduce_dispatch<float>(red, keys.data_ptr<int64_t>(), moved.data_ptr<float>(), pp, out.data_ptr<float>(), n, feat); break;
+    case at::kDouble: cpu_reduce_dispatch<double>(red, keys.data_ptr<int64_t>(), moved.data_ptr<double>(), pp, out.data_ptr<double>(), n, feat); break;
+    case at::kHalf: cpu_reduce_dispatch<at::Half>(red, keys.data_ptr<int64_t>(), moved.data_ptr<at::Half>(), pp, out.data_ptr<at::Half>(), n, feat); break;
+    case at::kBFloat16:
+      cpu_reduce_dispatch<at::BFloat16>(red, keys.data_ptr<int64_t>(), moved.data_ptr<at::BFloat16>(), pp, out.data_ptr<at::BFloat16>(), n, feat);
+      break;
+    default: TORCH_CHECK(false, "\"index_scatter_sorted\" not implemented for '", toString(moved.scalar_type()), "'");
+    }
+  }
+  return dim == 0 ? out : out.movedim(0, dim);
+}
+
+at::Tensor gather_rows_cpu_op(const at::Tensor &index, const at::Tensor &src) {
+  TORCH_CHECK(index.dim() == 1 && src.dim() >= 1, "gather_rows: index must be 1 dimensional");
+  return src.index_select(0, index);
+}
+
 // ---- gather ops -------------------------------------------------------------------------------------------------------------------
 void check_gather(const at::Tensor &si, const at::Tensor &di, const at::Tensor &src, int64_t ndim) {
   TORCH_CHECK(si.dim() == 1 && di.dim() == 1, "src_index and dst_index must be 1 dimensional");
@@ -1080,8 +1182,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("_slab_worthwhile(int nnz, int rows, int src_rows, int rowbytes) -> bool", slab_worthwhile_op);
 }
 
-// One implementation per op for both device keys: the argument checks (reference texts) come first, then CPU tensors are
-// refused - this package is the MI355X path and has no CPU fallback.
+// The GPU key ("CUDA" is what a ROCm build of PyTorch calls it).
 #define GEOT_IMPLS(m)                                                                \
   m.impl("index_scatter", index_scatter_op);                                         \
   m.impl("gather_scatter_impl", gather_scatter_op);                                  \
@@ -1101,4 +1202,24 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.impl("transposed_weight", transposed_weight_op)
 
 TORCH_LIBRARY_IMPL(geot, CUDA, m) { GEOT_IMPLS(m); }
-TORCH_LIBRARY_IMPL(geot, CPU, m) { GEOT_IMPLS(m); }
+#undef GEOT_IMPLS
+// CPU key: index_scatter computes (the reference registers a CPU kernel for it and for nothing else); the other
+// operators run their argument checks (reference texts) and then refuse CPU tensors, as the reference has no CPU kernel
+TORCH_LIBRARY_IMPL(geot, CPU, m) {
+  m.impl("index_scatter", index_scatter_cpu_op);
+  m.impl("gather_scatter_impl", gather_scatter_op);
+  m.impl("gather_weight_scatter_impl", gather_weight_scatter_op);
+  m.impl("sddmm_coo_impl", sddmm_coo_op);
+  m.impl("csr_gws_impl", csr_gws_op);
+  m.impl("mh_spmm", mh_spmm_op);
+  m.impl("gather_scatter", gather_scatter_op);
+  m.impl("gather_weight_scatter", gather_weight_scatter_op);
+  m.impl("csr_gws", csr_gws_op);
+  m.impl("gather_reduce", gather_reduce_op);
+  m.impl("gather_scatter_rows", gather_scatter_rows_op);
+  m.impl("gather_weight_scatter_rows", gather_weight_scatter_rows_op);
+  m.impl("mh_spmm_rows", mh_spmm_rows_op);
+  m.impl("gather_rows", gather_rows_cpu_op); // (the backward of the CPU index_scatter)
+  m.impl("transpose_edges", transpose_edges_op);
+  m.impl("transposed_weight", transposed_weight_op);
+}

@@ -30,7 +30,9 @@ Deliberate differences (all documented in DESIGN.md):
 * ``reduce``: sum / mean / min(amin) / max(amax) / prod with the semantics of the reference's CPU path
   (csrc/cpu/index_scatter_cpu.cpp:124-134); the reference's GPU kernels parse the argument but always add;
 * ``dim != 0`` is honoured (the reference validates ``dim`` but always reduces along dim 0);
-* CPU tensors raise: this package is the MI355X path and has no CPU fallback.
+* CPU tensors: ``index_scatter`` has a CPU key as in the reference (csrc/index_scatter.cpp:53; the plugin's own kernel,
+  intended operand); every other operator is GPU-only, as in the reference, and refuses CPU tensors.  GPU tensors are
+  served by the HIP kernels or not at all - there is no fallback.
 """
 from __future__ import annotations
 

@@ -137,18 +137,17 @@ def test_host_options_and_counters():
         ops.set_option("nope", 1)
     ops.clear_caches()
     assert ops.stats()["facts"] == 0
-    # CPU tensors never reach the probe: the doorway refuses them after the argument checks
-    with pytest.raises(RuntimeError, match="CPU tensors are not supported"):
-        torch.ops.geot.index_scatter(0, torch.tensor([0, 2, 1, 2]), torch.rand(4, 2), "sum", True)
+    # CPU tensors never reach the probe: the gather ops refuse them after the argument checks
     with pytest.raises(RuntimeError, match="CPU tensors are not supported"):
         torch.ops.geot.gather_scatter(torch.tensor([0, 1, 2, 3]), torch.tensor([0, 2, 1, 2]), torch.rand(4, 2))
 
 
 def test_cpu_tensors_fail_loudly_no_fallback():
+    """The gather ops have no CPU kernel in the reference either ([CUDA]-only registrations, csrc/gather_scatter.cpp:114-117):
+    CPU tensors are refused, nothing falls back.  (index_scatter is the one op with a CPU key, see test_cpu_key.py.)"""
     src = torch.rand(6, 4)
     idx = torch.tensor([0, 0, 1, 1, 2, 2])
-    for call in (lambda: geot_amd.index_scatter(0, src, idx),
-                 lambda: geot_amd.gather_scatter(idx, idx, src),
+    for call in (lambda: geot_amd.gather_scatter(idx, idx, src),
                  lambda: geot_amd.gather_weight_scatter(idx, idx, torch.rand(6), src),
                  lambda: geot_amd.mh_spmm(idx, idx, torch.rand(6, 2), src.view(6, 2, 2))):
         with pytest.raises(RuntimeError, match="CPU tensors are not supported"):
