@@ -77,7 +77,23 @@ struct SegParams {
   void *wsum;               // [windows][F] accumulators
   int64_t *wcnt;            // [windows] edge counts (mean)
   int *wflag;               // [windows] 1 = every tile of the window is `single`
+  // row-rule read-back published by the kernel itself (geot_publish_word): the first thread of the first workgroup
+  // copies *pub_src (the caller's index[-1]) to pub_dst[0] in pinned host memory, then pub_seq to pub_dst[1]
+  const int64_t *pub_src;
+  int64_t *pub_dst;
+  int64_t pub_seq;
 };
+
+// one 8-byte device word to the host while the kernel runs (fine-grained pinned memory): value first, fence, then
+// the sequence number the host is spinning on
+__device__ __forceinline__ void publish_word(const SegParams &p) {
+  if (p.pub_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const int64_t v = *p.pub_src;
+    __hip_atomic_store(p.pub_dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(p.pub_dst + 1, p.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 // Storage types: float, double, and the 16-bit types with fp32 accumulation (the reference's CPU path
 // accumulates half/bfloat16 in an fp32 buffer and converts once at the end,
@@ -198,6 +214,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  publish_word(p);
   // Gather modes: blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so give
   // every XCD a CONTIGUOUS range of tiles - neighbouring dst rows of a graph with locality gather
   // overlapping src rows, which then hit in that XCD's L2.  Pure placement: any mapping is correct.
@@ -546,6 +563,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
   __shared__ int pvL[2 * NW];
   __shared__ float pL[2 * NW][8];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  publish_word(p);
   constexpr int te = kThreads * S;
   const int64_t tile = blockIdx.x;
   const int64_t ts = tile * (int64_t)te;
@@ -707,6 +725,7 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   __shared__ float pL[2 * NW][8];
   typedef float f4_t __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  publish_word(p);
   int64_t tile = blockIdx.x;
   if constexpr (MODE != 0) { // contiguous tile ranges per XCD, as in the gather modes of seg_tile_kernel
     if (p.xcd_swizzle) {
@@ -1648,6 +1667,15 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
 inline bool is_aligned16(const void *a) { return ((uintptr_t)a & 15) == 0; }
 
 // mode: 0 index_scatter, 1 gather_scatter, 2 gather_weight_scatter, 3 mh edge-major, 4 mh head-major
+// one-shot request of the calling thread (geot_publish_word): consumed by the next segment op it launches
+struct PublishRequest {
+  bool armed = false;
+  const int64_t *src = nullptr;
+  int64_t *dst = nullptr;
+  int64_t seq = 0;
+};
+thread_local PublishRequest t_pub;
+
 template <typename T>
 int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_t *dst_index,
                    const void *weight, const void *src, void *dst, int64_t nnz, int64_t F,
@@ -1703,6 +1731,14 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.cg = P.cg;
   p.xcd_swizzle = g_xcd;
   p.nt_keys = g_nt_keys;
+  // a pending geot_publish_word is consumed by the first kernel of this call if that kernel is one of the three that
+  // publish (tile / lane / narrow kernel; not the LDS-bin kernel of the unsorted atomic path)
+  const bool lds_bin = !sorted && (size_t)K * (size_t)F * sizeof(T) <= 48 * 1024 && g_tune.lpr_log2 != 7;
+  const bool publish = t_pub.armed && nnz > 0 && !lds_bin;
+  p.pub_src = publish ? t_pub.src : nullptr;
+  p.pub_dst = publish ? t_pub.dst : nullptr;
+  p.pub_seq = publish ? t_pub.seq : 0;
+  if (publish) t_pub.armed = false;
   // Long-run regime (few keys: global pooling, hub-dominated graphs): average run >= 4096 edges and enough
   // tiles for a chain to span whole 64-tile windows -> one extra small launch (seg_wsum_kernel) between the
   // tile kernel and the fix-up.  Everything else keeps two launches.  "hub" option: 1 forces, 0 forbids.
@@ -2054,6 +2090,21 @@ int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t n
   if (dtype == GEOT_F16) return run_gather_rows<half_t>(index, src, dst, nnz, feat, src_rows, st);
   if (dtype == GEOT_BF16) return run_gather_rows<bf16_t>(index, src, dst, nnz, feat, src_rows, st);
   return fail(GEOT_EINVAL, "bad dtype");
+}
+
+int geot_publish_word(const int64_t *device_word, int64_t *host_slot2, int64_t seq) {
+  if (!device_word || !host_slot2) return fail(GEOT_EINVAL, "publish_word: null pointer");
+  t_pub.armed = true;
+  t_pub.src = device_word;
+  t_pub.dst = host_slot2;
+  t_pub.seq = seq;
+  return GEOT_OK;
+}
+
+int geot_publish_pending(void) {
+  const bool armed = t_pub.armed;
+  t_pub.armed = false;
+  return armed ? 1 : 0;
 }
 
 int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *stream) {

@@ -51,7 +51,9 @@ struct Options {
   int slab_mode = 0;         // GEOT_SLAB: -1 never, 0 auto, 1 always
   int transpose_cache = 4;   // GEOT_TRANSPOSE_CACHE (entries)
   int slab_keep = 2;
+  int publish_rows = 1;      // GEOT_PUBLISH_ROWS: small calls get index[-1] from their own first kernel (geot_publish_word)
   Options() {
+    if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;
     if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
     if (const char *e = std::getenv("GEOT_TRUST_VERSION")) trust_version = !std::strcmp(e, "0") ? 0 : (!std::strcmp(e, "2") ? 2 : 1);
     if (const char *e = std::getenv("GEOT_UNSORTED")) unsorted_mode = !std::strcmp(e, "atomic") ? 2 : (!std::strcmp(e, "sort") ? 1 : 0);
@@ -61,7 +63,7 @@ struct Options {
 };
 Options g_opt;
 struct Stats {
-  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0;
+  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0;
 };
 Stats g_stats;
 std::mutex g_mu; // guards the caches below (facts, transposed edge lists, slab plans)
@@ -171,15 +173,17 @@ at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
 
 // ---- pinned read-back slot per (thread, device) -------------------------------------------------------------------------
 struct Slot {
-  int64_t *host = nullptr;
+  int64_t *host = nullptr;   // [0..3] copies (probe, row rule), [4] word published by a kernel, [5] its sequence number
   hipEvent_t ev = nullptr;
+  int64_t seq = 0;
 };
 Slot &slot_for(int device) {
   static thread_local std::map<int, Slot> slots;
   Slot &s = slots[device];
   if (!s.host) {
-    TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), 4 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
+    TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
                 "hipHostMalloc failed");
+    std::memset(s.host, 0, 8 * sizeof(int64_t));
     TORCH_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
   }
   return s;
@@ -345,6 +349,8 @@ at::Tensor as_int64(const at::Tensor &t) {
   return wide;
 }
 
+constexpr int64_t kPublishMaxEdges = 1 << 20; // (larger calls keep the copy that completes under their kernels)
+
 // ---- the row rule without stalling the GPU ---------------------------------------------------------------------------------
 // launch(rows) allocates the output for `rows` rows and enqueues the kernels.  `guess` comes from the facts.
 template <typename Launch> at::Tensor with_row_rule(const at::Tensor &index, int64_t guess, bool guess_is_fresh, Launch launch) {
@@ -354,6 +360,47 @@ template <typename Launch> at::Tensor with_row_rule(const at::Tensor &index, int
   void *st = stream_of(index);
   Slot &s = slot_for(index.device().index());
   const int64_t *last = index_ptr(index) + (index.numel() - 1);
+  if (g_opt.speculate_rows && g_opt.publish_rows && index.numel() <= kPublishMaxEdges) {
+    // launch-bound calls: no copy, no event - the first kernel of the launch writes index[-1] and a sequence number into
+    // the pinned slot while it runs, the host spins on the sequence number (geot_publish_word)
+    const int64_t seq = ++s.seq;
+    GEOT_CALL(geot_publish_word(last, s.host + 4, seq));
+    at::Tensor out;
+    try {
+      out = launch(guess);
+    } catch (...) {
+      geot_publish_pending();
+      throw;
+    }
+    bool have = false;
+    if (!geot_publish_pending()) { // taken by that launch
+      for (int spin = 0; spin < 40000 && !have; ++spin) {
+        have = __atomic_load_n(&s.host[5], __ATOMIC_ACQUIRE) == seq;
+        if (!have) __builtin_ia32_pause();
+      }
+      if (!have) { // a long queue ahead of this call: wait properly
+        TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(st)) == hipSuccess, "hipStreamSynchronize failed");
+        have = __atomic_load_n(&s.host[5], __ATOMIC_ACQUIRE) == seq;
+        TORCH_CHECK(have, "geot: the row-count word was not published by the kernel");
+      }
+      s.host[0] = s.host[4];
+      std::lock_guard<std::mutex> lk(g_mu);
+      ++g_stats.published;
+    } else { // a path whose first kernel does not publish (small by the size rule above): read it back after the fact
+      TORCH_CHECK(hipMemcpyAsync(s.host, last, 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(st)) == hipSuccess, "hipMemcpyAsync failed");
+      TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(st)) == hipSuccess, "hipStreamSynchronize failed");
+    }
+    const int64_t rows = s.host[0] + 1;
+    if (rows != guess) {
+      {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ++g_stats.row_mismatches;
+      }
+      remember_rows(index, rows);
+      out = launch(rows);
+    }
+    return out;
+  }
   TORCH_CHECK(hipMemcpyAsync(s.host, last, 8, hipMemcpyDeviceToHost, static_cast<hipStream_t>(st)) == hipSuccess, "hipMemcpyAsync failed");
   if (!g_opt.speculate_rows) {
     TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(st)) == hipSuccess, "hipStreamSynchronize failed");
@@ -1110,6 +1157,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "slab_mode") p = &g_opt.slab_mode;
   else if (name == "transpose_cache") p = &g_opt.transpose_cache;
   else if (name == "slab_keep") p = &g_opt.slab_keep;
+  else if (name == "publish_rows") p = &g_opt.publish_rows;
   else if (name == "clear_caches") {
     g_facts.clear();
     g_transposed.clear();
@@ -1130,7 +1178,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
 std::vector<int64_t> host_stats_op() {
   std::lock_guard<std::mutex> lk(g_mu);
   return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
-          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size()};
+          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published};
 }
 
 // Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).

@@ -92,7 +92,8 @@ def clear_caches() -> None:
 
 
 def stats() -> dict:
-    names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans")
+    names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans",
+             "published")
     return dict(zip(names, torch.ops.geot._host_stats()))
 
 

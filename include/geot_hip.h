@@ -143,6 +143,15 @@ int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t n
  * anyway for the row count can route such calls to the atomic-free kernels. */
 int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *stream);
 
+/* Row-rule read-back without a copy engine round trip (launch-bound calls).  One-shot request of the calling thread: the
+ * FIRST kernel of the next geot_index_scatter* / geot_gather_* / geot_mh_spmm call this thread makes copies *device_word
+ * (normally &index[nnz-1]) to host_slot2[0] and then stores `seq` to host_slot2[1], while it runs.  host_slot2 is
+ * fine-grained pinned host memory (hipHostMalloc) the device can write; the host spins on host_slot2[1] == seq instead of
+ * hipMemcpyAsync + hipEventSynchronize.  geot_publish_pending() returns 1 (and disarms) if the request was NOT taken by
+ * that call (a path whose first kernel does not publish, an empty call): the host then reads the word back the usual way. */
+int geot_publish_word(const int64_t *device_word, int64_t *host_slot2, int64_t seq);
+int geot_publish_pending(void);
+
 /* The same pass with the key range: out4 = {index[nnz-1], descents, min(index), max(index)}.  The range sizes the sort
  * of an index with descents (below) and tells an index with negative keys apart. */
 int geot_index_probe_range(const int64_t *index, int64_t nnz, int64_t *out4, void *stream);

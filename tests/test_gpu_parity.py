@@ -551,6 +551,41 @@ def test_backward_when_last_node_has_no_out_edge(geot):
     assert torch.allclose(src.grad[:2], torch.full((2, 8), 2.0, device="cuda"))
 
 
+@pytest.mark.parametrize("nnz,publish", [(5000, 1), (5000, 0), (1_200_000, 1)])
+def test_row_rule_read_back_three_ways(geot, nnz, publish):
+    """index[-1] reaches the host (a) from the call's own first kernel, which writes it and a sequence number into pinned
+    memory while it runs (calls up to 1 M edges: geot_publish_word - no copy, no event), (b) by an 8-byte copy queued
+    ahead of the kernels (GEOT_PUBLISH_ROWS=0, and every larger call).  Each way catches a silent `.data` edit, for
+    every kernel family that publishes (tile, lane-sequential F <= 8, weighted gather) and for paths that do not."""
+    from geot_amd import ops
+    old = ops.set_option("publish_rows", publish)
+    try:
+        torch.manual_seed(nnz)
+        K = 700
+        index = torch.sort(torch.randint(0, K, (nnz,), device="cuda")).values
+        index[-1] = K - 1
+        si = torch.randint(0, K, (nnz,), device="cuda")
+        w = torch.rand(nnz, device="cuda")
+        for F in (1, 4, 48):
+            src = torch.rand(nnz, F, device="cuda")
+            x = torch.rand(K, F, device="cuda")
+            st0 = ops.stats()
+            for last in (K - 1, K - 1, K + 20, K - 1):
+                index.data[-1] = last                                # same identity, same version counter
+                ref = torch.zeros(last + 1, F, device="cuda", dtype=torch.float64).index_add_(0, index, src.double())
+                out = geot.index_scatter(0, src, index)
+                assert out.shape == (last + 1, F) and torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4), (F, last)
+                out = geot.gather_weight_scatter(si, index, w, x)
+                ref = torch.zeros(last + 1, F, device="cuda", dtype=torch.float64).index_add_(0, index, x.double()[si] * w.double()[:, None])
+                assert out.shape == (last + 1, F) and torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4), (F, last)
+            st1 = ops.stats()
+            assert st1["row_mismatches"] - st0["row_mismatches"] >= 2              # (the op that runs first after an edit sees it)
+            took_publish = st1["published"] - st0["published"]
+            assert (took_publish >= 6) if (publish and nnz <= (1 << 20)) else (took_publish == 0), (F, took_publish)
+    finally:
+        ops.set_option("publish_rows", old)
+
+
 def test_row_rule_is_verified_on_every_call(geot, oracle, monkeypatch):
     """The row count remembered for an index tensor is only a guess: index[-1] is read back and checked
     on every call.  `.data` writes change the content without bumping the version counter."""
