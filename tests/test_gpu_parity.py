@@ -156,7 +156,12 @@ def test_narrow_rows_both_kernels(geot, oracle, narrow):
                     obase = torch.full((rows * F + 1,), float("nan"), device="cuda")
                     got = hip.index_scatter_out(dev(index), src, obase[1:].view(rows, F), sorted=True)
                     want = hip.index_scatter_out(dev(index), src, torch.empty(rows, F, device="cuda"), sorted=True)
-                    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5) and bool(torch.isnan(obase[0]))
+                    # two summation orders of the same row (a hub row adds 9 000 cancelling terms): bound by the row's magnitude
+                    mag = torch.zeros(rows, F, device="cuda").index_add_(0, dev(index), src.abs())
+                    bad = (got - want).abs() > 2e-6 * mag + 1e-6
+                    rows_bad = torch.nonzero(bad.any(1)).flatten()[:8].tolist()
+                    assert not rows_bad, (name, F, rows_bad, got[rows_bad].tolist(), want[rows_bad].tolist())
+                    assert bool(torch.isnan(obase[0]))
         # NaN propagation through the lane-sequential max / min (ATen semantics, positions exact)
         if narrow == 1:
             index = shapes["powerlaw"]
