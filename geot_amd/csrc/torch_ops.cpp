@@ -181,8 +181,12 @@ Slot &slot_for(int device) {
   static thread_local std::map<int, Slot> slots;
   Slot &s = slots[device];
   if (!s.host) {
-    TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
-                "hipHostMalloc failed");
+    // fine-grained (coherent) pinned memory: a running kernel's stores become visible to the spinning host
+    if (hipHostMalloc(reinterpret_cast<void **>(&s.host), 8 * sizeof(int64_t), hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
+                  "hipHostMalloc failed");
+    }
     std::memset(s.host, 0, 8 * sizeof(int64_t));
     TORCH_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
   }
