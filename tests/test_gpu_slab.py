@@ -300,6 +300,43 @@ def test_slab_calls_are_hipgraph_capturable(geot):
         assert torch.allclose(dw, (g_[di] * x[si]).sum(1), rtol=1e-4, atol=1e-4)
 
 
+def test_dispatched_slab_path_is_capturable(geot):
+    """torch.cuda.graph around the dispatched operator on a graph that has a source-blocked plan: under capture the cached
+    plan (and the weight kept in plan order) is used, nothing is built or cached, replays follow new feature values."""
+    from geot_amd import ops
+    rng = np.random.default_rng(17)
+    n, nnz, F = 20_000, 1_200_000, 128
+    di = dev(powerlaw_index(nnz, n, 9))
+    si = dev(rng.integers(0, n, nnz).astype(np.int64))
+    w, x = torch.rand(nnz, device="cuda"), torch.rand(n, F, device="cuda")
+    old = ops.set_option("slab_mode", "always")
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(3):                                        # plan built, static weight permuted into plan order
+                geot.gather_weight_scatter(si, di, w, x)
+            s.synchronize()
+            st0 = ops.stats()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                y = geot.gather_weight_scatter(si, di, w, x)
+                ymax = torch.ops.geot.gather_reduce(si, di, None, x, "max")
+            st1 = ops.stats()
+        assert st1["slab_calls"] - st0["slab_calls"] == 2 and st1["plans_built"] == st0["plans_built"]
+        for rep in range(3):
+            x.uniform_()
+            g.replay()
+            torch.cuda.synchronize()
+            ref = torch.zeros(n, F, device="cuda", dtype=torch.float64).index_add_(0, di, x.double()[si] * w.double()[:, None])
+            assert torch.allclose(y.double(), ref, rtol=1e-5, atol=1e-4), rep
+            refmax = torch.full((n, F), float("-inf"), device="cuda").scatter_reduce_(0, di[:, None].expand(-1, F), x[si], "amax")
+            refmax[torch.bincount(di, minlength=n) == 0] = 0
+            assert torch.equal(ymax, refmax), rep
+    finally:
+        ops.set_option("slab_mode", old)
+
+
 def test_backward_computes_only_what_autograd_asks_for(geot):
     """A GCN's normalised adjacency does not require grad: no SDDMM; its transposed copy is kept while its content is
     unchanged.  Gradients against dense autograd in every combination."""
