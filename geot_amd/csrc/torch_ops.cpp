@@ -1208,11 +1208,16 @@ bool slab_worthwhile_op(int64_t nnz, int64_t rows, int64_t src_rows, int64_t row
 
 } // namespace
 
-// Schema strings: csrc/index_scatter.cpp:43-47, gather_scatter.cpp:16-17, gather_weight_scatter.cpp:12-16, csr_gws.cpp:12-13;
-// mh_spmm is a catch-all def in the reference (csrc/mh_spmm.cpp:23), named here.  geot::gather_scatter /
-// gather_weight_scatter / csr_gws are Python custom ops in the reference (geot/gather_scatter.py:7,
-// gather_weight_scatter.py:15, csr_gws.py:25) with the same schemas; defining them here saves a Python hop per call,
-// their fake and autograd rules are registered from Python exactly where the reference has them.
+// WHAT THIS PLUGIN DEFINES.  Exactly the operators the reference's csrc/*.cpp define - index_scatter
+// (csrc/index_scatter.cpp:43-47), gather_scatter_impl (csrc/gather_scatter.cpp:16-17), gather_weight_scatter_impl and
+// sddmm_coo_impl (csrc/gather_weight_scatter.cpp:12-16), csr_gws_impl (csrc/csr_gws.cpp:12-13), mh_spmm (a catch-all
+// def in the reference, csrc/mh_spmm.cpp:23; named here) - plus helpers under names the reference does not use.
+// geot::gather_scatter / gather_weight_scatter / csr_gws are NOT defined here: the reference defines them in Python
+// (torch.library.custom_op, geot/gather_scatter.py:7, gather_weight_scatter.py:15, csr_gws.py:25), so a definition in
+// this library would collide with the reference's unmodified wrappers ("Tried to register an operator ... multiple
+// times").  Whichever Python layer sits on top defines them - geot_amd/ops.py, or the reference's own files - and this
+// library only IMPLEMENTS them for the device keys (TORCH_LIBRARY_IMPL below; an impl may precede or follow its def):
+// GPU tensors then reach the C++ kernels straight from the dispatcher, no Python hop, under either Python layer.
 TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("index_scatter(int dim, Tensor index, Tensor src, str reduce, bool sorted) -> Tensor");
   m.def("gather_scatter_impl(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor");
@@ -1220,9 +1225,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor");
   m.def("csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src) -> Tensor");
   m.def("mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor");
-  m.def("gather_scatter(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor");
-  m.def("gather_weight_scatter(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor");
-  m.def("csr_gws(Tensor csrptr, Tensor csrind, Tensor weight, Tensor src) -> Tensor");
+  // helpers (names the reference does not use)
   m.def("gather_reduce(Tensor src_index, Tensor dst_index, Tensor? weight, Tensor src, str reduce) -> Tensor");
   m.def("gather_scatter_rows(Tensor src_index, Tensor dst_index, Tensor src, SymInt rows) -> Tensor");
   m.def("gather_weight_scatter_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");

@@ -18,7 +18,8 @@ Ops in the dispatcher namespace ``geot`` (device key CUDA -- which is what a ROC
     geot::sddmm_coo_impl(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2) -> Tensor
     geot::mh_spmm(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, str reduce) -> Tensor
     geot::csr_gws_impl(Tensor indptr, Tensor indices, Tensor weight, Tensor src) -> Tensor
-    geot::gather_scatter / geot::gather_weight_scatter / geot::csr_gws      (the differentiable ops)
+    geot::gather_scatter / geot::gather_weight_scatter / geot::csr_gws      (the differentiable ops: defined HERE, in
+                                                                             Python, as in the reference; kernels in _C.so)
 
 Deliberate differences (all documented in DESIGN.md):
 * the output row count still comes from ``index[-1] + 1``, read back from the device and checked on every call
@@ -47,6 +48,34 @@ if not os.path.exists(_lib.PLUGIN_PATH):
     raise ImportError(f"Could not find module '_C' in {os.path.dirname(_lib.PLUGIN_PATH)}: build it with `make shim` (or "
                       "`python -c 'import __graft_entry__ as g; g.build()'`).  geot_amd has no fallback path.")
 torch.ops.load_library(_lib.PLUGIN_PATH)
+
+# The three differentiable operators are DEFINED in Python, where the reference defines them (torch.library.custom_op in
+# geot/gather_scatter.py:7, geot/gather_weight_scatter.py:15, geot/csr_gws.py:25) - `_C.so` defines exactly what the
+# reference's csrc/*.cpp define and nothing under these names, so the reference's unmodified wrappers load on it as well
+# (INTEGRATION.md).  Only the schema lives here: `_C.so` registers the C++ kernels for the device keys of these names
+# (TORCH_LIBRARY_IMPL), so a call goes from the dispatcher straight into the host layer - no Python hop.
+PUBLIC_SCHEMAS = {
+    "gather_scatter": "gather_scatter(Tensor src_index, Tensor dst_index, Tensor src) -> Tensor",
+    "gather_weight_scatter": "gather_weight_scatter(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src) -> Tensor",
+    "csr_gws": "csr_gws(Tensor csrptr, Tensor csrind, Tensor weight, Tensor src) -> Tensor",
+}
+_fragment = torch.library.Library("geot", "FRAGMENT")
+
+
+def _has_schema(name: str) -> bool:
+    try:
+        torch._C._dispatch_find_schema_or_throw(f"geot::{name}", "")
+        return True
+    except RuntimeError:
+        return False
+
+
+#: names some OTHER Python layer defined before this module was imported (the reference's wrappers in the same process):
+#: their fake / autograd rules are that layer's, not ours
+_FOREIGN = {name for name in PUBLIC_SCHEMAS if _has_schema(name)}
+for _name, _schema in PUBLIC_SCHEMAS.items():
+    if _name not in _FOREIGN:
+        _fragment.define(_schema)
 
 _REDUCE_ENUM = {"max": "max", "amax": "max", "mean": "mean", "min": "min", "amin": "min",
                 "sum": "sum", "prod": "prod"}
@@ -124,14 +153,20 @@ def _(src_index, dst_index, weight, src):
     return _fake_rows(src, [src.shape[1]])
 
 
-@torch.library.register_fake("geot::gather_scatter")
-def _(src_index, dst_index, src):
+def _fake_gather_scatter(src_index, dst_index, src):
     return _fake_rows(src, [src.shape[1]])
 
 
-@torch.library.register_fake("geot::gather_weight_scatter")
-def _(src_index, dst_index, weight, src):
+if "gather_scatter" not in _FOREIGN:
+    torch.library.register_fake("geot::gather_scatter")(_fake_gather_scatter)
+
+
+def _fake_gather_weight_scatter(src_index, dst_index, weight, src):
     return _fake_rows(src, [src.shape[1]])
+
+
+if "gather_weight_scatter" not in _FOREIGN:
+    torch.library.register_fake("geot::gather_weight_scatter")(_fake_gather_weight_scatter)
 
 
 @torch.library.register_fake("geot::gather_reduce")
@@ -149,10 +184,13 @@ def _(indptr, indices, weight, src):
     return src.new_empty([indptr.shape[0], src.shape[1]])
 
 
-@torch.library.register_fake("geot::csr_gws")
-def _(csrptr, csrind, weight, src):
+def _fake_csr_gws(csrptr, csrind, weight, src):
     ctx = torch.library.get_ctx()
     return src.new_empty([ctx.new_dynamic_size(), src.shape[1]])
+
+
+if "csr_gws" not in _FOREIGN:
+    torch.library.register_fake("geot::csr_gws")(_fake_csr_gws)
 
 
 @torch.library.register_fake("geot::mh_spmm")
@@ -250,8 +288,10 @@ def _gws_backward(ctx, grad):
     return None, None, weight_grad, src_grad
 
 
-torch.library.register_autograd("geot::gather_scatter", _gs_backward, setup_context=_gs_setup_context)
-torch.library.register_autograd("geot::gather_weight_scatter", _gws_backward, setup_context=_gws_setup_context)
+if "gather_scatter" not in _FOREIGN:
+    torch.library.register_autograd("geot::gather_scatter", _gs_backward, setup_context=_gs_setup_context)
+if "gather_weight_scatter" not in _FOREIGN:
+    torch.library.register_autograd("geot::gather_weight_scatter", _gws_backward, setup_context=_gws_setup_context)
 torch.library.register_autograd("geot::gather_scatter_rows", lambda ctx, grad: (*_gs_backward(ctx, grad), None),
                                 setup_context=_gs_setup_context)
 torch.library.register_autograd("geot::gather_weight_scatter_rows", lambda ctx, grad: (*_gws_backward(ctx, grad), None),
