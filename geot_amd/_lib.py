@@ -30,7 +30,7 @@ SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes", "geot_mh_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
-    "geot_publish_word", "geot_publish_pending", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
+    "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_rows_per_group", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
@@ -123,6 +123,7 @@ def load() -> ctypes.CDLL:
     L.geot_index_probe_range.argtypes = [c_vp, c_i64, c_vp, c_vp]
     L.geot_publish_word.argtypes = [c_vp, c_vp, c_i64]
     L.geot_publish_pending.argtypes = []
+    L.geot_set_alarm_word.argtypes = [c_vp]
     L.geot_sort_supported.argtypes = [c_i64, c_i64, c_i64]
     L.geot_sort_workspace_bytes.restype = c_sz
     L.geot_sort_workspace_bytes.argtypes = [c_i64]

@@ -82,7 +82,21 @@ struct SegParams {
   const int64_t *pub_src;
   int64_t *pub_dst;
   int64_t pub_seq;
+  // descent guard (see seg_fixup_kernel): the staging loops of the sorted kernels ballot "key < previous key" for free
+  // and raise ctrl[kCtrlDescent]; the fix-up kernel then repairs the call in place.  mode: 0 index_scatter, 1 gather,
+  // 2 gather + weight[e], 3 / 4 multi-head weights edge- / head-major (the repair pass re-reads the operands).
+  int mode;
+  int64_t *alarm;           // pinned host word (or null): set when a call had to be repaired (geot_set_alarm_word)
 };
+
+// control words at the head of the workspace (zero between calls)
+enum { kCtrlGaps = 0, kCtrlTicket = 1, kCtrlDescent = 2, kCtrlZeroed = 3, kCtrlGo = 4, kCtrlChunk = 5, kCtrlDone = 6 };
+
+// wave-uniform: some lane saw its key below its predecessor's -> the index is NOT ascending, whatever the caller or the
+// host layer's remembered facts said.  One plain store; the fix-up kernel (next launch) reads it.
+__device__ __forceinline__ void raise_descent(const SegParams &p, bool desc) {
+  if (__ballot(desc) != 0ull && (threadIdx.x & 63) == 0) p.ctrl[kCtrlDescent] = 1ull;
+}
 
 // one 8-byte device word to the host while the kernel runs (fine-grained pinned memory): value first, fence, then
 // the sequence number the host is spinning on
@@ -265,7 +279,8 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   if constexpr (!GATHER) load_batch(0); // rows do not depend on the keys: get them moving first
 
   // ---- stage keys, run-start bitmasks (wave ballot), gather offsets, weights --------------------
-  for (int i0 = (tid >> 6) * 64; i0 < te; i0 += kThreads) {
+  unsigned long long descents = 0ull;
+  for (int i0 = __builtin_amdgcn_readfirstlane(tid >> 6) * 64; i0 < te; i0 += kThreads) { // (i0: wave-uniform, scalar loop)
     const int i = i0 + lane;
     const int64_t ge = ts + i;
     int64_t k = kNoKey;
@@ -279,6 +294,10 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if (i == 0) keysL[0] = kp;
     const unsigned long long m = __ballot(k != kp);
     if (lane == 0) maskL[i0 >> 6] = m;
+    // descent guard (see repair_call): a key below its predecessor.  Unsigned compare: the padding key -2 is never below
+    // anything; the -1 in front of edge 0 is excluded.  Only a wave-uniform bit is kept here (an SGPR: the row loads in
+    // flight leave no VGPR to spare); the flag is stored once, behind the loop.
+    if constexpr (!ATOMIC) descents |= __ballot((uint64_t)k < (uint64_t)kp && kp != -1);
     if constexpr (GATHER) {
       int64_t row = ge < p.nnz ? p.src_index[ge] : 0;
       if ((uint64_t)row >= (uint64_t)p.src_rows) row = 0; // out-of-range gather index: memory-safe
@@ -297,6 +316,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
   }
   if (tid == 0) keysL[te + 1] = ts + te < p.nnz ? p.dst_index[ts + te] : kNoKey;
+  if (descents != 0ull && lane == 0) p.ctrl[kCtrlDescent] = 1ull;
   __syncthreads();
 
   if constexpr (!ATOMIC) {
@@ -623,6 +643,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
   int64_t klast = __shfl(k[0], 0, 64); // the chunk's first edge opens its first run (no run ends there)
   int nrun = 0;                        // runs of this chunk that have already ended
   if (lane == 0 && klast > kbefore + 1) gapfill(kbefore + 1, klast);
+  raise_descent(p, lane == 0 && cs > 0 && cs < nnz && k[0] < kbefore);
 
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -630,6 +651,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
     if (lane == 0) kp = klast;
     const bool h = k[s] != kp;
     const unsigned long long hb = __ballot(h);
+    raise_descent(p, k[s] != kNoKey && k[s] < kp);
     if (h && k[s] > kp + 1) gapfill(kp + 1, k[s]);
     if ((hb & 1ull) && lane == 0) {
       // the run carried in ended exactly at the step boundary: nobody in this step continues it
@@ -880,6 +902,12 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   }
   int64_t cur = mk[0];
   if (cur > kprev + 1) gapfill(kprev + 1, cur);
+  {
+    bool desc = e0 > 0 && mk[0] != kNoKey && mk[0] < kprev;
+#pragma unroll
+    for (int e = 1; e < E; ++e) desc = desc || (mk[e] != kNoKey && mk[e] < mk[e - 1]);
+    raise_descent(p, desc);
+  }
   float acc[F], head[F];
 #pragma unroll
   for (int i = 0; i < F; ++i) { acc[i] = vals[i]; head[i] = 0.f; }
@@ -1039,6 +1067,91 @@ __global__ __launch_bounds__(kThreads) void seg_wsum_kernel(SegParams p, int64_t
   }
 }
 
+// ---- descent guard: repair of a call whose index was NOT ascending --------------------------------------------------
+// The reference's "sorted" kernels tolerate a wrong `sorted` promise because every run is flushed with atomicAdd into a
+// zeroed dst (csrc/cuda/index_scatter_kernel.cuh:180,197).  The atomic-free kernels here do not - and although the host
+// layer probes every index once per content, a write that does not move the tensor's version counter (`.data`, DLPack,
+// another extension's kernel) leaves a stale "ascending" fact behind; callers of the C ABI may simply pass sorted=1 on
+// faith.  So the staging loops ballot "key below its predecessor" (free: the keys are in registers there) and this
+// routine, entered by EVERY workgroup of the fix-up launch when the flag is up, redoes the call the reference's way:
+//   1. all workgroups zero dst (grid-stride), write their L2 back, take a ticket;
+//   2. the workgroup holding the last ticket opens phase 2; workgroups still waiting for that (bounded wait - a grid
+//      larger than the chip must let its later workgroups in, so a waiter gives up after a while and only the
+//      workgroups resident at the end help; the opener alone would be enough: no co-residency is ever REQUIRED) then
+//      claim chunks of 256 edges from a counter and add every edge's row into dst with float atomics;
+//   3. the last workgroup to leave re-zeroes the control words and raises the host's alarm word, so the host layer
+//      drops its facts about index tensors (the next call probes again and takes the sort path).
+// sum over fp32 / fp64 (exactly what the reference's atomics cover); any other reduction or a 16-bit dtype has no float
+// atomic to fall back on: its output is filled with NaN and the alarm says so - loud, never silently wrong.
+template <typename T, int RED>
+__device__ __forceinline__ void repair_call(const SegParams &p) {
+  constexpr bool kCanRepair = RED == RED_SUM && (std::is_same<T, float>::value || std::is_same<T, double>::value);
+  __shared__ long long s_word;
+  const int tid = threadIdx.x;
+  const int64_t G = gridDim.x;
+  T *dst = static_cast<T *>(p.dst);
+  const int64_t F = p.F, K = p.K, total = K * F;
+  const T fill = kCanRepair ? T(0) : (T)NAN;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + tid; i < total; i += G * kThreads) dst[i] = fill;
+  if constexpr (kCanRepair) {
+    __threadfence(); // the zeros must be in memory before any workgroup's (memory-side) atomics
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      long long go = 0;
+      if (atomicAdd(&p.ctrl[kCtrlZeroed], 1ull) == (unsigned long long)G - 1) {
+        atomicExch(&p.ctrl[kCtrlGo], 1ull);
+        go = 1;
+      } else {
+        for (int tries = 0; tries < 4096 && !go; ++tries) {
+          go = atomicAdd(&p.ctrl[kCtrlGo], 0ull) != 0ull;
+          if (!go) __builtin_amdgcn_s_sleep(64);
+        }
+      }
+      s_word = go;
+    }
+    __syncthreads();
+    const bool helper = s_word != 0;
+    __syncthreads();
+    if (helper) {
+      const T *src = static_cast<const T *>(p.src);
+      const T *w = static_cast<const T *>(p.weight);
+      const int64_t nch = (p.nnz + 255) >> 8;
+      for (;;) {
+        if (tid == 0) s_word = (long long)atomicAdd(&p.ctrl[kCtrlChunk], 1ull);
+        __syncthreads();
+        const int64_t ch = s_word;
+        __syncthreads();
+        if (ch >= nch) break;
+        const int64_t e0 = ch << 8;
+        const int64_t n = p.nnz - e0 < 256 ? p.nnz - e0 : 256;
+        for (int64_t idx = tid; idx < n * F; idx += kThreads) {
+          const int64_t el = idx / F, f = idx - el * F, e = e0 + el;
+          const int64_t k = p.dst_index[e];
+          if ((uint64_t)k >= (uint64_t)K) continue;
+          T v;
+          if (p.mode == 0) v = src[e * F + f];
+          else {
+            int64_t r = p.src_index[e];
+            if ((uint64_t)r >= (uint64_t)p.src_rows) r = 0; // as the tile kernel: memory-safe
+            v = src[r * F + f];
+            if (p.mode == 2) v *= w[e];
+            else if (p.mode == 3) v *= w[e * p.H + f / p.Fh];
+            else if (p.mode == 4) v *= w[(f / p.Fh) * p.nnz + e];
+          }
+          if constexpr (kCanRepair) atomicAdd(dst + k * F + f, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && atomicAdd(&p.ctrl[kCtrlDone], 1ull) == (unsigned long long)G - 1) {
+    // every workgroup has read the flag and finished its share: leave the control words zero for the next call
+    for (int i = 0; i <= kCtrlDone; ++i) atomicExch(&p.ctrl[i], 0ull);
+    if (p.alarm) __hip_atomic_store(p.alarm + (kCanRepair ? 0 : 1), (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Second launch (= the only cross-workgroup ordering the sorted path needs):
 //  (a) one LANE GROUP per tile (64/LPR tiles per wave): if the tile holds the FIRST carry of a
 //      chain (its head run continues from the previous tile, and that tile is where the run
@@ -1077,6 +1190,11 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
   for (int j = 0; j < J; ++j) {
     const int64_t f = (int64_t)j * lpr + c;
     cv[j] = (valid && f < F) ? red_op<A, RED>(carry[((tc - 1) * 2 + 1) * F + f], carry[(tc * 2) * F + f]) : A(0);
+  }
+  // descent guard: the tile kernel found the index not ascending -> redo the whole call with atomics (rare; wave-uniform)
+  if (p.ctrl[kCtrlDescent] != 0ull) {
+    repair_call<T, RED>(p);
+    return;
   }
   const bool first = valid && (m & 1) && !(mp & 2);
   const int64_t k = m >> 2;
@@ -1686,6 +1804,7 @@ struct PublishRequest {
   int64_t seq = 0;
 };
 thread_local PublishRequest t_pub;
+thread_local int64_t *t_alarm = nullptr; // geot_set_alarm_word: sticky, per calling thread
 
 template <typename T>
 int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_t *dst_index,
@@ -1742,6 +1861,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.cg = P.cg;
   p.xcd_swizzle = g_xcd;
   p.nt_keys = g_nt_keys;
+  p.mode = mode;
+  p.alarm = t_alarm;
   // a pending geot_publish_word is consumed by the first kernel of this call if that kernel is one of the three that
   // publish (tile / lane / narrow kernel; not the LDS-bin kernel of the unsorted atomic path)
   const bool lds_bin = !sorted && (size_t)K * (size_t)F * sizeof(T) <= 48 * 1024 && g_tune.lpr_log2 != 7;
@@ -1776,6 +1897,18 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   if (prof) HIP_TRY(hipEventRecord(rec.e1, st));
 
   int rc = GEOT_OK;
+#ifdef GEOT_HEADLINE_ONLY
+  // developer build (seconds instead of minutes; tools/isa.sh): only the kernels of the graded configuration are
+  // instantiated - fp32 index_scatter, 16 lanes per row, 16 loads in flight, nt loads + stores - plus its fix-up
+  if constexpr (std::is_same<T, float>::value) {
+    const SmemLayout L = smem_layout(P.lpr_log2, P.cg, 4, 4, false, 0);
+    hipLaunchKernelGGL((seg_tile_kernel<float, 4, false, 0, false, 3, RED_SUM, 16>), dim3((unsigned)P.num_tiles, (unsigned)P.nfb, 1), dim3(kThreads), L.bytes, st, p);
+    const int64_t tpb = (kThreads / 64) * (64 >> P.lpr_log2);
+    hipLaunchKernelGGL((seg_fixup_kernel<float, RED_SUM>), dim3((unsigned)((P.num_tiles + tpb - 1) / tpb)), dim3(kThreads), 0, st, p, P.num_tiles);
+  }
+  (void)lane_seq; (void)narrow_path; (void)nt; (void)use_wsum; (void)rec; (void)prof;
+  return GEOT_OK;
+#else
   if (nnz > 0) {
     if (!sorted) {
       if (mode != 0) return fail(GEOT_EUNSUPPORTED, "unsorted is index_scatter only");
@@ -1897,6 +2030,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     g_prof.recs.push_back(rec);
   }
   return GEOT_OK;
+#endif
 }
 
 int run_typed(int dtype, int mode, bool sorted, const int64_t *si, const int64_t *di,
@@ -2109,6 +2243,11 @@ int geot_publish_word(const int64_t *device_word, int64_t *host_slot2, int64_t s
   t_pub.src = device_word;
   t_pub.dst = host_slot2;
   t_pub.seq = seq;
+  return GEOT_OK;
+}
+
+int geot_set_alarm_word(int64_t *host_slot2) {
+  t_alarm = host_slot2;
   return GEOT_OK;
 }
 

@@ -63,7 +63,7 @@ struct Options {
 };
 Options g_opt;
 struct Stats {
-  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0;
+  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0;
 };
 Stats g_stats;
 std::mutex g_mu; // guards the caches below (facts, transposed edge lists, slab plans)
@@ -149,7 +149,16 @@ struct Produced {
     if (!ev) return;
     const auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(on.device().index());
     if (cur.stream() == stream) return;
-    TORCH_CHECK(hipStreamWaitEvent(cur.stream(), static_cast<hipEvent_t>(ev.get()), 0) == hipSuccess, "hipStreamWaitEvent failed");
+    if (tl_capturing) {
+      // a capturing stream must not wait for an event recorded outside the capture (capture isolation).  After torch's
+      // usual recipe - warm up, synchronize, capture on a fresh stream - the artefact is long done: nothing to wait for.
+      const hipError_t q = hipEventQuery(static_cast<hipEvent_t>(ev.get()));
+      if (q != hipSuccess) (void)hipGetLastError();
+      TORCH_CHECK(q == hipSuccess, "geot: a cached artefact of this call (index sort / plan / transposed edges) is still being produced on "
+                  "another stream and cannot be waited for inside a graph capture.  Run the call once and synchronize before capturing.");
+    } else {
+      TORCH_CHECK(hipStreamWaitEvent(cur.stream(), static_cast<hipEvent_t>(ev.get()), 0) == hipSuccess, "hipStreamWaitEvent failed");
+    }
     each([&](const at::Tensor &t) {
       if (t.defined() && t.is_cuda()) c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(t.storage().data_ptr(), cur);
     });
@@ -173,7 +182,8 @@ at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
 
 // ---- pinned read-back slot per (thread, device) -------------------------------------------------------------------------
 struct Slot {
-  int64_t *host = nullptr;   // [0..3] copies (probe, row rule), [4] word published by a kernel, [5] its sequence number
+  int64_t *host = nullptr;   // [0..3] copies (probe, row rule), [4] word published by a kernel, [5] its sequence number,
+                             // [6] / [7] descent alarm of the kernels (geot_set_alarm_word): a call repaired itself / NaN-filled its output
   hipEvent_t ev = nullptr;
   int64_t seq = 0;
 };
@@ -198,16 +208,25 @@ struct ContentKey {
   const void *storage;
   int64_t offset, numel;
   uint32_t version;
+  int64_t size[2], stride[2]; // two views of one storage with the same offset and numel but another shape are other contents
+  int dim, dtype;
   bool operator==(const ContentKey &o) const {
-    return storage == o.storage && offset == o.offset && numel == o.numel && version == o.version;
+    return storage == o.storage && offset == o.offset && numel == o.numel && version == o.version && dim == o.dim && dtype == o.dtype &&
+           size[0] == o.size[0] && size[1] == o.size[1] && stride[0] == o.stride[0] && stride[1] == o.stride[1];
   }
 };
 bool content_key(const at::Tensor &t, ContentKey *k) {
-  if (t.is_inference() || !t.has_storage()) return false; // inference tensors keep no version counter: never remembered
+  if (t.is_inference() || !t.has_storage() || t.dim() > 2) return false; // inference tensors keep no version counter: never remembered
   k->storage = t.storage().unsafeGetStorageImpl();
   k->offset = t.storage_offset();
   k->numel = t.numel();
   k->version = t._version();
+  k->dim = (int)t.dim();
+  k->dtype = (int)t.scalar_type();
+  for (int d = 0; d < 2; ++d) {
+    k->size[d] = d < t.dim() ? t.size(d) : 1;
+    k->stride[d] = d < t.dim() ? t.stride(d) : 0;
+  }
   return true;
 }
 struct Facts {
@@ -241,8 +260,36 @@ void probe_index(const at::Tensor &index, int64_t out4[4]) {
   std::memcpy(out4, s.host, 32);
 }
 
+void clear_all_caches_locked();
+
+// Descent alarm (include/geot_hip.h, geot_set_alarm_word): the sorted kernels verify "ascending" as they go and repair a
+// call whose index has descents on the device.  That only happens when a remembered fact was stale - the tensor was written
+// behind its version counter (.data, DLPack, a raw pointer) - so every remembered fact is dropped here: the next call
+// probes again and takes the sort path.  Checked at the start of every operator call (two pinned words).
+void check_alarm(Slot &s) {
+  if ((__atomic_load_n(&s.host[6], __ATOMIC_ACQUIRE) | __atomic_load_n(&s.host[7], __ATOMIC_ACQUIRE)) == 0) return;
+  const int64_t repaired = __atomic_exchange_n(&s.host[6], (int64_t)0, __ATOMIC_ACQ_REL);
+  const int64_t poisoned = __atomic_exchange_n(&s.host[7], (int64_t)0, __ATOMIC_ACQ_REL);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    clear_all_caches_locked();
+    ++g_stats.alarms;
+  }
+  TORCH_CHECK(!poisoned, "geot: an earlier call on this thread found DESCENTS in an index tensor that was ascending when it was probed: the "
+              "tensor was written behind its version counter (.data, DLPack, a raw pointer).  That call used a reduction or dtype without "
+              "float atomics to fall back on, so its output was filled with NaN.  The remembered facts have been dropped - repeat the call.");
+  if (repaired)
+    TORCH_WARN("geot: an index tensor was written behind its version counter (.data, DLPack, a raw pointer); the call that met it repaired "
+               "itself on the device (zero-fill + float atomics, slow).  The remembered facts about index tensors have been dropped.");
+}
+
 // index: contiguous, 1-D, int64, on the GPU, non-empty checked inside
 FactsView index_facts(const at::Tensor &index) {
+  {
+    Slot &s = slot_for(index.device().index());
+    check_alarm(s);
+    geot_set_alarm_word(s.host + 6); // (sticky per thread in the library; one slot per (thread, device))
+  }
   ContentKey k;
   const bool keyed = g_opt.trust_version && content_key(index, &k);
   if (keyed) {
@@ -1096,7 +1143,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
   require_gpu("transpose_edges", {&si, &di});
   GEOT_DEVICE_GUARD(si);
   ContentKey k1, k2;
-  const bool keyed = g_opt.transpose_cache > 0 && content_key(si, &k1) && content_key(di, &k2);
+  const bool keyed = g_opt.transpose_cache > 0 && g_opt.trust_version && content_key(si, &k1) && content_key(di, &k2);
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_transposed.begin(); it != g_transposed.end(); ++it)
@@ -1154,6 +1201,15 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
   return wp;
 }
 
+void clear_all_caches_locked() {
+  g_facts.clear();
+  g_transposed.clear();
+  g_slab.clear();
+  g_sightings.clear();
+  g_widened.clear();
+  g_expanded.clear();
+}
+
 // ---- introspection for tests / tools ------------------------------------------------------------------------------------------
 int64_t host_option_op(c10::string_view name, int64_t value) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1166,12 +1222,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "slab_keep") p = &g_opt.slab_keep;
   else if (name == "publish_rows") p = &g_opt.publish_rows;
   else if (name == "clear_caches") {
-    g_facts.clear();
-    g_transposed.clear();
-    g_slab.clear();
-    g_sightings.clear();
-    g_widened.clear();
-    g_expanded.clear();
+    clear_all_caches_locked();
     return 0;
   }
   TORCH_CHECK(p, "unknown host option ", name);
@@ -1185,7 +1236,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
 std::vector<int64_t> host_stats_op() {
   std::lock_guard<std::mutex> lk(g_mu);
   return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
-          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published};
+          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published, g_stats.alarms};
 }
 
 // Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).

@@ -122,7 +122,7 @@ def clear_caches() -> None:
 
 def stats() -> dict:
     names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans",
-             "published")
+             "published", "alarms")
     return dict(zip(names, torch.ops.geot._host_stats()))
 
 

@@ -152,6 +152,18 @@ int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *str
 int geot_publish_word(const int64_t *device_word, int64_t *host_slot2, int64_t seq);
 int geot_publish_pending(void);
 
+/* Descent guard of the SORTED calls.  `sorted != 0` / an ascending dst_index is a promise the reference never has to
+ * check: its "sorted" kernels flush every run with atomicAdd into a zeroed dst (csrc/cuda/index_scatter_kernel.cuh:180,197)
+ * and still add up when the promise is wrong.  The atomic-free kernels here need it, so they verify it as they go (one
+ * wave ballot per 64 keys while the keys are staged) and, when an index turns out to have descents, the call REPAIRS
+ * ITSELF on the device before it completes: dst is zero-filled and every edge is added with float atomics - the
+ * reference's own formulation (slow, correct; sum over fp32 / fp64).  Other reductions and the 16-bit dtypes have no
+ * float atomic: their dst is filled with NaN instead.  Nothing is ever silently wrong, and nothing is needed from the
+ * caller.  A host layer that caches facts about index tensors can ask to be told: host_slot2 = two int64 in
+ * fine-grained pinned host memory (hipHostMalloc), sticky for the calling thread (NULL = off); a repaired call stores 1
+ * to host_slot2[0], a NaN-filled one to host_slot2[1] (while it runs; the host clears the words when it has seen them). */
+int geot_set_alarm_word(int64_t *host_slot2);
+
 /* The same pass with the key range: out4 = {index[nnz-1], descents, min(index), max(index)}.  The range sizes the sort
  * of an index with descents (below) and tells an index with negative keys apart. */
 int geot_index_probe_range(const int64_t *index, int64_t nnz, int64_t *out4, void *stream);
