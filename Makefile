@@ -7,7 +7,7 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Iinclude -Wno-unused-value
 
 LIB = geot_amd/libgeot_hip.so
-SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip
+SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip geot_amd/csrc/seg_plan.hip
 
 .PHONY: all lib tools shim oracle ref clean
 all: lib tools

@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_HERE)
 LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip"),
-           os.path.join(_HERE, "csrc", "seg_sort.hip")]
+           os.path.join(_HERE, "csrc", "seg_sort.hip"), os.path.join(_HERE, "csrc", "seg_plan.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
 PLUGIN_SOURCE = os.path.join(_HERE, "csrc", "torch_ops.cpp")
@@ -33,6 +33,7 @@ SYMBOLS = [
     "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_rows_per_group", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm",
+    "geot_slab_plan_scratch_bytes", "geot_slab_plan_rows", "geot_slab_plan_groups", "geot_slab_plan_edges",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
 ]
 

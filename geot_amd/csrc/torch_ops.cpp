@@ -52,6 +52,7 @@ struct Options {
   int transpose_cache = 4;   // GEOT_TRANSPOSE_CACHE (entries)
   int slab_keep = 2;
   int publish_rows = 1;      // GEOT_PUBLISH_ROWS: small calls get index[-1] from their own first kernel (geot_publish_word)
+  int slab_builder = 0;      // Phase A: 0 = the device builder (csrc/seg_plan.hip), 1 = the ATen formulation (CPU tensors always; cross-check)
   Options() {
     if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;
     if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
@@ -501,10 +502,12 @@ bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t ro
   return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= 2.0;
 }
 
-// dst_index ascending.  Device scans / one stable sort, plus one host loop over the virtual rows.
-std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at::Tensor &dst_index, int64_t out_rows, int64_t src_rows,
-                                           int64_t rowbytes, int weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group,
-                                           int64_t units_override) {
+// Phase A in ATen: the reference formulation of the plan (generic passes, one stable sort, a host loop over the virtual
+// rows).  Serves CPU tensors (tests/test_slab_plan.py emulates the kernel on its output) and cross-checks the device
+// builder below, which produces the same arrays bit for bit (tests/test_gpu_slab.py).  dst_index ascending.
+std::shared_ptr<SlabPlanHolder> slab_build_aten(const at::Tensor &src_index, const at::Tensor &dst_index, int64_t out_rows, int64_t src_rows,
+                                                int64_t rowbytes, int weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group,
+                                                int64_t units_override) {
   auto H = std::make_shared<SlabPlanHolder>();
   const int64_t nnz = dst_index.numel();
   const int64_t lanes = rowbytes / 16;
@@ -627,6 +630,96 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
   return H;
 }
 
+// Phase A on the device (csrc/seg_plan.hip): three calls into the library, two 8..64-byte read-backs (the sizes of the
+// arrays allocated here), no host loop.  nullptr: the library declined (keys out of range, sort key beyond 32 bits).
+std::shared_ptr<SlabPlanHolder> slab_build_device(const at::Tensor &src_index, const at::Tensor &dst_index, int64_t out_rows, int64_t src_rows,
+                                                  int64_t rowbytes, int weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group,
+                                                  int64_t units_override) {
+  auto H = std::make_shared<SlabPlanHolder>();
+  const int64_t nnz = dst_index.numel();
+  const int64_t lanes = rowbytes / 16;
+  const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units() * (64 / lanes);
+  const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group(weight_mode, heads);
+  void *st = stream_of(dst_index);
+  geot_slab_plan_job job;
+  std::memset(&job, 0, sizeof(job));
+  job.src_index = index_ptr(src_index);
+  job.dst_index = index_ptr(dst_index);
+  job.nnz = nnz;
+  job.out_rows = out_rows;
+  job.src_rows = src_rows;
+  job.rowbytes = rowbytes;
+  job.slab_bytes = slab_bytes;
+  job.units = units;
+  job.rows_per_group = (int32_t)R;
+  const auto bopt = dst_index.options().dtype(at::kByte), iopt = dst_index.options().dtype(at::kInt), lopt = dst_index.options();
+  auto scratch = [&](int stage) { return at::empty({(int64_t)std::max<size_t>(geot_slab_plan_scratch_bytes(&job, stage), 256)}, bopt); };
+  auto declined = [&](int rc) {
+    if (rc == GEOT_EUNSUPPORTED) return true;
+    TORCH_CHECK(rc == GEOT_OK, "geot slab plan failed (code ", rc, "): ", geot_last_error());
+    return false;
+  };
+  at::Tensor s1 = scratch(1);
+  if (declined(geot_slab_plan_rows(&job, s1.data_ptr(), s1.numel(), st))) return nullptr;
+  const int64_t V = job.n_vrows, NS = job.n_split;
+  auto table = [&](int64_t n, const at::TensorOptions &o) { return n > 0 ? at::empty({n}, o) : at::zeros({1}, o); };
+  at::Tensor v_out = table(V, lopt), v_row = table(V, iopt), v_total = table(V, iopt);
+  at::Tensor c_row = table(NS, lopt), c_first = table(NS, lopt), c_count = table(NS, iopt), c_total = table(NS, lopt);
+  at::Tensor s2 = scratch(2);
+  if (declined(geot_slab_plan_groups(&job, s1.data_ptr(), s2.data_ptr(), s2.numel(), v_out.data_ptr<int64_t>(), v_row.data_ptr<int32_t>(),
+                                     v_total.data_ptr<int32_t>(), c_row.data_ptr<int64_t>(), c_first.data_ptr<int64_t>(), c_count.data_ptr<int32_t>(),
+                                     c_total.data_ptr<int64_t>(), st)))
+    return nullptr;
+  const int64_t G = job.n_groups;
+  at::Tensor g_begin = at::empty({G + 1}, lopt), g_v0 = at::empty({G}, iopt), g_nv = at::empty({G}, iopt);
+  at::Tensor e_src = at::empty({nnz}, iopt), e_dl = at::empty({nnz}, bopt), e_perm = at::empty({nnz}, iopt);
+  at::Tensor s3 = scratch(3);
+  if (declined(geot_slab_plan_edges(&job, s1.data_ptr(), s2.data_ptr(), s3.data_ptr(), s3.numel(), g_begin.data_ptr<int64_t>(), g_v0.data_ptr<int32_t>(),
+                                    g_nv.data_ptr<int32_t>(), e_src.data_ptr<int32_t>(), e_dl.data_ptr<uint8_t>(), e_perm.data_ptr<int32_t>(), st)))
+    return nullptr;
+  H->keep = {e_src, e_dl, e_perm, g_begin, g_v0, g_nv, v_out, c_row, c_first, c_count, v_row, v_total, c_total};
+  geot_slab_plan &P = H->plan;
+  P.e_src = e_src.data_ptr<int32_t>();
+  P.e_dl = e_dl.data_ptr<uint8_t>();
+  P.e_perm = e_perm.data_ptr<int32_t>();
+  P.g_begin = g_begin.data_ptr<int64_t>();
+  P.g_vrow0 = g_v0.data_ptr<int32_t>();
+  P.g_nv = g_nv.data_ptr<int32_t>();
+  P.v_out = v_out.data_ptr<int64_t>();
+  P.c_row = c_row.data_ptr<int64_t>();
+  P.c_first = c_first.data_ptr<int64_t>();
+  P.c_count = c_count.data_ptr<int32_t>();
+  P.v_row = v_row.data_ptr<int32_t>();
+  P.v_total = v_total.data_ptr<int32_t>();
+  P.c_total = c_total.data_ptr<int64_t>();
+  P.n_groups = G;
+  P.n_vrows = V;
+  P.n_carry = job.n_carry;
+  P.n_split = NS;
+  P.nnz = nnz;
+  P.units = (int32_t)units;
+  P.rows_per_group = (int32_t)R;
+  P.slab_shift = job.slab_shift;
+  P.n_slabs = job.n_slabs;
+  H->rounds = (G + units - 1) / units;
+  H->budget = job.budget;
+  H->cap = job.cap;
+  H->slabs = job.n_slabs;
+  H->slab_rows = (int64_t)1 << job.slab_shift;
+  return H;
+}
+
+std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at::Tensor &dst_index, int64_t out_rows, int64_t src_rows,
+                                           int64_t rowbytes, int weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group,
+                                           int64_t units_override) {
+  if (dst_index.is_cuda() && g_opt.slab_builder == 0 && dst_index.numel() > 0 && dst_index.numel() < ((int64_t)1 << 31) && out_rows > 0 &&
+      out_rows < ((int64_t)1 << 31)) {
+    if (auto H = slab_build_device(src_index, dst_index, out_rows, src_rows, rowbytes, weight_mode, heads, slab_bytes, rows_per_group, units_override))
+      return H;
+  }
+  return slab_build_aten(src_index, dst_index, out_rows, src_rows, rowbytes, weight_mode, heads, slab_bytes, rows_per_group, units_override);
+}
+
 constexpr int64_t kSlabBytes = 2 << 20; // measured (profiles/r02/bench_slab.txt)
 
 struct SlabEntry {
@@ -670,6 +763,8 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
       }
     }
   }
+  // (the build reads two small records back anyway: wait here, so that plan_us is the build and not the queue in front of it)
+  if (di.is_cuda()) (void)hipStreamSynchronize(static_cast<hipStream_t>(stream_of(di)));
   const auto t0 = std::chrono::steady_clock::now();
   std::shared_ptr<SlabPlanHolder> plan;
   try {
@@ -1221,6 +1316,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "transpose_cache") p = &g_opt.transpose_cache;
   else if (name == "slab_keep") p = &g_opt.slab_keep;
   else if (name == "publish_rows") p = &g_opt.publish_rows;
+  else if (name == "slab_builder") p = &g_opt.slab_builder;
   else if (name == "clear_caches") {
     clear_all_caches_locked();
     return 0;

@@ -204,8 +204,8 @@ int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *
  * Replaces the same reference kernels as geot_mh_spmm / geot_gather_weight_scatter / geot_gather_scatter
  * (csrc/cuda/mh_spmm_kernel.cuh:28-111, gather_weight_scatter_kernel.cuh:118-185, gather_scatter_kernel.cuh:118-186)
  * when a graph is dense enough for its source rows to be re-used out of an XCD's L2: Reddit scale runs ~2x
- * faster than the per-edge gather.  The edge list is pre-arranged ONCE (Phase A, done by the host layer -
- * geot_amd/slab.py - and kept per edge list): all arrays below are DEVICE memory in processing order.
+ * faster than the per-edge gather.  The edge list is pre-arranged ONCE (Phase A: geot_slab_plan_rows / _groups / _edges
+ * below, driven by the host layer and kept per edge list): all arrays below are DEVICE memory in processing order.
  *   units            lane-group streams of the persistent grid = geot_slab_units() * (64 / lanes per row)
  *   groups           <= rows_per_group consecutive (virtual) dst rows with about equal edge counts, ordered by
  *                    size (descending); group at position p is run by unit (p % units) in round (p / units)
@@ -246,6 +246,39 @@ size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total)
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
                    int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce,
                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Phase A on the device (csrc/seg_plan.hip): builds the arrays of a geot_slab_plan from the dst-sorted COO edge list in
+ * three stages.  The caller owns every buffer; the two read-backs of the whole procedure are the sizes it needs to
+ * allocate them (stages 1 and 2 synchronise `stream` for that; stage 3 is asynchronous).  The reference has no
+ * counterpart (its kernels gather per edge); its one per-graph pass is the row-pointer histogram of
+ * geot/match_replace/format_transform.py:5-25.
+ *   job      in: src_index / dst_index (int64, dst ascending, keys in [0, out_rows)), nnz < 2^31, out_rows, src_rows,
+ *            rowbytes (of a source row), slab_bytes (2 MiB: geot's measured choice), units (geot_slab_units() *
+ *            (1024 / rowbytes)), rows_per_group (geot_slab_rows_per_group).
+ *   stage 1  geot_slab_plan_rows: fills nonempty / budget / cap / n_vrows / n_split / n_carry / slab_shift / n_slabs.
+ *            scratch1: geot_slab_plan_scratch_bytes(job, 1) bytes, kept until stage 3 has run.
+ *   stage 2  geot_slab_plan_groups: writes v_out / v_row / v_total [n_vrows] and c_row / c_first / c_count / c_total
+ *            [n_split, at least 1 entry each], fills n_groups.  scratch2: ..._scratch_bytes(job, 2), kept likewise.
+ *   stage 3  geot_slab_plan_edges: writes g_begin [n_groups + 1], g_vrow0 / g_nv [n_groups], e_src / e_dl / e_perm [nnz].
+ *            scratch3: ..._scratch_bytes(job, 3) (16 B per edge + the sort's buffer), free once the stream has passed it.
+ * GEOT_EUNSUPPORTED: keys outside [0, out_rows), or groups x slabs x rows_per_group >= 2^32 (the host layer then keeps
+ * the per-edge kernels).  All scratch 256-byte aligned, no initialisation needed. */
+typedef struct geot_slab_plan_job {
+  const int64_t *src_index, *dst_index;
+  int64_t nnz, out_rows, src_rows, rowbytes, slab_bytes, units;
+  int32_t rows_per_group;
+  int64_t nonempty, budget, cap, n_vrows, n_split, n_carry; /* stage 1 */
+  int64_t n_groups;                                        /* stage 2 */
+  int32_t slab_shift, n_slabs;                             /* stage 1 */
+} geot_slab_plan_job;
+size_t geot_slab_plan_scratch_bytes(const geot_slab_plan_job *job, int stage);
+int geot_slab_plan_rows(geot_slab_plan_job *job, void *scratch1, size_t scratch1_bytes, void *stream);
+int geot_slab_plan_groups(geot_slab_plan_job *job, const void *scratch1, void *scratch2, size_t scratch2_bytes, int64_t *v_out,
+                          int32_t *v_row, int32_t *v_total, int64_t *c_row, int64_t *c_first, int32_t *c_count, int64_t *c_total,
+                          void *stream);
+int geot_slab_plan_edges(const geot_slab_plan_job *job, const void *scratch1, const void *scratch2, void *scratch3,
+                         size_t scratch3_bytes, int64_t *g_begin, int32_t *g_vrow0, int32_t *g_nv, int32_t *e_src, uint8_t *e_dl,
+                         int32_t *e_perm, void *stream);
 
 /* out[e] = < mat_1[dst(e), :], mat_2[src(e), :] > in ORIGINAL edge order over the plan's edges - geot_sddmm_coo
  * (sddmm_coo_cuda, csrc/cuda/header_cuda.h:28-30) for a graph that has a plan: the backward (d/dweight) of

@@ -364,3 +364,45 @@ def test_backward_computes_only_what_autograd_asks_for(geot):
     geot.gather_weight_scatter(si, di, w0, x1).backward(g)
     torch.zeros(n, F, device="cuda").index_add(0, di, x2[si] * w0[:, None]).backward(g)
     assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("nodes,nnz,rowbytes,wmode,heads,R,units,slab_bytes", [
+    (40_000, 3_000_000, 1024, 2, 4, 0, 0, 0),            # the library's own R / units / 2-MiB slabs
+    (70_000, 2_500_000, 512, 1, 1, 0, 0, 0),
+    (300, 200_000, 256, 0, 1, 4, 8, 256 * 37),           # few units: many rounds; tiny slabs
+    (50, 300_000, 256, 1, 1, 3, 16, 0),                  # almost everything is a split hub
+    (2_000, 400_000, 512, 1, 1, 5, 32, 512 * 11),
+    (232_965, 20_000_000, 1024, 2, 4, 0, 0, 0),          # configs[3]'s node count
+])
+def test_device_plan_builder_is_bit_identical_to_the_aten_formulation(geot, nodes, nnz, rowbytes, wmode, heads, R, units, slab_bytes):
+    """Phase A as device code (csrc/seg_plan.hip: row pointers by binary search, one scan of (virtual rows, split, carry
+    slots), greedy grouping by pointer doubling, two radix sorts) against the ATen formulation it replaced (torch_ops.cpp
+    slab_build_aten, whose arrays the numpy emulation of tests/test_slab_plan.py validates): every array and scalar equal."""
+    from geot_amd import ops, slab
+    rng = np.random.default_rng(nodes + R)
+    di = powerlaw_index(nnz, nodes, nodes + 1)
+    di[: nnz // 4] = di[nnz // 4]                        # a hub that is split into virtual rows
+    di = np.sort(di)
+    di[di == 5] = 6                                      # an empty key
+    si = rng.integers(-3, nodes + 3, nnz).astype(np.int64)      # a few out-of-range sources (clamped to the end slabs)
+    d_si, d_di = dev(si), dev(di)
+    plans = {}
+    for name, builder in (("device", 0), ("aten", 1)):
+        old = ops.set_option("slab_builder", builder)
+        try:
+            plans[name] = slab.build_plan(d_si, d_di, nodes, nodes, rowbytes, wmode, heads, slab_bytes=slab_bytes, rows_per_group=R or None,
+                                          units=units or None)
+        finally:
+            ops.set_option("slab_builder", old)
+    a, b = plans["device"], plans["aten"]
+    assert a.meta == b.meta
+    for f in ("n_groups", "n_vrows", "n_carry", "n_split", "nnz", "units", "rows_per_group", "slab_shift", "n_slabs"):
+        assert getattr(a.struct, f) == getattr(b.struct, f), f
+    assert a.struct.n_split >= 1
+    sizes = {"e_src": nnz, "e_dl": nnz, "e_perm": nnz, "g_begin": a.struct.n_groups + 1, "g_vrow0": a.struct.n_groups, "g_nv": a.struct.n_groups,
+             "v_out": a.struct.n_vrows, "v_row": a.struct.n_vrows, "v_total": a.struct.n_vrows, "c_row": a.struct.n_split,
+             "c_first": a.struct.n_split, "c_count": a.struct.n_split, "c_total": a.struct.n_split}
+    for name, n in sizes.items():
+        ta, tb = a.tensors[name], b.tensors[name]
+        assert ta.dtype == tb.dtype and ta.numel() == tb.numel() == n, (name, ta.dtype, tb.dtype, ta.numel(), tb.numel(), n)
+        assert torch.equal(ta, tb), name
