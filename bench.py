@@ -61,6 +61,7 @@ def parse_args():
                          "step); aligned = segment-aligned cuts, no data-path collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--only-secondary", default="", help="comma-separated entries of `secondary` to run (profiling sessions)")
     return ap.parse_args()
 
 
@@ -163,103 +164,152 @@ def device_ms(fn, iters, warmup=2):
     return a.elapsed_time(b) / iters
 
 
-def secondary(dev, scale=1.0, iters=5):
-    """BASELINE.json configs[2] and configs[3] on synthetic stand-ins (same generator as the headline workload;
-    sources uniform-random: no locality to exploit).  Roofline = SURVEY.md 8(d) COMPULSORY bytes / kernel time /
-    8 TB/s - re-gathered rows served by the caches are not credited."""
+SECONDARY = ("gws_cfg3", "gws_cfg3_local", "mh_spmm_cfg4", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16")
+
+
+def profiled(entry):
+    """PMC-derived fabric traffic of a secondary workload's kernel, from the round's profiling session (committed under
+    profiles/; tools/profile_round.sh + tools/derive_traffic.py) - a recorded measurement of the same kernel on the same
+    workload, not a measurement of this run: labelled with its source."""
+    for rnd in ("r03", "r02"):
+        f = os.path.join(ROOT, "profiles", rnd, "gather_kernels.json")
+        try:
+            k = json.load(open(f))["kernels"].get(entry)
+        except Exception:
+            k = None
+        if k and k.get("fabric_bytes_per_launch"):
+            return {"traffic": k["fabric_bytes_per_launch"], "traffic_over_compulsory": k.get("traffic_over_compulsory"),
+                    "l2_hit_rate": k.get("l2_hit_rate"), "kernel_ms_under_rocprofv3": k.get("average_ms"),
+                    "traffic_source": f"profiles/{rnd}/gather_kernels.json[{entry!r}] (rocprofv3 --pmc, same workload, recorded session)"}
+    return {"traffic": None, "traffic_source": None}
+
+
+def secondary(dev, scale=1.0, iters=5, only=None):
+    """BASELINE.json configs[2] and configs[3] on synthetic stand-ins (same generator as the headline workload).
+    Roofline = SURVEY.md 8(d) COMPULSORY bytes / kernel time / 8 TB/s - re-gathered rows served by the caches are not
+    credited.  configs[2] comes twice: sources uniform-random (the worst case: no locality at all, 13.5x compulsory traffic)
+    and sources within +-2000 rows of the destination (`gws_cfg3_local`: what a graph with community structure, like
+    ogbn-products itself, offers the XCD-aware tile order), each next to rocSPARSE's best CSR algorithm on the same matrix.
+    `*_bf16`: the same graphs with bfloat16 storage (fp32 accumulation) - ADDITIONAL lines, never the fp32 headline."""
     import torch
     import geot_amd as geot
-    from geot_amd import hip
+    from geot_amd import hip, ops, slab
     from tools import rocsparse
+    want = set(only) if only else set(SECONDARY)
     res = {}
 
-    # ---- configs[2]: gather_weight_scatter, ogbn-products scale, F=128, vs rocSPARSE CSR SpMM ---------------
-    nodes, nnz, F = int(2_449_029 * scale), int(123_718_280 * scale), 128
-    di = powerlaw_index(nnz, nodes, 7, dev)
-    g = torch.Generator(device=dev)
-    g.manual_seed(8)
-    si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
-    w = torch.rand(nnz, device=dev, generator=g)
-    x = torch.rand(nodes, F, device=dev, generator=g)
-    out = torch.empty(nodes, F, device=dev)
-    ms = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), iters)
-    op_ms = device_ms(lambda: geot.gather_weight_scatter(si, di, w, x), iters)
-    uniq = int(torch.unique(si).numel())
-    comp = nnz * 20 + uniq * 4 * F + nodes * 4 * F
-    entry = {"workload": f"gather_weight_scatter, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, feat={F}, "
-                         "fp32, int64 COO dst-sorted (stand-in of ogbn-products)",
-             "kernel_ms": ms, "op_ms_with_row_rule": op_ms, "edges_per_s": nnz / ms * 1e3,
-             "compulsory_bytes": comp, "distinct_src_rows": uniq,
-             "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                          "frac": comp / ms / 1e6 / HBM_PEAK_GBPS},
-             "gathered_row_bytes": nnz * 4 * F, "gathered_row_gbps": nnz * 4 * F / ms / 1e6}
-    try:
-        best, table, y = rocsparse.best_csr_spmm(di, si, w, x, nodes, iters=max(2, iters // 2))
-        hip.gather_weight_scatter_out(si, di, w, x, out)
-        torch.cuda.synchronize()
-        entry.update(rocsparse_best_ms=best["ms"], rocsparse_best_algorithm=best["algorithm"],
-                     rocsparse_index_width="int32 CSR (geot: int64 COO)", rocsparse_preprocess="excluded from timing",
-                     rocsparse_preprocess_buffer_bytes=best.get("preprocess_buffer_bytes"),
-                     rocsparse_all=table, speedup_vs_rocsparse_best=best["ms"] / ms,
-                     max_rel_diff_vs_rocsparse=float(((y - out).abs().max() / out.abs().max()).item()))
-        del y
-    except Exception as e:               # the comparator must never take the measurement down with it
-        entry["rocsparse_error"] = repr(e)
-    res["gws_cfg3"] = entry
-    del di, si, w, x, out
-    torch.cuda.empty_cache()
+    def gws(name, local, dtype):
+        nodes, nnz, F = int(2_449_029 * scale), int(123_718_280 * scale), 128
+        esize = 4 if dtype == torch.float32 else 2
+        di = powerlaw_index(nnz, nodes, 7, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(8)
+        if local:
+            si = (di + torch.randint(-2000, 2001, (nnz,), device=dev, generator=g)).clamp_(0, nodes - 1)
+        else:
+            si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+        w = torch.rand(nnz, device=dev, generator=g).to(dtype)
+        x = torch.rand(nodes, F, device=dev, generator=g).to(dtype)
+        out = torch.empty(nodes, F, device=dev, dtype=dtype)
+        ms = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), iters)
+        op_ms = device_ms(lambda: geot.gather_weight_scatter(si, di, w, x), iters)
+        uniq = int(torch.unique(si).numel())
+        comp = nnz * (16 + esize) + uniq * esize * F + nodes * esize * F
+        src_desc = "sources within +-2000 rows of the destination (uniform offset, clamped)" if local else "uniform-random src"
+        entry = {"workload": f"gather_weight_scatter, power-law dst / {src_desc}, {nodes} nodes, {nnz} edges, feat={F}, "
+                             f"{str(dtype).split('.')[-1]}, int64 COO dst-sorted (stand-in of ogbn-products)",
+                 "kernel_ms": ms, "op_ms_with_row_rule": op_ms, "edges_per_s": nnz / ms * 1e3,
+                 "compulsory_bytes": comp, "distinct_src_rows": uniq,
+                 "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": comp / ms / 1e6 / HBM_PEAK_GBPS, **profiled(name)},
+                 "gathered_row_bytes": nnz * esize * F, "gathered_row_gbps": nnz * esize * F / ms / 1e6}
+        if dtype == torch.float32:
+            try:
+                best, table, y = rocsparse.best_csr_spmm(di, si, w, x, nodes, iters=max(2, iters // 2))
+                hip.gather_weight_scatter_out(si, di, w, x, out)
+                torch.cuda.synchronize()
+                entry.update(rocsparse_best_ms=best["ms"], rocsparse_best_algorithm=best["algorithm"],
+                             rocsparse_index_width="int32 CSR (geot: int64 COO)", rocsparse_preprocess="excluded from timing",
+                             rocsparse_preprocess_buffer_bytes=best.get("preprocess_buffer_bytes"),
+                             rocsparse_all=table, speedup_vs_rocsparse_best=best["ms"] / ms,
+                             max_rel_diff_vs_rocsparse=float(((y - out).abs().max() / out.abs().max()).item()))
+                del y
+            except Exception as e:               # the comparator must never take the measurement down with it
+                entry["rocsparse_error"] = repr(e)
+        res[name] = entry
+        del di, si, w, x, out
+        torch.cuda.empty_cache()
 
-    # ---- configs[3]: mh_spmm, Reddit scale, heads=4 feat=64 ---------------------------------------------------
-    nodes, nnz, H, F = int(232_965 * scale), int(114_615_892 * scale), 4, 64
-    di = powerlaw_index(nnz, nodes, 11, dev)
-    g.manual_seed(12)
-    si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
-    w = torch.rand(nnz, H, device=dev, generator=g)
-    x = torch.rand(nodes, H, F, device=dev, generator=g)
-    out = torch.empty(nodes, H, F, device=dev)
-    ms_gather = device_ms(lambda: hip.mh_spmm_out(si, di, w, x, out, False), iters)     # per-edge gather kernel (seg_tile_kernel)
-    wt = w.t().contiguous()
-    ms_t = device_ms(lambda: hip.mh_spmm_out(si, di, wt, x, out, True), iters)
-    # Phase A by itself (csrc/seg_plan.hip, device code): wall time of one plan build on an idle stream, synchronised on
-    # both sides - the first plan this process builds, then a rebuild
-    from geot_amd import ops, slab
-    phase_a = []
-    if slab.worthwhile(nnz, nodes, nodes, H * F * 4):
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            plan = slab.build_plan(si, di, nodes, nodes, H * F * 4, 2, H)
-            torch.cuda.synchronize()
-            phase_a.append((time.perf_counter() - t0) * 1e3)
-            plan_bytes = plan.nbytes()
-            del plan
-    # the operator as dispatched: a graph this dense is re-arranged once (Phase A, on the second call with the same
-    # edge list) and then served by the source-blocked kernel (csrc/seg_slab.hip); device time, steady state
-    st0 = ops.stats()
-    ms = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters, warmup=3)
-    st1 = ops.stats()
-    hip.mh_spmm_out(si, di, w, x, out, False)
-    torch.cuda.synchronize()
-    diff = float(((geot.mh_spmm(si, di, w, x) - out).abs().max() / out.abs().max()).item())
-    slab_used = st1["slab_calls"] > st0["slab_calls"]
-    uniq = int(torch.unique(si).numel())
-    comp = nnz * (16 + 4 * H) + uniq * 4 * H * F + nodes * 4 * H * F
-    res["mh_spmm_cfg4"] = {
-        "workload": f"mh_spmm, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, heads={H} feat={F}, fp32 "
-                    "(stand-in of Reddit)",
-        "kernel_ms": ms, "kernel": "seg_slab_kernel<2, true> (+ memset, combine)" if slab_used else "seg_tile_kernel<float, 4, true, 2, ...>",
-        "source_blocked_path": slab_used,
-        "phase_a": "device builder csrc/seg_plan.hip; wall ms of one build on an idle stream, synchronised before and after",
-        "phase_a_ms_once_per_edge_list": phase_a[0] if phase_a else None,          # the first plan this process builds
-        "phase_a_ms_rebuilt_in_a_warm_process": min(phase_a[1:]) if len(phase_a) > 1 else None,
-        "phase_a_host_ms_as_dispatched": (st1["plan_us"] - st0["plan_us"]) / 1e3,   # host side of the second call (stage 3 runs on)
-        "plan_bytes": plan_bytes if phase_a else None,
-        "kernel_ms_per_edge_gather": ms_gather, "kernel_ms_per_edge_gather_head_major_weights": ms_t,
-        "speedup_vs_per_edge_gather": ms_gather / ms, "max_rel_diff_between_the_two_kernels": diff,
-        "edges_per_s": nnz / ms * 1e3, "compulsory_bytes": comp, "distinct_src_rows": uniq,
-        "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": comp / ms / 1e6 / HBM_PEAK_GBPS},
-        "gathered_row_bytes": nnz * 4 * H * F, "gathered_row_gbps": nnz * 4 * H * F / ms / 1e6}
+    def mh(name, dtype):
+        nodes, nnz, H, F = int(232_965 * scale), int(114_615_892 * scale), 4, 64
+        esize = 4 if dtype == torch.float32 else 2
+        di = powerlaw_index(nnz, nodes, 11, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(12)
+        si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+        w = torch.rand(nnz, H, device=dev, generator=g).to(dtype)
+        x = torch.rand(nodes, H, F, device=dev, generator=g).to(dtype)
+        out = torch.empty(nodes, H, F, device=dev, dtype=dtype)
+        ms_gather = device_ms(lambda: hip.mh_spmm_out(si, di, w, x, out, False), iters)     # per-edge gather kernel (seg_tile_kernel)
+        wt = w.t().contiguous()
+        ms_t = device_ms(lambda: hip.mh_spmm_out(si, di, wt, x, out, True), iters)
+        # Phase A by itself (csrc/seg_plan.hip, device code): wall time of one plan build on an idle stream, synchronised on
+        # both sides - the first plan this process builds, then a rebuild
+        phase_a, plan_bytes = [], None
+        if slab.worthwhile(nnz, nodes, nodes, H * F * esize):
+            R = slab.rows_per_group(2, H, dtype)
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                plan = slab.build_plan(si, di, nodes, nodes, H * F * esize, 2, H, rows_per_group=R)
+                torch.cuda.synchronize()
+                phase_a.append((time.perf_counter() - t0) * 1e3)
+                plan_bytes = plan.nbytes()
+                del plan
+        # the operator as dispatched: a graph this dense is re-arranged once (Phase A, on the second call with the same
+        # edge list) and then served by the source-blocked kernel (csrc/seg_slab.hip); device time, steady state
+        st0 = ops.stats()
+        ms = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters, warmup=3)
+        st1 = ops.stats()
+        hip.mh_spmm_out(si, di, w, x, out, False)
+        torch.cuda.synchronize()
+        diff = float(((geot.mh_spmm(si, di, w, x).float() - out.float()).abs().max() / out.float().abs().max()).item())
+        slab_used = st1["slab_calls"] > st0["slab_calls"]
+        uniq = int(torch.unique(si).numel())
+        comp = nnz * (16 + esize * H) + uniq * esize * H * F + nodes * esize * H * F
+        tname = "float" if dtype == torch.float32 else "bf16"
+        res[name] = {
+            "workload": f"mh_spmm, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, heads={H} feat={F}, "
+                        f"{str(dtype).split('.')[-1]} (stand-in of Reddit)",
+            "kernel_ms": ms,
+            "kernel": f"seg_slab_kernel<{tname}, 2, {'true' if H * F * esize == 1024 else 'false'}, sum> (+ memset, combine)" if slab_used
+                      else f"seg_tile_kernel<{tname}, ..., true, 2, ...>",
+            "source_blocked_path": slab_used,
+            "phase_a": "device builder csrc/seg_plan.hip; wall ms of one build on an idle stream, synchronised before and after",
+            "phase_a_ms_once_per_edge_list": phase_a[0] if phase_a else None,          # the first plan this process builds
+            "phase_a_ms_rebuilt_in_a_warm_process": min(phase_a[1:]) if len(phase_a) > 1 else None,
+            "phase_a_host_ms_as_dispatched": (st1["plan_us"] - st0["plan_us"]) / 1e3,   # host side of the second call (stage 3 runs on)
+            "plan_bytes": plan_bytes,
+            "kernel_ms_per_edge_gather": ms_gather, "kernel_ms_per_edge_gather_head_major_weights": ms_t,
+            "speedup_vs_per_edge_gather": ms_gather / ms, "max_rel_diff_between_the_two_kernels": diff,
+            "edges_per_s": nnz / ms * 1e3, "compulsory_bytes": comp, "distinct_src_rows": uniq,
+            "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": comp / ms / 1e6 / HBM_PEAK_GBPS, **profiled(name)},
+            "gathered_row_bytes": nnz * esize * H * F, "gathered_row_gbps": nnz * esize * H * F / ms / 1e6}
+        del di, si, w, wt, x, out
+        ops.clear_caches()
+        torch.cuda.empty_cache()
+
+    if "gws_cfg3" in want:
+        gws("gws_cfg3", False, torch.float32)
+    if "gws_cfg3_local" in want:
+        gws("gws_cfg3_local", True, torch.float32)
+    if "mh_spmm_cfg4" in want:
+        mh("mh_spmm_cfg4", torch.float32)
+    if "gws_cfg3_bf16" in want:
+        gws("gws_cfg3_bf16", False, torch.bfloat16)
+    if "mh_spmm_cfg4_bf16" in want:
+        mh("mh_spmm_cfg4_bf16", torch.bfloat16)
     return res
 
 
@@ -380,11 +430,12 @@ def main():
     main_ms = prof["main_ms"] / max(prof["calls"], 1)
     fix_ms = prof["fixup_ms"] / max(prof["calls"], 1)
     achieved = alg / (main_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_source = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if args.workload == "cfg2" and os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, recorded session; not measured in this run)"
         except Exception:
             traffic = None
 
@@ -398,7 +449,7 @@ def main():
                        "index_dtype": "int64", "step": step_desc},
             "hbm_gbps_whole_call": world * alg * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "kernel_ms": main_ms,
                          "fixup_kernel_ms": fix_ms, "algorithmic_bytes_per_launch": alg,
                          "frac_tile_plus_fixup": alg / ((main_ms + fix_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -420,7 +471,7 @@ def main():
             del index, src, out
             torch.cuda.empty_cache()
             try:
-                res["secondary"] = secondary(dev, scale=args.scale)
+                res["secondary"] = secondary(dev, scale=args.scale, only=[x for x in args.only_secondary.split(",") if x] or None)
             except Exception as e:
                 res["secondary"] = {"error": repr(e)}
         print(json.dumps(res))

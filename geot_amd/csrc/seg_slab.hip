@@ -59,6 +59,39 @@ constexpr int kProgIdle = 0x7f7f7f7f;
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
+// Storage types: float, and the 16-bit types with fp32 accumulation (as the per-edge kernels and the reference's CPU path,
+// csrc/cpu/index_scatter_cpu.cpp:78-86,114-116: one rounding, at the very end).  A lane always moves 16 bytes of a row:
+// 4 floats or 8 halves, i.e. NV = 1 or 2 float4 accumulators per lane.
+typedef _Float16 half_t;
+typedef __bf16 bf16_t;
+template <typename T> struct SlabVec { static constexpr int VEC = 16 / (int)sizeof(T), NV = VEC / 4; };
+
+template <typename T> __device__ __forceinline__ void slab_unpack(const f4_t &raw, f4_t (&m)[SlabVec<T>::NV]) {
+  if constexpr (sizeof(T) == 4) m[0] = raw;
+  else {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const t8 x = __builtin_bit_cast(t8, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[0][i] = (float)x[i];
+      m[1][i] = (float)x[4 + i];
+    }
+  }
+}
+template <typename T> __device__ __forceinline__ f4_t slab_pack(const f4_t (&m)[SlabVec<T>::NV]) {
+  if constexpr (sizeof(T) == 4) return m[0];
+  else {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    t8 x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[i] = (T)m[0][i];
+      x[4 + i] = (T)m[1][i];
+    }
+    return __builtin_bit_cast(f4_t, x);
+  }
+}
+
 // reductions over the messages of a row (codes of include/geot_hip.h, csrc/reducetype.h:3); mean = sum, divided by the
 // row's edge count when the row is written; min / max propagate NaN like ATen (csrc/cpu/index_scatter_cpu.cpp:124-134)
 template <int RED> __device__ __forceinline__ float slab_ident() {
@@ -89,9 +122,10 @@ template <int RED> __device__ __forceinline__ void slab_acc(f4_t &acc, const f4_
 //   * rows are gathered kU at a time; the fields of the batch (row number, row in group, weight) are fetched
 //     BEFORE the loads are issued; the accumulate loop's only LDS traffic is one 16-byte write + read per lane when
 //     the row changes (the open row is kept in registers).
-template <int WMODE, bool WAVE_ROW, int RED>
+template <typename T, int WMODE, bool WAVE_ROW, int RED>
 __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
+  constexpr int VEC = SlabVec<T>::VEC, NV = SlabVec<T>::NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,18 +134,23 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   const int sub = WAVE_ROW ? 0 : (lane >> p.lpr_log2), c = lane & (lpr - 1);
   const int R = P.rows_per_group;
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : p.H);
-  // LDS: accumulators [4 waves][G units][R rows][lpr lanes] float4 = 4 * R KiB, then the staged
-  // weights [4 waves][2 buffers][64 edge slots][hw]
-  float *accS = reinterpret_cast<float *>(smem) + ((size_t)(wave * G + sub) * R) * 4 * lpr;
-  float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 1024) + (size_t)wave * 2 * 64 * (hw > 0 ? hw : 1) +
+  // LDS: fp32 accumulators [4 waves][G units][R rows][lpr lanes][NV] float4 = 4 * R * NV KiB, then the staged
+  // weights [4 waves][2 buffers][64 edge slots][hw] (fp32)
+  float *accS = reinterpret_cast<float *>(smem) + ((size_t)(wave * G + sub) * R) * 4 * NV * lpr;
+  float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 1024 * NV) + (size_t)wave * 2 * 64 * (hw > 0 ? hw : 1) +
                  (size_t)sub * lpr * (hw > 0 ? hw : 1);
   const int wbuf_stride = 64 * (hw > 0 ? hw : 1);
   const int64_t unit = ((int64_t)blockIdx.x * 4 + wave) * G + sub;
   const int64_t units = P.units;
   const char *src = static_cast<const char *>(p.src);
-  const float *weight = static_cast<const float *>(p.weight);
-  float *dst = static_cast<float *>(p.dst);
-  const int h = WMODE >= 2 ? (c * 4) / p.Fh : 0;
+  const T *weight = static_cast<const T *>(p.weight);
+  T *dst = static_cast<T *>(p.dst);
+  const int h = WMODE >= 2 ? (c * VEC) / p.Fh : 0;
+  typedef T t4_t __attribute__((ext_vector_type(4)));
+  auto load_w4 = [&](int64_t pe) { // the 4 head weights of an edge (edge-major layout, H == 4) as floats: one 16- / 8-byte read
+    const t4_t x = *reinterpret_cast<const t4_t *>(weight + pe * 4);
+    return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+  };
   const uint32_t rb = p.rowbytes;
   const uint32_t src_rows = (uint32_t)p.src_rows;
 
@@ -168,7 +207,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     const int64_t e0 = has ? P.g_begin[pos] : 0;
     const int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
     const int nv = has ? P.g_nv[pos] : 0;
-    for (int l = 0; l < R; ++l) accV[(size_t)l * lpr + c] = f4_t{kIdent, kIdent, kIdent, kIdent};
+    for (int l = 0; l < R; ++l)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) accV[((size_t)l * lpr + c) * NV + q] = f4_t{kIdent, kIdent, kIdent, kIdent};
     int maxlen = len;
     if constexpr (!WAVE_ROW) {
       for (int o = 32; o >= lpr; o >>= 1) {         // max over the wave's units (wave-uniform loop bound)
@@ -176,7 +217,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         maxlen = other > maxlen ? other : maxlen;
       }
     }
-    f4_t acc = {kIdent, kIdent, kIdent, kIdent};
+    f4_t acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = f4_t{kIdent, kIdent, kIdent, kIdent};
     int cur = 255;                                   // no open row
 
     // fields of the first chunk, its weights into buffer 0
@@ -187,13 +230,13 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
       if constexpr (WMODE != 0) {
         const int64_t pe = valid ? (int64_t)P.e_perm[e0 + c] : 0;
-        if constexpr (WMODE == 1) wbase[c] = valid ? weight[p.w_in_plan_order ? e0 + c : pe] : 0.f;
+        if constexpr (WMODE == 1) wbase[c] = valid ? (float)weight[p.w_in_plan_order ? e0 + c : pe] : 0.f;
         if constexpr (WMODE == 2) {
-          if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + c * 4) = valid ? *reinterpret_cast<const f4_t *>(weight + pe * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
-          else for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? weight[pe * p.H + q] : 0.f;
+          if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + c * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
+          else for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
         }
         if constexpr (WMODE == 3)
-          for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? weight[(int64_t)q * P.nnz + pe] : 0.f;
+          for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -241,24 +284,33 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         }
         if constexpr (WMODE != 0) {
           if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
-            if constexpr (WMODE == 1) wn1 = nvalid ? weight[p.w_in_plan_order ? ne : n_pe] : 0.f;
+            if constexpr (WMODE == 1) wn1 = nvalid ? (float)weight[p.w_in_plan_order ? ne : n_pe] : 0.f;
             if constexpr (WMODE == 2) {
-              if (p.H == 4) { if (nvalid) wn4 = *reinterpret_cast<const f4_t *>(weight + n_pe * 4); }
+              if (p.H == 4) { if (nvalid) wn4 = load_w4(n_pe); }
             }
           }
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           if (dls[u] != cur) {                       // the open row goes back to LDS, the new one comes out of it
-            if (cur != 255) accV[(size_t)cur * lpr + c] = acc;
+            if (cur != 255) {
+#pragma unroll
+              for (int q = 0; q < NV; ++q) accV[((size_t)cur * lpr + c) * NV + q] = acc[q];
+            }
             cur = dls[u];
-            acc = cur != 255 ? accV[(size_t)cur * lpr + c] : f4_t{kIdent, kIdent, kIdent, kIdent};
+#pragma unroll
+            for (int q = 0; q < NV; ++q) acc[q] = cur != 255 ? accV[((size_t)cur * lpr + c) * NV + q] : f4_t{kIdent, kIdent, kIdent, kIdent};
           }
           // padding slots of a short unit (dl = 255): their sum goes to a row that is never written back, but a
           // max / min must not see their value at all
           if ((RED != GEOT_REDUCE_MAX && RED != GEOT_REDUCE_MIN) || dls[u] != 255) {
-            if constexpr (WMODE == 0) slab_acc<RED>(acc, v[u]);
-            else slab_acc<RED>(acc, v[u] * ws[u]);
+            f4_t m[NV];
+            slab_unpack<T>(v[u], m);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+              if constexpr (WMODE == 0) slab_acc<RED>(acc[q], m[q]);
+              else slab_acc<RED>(acc[q], m[q] * ws[u]);
+            }
           }
         }
       }
@@ -267,16 +319,19 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         if constexpr (WMODE == 1) wnext[c] = wn1;
         if constexpr (WMODE == 2) {
           if (p.H == 4) *reinterpret_cast<f4_t *>(wnext + c * 4) = wn4;
-          else for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? weight[n_pe * p.H + q] : 0.f;
+          else for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
         }
         if constexpr (WMODE == 3)
-          for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+          for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
         __builtin_amdgcn_wave_barrier();
       }
       my_src = n_src;
       my_dl = n_dl;
     }
-    if (cur != 255) accV[(size_t)cur * lpr + c] = acc;
+    if (cur != 255) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) accV[((size_t)cur * lpr + c) * NV + q] = acc[q];
+    }
     if (p.window >= 0 && my_slot >= 0) {             // done with this round: never hold the others back
       published = (r + 1) * p.n_slabs;
       if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
@@ -286,14 +341,20 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       const int64_t v0 = P.g_vrow0[pos];
       for (int l = 0; l < nv; ++l) {
         const int64_t t = P.v_out[v0 + l];
-        f4_t row = accV[(size_t)l * lpr + c];
+        f4_t row[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) row[q] = accV[((size_t)l * lpr + c) * NV + q];
         if constexpr (RED == GEOT_REDUCE_MEAN) {
-          if (t >= 0) row = row / (float)P.v_total[v0 + l];   // pieces of a split row are divided after the combine
+          if (t >= 0) {                                        // pieces of a split row are divided after the combine
+#pragma unroll
+            for (int q = 0; q < NV; ++q) row[q] = row[q] / (float)P.v_total[v0 + l];
+          }
         }
         if (t >= 0) {
-          if (t < p.K) *reinterpret_cast<f4_t *>(dst + t * p.F + c * 4) = row;
+          if (t < p.K) *reinterpret_cast<f4_t *>(dst + t * p.F + c * VEC) = slab_pack<T>(row);   // one rounding, here
         } else {
-          *reinterpret_cast<f4_t *>(p.carry + (-t - 1) * p.F + c * 4) = row;
+#pragma unroll
+          for (int q = 0; q < NV; ++q) *reinterpret_cast<f4_t *>(p.carry + (-t - 1) * p.F + c * VEC + 4 * q) = row[q];   // fp32
         }
       }
     }
@@ -461,8 +522,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
 }
 
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row)
-template <int RED>
+template <typename T, int RED>
 __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p) {
+  constexpr int VEC = SlabVec<T>::VEC, NV = SlabVec<T>::NV;
   const geot_slab_plan &P = p.plan;
   const int lpr = 1 << p.lpr_log2;
   const int g = threadIdx.x >> p.lpr_log2, c = threadIdx.x & (lpr - 1);
@@ -472,10 +534,17 @@ __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p
     const int64_t first = P.c_first[s];
     const int n = P.c_count[s];
     constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
-    f4_t acc = {kIdent, kIdent, kIdent, kIdent};
-    for (int i = 0; i < n; ++i) slab_acc<RED>(acc, *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * 4));
-    if constexpr (RED == GEOT_REDUCE_MEAN) acc = acc / (float)P.c_total[s];
-    if (row >= 0 && row < p.K) *reinterpret_cast<f4_t *>(static_cast<float *>(p.dst) + row * p.F + c * 4) = acc;
+    f4_t acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = f4_t{kIdent, kIdent, kIdent, kIdent};
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) slab_acc<RED>(acc[q], *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * VEC + 4 * q));
+    if constexpr (RED == GEOT_REDUCE_MEAN) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = acc[q] / (float)P.c_total[s];
+    }
+    if (row >= 0 && row < p.K) *reinterpret_cast<f4_t *>(static_cast<T *>(p.dst) + row * p.F + c * VEC) = slab_pack<T>(acc);
   }
 }
 
@@ -490,18 +559,21 @@ int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_block
 
 int geot_slab_units(void) { return 256 * g_slab_blocks * 4; } // waves of the persistent grid: 256 CUs x workgroups x 4
 
-static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads) {
+// nv: float4 accumulators per lane (1: fp32 storage, 2: 16-bit storage - 8 elements per 16-byte lane)
+static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads, int nv = 1) {
   const size_t hw = weight_mode <= 1 ? 1 : (size_t)heads;
-  return (size_t)4 * rows_per_group * 1024 + (size_t)4 * 2 * 64 * hw * sizeof(float); // + double-buffered weights
+  return (size_t)4 * rows_per_group * 1024 * nv + (size_t)4 * 2 * 64 * hw * sizeof(float); // + double-buffered weights
 }
 
-// two workgroups per CU inside the classic 64 KB per workgroup: R KiB of accumulators per wave + the staged weights
-int geot_slab_rows_per_group(int weight_mode, int64_t heads) {
+// the workgroups of a CU share its 160 KB of LDS: R * nv KiB of accumulators per wave + the staged weights
+int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype) {
+  const int nv = dtype == GEOT_F32 ? 1 : 2;
   int r = 16;
   const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (size_t)(156 * 1024) / g_slab_blocks / 1024 * 1024;
-  while (r > 1 && slab_lds_bytes(r, weight_mode, heads) > budget) --r;
+  while (r > 1 && slab_lds_bytes(r, weight_mode, heads, nv) > budget) --r;
   return r;
 }
+int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_rows_per_group_dtype(weight_mode, heads, GEOT_F32); }
 
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total) {
   if (!plan) return 0;
@@ -515,7 +587,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   const bool w_in_plan_order = weight_mode == 4;   // mode 4 = mode 1 with weight[] already permuted into plan order
   if (w_in_plan_order) weight_mode = 1;
   if (!plan || !src || !dst) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: null pointer");
-  if (dtype != GEOT_F32) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: float32 only");
+  if (dtype != GEOT_F32 && dtype != GEOT_F16 && dtype != GEOT_BF16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: float32, float16 or bfloat16");
+  const int tsize = dtype == GEOT_F32 ? 4 : 2, vec = 16 / tsize, nv = vec / 4;
   if (heads < 1 || feat < 1 || out_rows < 0) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: bad sizes");
   if (reduce != GEOT_REDUCE_SUM && reduce != GEOT_REDUCE_MEAN && reduce != GEOT_REDUCE_MAX && reduce != GEOT_REDUCE_MIN)
     return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: reduce must be sum, mean, max or min");
@@ -525,12 +598,12 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (weight_mode < 0 || weight_mode > 3 || (weight_mode != 0 && !weight))
     return geot_internal_fail(GEOT_EINVAL, "slab_spmm: weight_mode 0..4 (and a weight pointer for 1..4)");
   const int64_t F = heads * feat;
-  const int64_t rowbytes = F * 4;
+  const int64_t rowbytes = F * tsize;
   int lpr_log2 = -1;
-  for (int l = 4; l <= 6; ++l)
+  for (int l = 3; l <= 6; ++l)
     if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
-  if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: rows of 256, 512 or 1024 bytes only");
-  if ((4 * feat) % 16 != 0 && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of 4");
+  if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: rows of 128, 256, 512 or 1024 bytes only");
+  if (feat % vec != 0 && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of 16 bytes");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
   const int64_t waves = plan->units / (64 >> lpr_log2);
   if (plan->units % (64 >> lpr_log2) != 0 || waves % (4 * 256) != 0 || waves < 4 * 256 || waves > 4 * 256 * 4)
@@ -570,42 +643,42 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   }
   if (plan->n_groups > 0) {
-    const size_t lds = slab_lds_bytes(plan->rows_per_group, weight_mode, heads);
-    if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group)");
+    const size_t lds = slab_lds_bytes(plan->rows_per_group, weight_mode, heads, nv);
+    if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_dtype)");
     const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
     const bool wave_row = lpr_log2 == 6;
-#define GEOT_SLAB_LAUNCH(W, RED_)                                                                             \
-  if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<W, true, RED_>), grid, blk, lds, st, p);                  \
-  else hipLaunchKernelGGL((seg_slab_kernel<W, false, RED_>), grid, blk, lds, st, p)
-#define GEOT_SLAB_RED(W)                                                                                      \
+    int64_t cblocks = (plan->n_split + (kThreads >> lpr_log2) - 1) / (kThreads >> lpr_log2);
+    if (cblocks > 1024) cblocks = 1024;
+    const dim3 cgrid((unsigned)(cblocks > 0 ? cblocks : 1));
+    const bool combine = plan->n_split > 0;
+#define GEOT_SLAB_LAUNCH(T_, W, RED_)                                                                         \
+  do {                                                                                                        \
+    if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<T_, W, true, RED_>), grid, blk, lds, st, p);            \
+    else hipLaunchKernelGGL((seg_slab_kernel<T_, W, false, RED_>), grid, blk, lds, st, p);                    \
+    if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, RED_>), cgrid, blk, 0, st, p);               \
+  } while (0)
+#define GEOT_SLAB_RED(T_, W)                                                                                  \
   switch (reduce) {                                                                                           \
-  case GEOT_REDUCE_MEAN: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_MEAN); break;                                        \
-  case GEOT_REDUCE_MAX: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_MAX); break;                                          \
-  case GEOT_REDUCE_MIN: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_MIN); break;                                          \
-  default: GEOT_SLAB_LAUNCH(W, GEOT_REDUCE_SUM); break;                                                       \
+  case GEOT_REDUCE_MEAN: GEOT_SLAB_LAUNCH(T_, W, GEOT_REDUCE_MEAN); break;                                    \
+  case GEOT_REDUCE_MAX: GEOT_SLAB_LAUNCH(T_, W, GEOT_REDUCE_MAX); break;                                      \
+  case GEOT_REDUCE_MIN: GEOT_SLAB_LAUNCH(T_, W, GEOT_REDUCE_MIN); break;                                      \
+  default: GEOT_SLAB_LAUNCH(T_, W, GEOT_REDUCE_SUM); break;                                                   \
   }
-    switch (weight_mode) {
-    case 0: GEOT_SLAB_RED(0) break;
-    case 1: GEOT_SLAB_RED(1) break;
-    case 2: GEOT_SLAB_LAUNCH(2, GEOT_REDUCE_SUM); break;
-    default: GEOT_SLAB_LAUNCH(3, GEOT_REDUCE_SUM); break;
-    }
+#define GEOT_SLAB_MODE(T_)                                                                                    \
+  switch (weight_mode) {                                                                                      \
+  case 0: GEOT_SLAB_RED(T_, 0) break;                                                                         \
+  case 1: GEOT_SLAB_RED(T_, 1) break;                                                                         \
+  case 2: GEOT_SLAB_LAUNCH(T_, 2, GEOT_REDUCE_SUM); break;                                                    \
+  default: GEOT_SLAB_LAUNCH(T_, 3, GEOT_REDUCE_SUM); break;                                                   \
+  }
+    if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
+    else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
+    else { GEOT_SLAB_MODE(bf16_t) }
+#undef GEOT_SLAB_MODE
 #undef GEOT_SLAB_RED
 #undef GEOT_SLAB_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
-    if (plan->n_split > 0) {
-      int64_t blocks = (plan->n_split + (kThreads >> lpr_log2) - 1) / (kThreads >> lpr_log2);
-      if (blocks > 1024) blocks = 1024;
-      switch (reduce) {
-      case GEOT_REDUCE_MEAN: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_MEAN>, dim3((unsigned)blocks), blk, 0, st, p); break;
-      case GEOT_REDUCE_MAX: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_MAX>, dim3((unsigned)blocks), blk, 0, st, p); break;
-      case GEOT_REDUCE_MIN: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_MIN>, dim3((unsigned)blocks), blk, 0, st, p); break;
-      default: hipLaunchKernelGGL(seg_slab_combine_kernel<GEOT_REDUCE_SUM>, dim3((unsigned)blocks), blk, 0, st, p); break;
-      }
-      e = hipGetLastError();
-      if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
-    }
   }
   return GEOT_OK;
 }

@@ -490,12 +490,12 @@ struct SlabPlanHolder {
   Produced made, w_made; // events of Phase A / of the weight permutation (consumers on other streams wait for them)
 };
 
-bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes) {
+bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes, int dtype = GEOT_F32) {
   if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024) || nnz >= ((int64_t)1 << 31) || nnz < 8000000 || out_rows < 1 ||
       src_rows >= ((int64_t)1 << 31))
     return false;
   const int64_t units = (int64_t)geot_slab_units() * (1024 / rowbytes);
-  const int64_t rpg = geot_slab_rows_per_group(1, 1);
+  const int64_t rpg = geot_slab_rows_per_group_dtype(1, 1, dtype); // (16-bit storage: fp32 accumulators, half the rows per group)
   const int64_t rounds = std::max<int64_t>(1, (out_rows + rpg * units - 1) / (rpg * units));
   // uses of a source row per XCD and round; measured (profiles/r02/bench_slab_density_rule.txt, 120 M edges): 10 -> 1.50x,
   // 4.8 -> 1.34x, 2.8 -> 1.22x, 1.6 -> 1.09x, 0.8 -> 0.86x at 512-B rows; 8.8 -> 2.08x, 2.4 -> 1.62x, 1.0 -> 1.13x at 1 KiB
@@ -736,13 +736,19 @@ std::list<std::pair<ContentKey, ContentKey>> g_sightings; // edge lists seen onc
 
 std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Tensor &di, int64_t rows, const at::Tensor &src,
                                               int wmode, int64_t heads) {
-  if (g_opt.slab_mode < 0 || src.scalar_type() != at::kFloat || rows < 1) return nullptr;
-  const int64_t rowbytes = (src.numel() / std::max<int64_t>(src.size(0), 1)) * 4, nnz = di.numel();
-  if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024) || nnz == 0 || nnz >= ((int64_t)1 << 31)) return nullptr;
-  if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes)) return nullptr;
+  const bool f32 = src.scalar_type() == at::kFloat;
+  if (g_opt.slab_mode < 0 || rows < 1 || !(f32 || src.scalar_type() == at::kHalf || src.scalar_type() == at::kBFloat16)) return nullptr;
+  const int dt = dtype_code(src, "slab");
+  const int64_t rowbytes = (src.numel() / std::max<int64_t>(src.size(0), 1)) * src.element_size(), nnz = di.numel();
+  // rows of 256 / 512 / 1024 bytes; 128-byte rows run too but were measured slower than the per-edge kernels (DESIGN.md
+  // section 3.1d): only when the path is forced
+  if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024 && !(rowbytes == 128 && g_opt.slab_mode == 1)) || nnz == 0 ||
+      nnz >= ((int64_t)1 << 31))
+    return nullptr;
+  if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes, dt)) return nullptr;
   ContentKey k1, k2;
   if (!content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
-  const int rpg = geot_slab_rows_per_group(wmode, heads);
+  const int rpg = geot_slab_rows_per_group_dtype(wmode, heads, dt);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_slab.begin(); it != g_slab.end(); ++it)
@@ -768,7 +774,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   const auto t0 = std::chrono::steady_clock::now();
   std::shared_ptr<SlabPlanHolder> plan;
   try {
-    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, kSlabBytes, 0, 0);
+    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, kSlabBytes, rpg, 0);
   } catch (const c10::Error &) {
     // Phase A needs ~80 bytes per edge of transient memory and keeps 9: if that does not fit, the per-edge kernels serve
     // the call (and every later one: the sighting is forgotten, a later call may try again)
@@ -790,8 +796,8 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
 void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
               int red = GEOT_REDUCE_SUM) {
   auto &ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
-  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), GEOT_F32, red,
-                           ws.data_ptr(), ws.numel(), stream_of(src)));
+  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
+                           red, ws.data_ptr(), ws.numel(), stream_of(src)));
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.slab_calls;
 }
@@ -1083,7 +1089,7 @@ at::Tensor mh_spmm_common(const at::Tensor &si, const at::Tensor &di, const at::
   const int64_t heads = x.size(1), feat = x.size(2);
   auto launch = [&](int64_t rows) {
     at::Tensor o = at::empty({rows, heads, feat}, x.options());
-    if (!e.permuted && feat % 4 == 0 && heads <= 16) {
+    if (!e.permuted && (feat * x.element_size()) % 16 == 0 && heads <= 16) {
       // the source-blocked kernel reads weights through the edge permutation: edge-major [nnz, H] is one 16-byte read per
       // edge, head-major [H, nnz] would be H scattered 4-byte reads (H x 64-byte sectors) - transpose it once instead
       // (a streaming pass, ~0.6 ms at 115 M edges x 4 heads)
@@ -1187,10 +1193,10 @@ at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in,
               toString(weight_in.scalar_type()));
   GEOT_DEVICE_GUARD(src_in);
   at::Tensor indptr = as_int64(indptr_in), indices = as_int64(indices_in);
-  if (g_opt.slab_mode >= 0 && indices.numel() > 0 && indptr.numel() >= 2 && src_in.scalar_type() == at::kFloat) {
+  if (g_opt.slab_mode >= 0 && indices.numel() > 0 && indptr.numel() >= 2 && src_in.scalar_type() != at::kDouble) {
     // a graph dense enough for the source-blocked kernel: go through the COO path (row ids expanded once per indptr)
-    const int64_t rowbytes = src_in.size(1) * 4;
-    if (g_opt.slab_mode == 1 || slab_worthwhile(indices.numel(), indptr.size(0), src_in.size(0), rowbytes))
+    const int64_t rowbytes = src_in.size(1) * src_in.element_size();
+    if (g_opt.slab_mode == 1 || slab_worthwhile(indices.numel(), indptr.size(0), src_in.size(0), rowbytes, dtype_code(src_in, "csr_gws")))
       return gather_common("csr_gws_impl", indices, expand_indptr(indptr, indices.numel()), weight_in, src_in, GEOT_REDUCE_SUM, indptr.size(0));
   }
   at::Tensor weight = weight_in.contiguous(), src = src_in.contiguous();
@@ -1351,7 +1357,7 @@ std::vector<at::Tensor> slab_plan_op(const at::Tensor &si, const at::Tensor &di,
   return out;
 }
 
-bool slab_worthwhile_op(int64_t nnz, int64_t rows, int64_t src_rows, int64_t rowbytes) { return slab_worthwhile(nnz, rows, src_rows, rowbytes); }
+bool slab_worthwhile_op(int64_t nnz, int64_t rows, int64_t src_rows, int64_t rowbytes) { return slab_worthwhile(nnz, rows, src_rows, rowbytes, GEOT_F32); }
 
 } // namespace
 

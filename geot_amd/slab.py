@@ -79,18 +79,26 @@ def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: i
     reduce: 'sum' | 'mean' | 'max' | 'min' (weight modes 0 / 1)."""
     tensors = [src, out] + ([weight] if weight is not None else [])
     dev = hip._require_gpu(*tensors)
-    if src.dtype != torch.float32:
-        raise RuntimeError("slab_spmm: float32 only")
+    if src.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise RuntimeError("slab_spmm: float32, float16 or bfloat16")
+    if weight is not None and weight.dtype != src.dtype:
+        raise RuntimeError("slab_spmm: weight must have the dtype of src")
     L = _lib.load()
     with hip._on_device(dev):
         st = hip._stream_handle(dev)
         nbytes = int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), heads * feat))
         ws = hip.workspace(dev, nbytes, st)
         rc = L.geot_slab_spmm(ctypes.byref(plan.struct), None if weight is None else weight.data_ptr(), weight_mode,
-                              src.data_ptr(), out.data_ptr(), heads, feat, src.shape[0], out.shape[0], _lib.GEOT_F32,
+                              src.data_ptr(), out.data_ptr(), heads, feat, src.shape[0], out.shape[0], hip._dtype_code(src, "slab_spmm"),
                               hip._REDUCE_CODES[reduce], ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "geot_slab_spmm")
     return out
+
+
+def rows_per_group(weight_mode: int, heads: int, dtype: torch.dtype) -> int:
+    """R of a plan for this storage type (16-bit storage keeps fp32 accumulators in LDS: half the rows per group)."""
+    code = {torch.float32: _lib.GEOT_F32, torch.float16: _lib.GEOT_F16, torch.bfloat16: _lib.GEOT_BF16}[dtype]
+    return int(_lib.load().geot_slab_rows_per_group_dtype(weight_mode, heads, code))
 
 
 def slab_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

@@ -234,7 +234,8 @@ typedef struct geot_slab_plan {
 } geot_slab_plan;
 
 int geot_slab_units(void);                                     /* waves of the persistent grid */
-int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget */
+int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget (float32 storage) */
+int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /* ... 16-bit storage: fp32 accumulators, half the rows */
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
 /* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
  * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts),
@@ -242,7 +243,8 @@ size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total)
  * e.g. a normalised adjacency, permuted once by the caller).
  * reduce: GEOT_REDUCE_SUM | MEAN | MAX | MIN over the messages of a row (weight modes 0 / 1; the multi-head modes sum) -
  * the aggregations PyG call sites forward (GraphSAGE mean / max on Reddit-like graphs).
- * float32, rows (heads * feat * 4 bytes) of 256 / 512 / 1024 bytes.  dst is written in full. */
+ * float32 / float16 / bfloat16 storage (16-bit: fp32 accumulation, one rounding at the end, weights in the storage type),
+ * rows (heads * feat * element size) of 128 / 256 / 512 / 1024 bytes.  dst is written in full. */
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
                    int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce,
                    void *workspace, size_t workspace_bytes, void *stream);

@@ -467,3 +467,8 @@ def test_bench_secondary_object_small_scale():
     assert g["max_rel_diff_vs_rocsparse"] < 2e-5 and g["rocsparse_best_algorithm"] in ("csr_nnz_split", "csr_merge_path", "csr_row_split", "default")
     m = sec["mh_spmm_cfg4"]
     assert m["kernel_ms"] > 0 and 0 < m["roofline"]["frac"] < 1
+    loc = sec["gws_cfg3_local"]                                       # the stand-in with source locality, rocSPARSE beside it
+    assert loc["kernel_ms"] > 0 and loc["rocsparse_best_ms"] > 0 and loc["max_rel_diff_vs_rocsparse"] < 2e-5 and "+-2000" in loc["workload"]
+    for name in ("gws_cfg3_bf16", "mh_spmm_cfg4_bf16"):               # additional lines: 16-bit storage, never the headline
+        assert sec[name]["kernel_ms"] > 0 and "bfloat16" in sec[name]["workload"], name
+    assert r["dtype"] == "f32" and "traffic_source" in r["roofline"]

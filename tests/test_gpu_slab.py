@@ -406,3 +406,88 @@ def test_device_plan_builder_is_bit_identical_to_the_aten_formulation(geot, node
         ta, tb = a.tensors[name], b.tensors[name]
         assert ta.dtype == tb.dtype and ta.numel() == tb.numel() == n, (name, ta.dtype, tb.dtype, ta.numel(), tb.numel(), n)
         assert torch.equal(ta, tb), name
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nodes,nnz,H,Fh", [(40_000, 3_000_000, 4, 64), (70_000, 2_500_000, 1, 128), (20_000, 2_000_000, 1, 512),
+                                           (3000, 400_000, 2, 64), (30_000, 2_000_000, 1, 64)])
+def test_slab_16bit_storage_fp32_accumulate(geot, oracle, dtype, nodes, nnz, H, Fh):
+    """half / bfloat16 storage through the source-blocked kernel: 8 elements per 16-byte lane, fp32 accumulators in LDS,
+    weights in the storage type, ONE rounding when a row is written - the semantics of the per-edge kernels and of the
+    reference's CPU path (csrc/cpu/index_scatter_cpu.cpp:78-86,114-116).  Rows of 128 B (the last case) .. 1024 B."""
+    from geot_amd import slab
+    rng = np.random.default_rng(nodes + H)
+    di = powerlaw_index(nnz, nodes, nodes)
+    di[: nnz // 20] = di[nnz // 20]                                     # a hub that is split (fp32 carry slots)
+    di = np.sort(di)
+    di[di == 7] = 8                                                     # an empty key
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    F = H * Fh
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    scale = 1.0 / 16 if dtype == torch.float16 else 1.0                 # (the hub's sum must stay below float16's 65504)
+    x = torch.from_numpy(rng.random((nodes, H, Fh), dtype=np.float32) * scale).to(dtype)
+    d_si, d_di, d_x = dev(si), dev(di), x.cuda()
+    R = slab.rows_per_group(2 if H > 1 else 1, H, dtype)
+    assert R == slab.rows_per_group(2 if H > 1 else 1, H, torch.float32) // 2 or R >= 1
+    out = torch.empty(nodes, H, Fh, device="cuda", dtype=dtype)
+
+    def check(got, hi, what):
+        got = got.float().cpu().numpy().reshape(hi.shape)
+        assert np.all(np.abs(got - hi) <= ulp * np.abs(hi) + 1e-6), (what, float(np.max(np.abs(got - hi) / (np.abs(hi) + 1e-6))))
+        assert np.all(got[hi == 0] == 0), what
+
+    if H == 1:
+        w = torch.from_numpy(rng.random(nnz, dtype=np.float32)).to(dtype)
+        plan = slab.build_plan(d_si, d_di, nodes, nodes, F * 2, 1, 1, rows_per_group=R)
+        slab.slab_spmm_out(plan, w.cuda(), 1, d_x, out, 1, Fh)
+        check(out, oracle.gather_weight_scatter(si, di, w.float().numpy(), x.float().numpy().reshape(nodes, F), rows=nodes, acc64=True), "gws")
+        again = torch.empty_like(out)
+        slab.slab_spmm_out(plan, w.cuda(), 1, d_x, again, 1, Fh)
+        assert torch.equal(out, again)                                  # deterministic
+        wp = w.cuda()[plan.tensors["e_perm"].long()].contiguous()       # a static weight, permuted into plan order (mode 4)
+        slab.slab_spmm_out(plan, wp, 4, d_x, again, 1, Fh)
+        assert torch.equal(out, again)
+        slab.slab_spmm_out(plan, None, 0, d_x, out, 1, Fh)
+        hi = oracle.gather_scatter(si, di, x.float().numpy().reshape(nodes, F), rows=nodes, acc64=True)
+        check(out, hi, "gs")
+        for red, tred in (("max", "amax"), ("mean", "mean")):
+            slab.slab_spmm_out(plan, None, 0, d_x, out, 1, Fh, reduce=red)
+            want = torch.zeros(nodes, F, device="cuda").scatter_reduce(0, d_di[:, None].expand(-1, F), d_x.view(nodes, F)[d_si].float(), tred,
+                                                                       include_self=False)
+            check(out, want.cpu().numpy().astype(np.float64), red)
+    else:
+        w = torch.from_numpy(rng.random((nnz, H), dtype=np.float32)).to(dtype)
+        hi = oracle.mh_spmm(si, di, w.float().numpy(), x.float().numpy(), rows=nodes, acc64=True)
+        plan = slab.build_plan(d_si, d_di, nodes, nodes, F * 2, 2, H, rows_per_group=R)
+        slab.slab_spmm_out(plan, w.cuda(), 2, d_x, out, H, Fh)
+        check(out, hi, "mh edge-major")
+        slab.slab_spmm_out(plan, w.t().contiguous().cuda(), 3, d_x, out, H, Fh)
+        check(out, hi, "mh head-major")
+
+
+def test_host_layer_routes_16bit_dense_graphs_to_the_source_blocked_kernel(geot):
+    from geot_amd import ops
+    nodes, nnz, H, Fh = 30_000, 3_000_000, 4, 64
+    di = dev(powerlaw_index(nnz, nodes, 3))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    x = torch.rand(nodes, H, Fh, device="cuda", generator=g).bfloat16()
+    w = torch.rand(nnz, H, device="cuda", generator=g).bfloat16()
+    old = ops.set_option("slab_mode", "always")
+    try:
+        ops.clear_caches()
+        st0 = ops.stats()
+        got = geot.mh_spmm(si, di, w, x)
+        assert ops.stats()["slab_calls"] == st0["slab_calls"] + 1 and got.dtype == torch.bfloat16
+        ops.set_option("slab_mode", "never")
+        ref = geot.mh_spmm(si, di, w, x)                                 # the per-edge kernels, same storage type
+        assert torch.allclose(got.float(), ref.float(), rtol=2.0 ** -6, atol=1e-6)
+        ops.set_option("slab_mode", "always")
+        x2 = x.view(nodes, H * Fh)
+        w1 = w[:, 0].contiguous()
+        got = geot.gather_weight_scatter(si, di, w1, x2)
+        ops.set_option("slab_mode", "never")
+        assert torch.allclose(got.float(), geot.gather_weight_scatter(si, di, w1, x2).float(), rtol=2.0 ** -6, atol=1e-6)
+    finally:
+        ops.set_option("slab_mode", old)
+        ops.clear_caches()
