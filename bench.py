@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--cuts", choices=["equal", "aligned"], default="equal",
                     help="N > 1: equal = neighbouring shards share their boundary key (one small all_gather of partial rows per "
                          "step); aligned = segment-aligned cuts, no data-path collective")
+    ap.add_argument("--collective", choices=["all_gather", "reduce_scatter"], default="all_gather",
+                    help="N > 1, equal cuts: how the boundary-row partials travel in the TIMED steps (the other form is timed "
+                         "in a few extra steps and reported beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only-secondary", default="", help="comma-separated entries of `secondary` to run (profiling sessions)")
@@ -354,17 +357,17 @@ def main():
         alg = algorithmic_bytes(nnz, feat, rows)
         key_offset = rank * (rows - 1) if args.cuts == "equal" else rank * rows   # equal: neighbours share one key
         if distributed:
-            def step():
-                return sharding.sharded_index_scatter(index, src, key_offset=key_offset, timing=timing)[0]
+            def step(collective=args.collective):
+                return sharding.sharded_index_scatter(index, src, key_offset=key_offset, timing=timing, collective=collective)[0]
         else:
             def step():
                 return geot.index_scatter(0, src, index, "sum", True)
         kernel = "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"
         coll = "RCCL" if backend == "nccl" else backend
         workload = ("index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64 (BASELINE.json configs[1])"
-                    + (f" per GPU, neighbouring shards share their boundary key, boundary rows exchanged by a {coll} all_gather" if distributed else ""))
+                    + (f" per GPU, neighbouring shards share their boundary key, boundary rows exchanged by a {coll} {args.collective}" if distributed else ""))
         step_desc = ("sharding.sharded_index_scatter: 16-byte-per-rank key all_gather under the local kernels (tile + fix-up), "
-                     "all_gather of the first-row partials, owner add" if distributed else
+                     f"{args.collective} of the first-row partials, owner add" if distributed else
                      "geot.index_scatter(0, src, index, 'sum', True): read-back of index[-1] + alloc + tile kernel + fix-up kernel")
         metric = METRIC
     else:
@@ -380,8 +383,8 @@ def main():
         alg = nnz * 16 + uniq * 4 * feat + rows * 4 * feat                 # compulsory bytes
         key_offset = rank * (rows - 1) if args.cuts == "equal" else rank * rows
         if distributed:
-            def step():
-                return sharding.sharded_gather_scatter(src_index, index, src, key_offset=key_offset, timing=timing)[0]
+            def step(collective=args.collective):
+                return sharding.sharded_gather_scatter(src_index, index, src, key_offset=key_offset, timing=timing, collective=collective)[0]
         else:
             def step():
                 return geot.gather_scatter(src_index, index, src)
@@ -407,9 +410,22 @@ def main():
         out = step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    exchange_ms = None
-    if timing.get("exchange_events"):
-        exchange_ms = sum(a.elapsed_time(b) for a, b in timing["exchange_events"]) / len(timing["exchange_events"])
+    def mean_ms(events):
+        return sum(a.elapsed_time(b) for a, b in events) / len(events) if events else None
+
+    exchange_ms = mean_ms(timing.get("exchange_events"))
+    key_ms = mean_ms(timing.get("key_events"))
+    if key_ms is None and timing.get("key_wall_ms"):
+        key_ms = sum(timing["key_wall_ms"]) / len(timing["key_wall_ms"])
+    by_collective = {args.collective: exchange_ms}
+    if distributed:                                   # the other form of the boundary exchange, a few extra steps (untimed in `value`)
+        other = "reduce_scatter" if args.collective == "all_gather" else "all_gather"
+        timing.clear()
+        for _ in range(max(2, min(args.steps, 20))):
+            out = step(other)
+        sync_all()
+        by_collective[other] = mean_ms(timing.get("exchange_events"))
+        timing.clear()
     timing = None
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -458,7 +474,11 @@ def main():
                          "frac_of_box_read_ceiling": achieved / box["read_ceiling_gbps"]},
         }
         if distributed:
-            res["boundary_exchange_ms"] = exchange_ms      # rank 0: all_gather of first-row partials + owner adds (None: no key shared)
+            res["boundary_exchange_ms"] = exchange_ms      # rank 0, the timed steps' collective + owner adds (None: no key shared)
+            res["collective"] = args.collective
+            res["boundary_exchange_ms_by_collective"] = by_collective   # all_gather + owner add | reduce_scatter (north star's wording)
+            res["key_exchange_ms"] = key_ms                # 16-byte-per-rank all_gather of (first, last) keys + copy to the host, side stream
+            res["ranks_seen"] = dist.get_world_size()      # what the process group reports (after init_process_group)
             res["cuts"] = args.cuts
             res["dist_backend"] = backend
         if not distributed and args.workload == "cfg2" and not args.no_cpu_baseline:

@@ -9,9 +9,10 @@ into contiguous edge ranges, one per rank, and the output stays ROW-SHARDED:
 Two ways to cut:
   * ``segment_aligned_cuts``  snaps every cut to a segment start -> no data-path collective;
   * ``equal_edge_cuts``       exact edge balance -> a segment may straddle a cut; each rank's
-    partial first row is then exchanged with ONE small collective (all_gather of W rows of F
-    values - latency-bound, microseconds over xGMI) and added by the owner in rank order
-    (deterministic).  A hub that spans several ranks is handled by the same pass.
+    partial first row is then exchanged with ONE small collective - an all_gather of W rows of F
+    values added by the owner in rank order, or a reduce_scatter of a [W, F] buffer (``collective=``;
+    latency-bound either way, microseconds over xGMI).  A hub that spans several ranks is handled by
+    the same pass.
 Which case applies is decided per call from every rank's end keys (a 16-byte-per-rank all_gather that runs
 underneath the local kernels), so the host never waits for the reduction and the GPU never idles on the host.
 
@@ -110,8 +111,11 @@ def boundary_plan(firsts: List[int], lasts: List[int], rank: int) -> dict:
         joins = []                     # my whole shard lies inside a run owned by a lower rank: it adds my row
     prev_last = lasts[rank - 1] if rank > 0 else -1
     any_shared = any(lasts[r - 1] == firsts[r] for r in range(1, world))
+    # who owns my first row: the lowest rank that ENDS on my first key (ranks hold contiguous ranges of a sorted list, so
+    # every rank between it and me ends on that key too); myself when the previous rank ends on another key
+    owner = rank if owns_first else min(r for r in range(rank) if lasts[r] == first_key)
     return {"owns_first": owns_first, "joins": joins, "gap": (first_key - (prev_last + 1)) if owns_first else 0,
-            "first_row": (prev_last + 1) if owns_first else first_key + 1, "any_shared": any_shared}
+            "first_row": (prev_last + 1) if owns_first else first_key + 1, "any_shared": any_shared, "owner": owner}
 
 
 def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
@@ -119,7 +123,8 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
                           local_op: Optional[Callable] = None,
                           exchange: bool = True,
                           key_offset: Optional[int] = None,
-                          timing: Optional[dict] = None) -> Tuple[torch.Tensor, int]:
+                          timing: Optional[dict] = None,
+                          collective: str = "all_gather") -> Tuple[torch.Tensor, int]:
     """Row-sharded index_scatter over the ranks of ``group``.
 
     ``index_shard`` / ``src_shard`` are this rank's contiguous slice of the globally dst-sorted
@@ -143,8 +148,18 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
          (W x F values, native precision) follows the local kernels on the stream, and the owner adds the
          partials that belong to its last row in rank order (deterministic) - all queued, no host wait.
     Every rank issues the same collectives in the same order whatever its local verification says.
-    ``timing``: optional dict; receives hipEvent pairs around the exchange ("exchange_events").
+
+    ``collective``: how the first-row partials travel in step 3 (both give the same rows; W x F values either way):
+      * ``"all_gather"`` (default): every rank receives every rank's first-row partial and the owner adds the ones that
+        belong to its last row, in rank order;
+      * ``"reduce_scatter"`` (the north star's wording): every rank sends a [W, F] buffer that is zero except for row
+        ``owner(my first key)`` = its first-row partial; ``reduce_scatter(sum)`` hands rank o the sum of the partials it
+        owns - the adds happen inside RCCL - and o adds that one row to its last row.
+    ``timing``: optional dict; receives hipEvent pairs around the exchange ("exchange_events") and around the key
+    all_gather + copy on the side stream ("key_events"; "key_wall_ms" where the keys travel through the host).
     """
+    if collective not in ("all_gather", "reduce_scatter"):
+        raise ValueError("collective must be 'all_gather' or 'reduce_scatter'")
     local_op = local_op or _default_local_op
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -177,6 +192,10 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(main)                                      # the index is ready wherever main is now
         with torch.cuda.stream(side):                               # (tensors made here live in the side stream's pool)
+            kev = None
+            if timing is not None:
+                kev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                kev[0].record(side)
             mine = (ends_dev + off) if off else ends_dev.contiguous()
             if world > 1:
                 allkeys = torch.empty(2 * world, dtype=torch.int64, device=dev)
@@ -186,11 +205,18 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
             host, waiter = _pinned_slot(dev, world)
             host.copy_(allkeys, non_blocking=True)
             waiter.record(side)
+            if kev is not None:
+                kev[1].record(side)
+                timing.setdefault("key_events", []).append(kev)
     elif world > 1:
+        import time
+        t0 = time.perf_counter()
         mine = (ends_dev + off) if off else ends_dev.contiguous()
         send = mine.cpu() if via_host else mine
         host = torch.empty(2 * world, dtype=torch.int64, device=send.device)
         dist.all_gather_into_tensor(host, send, group=group)
+        if timing is not None:
+            timing.setdefault("key_wall_ms", []).append((time.perf_counter() - t0) * 1e3)
     else:
         host = (ends_dev + off) if off else ends_dev
 
@@ -221,12 +247,24 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
             ev[0].record(torch.cuda.current_stream(dev))
         xdtype = torch.float64 if local.dtype == torch.float64 else torch.float32   # exact for fp32 / 16-bit rows
         rec = local[0].reshape(-1).to(xdtype)
-        send = rec.cpu() if via_host else rec
-        recv = torch.empty(world * F, dtype=xdtype, device=send.device)
-        dist.all_gather_into_tensor(recv, send, group=group)
-        allrows = (recv.to(dev) if via_host else recv).view(world, F)
-        for r2 in plan["joins"]:                                    # rank order: deterministic
-            local[-1].add_(allrows[r2].view(feat_shape))            # in place: `local` is this call's own buffer
+        if collective == "reduce_scatter":
+            # row `owner` of my [W, F] buffer = my first-row partial (if another rank owns that row), everything else zero;
+            # the sum over ranks of row o is what rank o has to add to its last row
+            send = torch.zeros(world, F, dtype=xdtype, device=rec.device)
+            if not plan["owns_first"]:
+                send[plan["owner"]].copy_(rec)
+            send = send.view(-1).cpu() if via_host else send.view(-1)
+            recv = torch.empty(F, dtype=xdtype, device=send.device)
+            dist.reduce_scatter_tensor(recv, send, group=group)
+            if plan["joins"]:
+                local[-1].add_((recv.to(dev) if via_host else recv).view(feat_shape).to(local.dtype))
+        else:
+            send = rec.cpu() if via_host else rec
+            recv = torch.empty(world * F, dtype=xdtype, device=send.device)
+            dist.all_gather_into_tensor(recv, send, group=group)
+            allrows = (recv.to(dev) if via_host else recv).view(world, F)
+            for r2 in plan["joins"]:                                # rank order: deterministic
+                local[-1].add_(allrows[r2].view(feat_shape))        # in place: `local` is this call's own buffer
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))
             timing.setdefault("exchange_events", []).append(ev)
@@ -242,7 +280,8 @@ def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch
                            src: torch.Tensor, weight_shard: Optional[torch.Tensor] = None,
                            group: Optional[dist.ProcessGroup] = None,
                            local_op: Optional[Callable] = None, exchange: bool = True,
-                           key_offset: Optional[int] = None, timing: Optional[dict] = None) -> Tuple[torch.Tensor, int]:
+                           key_offset: Optional[int] = None, timing: Optional[dict] = None,
+                           collective: str = "all_gather") -> Tuple[torch.Tensor, int]:
     """Row-sharded gather_scatter / gather_weight_scatter (BASELINE.json configs[4]).
 
     The edge list (src_index, dst_index[, weight]) is sharded by contiguous dst-sorted edge ranges
@@ -266,7 +305,7 @@ def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch
     # the per-edge operand is only used for its feature shape: hand over one row of src
     proto = src[:1].expand(dst_index_shard.numel(), *src.shape[1:])
     return sharded_index_scatter(dst_index_shard, proto, group=group, local_op=as_index_scatter,
-                                 exchange=exchange, key_offset=key_offset, timing=timing)
+                                 exchange=exchange, key_offset=key_offset, timing=timing, collective=collective)
 
 
 def shard_edges(index: torch.Tensor, src: torch.Tensor, world: int, rank: int, aligned: bool = False):

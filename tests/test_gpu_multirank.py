@@ -89,6 +89,11 @@ host.copy_(allkeys, non_blocking=True)
 send = torch.arange(64, dtype=torch.float32, device=dev)
 recv = torch.empty(64, dtype=torch.float32, device=dev)
 dist.all_gather_into_tensor(recv, send)
+# ... and the reduce_scatter form of the boundary exchange: a [W, F] buffer in, this rank's row of the sum out
+rs_in = torch.arange(64, dtype=torch.float32, device=dev) + 0.5
+rs_out = torch.empty(64, dtype=torch.float32, device=dev)
+dist.reduce_scatter_tensor(rs_out, rs_in)
+assert torch.equal(rs_out, rs_in)
 # bench.py: max over ranks of the elapsed time, barrier
 t = torch.tensor([1.5], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -102,10 +107,12 @@ import geot_amd
 from geot_amd import sharding
 idx = torch.sort(torch.randint(0, 5000, (300000,), device=dev)).values
 src = torch.rand(300000, 64, device=dev)
-for _ in range(3):
-    out, first = sharding.sharded_index_scatter(idx, src)
 ref = geot_amd.index_scatter(0, src, idx)
-assert first == 0 and torch.equal(out, ref)
+for coll in ("all_gather", "reduce_scatter"):
+    for _ in range(3):
+        timing = {}
+        out, first = sharding.sharded_index_scatter(idx, src, collective=coll, timing=timing)
+    assert first == 0 and torch.equal(out, ref) and len(timing["key_events"]) == 1
 dist.destroy_process_group()
 print("RCCL OK")
 '''

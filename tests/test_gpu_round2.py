@@ -449,6 +449,9 @@ def test_bench_launches_its_own_ranks():
             assert r["scaling"] == "strong" and r["boundary_exchange_ms"] is None and r["config"]["nnz_per_gpu"] == 5_000_000
         else:
             assert r["scaling"] == "weak" and r["boundary_exchange_ms"] is not None and r["boundary_exchange_ms"] > 0
+            both = r["boundary_exchange_ms_by_collective"]                 # the first SCALE run needs no code change: both forms timed
+            assert both["all_gather"] > 0 and both["reduce_scatter"] > 0 and r["collective"] == "all_gather"
+        assert r["ranks_seen"] == gpus and r["key_exchange_ms"] > 0
         assert 0 < r["roofline"]["frac"] < 1
 
 

@@ -27,7 +27,7 @@ def _oracle_local_op(index_local, src_local, rows):
     return torch.from_numpy(api.index_scatter(index_local.numpy(), src_local.numpy(), rows=rows))
 
 
-def _worker(rank, world, port, case, aligned, q):
+def _worker(rank, world, port, case, aligned, q, collective="all_gather"):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -37,18 +37,21 @@ def _worker(rank, world, port, case, aligned, q):
         index = torch.from_numpy(case["index"])
         src = torch.from_numpy(case["src"])
         ish, ssh = sharding.shard_edges(index, src, world, rank, aligned=aligned)
-        out, first_row = sharding.sharded_index_scatter(ish, ssh, local_op=_oracle_local_op, exchange=not aligned)
+        timing = {}
+        out, first_row = sharding.sharded_index_scatter(ish, ssh, local_op=_oracle_local_op, exchange=not aligned, collective=collective,
+                                                        timing=timing)
+        assert len(timing.get("key_wall_ms", [])) == (1 if world > 1 else 0)          # the key exchange times itself
         q.put((rank, first_row, out.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _run(case, world, aligned):
+def _run(case, world, aligned, collective="all_gather"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, aligned, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, aligned, q, collective)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
@@ -86,6 +89,65 @@ def test_equal_edge_cuts_with_boundary_exchange(name, world):
     np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)
 
 
+def _both_worker(rank, world, port, cases, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geot_amd import sharding
+        res = {}
+        for name, case in cases.items():
+            ish, ssh = sharding.shard_edges(torch.from_numpy(case["index"]), torch.from_numpy(case["src"]), world, rank)
+            for coll in ("all_gather", "reduce_scatter"):
+                out, first_row = sharding.sharded_index_scatter(ish, ssh, local_op=_oracle_local_op, collective=coll)
+                res[(name, coll)] = (first_row, out.numpy().copy())
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_reduce_scatter_form_gives_the_rows_of_the_all_gather_form(world):
+    """BASELINE.json's north star names an "RCCL reduce-scatter over xGMI for boundary segments": every rank contributes
+    a [W, F] buffer whose row `owner(my first key)` is its first-row partial.  Same rows as the all_gather + owner-add form
+    for every cut pattern - one shared key per cut, a hub covering several whole ranks, tiny shards, gaps.  With
+    integer-valued data (every partial sum exact) the two forms agree bit for bit; with random data within rounding."""
+    from oracle import api
+    rng = np.random.default_rng(100 + world)
+    hub = np.sort(np.concatenate([rng.integers(0, 5, 700), np.full(5000, 5), rng.integers(6, 40, 1500)])).astype(np.int64)
+    cases = dict(_cases())
+    cases["hub_over_many_ranks"] = dict(index=hub, src=rng.random((len(hub), 4), dtype=np.float32))
+    cases["tiny"] = dict(index=np.array([0, 0, 0, 1, 1, 1, 1, 1, 4, 4, 4, 9, 9, 9, 9, 9], dtype=np.int64), src=rng.random((16, 3), dtype=np.float32))
+    for name in list(cases):                                 # + integer-valued twins: sums of small integers are exact
+        cases[name + "/exact"] = dict(index=cases[name]["index"], src=np.floor(cases[name]["src"] * 64).astype(np.float32))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_both_worker, args=(r, world, port, cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name, case in cases.items():
+        full = api.index_scatter(case["index"], case["src"], acc64=True)
+        for coll in ("all_gather", "reduce_scatter"):
+            got = np.concatenate([res[r][(name, coll)][1] for r in range(world)])
+            assert got.shape == full.shape, (name, coll)
+            if name.endswith("/exact"):
+                np.testing.assert_array_equal(got, full)
+            else:
+                np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-5)
+        for r in range(world):
+            a, b = res[r][(name, "all_gather")], res[r][(name, "reduce_scatter")]
+            assert a[0] == b[0] and a[1].shape == b[1].shape, (name, r)
+            if name.endswith("/exact"):
+                np.testing.assert_array_equal(a[1], b[1])
+
+
 def test_eight_ranks_hub_over_many_ranks_and_tiny_shards():
     """The world size of BASELINE.json configs[4]: a hub that covers ranks 2..5 completely (their whole shard lies inside
     one run owned by rank 1), then 8 ranks with TWO edges each."""
@@ -120,6 +182,7 @@ def test_boundary_plan_table():
     assert not p2["owns_first"] and p2["joins"] == []
     assert not p3["owns_first"] and p3["joins"] == [] and p3["first_row"] == 6
     assert p4["owns_first"] and p4["gap"] == 1 and p4["first_row"] == 8 and p4["joins"] == []
+    assert [p["owner"] for p in (p0, p1, p2, p3, p4)] == [0, 0, 0, 0, 4]    # who receives each rank's first-row partial
     q = [boundary_plan([0, 4, 9], [3, 8, 9], r) for r in range(3)]       # segment-aligned cuts: nothing shared
     assert not any(x["any_shared"] for x in q) and all(x["owns_first"] and x["joins"] == [] for x in q)
     assert [x["gap"] for x in q] == [0, 0, 0] and [x["first_row"] for x in q] == [0, 4, 9]
