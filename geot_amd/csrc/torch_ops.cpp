@@ -52,6 +52,7 @@ struct Options {
   int transpose_cache = 4;   // GEOT_TRANSPOSE_CACHE (entries)
   int slab_keep = 2;
   int publish_rows = 1;      // GEOT_PUBLISH_ROWS: small calls get index[-1] from their own first kernel (geot_publish_word)
+  int64_t cache_mb = 0;      // GEOT_CACHE_MB: byte budget of all cached artefacts together (0 = 1/8 of the device's memory)
   int slab_builder = 0;      // Phase A: 0 = the device builder (csrc/seg_plan.hip), 1 = the ATen formulation (CPU tensors always; cross-check)
   Options() {
     if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;
@@ -60,6 +61,7 @@ struct Options {
     if (const char *e = std::getenv("GEOT_UNSORTED")) unsorted_mode = !std::strcmp(e, "atomic") ? 2 : (!std::strcmp(e, "sort") ? 1 : 0);
     if (const char *e = std::getenv("GEOT_SLAB")) slab_mode = !std::strcmp(e, "0") ? -1 : (!std::strcmp(e, "1") ? 1 : 0);
     if (const char *e = std::getenv("GEOT_TRANSPOSE_CACHE")) transpose_cache = std::atoi(e);
+    if (const char *e = std::getenv("GEOT_CACHE_MB")) cache_mb = std::atoll(e);
   }
 };
 Options g_opt;
@@ -171,6 +173,16 @@ struct Produced {
     consume(on, [&](auto rec) { for (const at::Tensor &t : ts) rec(t); });
   }
 };
+
+// The caches below hold DERIVED artefacts only.  The user's tensors they were derived from are referenced weakly: a weak
+// reference pins the StorageImpl object (so its address - part of the content key - cannot be handed to a new tensor while
+// the entry lives: no aliasing of a dead tensor) but not its data; an entry whose source has died is dropped at the next
+// lookup, and all artefacts together stay under a byte budget (largest least-recently-used entry goes first).
+using WeakStorage = c10::weak_intrusive_ptr<c10::StorageImpl>;
+WeakStorage weak_of(const at::Tensor &t) { return t.storage().getWeakStorageImpl(); }
+int64_t nbytes_of(const at::Tensor &t) { return t.defined() ? (int64_t)t.numel() * (int64_t)t.element_size() : 0; }
+void enforce_cache_budget_locked(); // (defined behind the caches; call with g_mu held)
+void sweep_expired_locked();
 
 // one zero-initialised workspace per (device, stream), grown on demand (the ABI: one stream at a time per workspace)
 at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
@@ -365,6 +377,7 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t k
       }
       if (f.keys.defined() && ++holders > kSortedKeep) f.keys = f.perm = at::Tensor();
     }
+    enforce_cache_budget_locked();
   }
   return sorted;
 }
@@ -373,7 +386,8 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t k
 // geot/gather_weight_scatter.py:10-11, geot/csr_gws.py) -> the int64 the kernels read, converted once per content
 struct WidenedEntry {
   ContentKey key;
-  at::Tensor narrow, wide; // `narrow` is kept alive: its address cannot be recycled while the entry lives
+  WeakStorage narrow; // the caller's int32 tensor (weak: see WeakStorage)
+  at::Tensor wide;
   Produced made;
 };
 std::list<WidenedEntry> g_widened;
@@ -385,7 +399,7 @@ at::Tensor as_int64(const at::Tensor &t) {
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_widened.begin(); it != g_widened.end(); ++it)
-      if (it->key == k) {
+      if (it->key == k && !it->narrow.expired()) {
         g_widened.splice(g_widened.begin(), g_widened, it);
         g_widened.front().made.before_use(t, {&g_widened.front().wide});
         return g_widened.front().wide;
@@ -394,9 +408,10 @@ at::Tensor as_int64(const at::Tensor &t) {
   at::Tensor wide = t.to(at::kLong).contiguous();
   if (keyed && !tl_capturing) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_widened.push_front(WidenedEntry{k, t, wide, {}});
+    g_widened.push_front(WidenedEntry{k, weak_of(t), wide, {}});
     g_widened.front().made.mark(t);
     while (g_widened.size() > 6) g_widened.pop_back();
+    enforce_cache_budget_locked();
   }
   return wide;
 }
@@ -486,8 +501,14 @@ struct SlabPlanHolder {
   std::mutex wmu;
   bool w_seen_valid = false;
   ContentKey w_seen{}, w_key{};
-  at::Tensor w_given, w_planorder;
+  c10::optional<WeakStorage> w_given; // the weight tensor w_planorder was made from (weak)
+  at::Tensor w_planorder;
   Produced made, w_made; // events of Phase A / of the weight permutation (consumers on other streams wait for them)
+  int64_t bytes() const {
+    int64_t b = nbytes_of(w_planorder);
+    for (const at::Tensor &t : keep) b += nbytes_of(t);
+    return b;
+  }
 };
 
 bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes, int dtype = GEOT_F32) {
@@ -727,8 +748,7 @@ struct SlabEntry {
   int64_t rows, src_rows, rowbytes, heads;
   int wmode;
   int rpg;   // rows per group the plan was built for: the only thing the weight mode / head count changes
-  c10::weak_intrusive_ptr<c10::StorageImpl> w1, w2;
-  at::Tensor si, di; // keep the key tensors alive: their addresses cannot be recycled while the entry lives
+  WeakStorage w1, w2; // the edge list the plan was built from (weak: the plan goes when the edge list dies)
   std::shared_ptr<SlabPlanHolder> plan;
 };
 std::list<SlabEntry> g_slab;
@@ -751,6 +771,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   const int rpg = geot_slab_rows_per_group_dtype(wmode, heads, dt);
   {
     std::lock_guard<std::mutex> lk(g_mu);
+    sweep_expired_locked();
     for (auto it = g_slab.begin(); it != g_slab.end(); ++it)
       if (it->k1 == k1 && it->k2 == k2 && it->rows == rows && it->src_rows == src.size(0) && it->rowbytes == rowbytes &&
           it->rpg == rpg && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R)
@@ -787,9 +808,9 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.plans_built;
   g_stats.plan_us += us;
-  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, rpg, si.storage().getWeakStorageImpl(),
-                              di.storage().getWeakStorageImpl(), si, di, plan});
+  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, rpg, weak_of(si), weak_of(di), plan});
   while ((int)g_slab.size() > g_opt.slab_keep) g_slab.pop_back();
+  enforce_cache_budget_locked();
   return plan;
 }
 
@@ -1009,7 +1030,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
         ContentKey wk;
         if (has_w && g_opt.trust_version && content_key(e.w, &wk)) {
           std::lock_guard<std::mutex> lk(plan->wmu);
-          if (plan->w_planorder.defined() && plan->w_key == wk) {
+          if (plan->w_planorder.defined() && plan->w_key == wk && plan->w_given && !plan->w_given->expired()) {
             w_planorder = plan->w_planorder;
             plan->w_made.before_use(x, {&w_planorder});
           } else if (tl_capturing) {
@@ -1018,7 +1039,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
             plan->w_planorder = e.w.index_select(0, plan->keep[2]);
             plan->w_made.mark(x);
             plan->w_key = wk;
-            plan->w_given = e.w;                       // kept alive: its address cannot be recycled under this key
+            plan->w_given = weak_of(e.w);              // (weak: pins the address under this key, not the data)
             w_planorder = plan->w_planorder;
           } else {
             plan->w_seen = wk;
@@ -1154,7 +1175,8 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
 // CSR call shares the index facts, the row-count handling and the source-blocked path of the COO ops)
 struct ExpandedEntry {
   ContentKey key;
-  at::Tensor indptr, dst_index;
+  WeakStorage indptr; // the caller's row pointers (weak)
+  at::Tensor dst_index;
   Produced made;
 };
 std::list<ExpandedEntry> g_expanded;
@@ -1165,7 +1187,7 @@ at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_expanded.begin(); it != g_expanded.end(); ++it)
-      if (it->key == k && it->dst_index.numel() == nnz) {
+      if (it->key == k && it->dst_index.numel() == nnz && !it->indptr.expired()) {
         g_expanded.splice(g_expanded.begin(), g_expanded, it);
         g_expanded.front().made.before_use(indptr, {&g_expanded.front().dst_index});
         return g_expanded.front().dst_index;
@@ -1176,9 +1198,10 @@ at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   at::Tensor dst_index = at::repeat_interleave(counts, c10::optional<int64_t>(nnz));
   if (keyed && !tl_capturing) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_expanded.push_front(ExpandedEntry{k, indptr, dst_index, {}});
+    g_expanded.push_front(ExpandedEntry{k, weak_of(indptr), dst_index, {}});
     g_expanded.front().made.mark(indptr);
     while (g_expanded.size() > 4) g_expanded.pop_back();
+    enforce_cache_budget_locked();
   }
   return dst_index;
 }
@@ -1230,13 +1253,16 @@ at::Tensor gather_rows_op(const at::Tensor &index_in, const at::Tensor &src_in) 
 // keeps its key tensors alive: a freed edge list's address can never be handed to a new one while the entry lives.
 struct TransposedEntry {
   ContentKey k1, k2;
-  at::Tensor si, di, perm, si_sorted, di_perm;
+  WeakStorage w1, w2; // the edge list (weak)
+  at::Tensor perm, si_sorted, di_perm;
   // the per-edge weight in transposed order, kept for the content it was made from (a static weight - a normalised
   // adjacency that does not require grad - is permuted once, not on every backward call)
   bool w_valid = false;
   ContentKey wkey{};
-  at::Tensor w_given, w_perm;
+  c10::optional<WeakStorage> w_given;
+  at::Tensor w_perm;
   Produced made, w_made;
+  int64_t bytes() const { return nbytes_of(perm) + nbytes_of(si_sorted) + nbytes_of(di_perm) + nbytes_of(w_perm); }
 };
 std::list<TransposedEntry> g_transposed;
 
@@ -1247,6 +1273,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
   const bool keyed = g_opt.transpose_cache > 0 && g_opt.trust_version && content_key(si, &k1) && content_key(di, &k2);
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
+    sweep_expired_locked();
     for (auto it = g_transposed.begin(); it != g_transposed.end(); ++it)
       if (it->k1 == k1 && it->k2 == k2) {
         g_transposed.splice(g_transposed.begin(), g_transposed, it);
@@ -1263,9 +1290,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.transposes;
   if (keyed && !tl_capturing) {
-    g_transposed.push_front(TransposedEntry{k1, k2, si, di, perm, sorted.first, di_perm});
+    g_transposed.push_front(TransposedEntry{k1, k2, weak_of(si), weak_of(di), perm, sorted.first, di_perm});
     g_transposed.front().made.mark(si);
     while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
+    enforce_cache_budget_locked();
   }
   return {perm, sorted.first, di_perm};
 }
@@ -1282,7 +1310,7 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &e : g_transposed)
-      if (e.k1 == k1 && e.k2 == k2 && e.w_valid && e.wkey == wk) {
+      if (e.k1 == k1 && e.k2 == k2 && e.w_valid && e.wkey == wk && e.w_given && !e.w_given->expired()) {
         e.w_made.before_use(weight, {&e.w_perm});
         return e.w_perm;
       }
@@ -1294,12 +1322,83 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
       if (e.k1 == k1 && e.k2 == k2) {
         e.w_valid = true;
         e.wkey = wk;
-        e.w_given = weight;
+        e.w_given = weak_of(weight);
         e.w_perm = wp;
         e.w_made.mark(weight);
       }
   }
   return wp;
+}
+
+void sweep_expired_locked() {
+  g_widened.remove_if([](const WidenedEntry &e) { return e.narrow.expired(); });
+  g_expanded.remove_if([](const ExpandedEntry &e) { return e.indptr.expired(); });
+  g_transposed.remove_if([](const TransposedEntry &e) { return e.w1.expired() || e.w2.expired(); });
+  g_slab.remove_if([](const SlabEntry &e) { return e.w1.expired() || e.w2.expired(); });
+  for (auto &f : g_facts)
+    if (f.weak.expired()) f.keys = f.perm = at::Tensor();
+}
+
+int64_t cache_bytes_locked() {
+  int64_t b = 0;
+  for (auto &f : g_facts) b += nbytes_of(f.keys) + nbytes_of(f.perm);
+  for (auto &e : g_widened) b += nbytes_of(e.wide);
+  for (auto &e : g_expanded) b += nbytes_of(e.dst_index);
+  for (auto &e : g_transposed) b += e.bytes();
+  for (auto &e : g_slab) b += e.plan->bytes();
+  return b;
+}
+
+int64_t cache_budget_bytes() {
+  if (g_opt.cache_mb > 0) return g_opt.cache_mb << 20;
+  static const int64_t def = [] {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) {
+      (void)hipGetLastError();
+      return (int64_t)32 << 30;
+    }
+    return (int64_t)(total_b / 8);
+  }();
+  return def;
+}
+
+// all cached artefacts together stay under the budget: dead sources first, then the largest least-recently-used entry of any
+// cache (the newest entry of each cache is the one just made or used: it goes last)
+void enforce_cache_budget_locked() {
+  sweep_expired_locked();
+  const int64_t budget = cache_budget_bytes();
+  for (int guard = 0; guard < 64 && cache_bytes_locked() > budget; ++guard) {
+    int64_t best = 0;
+    int which = -1;
+    auto consider = [&](int id, int64_t b, size_t n) {
+      if (n > 1 && b > best) { best = b; which = id; }
+    };
+    if (!g_widened.empty()) consider(0, nbytes_of(g_widened.back().wide), g_widened.size());
+    if (!g_expanded.empty()) consider(1, nbytes_of(g_expanded.back().dst_index), g_expanded.size());
+    if (!g_transposed.empty()) consider(2, g_transposed.back().bytes(), g_transposed.size());
+    if (!g_slab.empty()) consider(3, g_slab.back().plan->bytes(), g_slab.size());
+    Facts *oldest_sorted = nullptr;
+    size_t sorted_holders = 0;
+    for (auto &f : g_facts)
+      if (f.keys.defined()) { oldest_sorted = &f; ++sorted_holders; }
+    if (oldest_sorted) consider(4, nbytes_of(oldest_sorted->keys) + nbytes_of(oldest_sorted->perm), sorted_holders);
+    if (which < 0) { // one entry per cache left: drop the largest of those too, whatever it is
+      auto any = [&](int id, int64_t b) { if (b > best) { best = b; which = id; } };
+      if (!g_widened.empty()) any(0, nbytes_of(g_widened.back().wide));
+      if (!g_expanded.empty()) any(1, nbytes_of(g_expanded.back().dst_index));
+      if (!g_transposed.empty()) any(2, g_transposed.back().bytes());
+      if (!g_slab.empty()) any(3, g_slab.back().plan->bytes());
+      if (oldest_sorted) any(4, nbytes_of(oldest_sorted->keys) + nbytes_of(oldest_sorted->perm));
+      if (which < 0) break;
+    }
+    switch (which) {
+    case 0: g_widened.pop_back(); break;
+    case 1: g_expanded.pop_back(); break;
+    case 2: g_transposed.pop_back(); break;
+    case 3: g_slab.pop_back(); break;
+    default: oldest_sorted->keys = oldest_sorted->perm = at::Tensor(); break;
+    }
+  }
 }
 
 void clear_all_caches_locked() {
@@ -1326,6 +1425,13 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "clear_caches") {
     clear_all_caches_locked();
     return 0;
+  } else if (name == "cache_mb") {
+    const int64_t old = g_opt.cache_mb;
+    if (value != INT64_MIN) {
+      g_opt.cache_mb = value;
+      enforce_cache_budget_locked();
+    }
+    return old;
   }
   TORCH_CHECK(p, "unknown host option ", name);
   const int old = *p;
@@ -1337,8 +1443,10 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
 
 std::vector<int64_t> host_stats_op() {
   std::lock_guard<std::mutex> lk(g_mu);
+  sweep_expired_locked();
   return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
-          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published, g_stats.alarms};
+          (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published, g_stats.alarms,
+          cache_bytes_locked()};
 }
 
 // Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).

@@ -281,3 +281,40 @@ def test_cfg4_full_size_properties(geot):
     assert torch.allclose(got, want, rtol=1e-8), (got - want).abs().max()
     ops.clear_caches()
     torch.cuda.empty_cache()
+
+
+def test_cached_artefacts_follow_their_sources_and_a_byte_budget(geot):
+    """The host layer's caches hold derived artefacts only: the tensors they were derived from are referenced weakly (an
+    entry dies with its source instead of pinning the user's edge list) and all artefacts together stay under a byte budget."""
+    from geot_amd import ops
+    ops.clear_caches()
+    nnz, nodes = 2_000_000, 50_000
+    g = torch.Generator(device="cuda").manual_seed(0)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    di = torch.sort(torch.randint(0, nodes, (nnz,), device="cuda", generator=g)).values
+    perm, s_sorted, d_perm = torch.ops.geot.transpose_edges(si, di)
+    st = ops.stats()
+    assert st["transposed"] == 1 and st["cache_bytes"] >= 3 * 8 * nnz
+    assert torch.equal(torch.ops.geot.transpose_edges(si, di)[0], perm) and ops.stats()["transposes"] == st["transposes"]    # served from the cache
+    before = torch.cuda.memory_allocated()
+    del si
+    st2 = ops.stats()                                      # (stats sweep entries whose source has died)
+    assert st2["transposed"] == 0 and st2["cache_bytes"] < st["cache_bytes"]
+    del perm, s_sorted, d_perm
+    assert torch.cuda.memory_allocated() <= before - 4 * 8 * nnz + (1 << 20)          # the edge list AND the artefacts are gone
+    # budget: artefacts of 48 MB against a 16 MiB budget are not kept (the call still returns them)
+    old = ops.set_option("cache_mb", 16)
+    try:
+        si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+        a = torch.ops.geot.transpose_edges(si, di)
+        assert ops.stats()["cache_bytes"] <= 16 << 20
+        b = torch.ops.geot.transpose_edges(si, di)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+        x = torch.rand(nodes, 32, device="cuda", requires_grad=True)               # ... and training through it still works
+        y = geot.gather_scatter(si, di, x)
+        y.sum().backward()
+        want = torch.zeros(nodes, device="cuda").index_add_(0, si, torch.ones(nnz, device="cuda"))
+        assert torch.allclose(x.grad[:, 0], want)
+    finally:
+        ops.set_option("cache_mb", old)
+        ops.clear_caches()
