@@ -2361,8 +2361,17 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!buf || bytes < (1u << 20) || iters < 1) return fail(GEOT_EINVAL, "profile_box: needs a device buffer of >= 1 MiB");
   unsigned long long *d = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Cleanup { // (every early return below frees what has been made so far)
+    unsigned long long *&d;
+    hipEvent_t &e0, &e1;
+    ~Cleanup() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (d) (void)hipFree(d);
+    }
+  } cleanup{d, e0, e1};
   HIP_TRY(hipMalloc(&d, 64));
-  hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   float best = 1e30f;
@@ -2383,9 +2392,6 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
   HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (sclk_mhz) *sclk_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0; // s_memrealtime ticks at 100 MHz
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  HIP_TRY(hipFree(d));
   return GEOT_OK;
 }
 

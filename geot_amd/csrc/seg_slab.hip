@@ -557,7 +557,29 @@ int g_slab_window = 2;  // experiment knob ("slab_window" of geot_set_option): -
 
 int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
 
-int geot_slab_units(void) { return 256 * g_slab_blocks * 4; } // waves of the persistent grid: 256 CUs x workgroups x 4
+// The persistent grid is sized for the device the process runs on: CUs and LDS per CU are read once (a partitioned
+// MI355X - CPX / DPX - or a CU-masked process reports fewer CUs; the build container has no device at all: MI355X's
+// numbers).  The density rule (slab_worthwhile in the host layer) was measured on the full 256-CU chip: on anything else
+// geot_slab_full_chip() is 0 and the automatic routing keeps the per-edge kernels.
+struct SlabDevice { int cus; size_t lds; };
+static const SlabDevice &slab_device() {
+  static const SlabDevice d = [] {
+    SlabDevice r{256, (size_t)160 * 1024};
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) {
+      r.cus = p.multiProcessorCount;
+      if (p.maxSharedMemoryPerMultiProcessor >= 64 * 1024) r.lds = p.maxSharedMemoryPerMultiProcessor;
+    } else {
+      (void)hipGetLastError();
+    }
+    return r;
+  }();
+  return d;
+}
+int geot_slab_full_chip(void) { return slab_device().cus == 256 && slab_device().lds >= (size_t)160 * 1024; }
+
+int geot_slab_units(void) { return slab_device().cus * g_slab_blocks * 4; } // waves of the persistent grid: CUs x workgroups x 4
 
 // nv: float4 accumulators per lane (1: fp32 storage, 2: 16-bit storage - 8 elements per 16-byte lane)
 static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads, int nv = 1) {
@@ -569,7 +591,7 @@ static size_t slab_lds_bytes(int rows_per_group, int weight_mode, int64_t heads,
 int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype) {
   const int nv = dtype == GEOT_F32 ? 1 : 2;
   int r = 16;
-  const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (size_t)(156 * 1024) / g_slab_blocks / 1024 * 1024;
+  const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (slab_device().lds - 4 * 1024) / g_slab_blocks / 1024 * 1024;
   while (r > 1 && slab_lds_bytes(r, weight_mode, heads, nv) > budget) --r;
   return r;
 }
@@ -606,8 +628,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (feat % vec != 0 && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of 16 bytes");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
   const int64_t waves = plan->units / (64 >> lpr_log2);
-  if (plan->units % (64 >> lpr_log2) != 0 || waves % (4 * 256) != 0 || waves < 4 * 256 || waves > 4 * 256 * 4)
-    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: the plan's unit count is not 256 CUs x (1..4 workgroups) x 4 waves");
+  const int64_t cu_waves = (int64_t)4 * slab_device().cus;
+  if (plan->units % (64 >> lpr_log2) != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
+    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: the plan's unit count is not a whole number of 4-wave workgroups, at most 4 per CU of this device");
   if (plan->rows_per_group < 1 || plan->rows_per_group > 32) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group 1..32");
   if (heads > 16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: at most 16 heads");
   const size_t need = geot_slab_workspace_bytes(plan, F);
@@ -696,8 +719,9 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
   if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: rows of 256, 512 or 1024 bytes only");
   if ((((uintptr_t)mat_1) | ((uintptr_t)mat_2) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 16-byte aligned operands");
   const int64_t waves = plan->units / (64 >> lpr_log2);
-  if (plan->units % (64 >> lpr_log2) != 0 || waves % (4 * 256) != 0 || waves < 4 * 256 || waves > 4 * 256 * 4)
-    return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan's unit count is not 256 CUs x (1..4 workgroups) x 4 waves");
+  const int64_t cu_waves = (int64_t)4 * slab_device().cus;
+  if (plan->units % (64 >> lpr_log2) != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
+    return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan's unit count is not a whole number of 4-wave workgroups, at most 4 per CU of this device");
   if (!workspace || workspace_bytes < 256 + kSyncBytes) return geot_internal_fail(GEOT_EWORKSPACE, "slab_sddmm: workspace too small");
   if (plan->n_groups == 0) return GEOT_OK;
   SlabParams p;

@@ -513,7 +513,7 @@ struct SlabPlanHolder {
 
 bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes, int dtype = GEOT_F32) {
   if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024) || nnz >= ((int64_t)1 << 31) || nnz < 8000000 || out_rows < 1 ||
-      src_rows >= ((int64_t)1 << 31))
+      src_rows >= ((int64_t)1 << 31) || !geot_slab_full_chip()) // (a partitioned / CU-masked device: the rule below was not measured there)
     return false;
   const int64_t units = (int64_t)geot_slab_units() * (1024 / rowbytes);
   const int64_t rpg = geot_slab_rows_per_group_dtype(1, 1, dtype); // (16-bit storage: fp32 accumulators, half the rows per group)

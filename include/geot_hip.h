@@ -233,7 +233,8 @@ typedef struct geot_slab_plan {
   int32_t slab_shift, n_slabs; /* the plan's slabs: source row >> slab_shift, n_slabs of them (0 / 0: unknown -> no pacing) */
 } geot_slab_plan;
 
-int geot_slab_units(void);                                     /* waves of the persistent grid */
+int geot_slab_units(void);                                     /* waves of the persistent grid: CUs of this device x workgroups per CU x 4 */
+int geot_slab_full_chip(void);                                 /* 1: all 256 CUs / 160 KB LDS (what the density rule was measured on) */
 int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget (float32 storage) */
 int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /* ... 16-bit storage: fp32 accumulators, half the rows */
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
