@@ -33,6 +33,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <mutex>
 #include <string>
@@ -87,6 +88,9 @@ struct SegParams {
   // 2 gather + weight[e], 3 / 4 multi-head weights edge- / head-major (the repair pass re-reads the operands).
   int mode;
   int64_t *alarm;           // pinned host word (or null): set when a call had to be repaired (geot_set_alarm_word)
+#ifdef GEOT_EXP_HANDOFF
+  unsigned long long exp_epoch; // cost probe of a single-launch form (tools/handoff_probe.sh): this call's number
+#endif
 };
 
 // control words at the head of the workspace (zero between calls)
@@ -450,6 +454,13 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   const int64_t kprev_tile = keysL[0];
   const int64_t knext_tile = keysL[n + 1];
   const int ne = 2 * ng;
+#ifdef GEOT_EXP_HANDOFF
+  A exp_head[VEC];
+  bool exp_head_ends_here = false;
+  int64_t exp_key = -1;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) exp_head[q] = A(0);
+#endif
   for (int i = g; i < ne; i += ng) {
     const int64_t k = pkL[i];
     if (i > 0 && pkL[i - 1] == k) continue; // not the first partial of its run
@@ -501,6 +512,23 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
     if (!active) continue;
     A *cslot = static_cast<A *>(p.carry) + (tile * 2) * F + f0;
+#ifdef GEOT_EXP_HANDOFF
+    if constexpr (std::is_same<T, float>::value && VEC == 4) {
+      if (cslot_id >= 0) { // write-through (sc1) carry: visible to the other XCDs without an L2 write-back
+        typedef float f4x __attribute__((ext_vector_type(4)));
+        const f4x v4 = {sum[0], sum[1], sum[2], sum[3]};
+        A *dstp = cslot + (cslot_id == 1 ? F : 0);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(v4) : "memory");
+        if (cslot_id == 0) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) exp_head[q] = sum[q];
+          exp_head_ends_here = !(at_end && k == knext_tile);
+          exp_key = k;
+        }
+        continue;
+      }
+    }
+#endif
     if (cslot_id == 0) {
       // continues a run that started in an earlier tile: slot 0, added by seg_fixup_kernel
       store_vec<A, VEC>(cslot, sum);
@@ -515,6 +543,33 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       store_vec<T, VEC, NTS>(dstf + k * F, sum);
     }
   }
+#ifdef GEOT_EXP_HANDOFF
+  // COST PROBE of a single-launch form (not a product path; the fix-up launch still finishes every row): every tile drains
+  // its stores and publishes a flag; the tile in which a straddling run ENDS polls its predecessor's flag, reads that tile's
+  // tail partial (write-through store, sc1 load) and writes the row itself - what the second launch does today for chains of
+  // two tiles.  tools/handoff_probe.sh times this build against the product build on one box.
+  if constexpr (std::is_same<T, float>::value && VEC == 4 && !ATOMIC) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(p.ccnt); // [tiles][2], unused by sums
+    if (tid == 0) __hip_atomic_store(&flags[tile * 2], p.exp_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g == 0 && tile > 0 && exp_head_ends_here && active) {
+      bool ready = false;
+      for (int tries = 0; tries < 200000 && !ready; ++tries) {
+        ready = __hip_atomic_load(&flags[(tile - 1) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.exp_epoch;
+        if (!ready) __builtin_amdgcn_s_sleep(2);
+      }
+      typedef float f4x __attribute__((ext_vector_type(4)));
+      f4x t4;
+      const A *tail = static_cast<const A *>(p.carry) + ((tile - 1) * 2 + 1) * F + f0;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t4) : "v"(tail) : "memory");
+      A row[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) row[q] = t4[q] + exp_head[q];
+      if ((uint64_t)exp_key < (uint64_t)K) store_vec<T, VEC, NTS>(dstf + exp_key * F, row);
+    }
+  }
+#endif
 }
 
 // Tile bookkeeping + merge of the 2*NW wave partials of the narrow-row kernels (same rules as seg_tile_kernel:
@@ -1654,12 +1709,21 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   //  * launch-bound sizes (<= 400 k edges) take the 8-lane groups whatever the run length: twice the tiles in flight
   //    (index_scatter F=16 on 100-150 k edges: 18 -> 14 us per call).
   if (!atomic_flush && l < 3 && (gather || nnz >= 24 * (K > 0 ? K : 1) || nnz <= 400000)) l = 3;
+  //  * launch-bound sizes with LONG runs (>= 128 edges per row: pooling over small graphs, hub-dominated batches): one more
+  //    doubling of the lane group, up to 32 lanes - half the partials in the tile's LDS merge, which is what such a call
+  //    waits for (round-3 sweep, profiles/r03/sweep_rule.csv: 100-300 k edges, avg 500, F = 16..64: 17-22 -> 13-17 us).
+  const bool small_long = !atomic_flush && nnz <= 400000 && nnz >= 128 * (K > 0 ? K : 1);
+  if (small_long && l < 5 && l <= natural) l = natural + 1 < 3 ? 3 : natural + 1;
   if (g_tune.lpr_log2 >= natural && g_tune.lpr_log2 <= 6) l = g_tune.lpr_log2;
   P.lpr_log2 = l;
   const int ng = kThreads >> l;
   int cg = (gather ? 1024 : 512) / ng;
   if (l > natural) cg = 32;
   if (!gather && tsize == 4 && l == 5) cg = 32;
+  // 1-KiB streamed rows (fp32 F = 256: a whole wave per row): 16 loads in flight over 32- / 64-edge groups (round-3 sweep:
+  // -2..-4 % at 10 M edges, -10..-15 % at 0.3-1 M edges against 128-edge groups with 8 loads in flight)
+  const bool wide_u16 = !gather && !atomic_flush && tsize == 4 && vec == 4 && l == 6;
+  if (wide_u16) cg = nnz > 2000000 ? 64 : 32;
   // launch-bound sizes: a lane group walks its cg edges in dependent batches of U row loads, so on a chip that the grid
   // does not fill (< ~400 tiles) shorter groups = more tiles finish sooner.  Measured on graphs of 15 k - 250 k edges
   // (graph replay, us per call): gws F=64 19.6 -> 12.4 / 21.6 -> 14.2, F=128 26.9 -> 11.6 / 29.0 -> 19.6, index_scatter
@@ -1667,6 +1731,7 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   if (!atomic_flush && nnz > 0) {
     int64_t cap = nnz / ((int64_t)ng * 400) / 16 * 16;
     if (cap < 16) cap = 16;
+    if (small_long && l <= 4 && cap < 32) cap = 32; // (long runs: 32-edge groups beat 16-edge ones even when that halves the tiles)
     if (cap < cg) cg = (int)cap;
   }
   if (g_tune.cg > 0) cg = g_tune.cg;
@@ -1681,7 +1746,7 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
     cg -= 16;
   P.cg = cg;
   P.te = ng * cg;
-  P.unroll = (!gather && !atomic_flush && tsize == 4 && vec == 4 && l == 4 && cg % 16 == 0) ? 16 : 8;
+  P.unroll = (!gather && !atomic_flush && tsize == 4 && vec == 4 && (l == 4 || wide_u16) && cg % 16 == 0) ? 16 : 8;
   if (g_unroll == 8 || (g_unroll == 16 && cg % 16 == 0 && tsize == 4 && vec == 4)) P.unroll = g_unroll;
   P.num_tiles = nnz > 0 ? (nnz + P.te - 1) / P.te : 0;
   const int64_t fb = ((int64_t)1 << l) * vec;
@@ -1863,6 +1928,10 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.nt_keys = g_nt_keys;
   p.mode = mode;
   p.alarm = t_alarm;
+#ifdef GEOT_EXP_HANDOFF
+  static std::atomic<unsigned long long> exp_calls{0};
+  p.exp_epoch = ++exp_calls;
+#endif
   // a pending geot_publish_word is consumed by the first kernel of this call if that kernel is one of the three that
   // publish (tile / lane / narrow kernel; not the LDS-bin kernel of the unsorted atomic path)
   const bool lds_bin = !sorted && (size_t)K * (size_t)F * sizeof(T) <= 48 * 1024 && g_tune.lpr_log2 != 7;
@@ -1904,9 +1973,22 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     const SmemLayout L = smem_layout(P.lpr_log2, P.cg, 4, 4, false, 0);
     hipLaunchKernelGGL((seg_tile_kernel<float, 4, false, 0, false, 3, RED_SUM, 16>), dim3((unsigned)P.num_tiles, (unsigned)P.nfb, 1), dim3(kThreads), L.bytes, st, p);
     const int64_t tpb = (kThreads / 64) * (64 >> P.lpr_log2);
-    hipLaunchKernelGGL((seg_fixup_kernel<float, RED_SUM>), dim3((unsigned)((P.num_tiles + tpb - 1) / tpb)), dim3(kThreads), 0, st, p, P.num_tiles);
+#ifdef GEOT_EXP_HANDOFF
+    static const bool skip_fixup = std::getenv("GEOT_EXP_NOFIX") != nullptr; // (probe only: wrong rows, right timing)
+#else
+    const bool skip_fixup = false;
+#endif
+    if (prof) HIP_TRY(hipEventRecord(rec.e2, st));
+    if (!skip_fixup)
+      hipLaunchKernelGGL((seg_fixup_kernel<float, RED_SUM>), dim3((unsigned)((P.num_tiles + tpb - 1) / tpb)), dim3(kThreads), 0, st, p, P.num_tiles);
+    if (prof) {
+      HIP_TRY(hipEventRecord(rec.e3, st));
+      rec.has_fix = true;
+      std::lock_guard<std::mutex> lk(g_prof.mu);
+      g_prof.recs.push_back(rec);
+    }
   }
-  (void)lane_seq; (void)narrow_path; (void)nt; (void)use_wsum; (void)rec; (void)prof;
+  (void)lane_seq; (void)narrow_path; (void)nt; (void)use_wsum;
   return GEOT_OK;
 #else
   if (nnz > 0) {

@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_round")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 COPY_BYTES = 2_684_354_560            # tools/kbench copy: 160 Mi float4 elements
@@ -94,65 +94,85 @@ json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent
 print(json.dumps(res, indent=1))
 
 
-# ---- the gather-mode kernels of bench.py's `secondary` workloads (cfg3 gws, cfg4 mh_spmm) and rocSPARSE beside them:
-#      kernel-trace time, fabric-side bytes (FETCH_SIZE x2 - 16-B-per-lane row reads, same shape as the calibration
-#      copy - + WRITE_SIZE), L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS)), against SURVEY 8(d)'s compulsory bytes
+# ---- the kernels of bench.py's `secondary` workloads, one profiling pass set per workload (tools/profile_round.sh):
+#      kernel-trace time, fabric-side bytes (FETCH_SIZE x2 - 16-B-per-lane row reads, same shape as the calibration copy -
+#      + WRITE_SIZE), L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS)), against SURVEY 8(d)'s compulsory bytes.  Keys of
+#      gather_kernels.json["kernels"]: the workload's own name = the kernel bench.py times for it (what bench.py's
+#      `roofline.traffic` of that entry quotes), "<workload>/<comparator>" = the other kernels seen in the same passes.
+import re
+
+
 def per_kernel(path):
     d = {}
+    if not os.path.exists(path):
+        return d
     with open(path) as f:
         for r in csv.DictReader(f):
             d.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     return {k: mean(v) for k, v in d.items()}
 
 
-pm = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"):
-    p = os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv")
-    if os.path.exists(p):
-        shutil.copy(p, os.path.join(dst, f"pmc_{c}.csv"))
-        pm[c] = per_kernel(p)
-kt = {}
-with open(os.path.join(src, "kt", "bench_kernel_stats.csv")) as f:
-    for r in csv.DictReader(f):
-        kt[r["Name"]] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6}
-sec = {}
-try:
-    sec = json.load(open(os.path.join(src, "bench_under_kernel_trace.json"))).get("secondary", {})
-except Exception:
-    pass
-want = {"gws_cfg3 (gather_weight_scatter, 124 M edges, F=128)": ("seg_tile_kernel<float, 4, true, 1,", "gws_cfg3"),
-        "mh_spmm_cfg4 [nnz,H] (115 M edges, H=4 F=64)": ("seg_tile_kernel<float, 4, true, 2,", "mh_spmm_cfg4"),
-        "mh_spmm_cfg4 [H,nnz]": ("seg_tile_kernel<float, 4, true, 3,", "mh_spmm_cfg4"),
-        "mh_spmm_cfg4 source-blocked (seg_slab_kernel<2, true, sum>)": ("seg_slab_kernel<2, true,", "mh_spmm_cfg4"),
-        "rocSPARSE csr_nnz_split on the cfg3 matrix": ("csrmmnt_nnz_split_main_kernel", "gws_cfg3"),
-        "rocSPARSE csr_merge_path on the cfg3 matrix": ("csrmmnt_merge_path_main_kernel", "gws_cfg3"),
-        "rocSPARSE csr_row_split on the cfg3 matrix": ("csrmmnt_row_split", "gws_cfg3")}
+def kernel_times(path):
+    kt = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                kt[r["Name"]] = {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6}
+    return kt
+
+
+T16 = r"(__bf16|bf16_t|hip_bfloat16|__hip_bfloat16|_Float16|__half|half_t)"
+WORKLOADS = {
+    "gws_cfg3": [("", r"seg_tile_kernel<float, 4, true, 1,"), ("/rocsparse csr_nnz_split", r"csrmmnt_nnz_split_main_kernel"),
+                 ("/rocsparse csr_merge_path", r"csrmmnt_merge_path_main_kernel"), ("/rocsparse csr_row_split", r"csrmmnt_row_split")],
+    "gws_cfg3_local": [("", r"seg_tile_kernel<float, 4, true, 1,"), ("/rocsparse csr_nnz_split", r"csrmmnt_nnz_split_main_kernel"),
+                       ("/rocsparse csr_merge_path", r"csrmmnt_merge_path_main_kernel")],
+    "mh_spmm_cfg4": [("", r"seg_slab_kernel<float, 2, true,"), ("/per-edge [nnz,H]", r"seg_tile_kernel<float, 4, true, 2,"),
+                     ("/per-edge [H,nnz]", r"seg_tile_kernel<float, 4, true, 3,"), ("/phase A edge keys", r"plan_edge_keys_kernel"),
+                     ("/phase A edge out", r"plan_edge_out_kernel")],
+    "gws_cfg3_bf16": [("", r"seg_tile_kernel<" + T16 + r", 8, true, 1,")],
+    "mh_spmm_cfg4_bf16": [("", r"seg_slab_kernel<" + T16 + r", 2, false,"), ("/per-edge [nnz,H]", r"seg_tile_kernel<" + T16 + r", 8, true, 2,")],
+}
 gather = {}
-for label, (pat, seckey) in want.items():
-    name = next((k for k in kt if pat in k), None)
-    if name is None:
+for w, wanted in WORKLOADS.items():
+    kt = kernel_times(os.path.join(src, f"kt_{w}", "bench_kernel_stats.csv"))
+    if not kt:
         continue
-    g = {"kernel": name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], **kt[name]}
-    fetch = next((v for k, v in pm.get("FETCH_SIZE", {}).items() if pat in k), None)
-    write = next((v for k, v in pm.get("WRITE_SIZE", {}).items() if pat in k), None)
-    hit = next((v for k, v in pm.get("TCC_HIT_sum", {}).items() if pat in k), None)
-    miss = next((v for k, v in pm.get("TCC_MISS_sum", {}).items() if pat in k), None)
-    atom = next((v for k, v in pm.get("TCC_EA0_ATOMIC_sum", {}).items() if pat in k), None)
-    if fetch is not None and write is not None:
-        g["fabric_bytes_per_launch"] = int(fetch * 2048 + write * 1024)
-        g["FETCH_SIZE_KB_raw"], g["WRITE_SIZE_KB_raw"] = fetch, write
-    if hit is not None and miss is not None and hit + miss > 0:
-        g["l2_hit_rate"] = hit / (hit + miss)
-    if atom is not None:
-        g["TCC_EA0_ATOMIC_sum"] = atom
-    comp = sec.get(seckey, {}).get("compulsory_bytes")
-    if comp:
-        g["compulsory_bytes"] = comp
-        g["frac_of_8TBps_on_compulsory_bytes"] = comp / (g["average_ms"] * 1e-3) / 8e12
-        if "fabric_bytes_per_launch" in g:
-            g["traffic_over_compulsory"] = g["fabric_bytes_per_launch"] / comp
-    gather[label] = g
-json.dump({"method": "same rocprofv3 session as traffic.json (tools/profile_round.sh): --kernel-trace --stats for the times, one "
-                     "--pmc counter per pass for the bytes; FETCH_SIZE doubled (gfx950, 16-B-per-lane reads)",
+    shutil.copy(os.path.join(src, f"kt_{w}", "bench_kernel_stats.csv"), os.path.join(dst, f"kernel_stats__{w}.csv"))
+    pm = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"):
+        pth = os.path.join(src, f"pmc_{c}__{w}", "pmc_counter_collection.csv")
+        pm[c] = per_kernel(pth)
+        if os.path.exists(pth):
+            shutil.copy(pth, os.path.join(dst, f"pmc_{c}__{w}.csv"))
+    try:
+        sec = json.load(open(os.path.join(src, f"kt_{w}.json"))).get("secondary", {}).get(w, {})
+    except Exception:
+        sec = {}
+    for suffix, pat in wanted:
+        rx = re.compile(pat)
+        name = next((k for k in kt if rx.search(k)), None)
+        if name is None:
+            continue
+        g = {"kernel": name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0], **kt[name]}
+        pick = lambda c: next((v for k, v in pm.get(c, {}).items() if rx.search(k)), None)  # noqa: E731
+        fetch, write, hit, miss, atom = (pick(c) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"))
+        if fetch is not None and write is not None:
+            g["fabric_bytes_per_launch"] = int(fetch * 2048 + write * 1024)
+            g["FETCH_SIZE_KB_raw"], g["WRITE_SIZE_KB_raw"] = fetch, write
+        if hit is not None and miss is not None and hit + miss > 0:
+            g["l2_hit_rate"] = hit / (hit + miss)
+        if atom is not None:
+            g["TCC_EA0_ATOMIC_sum"] = atom
+        comp = sec.get("compulsory_bytes")
+        if comp and not suffix.startswith("/phase A"):
+            g["compulsory_bytes"] = comp
+            g["frac_of_8TBps_on_compulsory_bytes"] = comp / (g["average_ms"] * 1e-3) / 8e12
+            if "fabric_bytes_per_launch" in g:
+                g["traffic_over_compulsory"] = g["fabric_bytes_per_launch"] / comp
+        gather[w + suffix] = g
+json.dump({"method": "one rocprofv3 pass set per workload (tools/profile_round.sh: bench.py --only-secondary <workload>): --kernel-trace "
+                     "--stats for the times, one --pmc counter per pass for the bytes; FETCH_SIZE doubled (gfx950, 16-B-per-lane reads); "
+                     "counters in KB",
            "kernels": gather}, open(os.path.join(dst, "gather_kernels.json"), "w"), indent=1)
 print(json.dumps(gather, indent=1))

@@ -61,7 +61,7 @@ def main():
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
 
     datasets = []
-    sizes = [1_000_000] if a.quick else [1_000_000, 10_000_000]
+    sizes = [1_000_000] if a.quick else [100_000, 300_000, 1_000_000, 10_000_000]    # (the two small sizes: the launch-bound tile shapes)
     for nnz in sizes:
         for avg in ([10, 500] if a.quick else [2, 10, 50, 500]):
             for cv in ([1.0] if a.quick else [0.3, 1.5]):
