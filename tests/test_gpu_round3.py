@@ -318,3 +318,105 @@ def test_cached_artefacts_follow_their_sources_and_a_byte_budget(geot):
     finally:
         ops.set_option("cache_mb", old)
         ops.clear_caches()
+
+
+# ---- in-kernel hand-off of the tile carries (seg_tile_kernel "hand-off"): the run that straddles tiles is finished by the
+# ---- tile in which it ends; the second launch only tidies up
+def _handoff_cases():
+    rng = np.random.default_rng(33)
+    cases = []
+    for name, nnz, K, F, dtype in (("powerlaw F=64", 3_000_000, 300_000, 64, torch.float32),
+                                   ("every run spans several tiles", 4_000_000, 2_000, 64, torch.float32),
+                                   ("mixed: hubs over dozens of tiles + short runs", 2_000_000, 40_000, 64, torch.float32),
+                                   ("F=16", 1_500_000, 100_000, 16, torch.float32),
+                                   ("F=256 (a wave per row, 16 loads in flight)", 1_000_000, 50_000, 256, torch.float32),
+                                   ("F=48 (ragged lanes)", 1_000_000, 30_000, 48, torch.float32),
+                                   ("bf16 F=64 (8 elements per lane)", 2_000_000, 20_000, 64, torch.bfloat16)):
+        if name.startswith("mixed"):
+            from conftest import powerlaw_index
+            index = powerlaw_index(nnz, K, 5)
+            index[: nnz // 3] = index[nnz // 3]                      # one hub over a third of the edges (hundreds of tiles)
+            index = np.sort(index)
+        elif name.startswith("every"):
+            index = np.sort(rng.integers(0, K, nnz)).astype(np.int64)
+        else:
+            from conftest import powerlaw_index
+            index = powerlaw_index(nnz, K, F)
+        index[-1] = K - 1
+        cases.append((name, index, K, F, dtype))
+    return cases
+
+
+def test_handoff_results_with_data_that_changes_every_call(geot):
+    """The carry rows travel between workgroups through write-through stores and flag words while the kernel runs.  A stale
+    read - a cached line of the PREVIOUS call's carry row - can only show when the data differ from call to call: the same
+    index, new values every call, every result against float64; repeated calls bit-equal; the classic second pass agrees."""
+    from geot_amd import hip
+    for name, index, K, F, dtype in _handoff_cases():
+        t_index = dev(index)
+        nnz = index.size
+        base = torch.rand(nnz, F, device="cuda")
+        ref0 = torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, base.to(dtype).double())
+        tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+        for it in range(12):
+            scale = float(it + 1)
+            src = (base * scale).to(dtype)
+            want = ref0 * scale if dtype == torch.float32 else torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, src.double())
+            out = geot.index_scatter(0, src, t_index, "sum", True)
+            assert torch.allclose(out.double(), want, rtol=tol, atol=1e-6 * scale), (name, it)
+            if it in (3, 7):
+                assert torch.equal(out, geot.index_scatter(0, src, t_index, "sum", True)), (name, "not reproducible")
+                hip.set_option("handoff", 0)
+                try:
+                    classic = geot.index_scatter(0, src, t_index, "sum", True)
+                finally:
+                    hip.set_option("handoff", 1)
+                assert torch.allclose(out.double(), classic.double(), rtol=tol, atol=1e-6 * scale), (name, "classic second pass disagrees")
+        mx = geot.index_scatter(0, src, t_index, "max", True)
+        want = torch.zeros(K, F, device="cuda").scatter_reduce(0, t_index[:, None].expand(-1, F), src.float(), "amax", include_self=False)
+        assert torch.equal(mx.float(), want), (name, "max")
+        del base, ref0, src, want, out, mx
+
+
+def test_handoff_gives_up_gracefully_and_the_second_launch_finishes_the_call(geot):
+    """`handoff_tries` = 0: a tile samples its predecessor's flag ONCE and, if it is not up yet, leaves the run to the second
+    launch, which then redoes every straddling run from the carry rows (and lowers the flags): same results, whatever mix of
+    in-kernel and deferred runs the timing of a call produces; afterwards the normal mode works on the same workspace."""
+    from geot_amd import hip
+    name, index, K, F, dtype = _handoff_cases()[2]
+    t_index = dev(index)
+    src = torch.rand(index.size, F, device="cuda")
+    want = torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, src.double())
+    hip.set_option("handoff_tries", 0)
+    try:
+        for _ in range(6):
+            out = geot.index_scatter(0, src, t_index, "sum", True)
+            assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-6)
+    finally:
+        hip.set_option("handoff_tries", 400000)
+    out = geot.index_scatter(0, src, t_index, "sum", True)
+    assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-6)
+    assert torch.equal(out, geot.index_scatter(0, src, t_index, "sum", True))
+
+
+def test_handoff_inside_a_replayed_graph(geot):
+    """A captured call carries its flag tag with it: every replay re-uses it, so the second launch lowers the flags again.
+    Replays with new data, interleaved with eager calls of another shape on the same stream (same workspace)."""
+    name, index, K, F, dtype = _handoff_cases()[0]
+    t_index = dev(index)
+    src = torch.rand(index.size, F, device="cuda")
+    other_i = dev(np.sort(np.random.default_rng(1).integers(0, 5000, 700_000)).astype(np.int64))
+    other_s = torch.rand(700_000, 32, device="cuda")
+    geot.index_scatter(0, src, t_index, "sum", True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = geot.index_scatter(0, src, t_index, "sum", True)
+    for it in range(6):
+        src.copy_(torch.rand_like(src) * (it + 1))
+        g.replay()
+        want = torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, src.double())
+        assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-5), it
+        o2 = geot.index_scatter(0, other_s, other_i, "sum", True)
+        w2 = torch.zeros(int(other_i[-1]) + 1, 32, device="cuda", dtype=torch.float64).index_add_(0, other_i, other_s.double())
+        assert torch.allclose(o2.double(), w2, rtol=1e-5, atol=1e-5), it
