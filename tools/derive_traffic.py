@@ -130,8 +130,10 @@ WORKLOADS = {
     "mh_spmm_cfg4": [("", r"seg_slab_kernel<float, 2, true,"), ("/per-edge [nnz,H]", r"seg_tile_kernel<float, 4, true, 2,"),
                      ("/per-edge [H,nnz]", r"seg_tile_kernel<float, 4, true, 3,"), ("/phase A edge keys", r"plan_edge_keys_kernel"),
                      ("/phase A edge out", r"plan_edge_out_kernel")],
-    "gws_cfg3_bf16": [("", r"seg_tile_kernel<" + T16 + r", 8, true, 1,")],
-    "mh_spmm_cfg4_bf16": [("", r"seg_slab_kernel<" + T16 + r", 2, false,"), ("/per-edge [nnz,H]", r"seg_tile_kernel<" + T16 + r", 8, true, 2,")],
+    # (rocprofv3 leaves the __bf16 instantiations mangled: DF16b)
+    "gws_cfg3_bf16": [("", r"seg_tile_kernel(<" + T16 + r", 8, true, 1,|IDF16bLi8ELb1ELi1E)")],
+    "mh_spmm_cfg4_bf16": [("", r"seg_slab_kernel(<" + T16 + r", 2, false,|IDF16bLi2ELb0E)"),
+                          ("/per-edge [nnz,H]", r"seg_tile_kernel(<" + T16 + r", 8, true, 2,|IDF16bLi8ELb1ELi2E)")],
 }
 gather = {}
 for w, wanted in WORKLOADS.items():
@@ -143,7 +145,7 @@ for w, wanted in WORKLOADS.items():
     for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_ATOMIC_sum"):
         pth = os.path.join(src, f"pmc_{c}__{w}", "pmc_counter_collection.csv")
         pm[c] = per_kernel(pth)
-        if os.path.exists(pth):
+        if os.path.exists(pth) and c != "TCC_EA0_ATOMIC_sum":      # (the per-kernel atomic count is in gather_kernels.json)
             shutil.copy(pth, os.path.join(dst, f"pmc_{c}__{w}.csv"))
     try:
         sec = json.load(open(os.path.join(src, f"kt_{w}.json"))).get("secondary", {}).get(w, {})
