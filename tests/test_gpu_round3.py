@@ -322,6 +322,11 @@ def test_cached_artefacts_follow_their_sources_and_a_byte_budget(geot):
 
 # ---- in-kernel hand-off of the tile carries (seg_tile_kernel "hand-off"): the run that straddles tiles is finished by the
 # ---- tile in which it ends; the second launch only tidies up
+def _segment_sums(index, values64, rows):
+    """float64 sums per key of an ASCENDING index (a segmented reduction: index_add_ into a hub's one row takes seconds)."""
+    return torch.segment_reduce(values64, "sum", lengths=torch.bincount(index, minlength=rows), axis=0, unsafe=True)
+
+
 def _handoff_cases():
     rng = np.random.default_rng(33)
     cases = []
@@ -356,12 +361,12 @@ def test_handoff_results_with_data_that_changes_every_call(geot):
         t_index = dev(index)
         nnz = index.size
         base = torch.rand(nnz, F, device="cuda")
-        ref0 = torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, base.to(dtype).double())
+        ref0 = _segment_sums(t_index, base.to(dtype).double(), K)
         tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
         for it in range(12):
             scale = float(it + 1)
             src = (base * scale).to(dtype)
-            want = ref0 * scale if dtype == torch.float32 else torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, src.double())
+            want = ref0 * scale if dtype == torch.float32 else _segment_sums(t_index, src.double(), K)
             out = geot.index_scatter(0, src, t_index, "sum", True)
             assert torch.allclose(out.double(), want, rtol=tol, atol=1e-6 * scale), (name, it)
             if it in (3, 7):
@@ -386,7 +391,7 @@ def test_handoff_gives_up_gracefully_and_the_second_launch_finishes_the_call(geo
     name, index, K, F, dtype = _handoff_cases()[2]
     t_index = dev(index)
     src = torch.rand(index.size, F, device="cuda")
-    want = torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, src.double())
+    want = _segment_sums(t_index, src.double(), K)
     hip.set_option("handoff_tries", 0)
     try:
         for _ in range(6):
@@ -415,7 +420,7 @@ def test_handoff_inside_a_replayed_graph(geot):
     for it in range(6):
         src.copy_(torch.rand_like(src) * (it + 1))
         g.replay()
-        want = torch.zeros(K, F, device="cuda", dtype=torch.float64).index_add_(0, t_index, src.double())
+        want = _segment_sums(t_index, src.double(), K)
         assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-5), it
         o2 = geot.index_scatter(0, other_s, other_i, "sum", True)
         w2 = torch.zeros(int(other_i[-1]) + 1, 32, device="cuda", dtype=torch.float64).index_add_(0, other_i, other_s.double())

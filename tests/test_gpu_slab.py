@@ -163,8 +163,10 @@ def test_slab_reductions_match_the_per_edge_kernels(geot, reduce):
         if reduce in ("max", "min"):
             ref = torch.zeros(nodes, F, device="cuda").scatter_reduce(0, di[:, None].expand(-1, F), msg, kind, include_self=False)
         else:                                  # float64 reference + the magnitude the fp32 error bound scales with
-            ref = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, di, msg.double())
-            mag = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, di, msg.double().abs())
+            # (di is ascending: a segmented reduction - index_add_ would hammer the hub's one row with atomics for seconds)
+            lengths = torch.bincount(di, minlength=nodes)
+            ref = torch.segment_reduce(msg.double(), "sum", lengths=lengths, axis=0, unsafe=True)
+            mag = torch.segment_reduce(msg.double().abs(), "sum", lengths=lengths, axis=0, unsafe=True)
             if reduce == "mean":
                 cnt = torch.bincount(di, minlength=nodes).clamp(min=1).double()[:, None]
                 ref, mag = ref / cnt, mag / cnt

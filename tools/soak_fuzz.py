@@ -68,14 +68,36 @@ def main():
         hip.set_option("hub", hub)
         hip.set_option("narrow", narrow)
         hip.tune(cg, 0, -1, -1)
+        handoff, tries = int(rng.choice([1, 1, 1, 0])), int(rng.choice([400000, 400000, 0]))   # round 3: in-kernel hand-off on / off / forced to give up
+        hip.set_option("handoff", handoff)
+        hip.set_option("handoff_tries", tries)
         red = str(rng.choice(["sum", "sum", "mean", "max", "min"]))
         op = str(rng.choice(a.ops.split(",")))
         covered[(op, red)] = covered.get((op, red), 0) + 1
-        tag = f"it={it} op={op} nnz={nnz} F={F} keys={index[-1] + 1} red={red} hub={hub} narrow={narrow} cg={cg} slab={slab_always}"
+        tag = f"it={it} op={op} nnz={nnz} F={F} keys={index[-1] + 1} red={red} hub={hub} narrow={narrow} cg={cg} slab={slab_always} handoff={handoff}/{tries}"
         if slab_always and not op.startswith("is"):
             covered[("slab", red)] = covered.get(("slab", red), 0) + 1
         src = rng.standard_normal((nnz, F)).astype(np.float32)
-        if op.startswith("is"):
+        if op == "is" and red == "sum" and rng.integers(0, 6) == 0 and nnz > 5000 and np.all(index[:-1] <= index[1:]):
+            # round 3: descents written behind the version counter - the stale "ascending" fact is met by the descent guard
+            import warnings
+            covered[("is_data_scramble", red)] = covered.get(("is_data_scramble", red), 0) + 1
+            t_index, t_src = t(index), t(src)
+            geot.index_scatter(0, t_src, t_index, red, True)
+            at = rng.integers(1, nnz - 1002, 25)
+            bad = index.copy()
+            bad[at], bad[at + 1000] = index[at + 1000].copy(), index[at].copy()
+            t_index.data.copy_(t(bad))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out = geot.index_scatter(0, t_src, t_index, red, True).cpu().numpy()
+                torch.cuda.synchronize()
+                geot.index_scatter(0, t_src[:16], t_index[:16].clone(), red, True)       # (the host notices the alarm here)
+            order = np.argsort(bad, kind="stable")
+            hi = oracle.index_scatter(bad[order], src[order], rows=out.shape[0], acc64=True)
+            mag = oracle.index_scatter(bad[order], np.abs(src[order]), rows=out.shape[0], acc64=True)
+            ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= 2e-5 * mag + 1e-30)
+        elif op.startswith("is"):
             out = geot.index_scatter(0, t(src), t(index), red, op == "is").cpu().numpy()
             if red == "sum":
                 hi = oracle.index_scatter(index, src, acc64=True)
@@ -118,6 +140,7 @@ def main():
         if it % 20 == 0:
             print("ok", tag, flush=True)
     hip.set_option("hub", -1); hip.set_option("narrow", 1); hip.tune(0, 0, -1, -1); geot.ops.set_option("slab_mode", "auto")
+    hip.set_option("handoff", 1); hip.set_option("handoff_tries", 400000)
     print("covered (op, reduce): " + ", ".join(f"{o}/{r}={n}" for (o, r), n in sorted(covered.items())))
     print(f"SOAK PASSED ({a.iters} cases, seed {a.seed})")
 
