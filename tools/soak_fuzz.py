@@ -68,7 +68,7 @@ def main():
         hip.set_option("hub", hub)
         hip.set_option("narrow", narrow)
         hip.tune(cg, 0, -1, -1)
-        handoff, tries = int(rng.choice([1, 1, 1, 0])), int(rng.choice([400000, 400000, 0]))   # round 3: in-kernel hand-off on / off / forced to give up
+        handoff, tries = int(rng.choice([1, 1, 2, 0])), int(rng.choice([400000, 400000, 0]))   # round 3: in-kernel hand-off on / off / forced to give up
         hip.set_option("handoff", handoff)
         hip.set_option("handoff_tries", tries)
         red = str(rng.choice(["sum", "sum", "mean", "max", "min"]))
