@@ -367,8 +367,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
 // accumulators; the m2 rows are gathered slab by slab in the same loose lockstep.  The 8 dot products of a batch are
 // reduced across the unit's lanes together (3 halving exchanges + log2(lpr/8) plain ones instead of 8 x log2(lpr)),
 // and written to out[original edge id] by the 8 lanes that end up holding them.
-template <bool WAVE_ROW>
+template <typename T, bool WAVE_ROW>
 __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) {
+  constexpr int VEC = SlabVec<T>::VEC, NV = SlabVec<T>::NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -380,8 +381,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   const int64_t unit = ((int64_t)blockIdx.x * 4 + wave) * G + sub;
   const int64_t units = P.units;
   const char *m2 = static_cast<const char *>(p.src);
-  const float *m1 = static_cast<const float *>(p.weight);   // (the dst-side matrix travels in the `weight` slot)
-  float *out = static_cast<float *>(p.dst);
+  const T *m1 = static_cast<const T *>(p.weight);           // (the dst-side matrix travels in the `weight` slot)
+  T *out = static_cast<T *>(p.dst);
   const uint32_t rb = p.rowbytes;
   const uint32_t src_rows = (uint32_t)p.src_rows;
 
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
     for (int l = 0; l < nv; ++l) {                       // the group's m1 rows (pieces of a split hub share their row)
       const int64_t row = P.v_row[v0 + l];
-      rowV[(size_t)l * lpr + c] = (row >= 0 && row < p.K) ? *reinterpret_cast<const f4_t *>(m1 + row * p.F + c * 4)
+      rowV[(size_t)l * lpr + c] = (row >= 0 && row < p.K) ? *reinterpret_cast<const f4_t *>(m1 + row * p.F + c * VEC)   // (16 raw bytes)
                                                           : f4_t{0.f, 0.f, 0.f, 0.f};
     }
     int maxlen = len;
@@ -439,7 +440,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
       }
     }
     int cur = 255;
-    f4_t mrow = {0.f, 0.f, 0.f, 0.f};
+    f4_t mrow[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) mrow[q] = f4_t{0.f, 0.f, 0.f, 0.f};
     int my_src = 0, my_dl = 255, my_pe = 0;
     {
       const bool valid = c < len;
@@ -483,9 +486,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
         for (int u = 0; u < kU; ++u) {
           if (dls[u] != cur) {
             cur = dls[u];
-            mrow = cur != 255 ? rowV[(size_t)cur * lpr + c] : f4_t{0.f, 0.f, 0.f, 0.f};
+            slab_unpack<T>(cur != 255 ? rowV[(size_t)cur * lpr + c] : f4_t{0.f, 0.f, 0.f, 0.f}, mrow);
           }
-          pd[u] = v[u][0] * mrow[0] + v[u][1] * mrow[1] + v[u][2] * mrow[2] + v[u][3] * mrow[3];
+          f4_t x[NV];
+          slab_unpack<T>(v[u], x);
+          float dot = 0.f;
+#pragma unroll
+          for (int q = 0; q < NV; ++q) dot += x[q][0] * mrow[q][0] + x[q][1] * mrow[q][1] + x[q][2] * mrow[q][2] + x[q][3] * mrow[q][3];
+          pd[u] = dot;
         }
         // 8 values x lpr lanes -> lane l < 8 of the unit holds the total of value 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)
         const bool b0 = c & 1, b1 = c & 2, b2 = c & 4;
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
         for (int o = 8; o < lpr; o <<= 1) s1 += __shfl_xor(s1, o, 64);
         const int j = 4 * (c & 1) + 2 * ((c >> 1) & 1) + ((c >> 2) & 1);
         const int pe = __shfl(my_pe, b + j, lpr);          // original edge id of the batch's j-th edge
-        if (c < 8 && b + j < n_here) out[pe] = s1;
+        if (c < 8 && b + j < n_here) out[pe] = (T)s1;
       }
       my_src = n_src;
       my_dl = n_dl;
@@ -710,9 +718,9 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
                     int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!plan || !mat_1 || !mat_2 || !out) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: null pointer");
-  if (dtype != GEOT_F32) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: float32 only");
+  if (dtype != GEOT_F32 && dtype != GEOT_F16 && dtype != GEOT_BF16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: float32, float16 or bfloat16");
   if (!plan->v_row) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan has no v_row table");
-  const int64_t rowbytes = feat * 4;
+  const int64_t rowbytes = feat * (dtype == GEOT_F32 ? 4 : 2);
   int lpr_log2 = -1;
   for (int l = 4; l <= 6; ++l)
     if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
@@ -751,8 +759,15 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
   }
   const size_t lds = (size_t)4 * plan->rows_per_group * 1024;
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
-  if (lpr_log2 == 6) hipLaunchKernelGGL(seg_slab_sddmm_kernel<true>, grid, blk, lds, st, p);
-  else hipLaunchKernelGGL(seg_slab_sddmm_kernel<false>, grid, blk, lds, st, p);
+#define GEOT_SLAB_SDDMM(T_)                                                                                  \
+  do {                                                                                                        \
+    if (lpr_log2 == 6) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, true>), grid, blk, lds, st, p);          \
+    else hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, false>), grid, blk, lds, st, p);                       \
+  } while (0)
+  if (dtype == GEOT_F32) GEOT_SLAB_SDDMM(float);
+  else if (dtype == GEOT_F16) GEOT_SLAB_SDDMM(half_t);
+  else GEOT_SLAB_SDDMM(bf16_t);
+#undef GEOT_SLAB_SDDMM
   e = hipGetLastError();
   if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   return GEOT_OK;

@@ -1149,17 +1149,17 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
   at::Tensor si = as_int64(si_in), di = as_int64(di_in);
   at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
   at::Tensor out = at::empty({di.size(0)}, m1.options());
-  if (m1.scalar_type() == at::kFloat && di.numel() > 0 && m1.size(0) < ((int64_t)1 << 31)) {
+  if (m1.scalar_type() != at::kDouble && m1.scalar_type() == m2.scalar_type() && di.numel() > 0 && m1.size(0) < ((int64_t)1 << 31)) {
     // a dense graph that has (or now earns) a source-blocked plan - the forward gather_weight_scatter's - and an
     // ascending dst_index (known from the facts): SDDMM over the plan, the gathered m2 rows re-used out of L2
-    const int64_t rowbytes = m1.size(1) * 4;
+    const int64_t rowbytes = m1.size(1) * m1.element_size();
     if ((rowbytes == 256 || rowbytes == 512 || rowbytes == 1024) &&
-        (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(di.numel(), m1.size(0), m2.size(0), rowbytes))) &&
+        (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(di.numel(), m1.size(0), m2.size(0), rowbytes, dtype_code(m1, "sddmm_coo")))) &&
         (tl_capturing || index_facts(di).ascending)) { // (under capture only an existing plan is used: built on an ascending di)
       if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 1, 1)) {
         auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
-        GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), out.data_ptr(), m1.size(1), m1.size(0), m2.size(0), GEOT_F32,
-                                  ws.data_ptr(), ws.numel(), stream_of(m1)));
+        GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), out.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
+                                  dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
         std::lock_guard<std::mutex> lk(g_mu);
         ++g_stats.slab_calls;
         return out;

@@ -109,6 +109,6 @@ def slab_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out
         st = hip._stream_handle(dev)
         ws = hip.workspace(dev, int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), mat_1.shape[1])), st)
         rc = L.geot_slab_sddmm(ctypes.byref(plan.struct), mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), mat_1.shape[1],
-                               mat_1.shape[0], mat_2.shape[0], _lib.GEOT_F32, ws.data_ptr(), ws.numel(), st)
+                               mat_1.shape[0], mat_2.shape[0], hip._dtype_code(mat_1, "slab_sddmm"), ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "geot_slab_sddmm")
     return out

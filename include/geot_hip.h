@@ -285,7 +285,8 @@ int geot_slab_plan_edges(const geot_slab_plan_job *job, const void *scratch1, co
 
 /* out[e] = < mat_1[dst(e), :], mat_2[src(e), :] > in ORIGINAL edge order over the plan's edges - geot_sddmm_coo
  * (sddmm_coo_cuda, csrc/cuda/header_cuda.h:28-30) for a graph that has a plan: the backward (d/dweight) of
- * gather_weight_scatter on a dense graph.  float32, rows of 256 / 512 / 1024 bytes; workspace as geot_slab_spmm. */
+ * gather_weight_scatter on a dense graph.  float32 / float16 / bfloat16 (fp32 dot products, out in the storage type), rows
+ * of 256 / 512 / 1024 bytes; workspace as geot_slab_spmm. */
 int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, int64_t feat,
                     int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 

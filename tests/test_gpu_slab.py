@@ -493,3 +493,32 @@ def test_host_layer_routes_16bit_dense_graphs_to_the_source_blocked_kernel(geot)
     finally:
         ops.set_option("slab_mode", old)
         ops.clear_caches()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nodes,nnz,F", [(30_000, 2_000_000, 128), (20_000, 2_000_000, 512), (300, 200_000, 256)])
+def test_slab_sddmm_16bit_storage(geot, oracle, dtype, nodes, nnz, F):
+    """d/dweight over the plan with half / bfloat16 operands: fp32 dot products, the result rounded once to the storage type."""
+    from geot_amd import hip, slab
+    rng = np.random.default_rng(nodes + F)
+    di = powerlaw_index(nnz, nodes, nodes + 2)
+    di[: nnz // 6] = di[nnz // 6]
+    di = np.sort(di)
+    src_rows = nodes + 11
+    si = rng.integers(0, src_rows, nnz).astype(np.int64)
+    m1 = torch.from_numpy(rng.standard_normal((nodes, F)).astype(np.float32)).to(dtype)
+    m2 = torch.from_numpy(rng.standard_normal((src_rows, F)).astype(np.float32)).to(dtype)
+    plan = slab.build_plan(dev(si), dev(di), nodes, src_rows, F * 2, 1, 1, rows_per_group=slab.rows_per_group(1, 1, dtype))
+    out = torch.full((nnz,), float("nan"), device="cuda", dtype=dtype)
+    slab.slab_sddmm_out(plan, m1.cuda(), m2.cuda(), out)
+    assert not torch.isnan(out.float()).any()
+    ref = oracle.sddmm_coo(si, di, m1.float().numpy(), m2.float().numpy(), acc64=True)
+    mag = oracle.sddmm_coo(si, di, m1.float().abs().numpy(), m2.float().abs().numpy(), acc64=True)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    got = out.float().cpu().numpy()
+    assert np.all(np.abs(got - ref) <= ulp * np.abs(ref) + 2e-5 * mag + 1e-6)
+    tile = hip.sddmm_coo_out(dev(si), dev(di), m1.cuda(), m2.cuda(), torch.empty(nnz, device="cuda", dtype=dtype))
+    assert torch.allclose(out.float(), tile.float(), rtol=4 * ulp, atol=4 * ulp)
+    again = torch.empty_like(out)
+    slab.slab_sddmm_out(plan, m1.cuda(), m2.cuda(), again)
+    assert torch.equal(out, again)
