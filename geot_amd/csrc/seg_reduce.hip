@@ -2039,7 +2039,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // one feature block, no per-run counts; the few-key regime keeps the window sums and the classic second pass.
   static std::atomic<unsigned long long> epoch_counter{0};
   const bool acc_f32 = std::is_same<typename AccOf<T>::type, float>::value;
-  // Measured (tools/_ab: F = 16..256 x 1-10 M edges, fp32 / bf16, alternating modes on one box): rows of >= 256 bytes gain
+  // Measured (tools/bench_handoff_ab.py: F = 16..256 x 1-10 M edges, fp32 / bf16, alternating modes on one box): rows of >= 256 bytes gain
   // 2.5-8 % at every size; rows of <= 128 bytes gain 2-5 % up to ~1 M edges and LOSE 2-16 % beyond (short tiles: the drain at
   // the end of every workgroup is a larger share of its life) - those keep the classic second pass.  `handoff` = 2 forces.
   const bool ho_pays = p.rowbytes >= 256 || nnz <= 2000000 || g_handoff == 2;

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""A/B of the in-kernel hand-off by row width: hip.index_scatter_out (tile kernel + second launch, HIP events, best of 2 x 60 calls),
+`handoff` option 1 vs 0 alternating on one box, F = 16..256 x 1-10 M edges, fp32 / bf16 (profiles/r03/handoff_ab_by_row_width.txt)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import powerlaw_index, device_ms
 import geot_amd as geot
 from geot_amd import hip
