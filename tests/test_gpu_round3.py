@@ -425,3 +425,34 @@ def test_handoff_inside_a_replayed_graph(geot):
         o2 = geot.index_scatter(0, other_s, other_i, "sum", True)
         w2 = torch.zeros(int(other_i[-1]) + 1, 32, device="cuda", dtype=torch.float64).index_add_(0, other_i, other_s.double())
         assert torch.allclose(o2.double(), w2, rtol=1e-5, atol=1e-5), it
+
+
+def test_handoff_under_uneven_load(geot):
+    """The micro-architecture guide's advice for every inter-workgroup hand-off: test it under UNEVEN load, with data that
+    changes, checking every word.  A second stream keeps the chip busy with streaming and compute kernels of varying length
+    while the reductions run (their workgroups then start late, in bursts, and out of step with their neighbours)."""
+    name, index, K, F, dtype = _handoff_cases()[2]                  # hubs over hundreds of tiles + short runs
+    t_index = dev(index)
+    nnz = index.size
+    base = torch.rand(nnz, F, device="cuda")
+    ref0 = _segment_sums(t_index, base.double(), K)
+    noise_stream = torch.cuda.Stream()
+    a = torch.rand(4096, 4096, device="cuda")
+    big = torch.rand(64 << 20, device="cuda")
+    main = torch.cuda.current_stream()
+    for it in range(24):
+        with torch.cuda.stream(noise_stream):
+            for rep in range(1 + it % 4):                           # bursts of different length on the other stream
+                if (it + rep) % 2:
+                    a = torch.mm(a, a).clamp_(-1, 1)
+                else:
+                    big.mul_(1.0001)
+        src = base * float(it + 1)
+        out = geot.index_scatter(0, src, t_index, "sum", True)
+        main.synchronize()
+        assert torch.allclose(out.double(), ref0 * float(it + 1), rtol=1e-5, atol=1e-5 * (it + 1)), it
+        mx = geot.index_scatter(0, src, t_index, "max", True)
+        if it % 6 == 0:
+            want = torch.zeros(K, F, device="cuda").scatter_reduce(0, t_index[:, None].expand(-1, F), src, "amax", include_self=False)
+            assert torch.equal(mx, want), it
+    torch.cuda.synchronize()
