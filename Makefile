@@ -15,6 +15,7 @@ all: lib tools
 lib: $(LIB)
 $(LIB): $(SRC) include/geot_hip.h geot_amd/csrc/internal.h
 	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
+	python3 geot_amd/_lib.py
 
 tools: tools/kbench
 tools/kbench: tools/kbench.cpp $(LIB) include/geot_hip.h
@@ -30,6 +31,7 @@ geot_amd/_C.so: geot_amd/csrc/torch_ops.cpp $(LIB) include/geot_hip.h
 	  -Iinclude -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
 	  geot_amd/csrc/torch_ops.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -ltorch_hip -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
 	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
+	python3 geot_amd/_lib.py
 
 oracle:
 	$(MAKE) -C oracle oracle
@@ -37,5 +39,5 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f $(LIB) tools/kbench geot_amd/_C.so
+	rm -f $(LIB) tools/kbench geot_amd/_C.so geot_amd/*.srchash
 	$(MAKE) -C oracle clean

@@ -19,6 +19,8 @@ SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "c
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
 PLUGIN_SOURCE = os.path.join(_HERE, "csrc", "torch_ops.cpp")
+LIB_INPUTS = SOURCES + [HEADER, os.path.join(_HERE, "csrc", "internal.h")]
+PLUGIN_INPUTS = [PLUGIN_SOURCE, HEADER]
 
 GEOT_OK = 0
 GEOT_F32, GEOT_F64, GEOT_F16, GEOT_BF16 = 0, 1, 2, 3
@@ -56,11 +58,39 @@ def hipcc() -> str:
     return "hipcc"
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _digest(paths) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(binary: str, sources) -> bool:
+    """Is `binary` older than its sources?  By CONTENT where a stamp (written next to the binary by the build) exists - file
+    times do not survive every copy of the tree (the GPU box gets a snapshot), and a spurious rebuild costs minutes - else by
+    modification time."""
+    if not os.path.exists(binary):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(p) > t for p in SOURCES + [HEADER, os.path.join(_HERE, "csrc", "internal.h")])
+    stamp = binary + ".srchash"
+    if os.path.exists(stamp):
+        with open(stamp) as f:
+            return f.read().strip() != _digest(sources)
+    t = os.path.getmtime(binary)
+    return any(os.path.getmtime(p) > t for p in sources)
+
+
+def stamp() -> None:
+    """Record the content of the sources each existing binary was built from (`make lib shim` calls this)."""
+    for binary, sources in ((LIB_PATH, LIB_INPUTS), (PLUGIN_PATH, PLUGIN_INPUTS)):
+        if os.path.exists(binary):
+            with open(binary + ".srchash", "w") as f:
+                f.write(_digest(sources) + "\n")
+
+
+def needs_build() -> bool:
+    return _stale(LIB_PATH, LIB_INPUTS)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -71,14 +101,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        stamp()
     return LIB_PATH
 
 
 def plugin_needs_build() -> bool:
-    if not os.path.exists(PLUGIN_PATH):
-        return True
-    t = os.path.getmtime(PLUGIN_PATH)
-    return any(os.path.getmtime(p) > t for p in (PLUGIN_SOURCE, HEADER))
+    return _stale(PLUGIN_PATH, PLUGIN_INPUTS)
 
 
 def build_plugin(force: bool = False, verbose: bool = False) -> str:
@@ -95,6 +123,7 @@ def build_plugin(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        stamp()
     return PLUGIN_PATH
 
 
@@ -170,3 +199,7 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != GEOT_OK:
         raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+if __name__ == "__main__":      # `python3 geot_amd/_lib.py` (from the Makefile): stamp the binaries that exist
+    stamp()
