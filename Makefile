@@ -7,15 +7,17 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Iinclude -Wno-unused-value
 
 LIB = geot_amd/libgeot_hip.so
-SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip geot_amd/csrc/seg_plan.hip
+SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip geot_amd/csrc/seg_plan.hip \
+      geot_amd/csrc/seg_guard.hip
 
 .PHONY: all lib tools shim oracle ref clean
 all: lib tools
 
+# one object per source under geot_amd/csrc/.obj, the stale ones compiled side by side, one link; staleness by content
+# (geot_amd/_lib.py holds the recipe: hipcc $(HIPFLAGS) -c <src> -o <obj>, then hipcc -shared <objs> -o $(LIB))
 lib: $(LIB)
 $(LIB): $(SRC) include/geot_hip.h geot_amd/csrc/internal.h
-	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
-	python3 geot_amd/_lib.py
+	python3 geot_amd/_lib.py lib
 
 tools: tools/kbench
 tools/kbench: tools/kbench.cpp $(LIB) include/geot_hip.h
@@ -31,7 +33,7 @@ geot_amd/_C.so: geot_amd/csrc/torch_ops.cpp $(LIB) include/geot_hip.h
 	  -Iinclude -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
 	  geot_amd/csrc/torch_ops.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -ltorch_hip -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
 	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
-	python3 geot_amd/_lib.py
+	python3 geot_amd/_lib.py stamp-plugin
 
 oracle:
 	$(MAKE) -C oracle oracle
@@ -39,5 +41,5 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f $(LIB) tools/kbench geot_amd/_C.so geot_amd/*.srchash
+	rm -rf $(LIB) tools/kbench geot_amd/_C.so geot_amd/*.srchash geot_amd/csrc/.obj
 	$(MAKE) -C oracle clean

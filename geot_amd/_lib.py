@@ -15,7 +15,8 @@ _ROOT = os.path.dirname(_HERE)
 LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip"),
-           os.path.join(_HERE, "csrc", "seg_sort.hip"), os.path.join(_HERE, "csrc", "seg_plan.hip")]
+           os.path.join(_HERE, "csrc", "seg_sort.hip"), os.path.join(_HERE, "csrc", "seg_plan.hip"),
+           os.path.join(_HERE, "csrc", "seg_guard.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
 PLUGIN_SOURCE = os.path.join(_HERE, "csrc", "torch_ops.cpp")
@@ -32,7 +33,7 @@ SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes", "geot_mh_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
-    "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
+    "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_content_fingerprint", "geot_content_fingerprint_scratch_bytes", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm",
     "geot_slab_plan_scratch_bytes", "geot_slab_plan_rows", "geot_slab_plan_groups", "geot_slab_plan_edges",
@@ -81,10 +82,11 @@ def _stale(binary: str, sources) -> bool:
     return any(os.path.getmtime(p) > t for p in sources)
 
 
-def stamp() -> None:
-    """Record the content of the sources each existing binary was built from (`make lib shim` calls this)."""
+def stamp(which=None) -> None:
+    """Record the content of the sources a binary was built from.  `which`: LIB_PATH or PLUGIN_PATH - the one just built; None
+    (`make shim`'s g++ recipe, which builds behind this module's back) stamps whichever exists."""
     for binary, sources in ((LIB_PATH, LIB_INPUTS), (PLUGIN_PATH, PLUGIN_INPUTS)):
-        if os.path.exists(binary):
+        if os.path.exists(binary) and which in (None, binary):
             with open(binary + ".srchash", "w") as f:
                 f.write(_digest(sources) + "\n")
 
@@ -93,15 +95,40 @@ def needs_build() -> bool:
     return _stale(LIB_PATH, LIB_INPUTS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU; ~10 s)."""
+OBJ_DIR = os.path.join(_HERE, "csrc", ".obj")        # per-source objects (git-ignored; they do not travel with a snapshot)
+HIPFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", os.path.join(_ROOT, "include")]
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+    """Cross-compile the HIP library for gfx950 in-tree (works without a GPU).  One object per source, the stale ones compiled
+    side by side (seg_reduce.hip alone is ~3 minutes: all the instantiations of the tile kernel), then one link."""
     if force or needs_build():
-        cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-I", os.path.join(_ROOT, "include"), *SOURCES, "-o", LIB_PATH]
+        from concurrent.futures import ThreadPoolExecutor
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        shared = LIB_INPUTS[len(SOURCES):]
+        todo, objs = [], []
+        for src in SOURCES:
+            obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [src] + shared) or not os.path.exists(obj + ".srchash"):
+                todo.append((src, obj))
+
+        def compile_one(job):
+            src, obj = job
+            cmd = [hipcc(), *HIPFLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            with open(obj + ".srchash", "w") as f:
+                f.write(_digest([src] + shared) + "\n")
+
+        with ThreadPoolExecutor(max_workers=jobs or min(4, os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, todo))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        stamp()
+        stamp(LIB_PATH)
     return LIB_PATH
 
 
@@ -123,7 +150,7 @@ def build_plugin(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        stamp()
+        stamp(PLUGIN_PATH)
     return PLUGIN_PATH
 
 
@@ -154,6 +181,8 @@ def load() -> ctypes.CDLL:
     L.geot_publish_word.argtypes = [c_vp, c_vp, c_i64]
     L.geot_publish_pending.argtypes = []
     L.geot_set_alarm_word.argtypes = [c_vp]
+    L.geot_content_fingerprint.argtypes = [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_i64, c_vp, c_vp]
+    L.geot_content_fingerprint_scratch_bytes.restype = c_sz
     L.geot_sort_supported.argtypes = [c_i64, c_i64, c_i64]
     L.geot_sort_workspace_bytes.restype = c_sz
     L.geot_sort_workspace_bytes.argtypes = [c_i64]
@@ -201,5 +230,15 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
 
 
-if __name__ == "__main__":      # `python3 geot_amd/_lib.py` (from the Makefile): stamp the binaries that exist
-    stamp()
+if __name__ == "__main__":      # `python3 geot_amd/_lib.py [lib|plugin|stamp]` (the Makefile's recipes)
+    import sys
+    what = sys.argv[1] if len(sys.argv) > 1 else "stamp"
+    if what == "lib":
+        build(verbose=True)
+    elif what == "plugin":
+        build(verbose=True)
+        build_plugin(verbose=True)
+    elif what == "stamp-plugin":
+        stamp(PLUGIN_PATH)
+    else:
+        stamp()

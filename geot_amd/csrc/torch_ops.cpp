@@ -54,6 +54,7 @@ struct Options {
   int publish_rows = 1;      // GEOT_PUBLISH_ROWS: small calls get index[-1] from their own first kernel (geot_publish_word)
   int64_t cache_mb = 0;      // GEOT_CACHE_MB: byte budget of all cached artefacts together (0 = 1/8 of the device's memory)
   int slab_builder = 0;      // Phase A: 0 = the device builder (csrc/seg_plan.hip), 1 = the ATen formulation (CPU tensors always; cross-check)
+  int content_guard = 1;     // GEOT_CONTENT_GUARD: every use of a remembered product re-reads the tensors it was derived from (fingerprint)
   Options() {
     if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;
     if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
@@ -62,11 +63,12 @@ struct Options {
     if (const char *e = std::getenv("GEOT_SLAB")) slab_mode = !std::strcmp(e, "0") ? -1 : (!std::strcmp(e, "1") ? 1 : 0);
     if (const char *e = std::getenv("GEOT_TRANSPOSE_CACHE")) transpose_cache = std::atoi(e);
     if (const char *e = std::getenv("GEOT_CACHE_MB")) cache_mb = std::atoll(e);
+    if (const char *e = std::getenv("GEOT_CONTENT_GUARD")) content_guard = std::strcmp(e, "0") != 0;
   }
 };
 Options g_opt;
 struct Stats {
-  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0;
+  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0, stale_products = 0, guard_checks = 0;
 };
 Stats g_stats;
 std::mutex g_mu; // guards the caches below (facts, transposed edge lists, slab plans)
@@ -197,24 +199,131 @@ at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
 struct Slot {
   int64_t *host = nullptr;   // [0..3] copies (probe, row rule), [4] word published by a kernel, [5] its sequence number,
                              // [6] / [7] descent alarm of the kernels (geot_set_alarm_word): a call repaired itself / NaN-filled its output
+                             // [8 + 2i], [9 + 2i], i < kGuardSlots: verdict and sequence number of a content fingerprint (guard_check)
   hipEvent_t ev = nullptr;
   int64_t seq = 0;
+  int guard_next = 0;
 };
+constexpr int kGuardSlots = 8;
+constexpr size_t kSlotWords = 8 + 2 * kGuardSlots;
 Slot &slot_for(int device) {
   static thread_local std::map<int, Slot> slots;
   Slot &s = slots[device];
   if (!s.host) {
     // fine-grained (coherent) pinned memory: a running kernel's stores become visible to the spinning host
-    if (hipHostMalloc(reinterpret_cast<void **>(&s.host), 8 * sizeof(int64_t), hipHostMallocCoherent) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&s.host), kSlotWords * sizeof(int64_t), hipHostMallocCoherent) != hipSuccess) {
       (void)hipGetLastError();
-      TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), 8 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
+      TORCH_CHECK(hipHostMalloc(reinterpret_cast<void **>(&s.host), kSlotWords * sizeof(int64_t), hipHostMallocDefault) == hipSuccess,
                   "hipHostMalloc failed");
     }
-    std::memset(s.host, 0, 8 * sizeof(int64_t));
+    std::memset(s.host, 0, kSlotWords * sizeof(int64_t));
     TORCH_CHECK(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
   }
   return s;
 }
+
+// ---- content guard of the remembered products (csrc/seg_guard.hip) -----------------------------------------------------------
+// Everything the caches below keep was derived from the caller's index tensors and is found again by their identity and
+// version counter.  A write behind the version counter (.data, DLPack, a raw pointer) leaves a product that describes bytes
+// that are gone; the reference, which keeps nothing, would follow the new bytes.  So a product carries the fingerprint of
+// the tensors it was made from (guard_store), every later use re-reads them and compares on the device (guard_check:
+// 8-16 streamed bytes per edge, enqueued in FRONT of the call's kernels, verdict published into pinned memory), and the
+// operator looks at the verdicts before it returns (guard_settle; by then the call has waited for its own read-back, or
+// waits here for the fingerprint alone - the kernels behind it keep running).  One mismatch drops every remembered product
+// and the operator runs once more from the caller's bytes: the result the caller gets is always the one of the tensors as
+// they are.  Off under graph capture (a captured call is a contract about static content anyway), with trust_version 2
+// (the caller opted out of read-backs) and with content_guard 0.
+struct PendingVerdict {
+  int64_t *slot; // pinned: [0] verdict, [1] sequence number
+  int64_t seq;
+  void *stream;
+};
+thread_local std::vector<PendingVerdict> tl_pending;
+thread_local bool tl_guard_tripped = false;
+// (fingerprint, first tensor) pairs this operator call has already asked about: transposed_weight looks the edge list up
+// through transpose_edges and then again for the weight - one read of the edge list answers both
+thread_local std::vector<std::pair<const void *, const void *>> tl_asked;
+
+bool guard_on() { return g_opt.content_guard && g_opt.trust_version == 1 && !tl_capturing; }
+// (the fingerprint reads one flat range per tensor)
+bool guardable(std::initializer_list<const at::Tensor *> ts) {
+  for (const at::Tensor *t : ts)
+    if (!t->defined() || !t->is_cuda() || !t->is_contiguous() || (t->element_size() & 1)) return false;
+  return true;
+}
+// may this call look a product of these tensors up / remember one?
+bool may_remember(std::initializer_list<const at::Tensor *> ts) { return g_opt.trust_version && (!guard_on() || guardable(ts)); }
+
+at::Tensor &guard_scratch(const at::Tensor &like) { // per (device, stream): the kernel's ticket and per-workgroup sums
+  static thread_local std::map<std::pair<int, void *>, at::Tensor> sc;
+  auto &t = sc[{(int)like.device().index(), stream_of(like)}];
+  if (!t.defined()) t = at::zeros({(int64_t)geot_content_fingerprint_scratch_bytes()}, like.options().dtype(at::kByte));
+  return t;
+}
+
+void guard_drain() {
+  for (const PendingVerdict &p : tl_pending) {
+    bool have = false;
+    for (int spin = 0; spin < 200000 && !have; ++spin) {
+      have = __atomic_load_n(&p.slot[1], __ATOMIC_ACQUIRE) == p.seq;
+      if (!have) __builtin_ia32_pause();
+    }
+    if (!have) { // a long queue in front of the fingerprint: wait properly
+      TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(p.stream)) == hipSuccess, "hipStreamSynchronize failed");
+      have = __atomic_load_n(&p.slot[1], __ATOMIC_ACQUIRE) == p.seq;
+    }
+    if (!have || __atomic_load_n(&p.slot[0], __ATOMIC_ACQUIRE) != 1) tl_guard_tripped = true; // (no verdict counts as a changed content)
+  }
+  tl_pending.clear();
+}
+
+void launch_fingerprint(std::initializer_list<const at::Tensor *> ts, at::Tensor &fp, bool compare, int64_t *slot, int64_t seq) {
+  const void *bufs[4];
+  size_t bytes[4];
+  int n = 0;
+  const at::Tensor *first = nullptr;
+  for (const at::Tensor *t : ts) {
+    TORCH_CHECK(n < 4, "guard: at most four tensors per product");
+    if (!first) first = t;
+    bufs[n] = t->data_ptr();
+    bytes[n] = (size_t)t->numel() * (size_t)t->element_size();
+    ++n;
+  }
+  GEOT_CALL(geot_content_fingerprint(bufs, bytes, n, reinterpret_cast<unsigned long long *>(fp.data_ptr<int64_t>()), compare ? 1 : 0, slot, seq,
+                                     guard_scratch(*first).data_ptr(), stream_of(*first)));
+}
+
+// fingerprint of `ts` as they are now, for a product that is being made from them (undefined when the guard is off)
+at::Tensor guard_store(std::initializer_list<const at::Tensor *> ts) {
+  if (!guard_on() || !guardable(ts)) return at::Tensor();
+  at::Tensor fp = at::empty({2}, (*ts.begin())->options().dtype(at::kLong));
+  launch_fingerprint(ts, fp, false, nullptr, 0);
+  return fp;
+}
+
+// a remembered product is about to be used: are `ts` still the bytes it was made from?  (answered at guard_settle)
+void guard_check(const at::Tensor &fp, std::initializer_list<const at::Tensor *> ts) {
+  if (!guard_on() || !fp.defined() || !guardable(ts)) return;
+  const std::pair<const void *, const void *> what{fp.data_ptr(), (*ts.begin())->data_ptr()};
+  for (const auto &a : tl_asked)
+    if (a == what) return;
+  tl_asked.push_back(what);
+  if ((int)tl_pending.size() >= kGuardSlots) guard_drain();
+  Slot &s = slot_for((*ts.begin())->device().index());
+  int64_t *slot = s.host + 8 + 2 * (s.guard_next++ % kGuardSlots);
+  const int64_t seq = ++s.seq;
+  at::Tensor f = fp;
+  launch_fingerprint(ts, f, true, slot, seq);
+  tl_pending.push_back(PendingVerdict{slot, seq, stream_of(**ts.begin())});
+}
+
+void clear_all_caches_locked();
+// true: every product this operator call used was made from the bytes the tensors hold now
+bool guard_settle();
+// is `t` itself one of the remembered products (the transposed edge list handed to the backward pass)?  What is derived from
+// those - the plan of the transposed graph, its weight in plan order - needs no fingerprint of its own: nobody but this file
+// writes them, and the entry they belong to is checked against the caller's tensors in the same backward pass.
+bool owned_product(const at::Tensor &t);
 
 // ---- facts of an index tensor, keyed on its content identity ---------------------------------------------------------------
 struct ContentKey {
@@ -250,6 +359,7 @@ struct Facts {
   int64_t kmin, kmax;    // key range (sizes the sort of an index with descents)
   at::Tensor keys, perm; // stable sort of an index with descents (a few entries keep theirs)
   Produced made;         // ... and the event of that sort
+  at::Tensor sort_fp;    // ... and the fingerprint of the index it sorted (guard_store)
 };
 std::list<Facts> g_facts; // most recent first, <= 16 entries
 constexpr size_t kFactsMax = 16, kSortedKeep = 4;
@@ -355,16 +465,18 @@ std::pair<at::Tensor, at::Tensor> stable_sort_index(const at::Tensor &index, int
 // (keys ascending, perm) of an index with descents
 std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t kmin, int64_t kmax) {
   ContentKey k;
-  const bool keyed = g_opt.trust_version && content_key(index, &k);
+  const bool keyed = may_remember({&index}) && content_key(index, &k);
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &f : g_facts)
       if (f.key == k && !f.weak.expired() && f.keys.defined()) {
         f.made.before_use(index, {&f.keys, &f.perm});
+        guard_check(f.sort_fp, {&index});
         return {f.keys, f.perm};
       }
   }
   auto sorted = stable_sort_index(index, kmin, kmax);
+  at::Tensor fp = keyed && !tl_capturing ? guard_store({&index}) : at::Tensor();
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.sorts;
   if (keyed && !tl_capturing) {
@@ -373,6 +485,7 @@ std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t k
       if (f.key == k) {
         f.keys = sorted.first;
         f.perm = sorted.second;
+        f.sort_fp = fp;
         f.made.mark(index);
       }
       if (f.keys.defined() && ++holders > kSortedKeep) f.keys = f.perm = at::Tensor();
@@ -389,26 +502,29 @@ struct WidenedEntry {
   WeakStorage narrow; // the caller's int32 tensor (weak: see WeakStorage)
   at::Tensor wide;
   Produced made;
+  at::Tensor fp; // fingerprint of the narrow tensor (guard_store)
 };
 std::list<WidenedEntry> g_widened;
 
 at::Tensor as_int64(const at::Tensor &t) {
   if (t.scalar_type() == at::kLong) return t.contiguous();
   ContentKey k;
-  const bool keyed = g_opt.trust_version && content_key(t, &k);
+  const bool keyed = may_remember({&t}) && content_key(t, &k);
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_widened.begin(); it != g_widened.end(); ++it)
       if (it->key == k && !it->narrow.expired()) {
         g_widened.splice(g_widened.begin(), g_widened, it);
         g_widened.front().made.before_use(t, {&g_widened.front().wide});
+        guard_check(g_widened.front().fp, {&t});
         return g_widened.front().wide;
       }
   }
   at::Tensor wide = t.to(at::kLong).contiguous();
   if (keyed && !tl_capturing) {
+    at::Tensor fp = guard_store({&t});
     std::lock_guard<std::mutex> lk(g_mu);
-    g_widened.push_front(WidenedEntry{k, weak_of(t), wide, {}});
+    g_widened.push_front(WidenedEntry{k, weak_of(t), wide, {}, fp});
     g_widened.front().made.mark(t);
     while (g_widened.size() > 6) g_widened.pop_back();
     enforce_cache_budget_locked();
@@ -504,6 +620,7 @@ struct SlabPlanHolder {
   c10::optional<WeakStorage> w_given; // the weight tensor w_planorder was made from (weak)
   at::Tensor w_planorder;
   Produced made, w_made; // events of Phase A / of the weight permutation (consumers on other streams wait for them)
+  at::Tensor fp, w_fp;   // fingerprints of the edge list / of the weight those were made from (guard_store)
   int64_t bytes() const {
     int64_t b = nbytes_of(w_planorder);
     for (const at::Tensor &t : keep) b += nbytes_of(t);
@@ -767,7 +884,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
     return nullptr;
   if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes, dt)) return nullptr;
   ContentKey k1, k2;
-  if (!content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
+  if (!may_remember({&si, &di}) || !content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
   const int rpg = geot_slab_rows_per_group_dtype(wmode, heads, dt);
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -777,6 +894,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
           it->rpg == rpg && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R)
         g_slab.splice(g_slab.begin(), g_slab, it);
         g_slab.front().plan->made.before_use(src, g_slab.front().plan->keep);
+        guard_check(g_slab.front().plan->fp, {&si, &di});
         return g_slab.front().plan;
       }
     if (tl_capturing) return nullptr; // Phase A synchronises: never inside a capture (the per-edge kernels serve the call)
@@ -804,6 +922,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
     return nullptr;
   }
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  plan->fp = owned_product(si) && owned_product(di) ? at::Tensor() : guard_store({&si, &di});
   plan->made.mark(src);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.plans_built;
@@ -1028,15 +1147,17 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
         int wmode = has_w ? 1 : 0;
         at::Tensor w_planorder;                        // (keeps the permuted copy alive across the launch)
         ContentKey wk;
-        if (has_w && g_opt.trust_version && content_key(e.w, &wk)) {
+        if (has_w && may_remember({&e.w}) && content_key(e.w, &wk)) {
           std::lock_guard<std::mutex> lk(plan->wmu);
           if (plan->w_planorder.defined() && plan->w_key == wk && plan->w_given && !plan->w_given->expired()) {
             w_planorder = plan->w_planorder;
             plan->w_made.before_use(x, {&w_planorder});
+            guard_check(plan->w_fp, {&e.w});
           } else if (tl_capturing) {
             // (no new cache content during a capture)
           } else if (plan->w_seen_valid && plan->w_seen == wk) { // the same weight content again: permute it once
             plan->w_planorder = e.w.index_select(0, plan->keep[2]);
+            plan->w_fp = owned_product(e.w) ? at::Tensor() : guard_store({&e.w});
             plan->w_made.mark(x);
             plan->w_key = wk;
             plan->w_given = weak_of(e.w);              // (weak: pins the address under this key, not the data)
@@ -1178,18 +1299,20 @@ struct ExpandedEntry {
   WeakStorage indptr; // the caller's row pointers (weak)
   at::Tensor dst_index;
   Produced made;
+  at::Tensor fp; // fingerprint of the row pointers (guard_store)
 };
 std::list<ExpandedEntry> g_expanded;
 
 at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   ContentKey k;
-  const bool keyed = g_opt.trust_version && content_key(indptr, &k);
+  const bool keyed = may_remember({&indptr}) && content_key(indptr, &k);
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_expanded.begin(); it != g_expanded.end(); ++it)
       if (it->key == k && it->dst_index.numel() == nnz && !it->indptr.expired()) {
         g_expanded.splice(g_expanded.begin(), g_expanded, it);
         g_expanded.front().made.before_use(indptr, {&g_expanded.front().dst_index});
+        guard_check(g_expanded.front().fp, {&indptr});
         return g_expanded.front().dst_index;
       }
   }
@@ -1197,8 +1320,9 @@ at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   at::Tensor counts = (indptr.slice(0, 1, nrow + 1) - indptr.slice(0, 0, nrow)).clamp_min(0);
   at::Tensor dst_index = at::repeat_interleave(counts, c10::optional<int64_t>(nnz));
   if (keyed && !tl_capturing) {
+    at::Tensor fp = guard_store({&indptr});
     std::lock_guard<std::mutex> lk(g_mu);
-    g_expanded.push_front(ExpandedEntry{k, weak_of(indptr), dst_index, {}});
+    g_expanded.push_front(ExpandedEntry{k, weak_of(indptr), dst_index, {}, fp});
     g_expanded.front().made.mark(indptr);
     while (g_expanded.size() > 4) g_expanded.pop_back();
     enforce_cache_budget_locked();
@@ -1262,15 +1386,26 @@ struct TransposedEntry {
   c10::optional<WeakStorage> w_given;
   at::Tensor w_perm;
   Produced made, w_made;
+  at::Tensor fp, w_fp; // fingerprints of the edge list / of the weight (guard_store)
   int64_t bytes() const { return nbytes_of(perm) + nbytes_of(si_sorted) + nbytes_of(di_perm) + nbytes_of(w_perm); }
 };
 std::list<TransposedEntry> g_transposed;
+
+bool owned_product(const at::Tensor &t) {
+  if (!t.defined() || !t.has_storage()) return false;
+  const void *st = t.storage().unsafeGetStorageImpl();
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (const TransposedEntry &e : g_transposed)
+    for (const at::Tensor *p : {&e.perm, &e.si_sorted, &e.di_perm, &e.w_perm})
+      if (p->defined() && p->storage().unsafeGetStorageImpl() == st) return true;
+  return false;
+}
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tensor &si, const at::Tensor &di) {
   require_gpu("transpose_edges", {&si, &di});
   GEOT_DEVICE_GUARD(si);
   ContentKey k1, k2;
-  const bool keyed = g_opt.transpose_cache > 0 && g_opt.trust_version && content_key(si, &k1) && content_key(di, &k2);
+  const bool keyed = g_opt.transpose_cache > 0 && may_remember({&si, &di}) && content_key(si, &k1) && content_key(di, &k2);
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     sweep_expired_locked();
@@ -1278,6 +1413,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
       if (it->k1 == k1 && it->k2 == k2) {
         g_transposed.splice(g_transposed.begin(), g_transposed, it);
         it->made.before_use(si, {&it->perm, &it->si_sorted, &it->di_perm});
+        guard_check(it->fp, {&si, &di});
         return {it->perm, it->si_sorted, it->di_perm};
       }
   }
@@ -1287,10 +1423,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
   if (sic.numel() > 0 && !tl_capturing) probe_index(sic, p);              // the key range sizes the sort
   auto sorted = sic.numel() > 0 ? stable_sort_index(sic, p[2], p[3]) : std::make_pair(sic, sic);
   at::Tensor perm = sorted.second, di_perm = di.index_select(0, perm);
+  at::Tensor fp = keyed && !tl_capturing ? guard_store({&si, &di}) : at::Tensor();
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.transposes;
   if (keyed && !tl_capturing) {
     g_transposed.push_front(TransposedEntry{k1, k2, weak_of(si), weak_of(di), perm, sorted.first, di_perm});
+    g_transposed.front().fp = fp;
     g_transposed.front().made.mark(si);
     while ((int)g_transposed.size() > g_opt.transpose_cache) g_transposed.pop_back();
     enforce_cache_budget_locked();
@@ -1305,18 +1443,20 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
   auto tr = transpose_edges_op(si, di);           // (cached) permutation by source
   const at::Tensor &perm = std::get<0>(tr);
   ContentKey k1, k2, wk;
-  const bool keyed = g_opt.transpose_cache > 0 && g_opt.trust_version && content_key(si, &k1) && content_key(di, &k2) &&
+  const bool keyed = g_opt.transpose_cache > 0 && may_remember({&si, &di, &weight}) && content_key(si, &k1) && content_key(di, &k2) &&
                      content_key(weight, &wk) && !weight.requires_grad();
   if (keyed) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &e : g_transposed)
       if (e.k1 == k1 && e.k2 == k2 && e.w_valid && e.wkey == wk && e.w_given && !e.w_given->expired()) {
         e.w_made.before_use(weight, {&e.w_perm});
+        guard_check(e.w_fp, {&weight});
         return e.w_perm;
       }
   }
   at::Tensor wp = weight.index_select(0, perm);
   if (keyed && !tl_capturing) {
+    at::Tensor wfp = guard_store({&weight});
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &e : g_transposed)
       if (e.k1 == k1 && e.k2 == k2) {
@@ -1324,6 +1464,7 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
         e.wkey = wk;
         e.w_given = weak_of(weight);
         e.w_perm = wp;
+        e.w_fp = wfp;
         e.w_made.mark(weight);
       }
   }
@@ -1410,6 +1551,50 @@ void clear_all_caches_locked() {
   g_expanded.clear();
 }
 
+bool guard_settle() {
+  const size_t asked = tl_asked.size();
+  tl_asked.clear();
+  guard_drain();
+  const bool tripped = tl_guard_tripped;
+  tl_guard_tripped = false;
+  if (asked || tripped) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_stats.guard_checks += (int64_t)asked;
+    if (tripped) {
+      clear_all_caches_locked();
+      ++g_stats.stale_products;
+    }
+  }
+  return !tripped;
+}
+
+// every registered operator goes through this: run, look at the verdicts of the products the call used, and when one of
+// them described bytes that are gone, run once more (every cache is empty by then: the call derives what it needs afresh)
+template <auto Fn> struct Guarded;
+template <typename R, typename... A, R (*Fn)(A...)> struct Guarded<Fn> {
+  static R call(A... a) {
+    try {
+      R out = Fn(a...);
+      if (guard_settle()) return out;
+    } catch (...) {
+      (void)guard_settle();
+      throw;
+    }
+    TORCH_WARN("geot: a tensor this call depends on (an index, row pointers or a static edge weight) was written behind its version "
+               "counter (.data, DLPack, a raw pointer): what had been derived from its earlier content was dropped and the call was run "
+               "again from the bytes it holds now.");
+    try {
+      R out = Fn(a...);
+      (void)guard_settle();
+      return out;
+    } catch (...) {
+      (void)guard_settle();
+      throw;
+    }
+  }
+};
+#define GUARDED(fn) (&Guarded<&fn>::call)
+
 // ---- introspection for tests / tools ------------------------------------------------------------------------------------------
 int64_t host_option_op(c10::string_view name, int64_t value) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1422,6 +1607,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "slab_keep") p = &g_opt.slab_keep;
   else if (name == "publish_rows") p = &g_opt.publish_rows;
   else if (name == "slab_builder") p = &g_opt.slab_builder;
+  else if (name == "content_guard") p = &g_opt.content_guard;
   else if (name == "clear_caches") {
     clear_all_caches_locked();
     return 0;
@@ -1446,7 +1632,7 @@ std::vector<int64_t> host_stats_op() {
   sweep_expired_locked();
   return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
           (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published, g_stats.alarms,
-          cache_bytes_locked()};
+          cache_bytes_locked(), g_stats.stale_products, g_stats.guard_checks};
 }
 
 // Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).
@@ -1503,22 +1689,22 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
 
 // The GPU key ("CUDA" is what a ROCm build of PyTorch calls it).
 #define GEOT_IMPLS(m)                                                                \
-  m.impl("index_scatter", index_scatter_op);                                         \
-  m.impl("gather_scatter_impl", gather_scatter_op);                                  \
-  m.impl("gather_weight_scatter_impl", gather_weight_scatter_op);                    \
-  m.impl("sddmm_coo_impl", sddmm_coo_op);                                            \
-  m.impl("csr_gws_impl", csr_gws_op);                                                \
-  m.impl("mh_spmm", mh_spmm_op);                                                     \
-  m.impl("gather_scatter", gather_scatter_op);                                       \
-  m.impl("gather_weight_scatter", gather_weight_scatter_op);                         \
-  m.impl("csr_gws", csr_gws_op);                                                     \
-  m.impl("gather_reduce", gather_reduce_op);                                         \
-  m.impl("gather_scatter_rows", gather_scatter_rows_op);                             \
-  m.impl("gather_weight_scatter_rows", gather_weight_scatter_rows_op);               \
-  m.impl("mh_spmm_rows", mh_spmm_rows_op);                                           \
-  m.impl("gather_rows", gather_rows_op);                                             \
-  m.impl("transpose_edges", transpose_edges_op);                                     \
-  m.impl("transposed_weight", transposed_weight_op)
+  m.impl("index_scatter", GUARDED(index_scatter_op));                                         \
+  m.impl("gather_scatter_impl", GUARDED(gather_scatter_op));                                  \
+  m.impl("gather_weight_scatter_impl", GUARDED(gather_weight_scatter_op));                    \
+  m.impl("sddmm_coo_impl", GUARDED(sddmm_coo_op));                                            \
+  m.impl("csr_gws_impl", GUARDED(csr_gws_op));                                                \
+  m.impl("mh_spmm", GUARDED(mh_spmm_op));                                                     \
+  m.impl("gather_scatter", GUARDED(gather_scatter_op));                                       \
+  m.impl("gather_weight_scatter", GUARDED(gather_weight_scatter_op));                         \
+  m.impl("csr_gws", GUARDED(csr_gws_op));                                                     \
+  m.impl("gather_reduce", GUARDED(gather_reduce_op));                                         \
+  m.impl("gather_scatter_rows", GUARDED(gather_scatter_rows_op));                             \
+  m.impl("gather_weight_scatter_rows", GUARDED(gather_weight_scatter_rows_op));               \
+  m.impl("mh_spmm_rows", GUARDED(mh_spmm_rows_op));                                           \
+  m.impl("gather_rows", GUARDED(gather_rows_op));                                             \
+  m.impl("transpose_edges", GUARDED(transpose_edges_op));                                     \
+  m.impl("transposed_weight", GUARDED(transposed_weight_op))
 
 TORCH_LIBRARY_IMPL(geot, CUDA, m) { GEOT_IMPLS(m); }
 #undef GEOT_IMPLS

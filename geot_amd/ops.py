@@ -104,7 +104,9 @@ _SLAB = {"never": -1, "auto": 0, "always": 1}
 def set_option(name: str, value) -> int:
     """speculate_rows (0|1), trust_version (0|1), unsorted_mode ('auto'|'sort'|'atomic'), slab_mode
     ('never'|'auto'|'always'), transpose_cache (entries), slab_keep (plans), cache_mb (byte budget of all cached
-    artefacts together, MiB; 0 = 1/8 of the device's memory), slab_builder (0 device | 1 ATen).  Returns the previous value."""
+    artefacts together, MiB; 0 = 1/8 of the device's memory), slab_builder (0 device | 1 ATen), content_guard (0|1: every use
+    of a remembered product re-reads the tensors it was derived from and compares fingerprints; a write behind the version
+    counter then costs one repeated call instead of a wrong result).  Returns the previous value."""
     if name == "unsorted_mode" and isinstance(value, str):
         value = _UNSORTED[value]
     if name == "slab_mode" and isinstance(value, str):
@@ -123,7 +125,7 @@ def clear_caches() -> None:
 
 def stats() -> dict:
     names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans",
-             "published", "alarms", "cache_bytes")
+             "published", "alarms", "cache_bytes", "stale_products", "guard_checks")
     return dict(zip(names, torch.ops.geot._host_stats()))
 
 

@@ -164,6 +164,19 @@ int geot_publish_pending(void);
  * to host_slot2[0], a NaN-filled one to host_slot2[1] (while it runs; the host clears the words when it has seen them). */
 int geot_set_alarm_word(int64_t *host_slot2);
 
+/* Content fingerprint: the guard of what a host layer derives from index tensors and keeps (slab plans, sorted edge
+ * lists ...).  The reference keeps nothing between calls (csrc/gather_scatter.cpp:25-34 reads the caller's tensors every
+ * time), so a host layer that does must notice bytes that changed behind the tensors' version counters.  128-bit,
+ * position-sensitive, not cryptographic.  bufs[0..nbufs) (1..4 device buffers, 2-byte aligned, whole 2-byte words) are read
+ * once, streamed.  compare == 0: the fingerprint is STORED to fp[0..1] (device).  compare != 0: it is compared with
+ * fp[0..1] on the device.  verdict2 (two int64 of fine-grained pinned host memory, or NULL): [0] = 1 (stored / equal) or
+ * 2 (different), then [1] = seq, written by the kernel when it is done - the host polls [1].  scratch:
+ * geot_content_fingerprint_scratch_bytes() of device memory, zero on entry, first word left zero (one stream at a time).
+ * Asynchronous on `stream`. */
+size_t geot_content_fingerprint_scratch_bytes(void);
+int geot_content_fingerprint(const void *const *bufs, const size_t *bytes, int nbufs, unsigned long long *fp, int compare,
+                             int64_t *verdict2, int64_t seq, void *scratch, void *stream);
+
 /* The same pass with the key range: out4 = {index[nnz-1], descents, min(index), max(index)}.  The range sizes the sort
  * of an index with descents (below) and tells an index with negative keys apart. */
 int geot_index_probe_range(const int64_t *index, int64_t nnz, int64_t *out4, void *stream);

@@ -20,5 +20,5 @@ for F in (64, 128):
         alg = NNZ * (es * F + 8) + KEYS * es * F
         for red in ("sum", "max", "mean"):
             t = timeit(lambda: hip.index_scatter_out(index, src, out, True, red))
-            print(f"F={F:3d} {str(dt)[6:]:9s} {red:4s}: {t:.4f} ms  {NNZ / t / 1e6:6.2f} Gedge/s  {alg / t / 1e9:.2f} TB/s algorithmic ({alg / t / 1e9 / 80:.1f}% of 8 TB/s)")
+            print(f"F={F:3d} {str(dt)[6:]:9s} {red:4s}: {t:.4f} ms  {NNZ / t / 1e6:6.2f} Gedge/s  {alg / t / 1e9:.2f} TB/s algorithmic ({alg / t / 1e9 / 8 * 100:.1f}% of 8 TB/s)")
         del src, out

@@ -112,7 +112,32 @@ def main():
             si = rng.integers(0, nodes, nnz).astype(np.int64)
             x = rng.standard_normal((nodes, F)).astype(np.float32)
             w = rng.random(nnz, dtype=np.float32) + 0.25 if op == "gws" else None
-            if red == "sum":
+            if red == "sum" and rng.integers(0, 5) == 0:
+                # round 3: a NEW edge list / weight written into the same tensors behind the version counter, after the
+                # host has remembered what it derived from the old one (plan, weight in plan order): the content guard
+                import warnings
+                covered[("content_swap", op)] = covered.get(("content_swap", op), 0) + 1
+                t_si, t_di, t_x = t(si), t(index), t(x)
+                t_w = t(w) if w is not None else None
+                call = (lambda: geot.gather_weight_scatter(t_si, t_di, t_w, t_x)) if w is not None else (lambda: geot.gather_scatter(t_si, t_di, t_x))
+                for _ in range(3):
+                    call()
+                si = rng.integers(0, nodes, nnz).astype(np.int64)
+                t_si.data.copy_(t(si))
+                if w is not None and rng.integers(0, 2):
+                    w = rng.random(nnz, dtype=np.float32) + 0.25
+                    t_w.data.copy_(t(w))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out = call().cpu().numpy()
+                if w is not None:
+                    hi = oracle.gather_weight_scatter(si, index, w, x, acc64=True)
+                    mag = oracle.gather_weight_scatter(si, index, w, np.abs(x), acc64=True)
+                else:
+                    hi = oracle.gather_scatter(si, index, x, acc64=True)
+                    mag = oracle.gather_scatter(si, index, np.abs(x), acc64=True)
+                ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= 2e-5 * mag + 1e-30) and np.all(out[mag == 0] == 0)
+            elif red == "sum":
                 if op == "gws":
                     out = geot.gather_weight_scatter(t(si), t(index), t(w), t(x)).cpu().numpy()
                     hi = oracle.gather_weight_scatter(si, index, w, x, acc64=True)
