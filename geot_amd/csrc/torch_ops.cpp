@@ -1471,6 +1471,14 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
   return wp;
 }
 
+// both lookups of a weighted backward pass in ONE operator call (one read of the edge list for the content guard, one wait)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> transpose_edges_weighted_op(const at::Tensor &si, const at::Tensor &di,
+                                                                                       const at::Tensor &weight) {
+  auto tr = transpose_edges_op(si, di);
+  at::Tensor wp = transposed_weight_op(si, di, weight);
+  return {std::get<0>(tr), std::get<1>(tr), std::get<2>(tr), wp};
+}
+
 void sweep_expired_locked() {
   g_widened.remove_if([](const WidenedEntry &e) { return e.narrow.expired(); });
   g_expanded.remove_if([](const ExpandedEntry &e) { return e.indptr.expired(); });
@@ -1680,6 +1688,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("gather_rows(Tensor index, Tensor src) -> Tensor");
   m.def("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)");
   m.def("transposed_weight(Tensor src_index, Tensor dst_index, Tensor weight) -> Tensor");
+  m.def("transpose_edges_weighted(Tensor src_index, Tensor dst_index, Tensor weight) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("_host_option(str name, int value) -> int", host_option_op);
   m.def("_host_stats() -> int[]", host_stats_op);
   m.def("_slab_plan(Tensor src_index, Tensor dst_index, int rows, int src_rows, int rowbytes, int weight_mode, int heads, int slab_bytes, "
@@ -1704,7 +1713,8 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.impl("mh_spmm_rows", GUARDED(mh_spmm_rows_op));                                           \
   m.impl("gather_rows", GUARDED(gather_rows_op));                                             \
   m.impl("transpose_edges", GUARDED(transpose_edges_op));                                     \
-  m.impl("transposed_weight", GUARDED(transposed_weight_op))
+  m.impl("transposed_weight", GUARDED(transposed_weight_op));                               \
+  m.impl("transpose_edges_weighted", GUARDED(transpose_edges_weighted_op))
 
 TORCH_LIBRARY_IMPL(geot, CUDA, m) { GEOT_IMPLS(m); }
 #undef GEOT_IMPLS
@@ -1727,4 +1737,5 @@ TORCH_LIBRARY_IMPL(geot, CPU, m) {
   m.impl("gather_rows", gather_rows_cpu_op); // (the backward of the CPU index_scatter)
   m.impl("transpose_edges", transpose_edges_op);
   m.impl("transposed_weight", transposed_weight_op);
+  m.impl("transpose_edges_weighted", transpose_edges_weighted_op);
 }

@@ -226,6 +226,12 @@ def _(src_index, dst_index, weight):
     return weight.new_empty(weight.shape)
 
 
+@torch.library.register_fake("geot::transpose_edges_weighted")
+def _(src_index, dst_index, weight):
+    return (src_index.new_empty(src_index.shape), src_index.new_empty(src_index.shape), dst_index.new_empty(dst_index.shape),
+            weight.new_empty(weight.shape))
+
+
 @torch.library.register_fake("geot::transpose_edges")
 def _(src_index, dst_index):
     return src_index.new_empty(src_index.shape), src_index.new_empty(src_index.shape), dst_index.new_empty(dst_index.shape)
@@ -276,14 +282,13 @@ def _gws_backward(ctx, grad):
     """
     src_index, dst_index, weight, src = ctx.saved_tensors
     grad = grad.contiguous()
-    _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
-    # the weights in transposed edge order (kept by the host layer while the weight tensor's content is unchanged and
-    # it does not require grad: a normalised adjacency is permuted once, not on every backward call)
     # (only the gradients autograd asks for: a GCN's normalised adjacency does not require grad - no SDDMM then)
     need_w, need_src = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
     src_grad = weight_grad = None
     if need_src:
-        weight_bwd = torch.ops.geot.transposed_weight(src_index, dst_index, weight.detach())
+        # the transposed edge list and the weights in its order, looked up in one operator call (kept by the host layer while
+        # the tensors' content is unchanged; a weight that does not require grad - a normalised adjacency - is permuted once)
+        _, dst_index_bwd, src_index_bwd, weight_bwd = torch.ops.geot.transpose_edges_weighted(src_index, dst_index, weight.detach())
         src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight_bwd, grad,
                                                              src.shape[0])
     if need_w:

@@ -51,17 +51,19 @@ def cases(g):
         "gather_rows": (G.gather_rows.default, (g["di"], g["x"])),
         "transpose_edges": (G.transpose_edges.default, (g["si"], g["di"])),
         "transposed_weight": (G.transposed_weight.default, (g["si"], g["di"], g["w"])),
+        "transpose_edges_weighted": (G.transpose_edges_weighted.default, (g["si"], g["di"], g["w"])),
         "coo_to_csr": (G.coo_to_csr.default, (g["di"],)),
     }
 
 
 NAMES = ["index_scatter", "index_scatter_grad", "index_scatter_mean", "gather_scatter", "gather_weight_scatter", "gather_scatter_impl",
          "gather_weight_scatter_impl", "gather_reduce", "gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm", "mh_spmm_rows",
-         "sddmm_coo_impl", "csr_gws", "csr_gws_impl", "gather_rows", "transpose_edges", "transposed_weight", "coo_to_csr"]
+         "sddmm_coo_impl", "csr_gws", "csr_gws_impl", "gather_rows", "transpose_edges", "transposed_weight", "transpose_edges_weighted",
+         "coo_to_csr"]
 
 
 STATIC_SHAPE = {"gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm_rows", "sddmm_coo_impl", "gather_rows", "transpose_edges",
-                "transposed_weight", "csr_gws_impl"}
+                "transposed_weight", "transpose_edges_weighted", "csr_gws_impl"}
 
 
 @pytest.mark.parametrize("name", NAMES)
