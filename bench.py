@@ -274,6 +274,10 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         st0 = ops.stats()
         ms = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters, warmup=3)
         st1 = ops.stats()
+        # the same with the content guard off: what the fingerprint re-check of the remembered plan costs (csrc/seg_guard.hip)
+        guard_was = ops.set_option("content_guard", 0)
+        ms_unguarded = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters, warmup=1)
+        ops.set_option("content_guard", guard_was)
         hip.mh_spmm_out(si, di, w, x, out, False)
         torch.cuda.synchronize()
         diff = float(((geot.mh_spmm(si, di, w, x).float() - out.float()).abs().max() / out.float().abs().max()).item())
@@ -285,6 +289,8 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             "workload": f"mh_spmm, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, heads={H} feat={F}, "
                         f"{str(dtype).split('.')[-1]} (stand-in of Reddit)",
             "kernel_ms": ms,
+            "content_guard": "on: every call re-reads both index arrays and compares their fingerprint with the plan's (kernel_ms includes it)",
+            "kernel_ms_without_content_guard": ms_unguarded,
             "kernel": f"seg_slab_kernel<{tname}, 2, {'true' if H * F * esize == 1024 else 'false'}, sum> (+ memset, combine)" if slab_used
                       else f"seg_tile_kernel<{tname}, ..., true, 2, ...>",
             "source_blocked_path": slab_used,
