@@ -185,3 +185,24 @@ def test_product_never_touches_the_oracle():
     import sys
     assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules
                    if getattr(sys.modules[m], "__file__", None) and "geot_amd" in (sys.modules[m].__file__ or ""))
+
+
+def test_build_staleness_is_decided_by_content_not_by_file_times(tmp_path):
+    """geot_amd/_lib.py: a snapshot copy of the tree (the GPU box gets one) keeps no file times; a binary with a stamp is stale
+    exactly when the CONTENT of its sources differs from what it was built from, and the shipped binaries are not stale."""
+    import time
+    from geot_amd import _lib
+    src, binary = tmp_path / "a.hip", tmp_path / "lib.so"
+    src.write_text("v1")
+    assert _lib._stale(str(binary), [str(src)])                       # no binary
+    binary.write_text("built from v1")
+    time.sleep(0.01)
+    os.utime(src)                                                      # source looks newer
+    assert _lib._stale(str(binary), [str(src)])                        # no stamp: file times decide
+    (tmp_path / "lib.so.srchash").write_text(_lib._digest([str(src)]) + "\n")
+    assert not _lib._stale(str(binary), [str(src)])                    # stamp: same content, whatever the times say
+    src.write_text("v2")
+    os.utime(binary)                                                   # binary looks newer
+    assert _lib._stale(str(binary), [str(src)])                        # ... and other content is stale, whatever the times say
+    assert not _lib.needs_build() and not _lib.plugin_needs_build()    # what travels with the tree is what the sources build
+    assert set(_lib.LIB_INPUTS) >= set(_lib.SOURCES) and _lib.HEADER in _lib.LIB_INPUTS and _lib.HEADER in _lib.PLUGIN_INPUTS
