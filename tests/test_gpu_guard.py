@@ -291,3 +291,49 @@ def test_guard_costs_nothing_where_it_is_off_and_little_where_it_is_on(geot, ops
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_two_threads_one_of_them_rewriting_its_edge_list(geot, ops):
+    """Operator calls release the GIL: one thread's stale product drops every cache while the other thread is in the middle of
+    using its own plan.  Both must keep getting the result of the bytes they hold."""
+    import threading
+    from geot_amd import hip
+    rng = np.random.default_rng(16)
+    nnz, K, F = 500_000, 2_500, 64
+    ops.set_option("slab_mode", "always")
+    errors = []
+
+    def expected(t_si, t_di, t_x):
+        out = torch.empty(K, F, device="cuda")
+        hip.gather_scatter_out(t_si, t_di, t_x, out)                           # per-edge kernels through the C ABI: no host caches
+        return out
+
+    def worker(seed, rewrite):
+        try:
+            r = np.random.default_rng(seed)
+            si, di = graph(r, nnz, K)
+            t_si, t_di, t_x = dev(si), dev(di), dev(r.random((K, F), dtype=np.float32))
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                want = expected(t_si, t_di, t_x)
+                for it in range(40):
+                    if rewrite and it % 3 == 2:
+                        behind_the_version_counter(t_si, r.integers(0, K, nnz).astype(np.int64))
+                        want = expected(t_si, t_di, t_x)
+                    got = geot.gather_scatter(t_si, t_di, t_x)
+                    err = float(((got - want).abs().max() / want.abs().max()).item())
+                    if not err < 1e-5:
+                        errors.append((seed, it, err))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(100, False)), threading.Thread(target=worker, args=(101, True)),
+               threading.Thread(target=worker, args=(102, True))]
+    stale0 = ops.stats()["stale_products"]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    assert ops.stats()["stale_products"] >= stale0 + 10
