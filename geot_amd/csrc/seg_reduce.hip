@@ -1826,10 +1826,18 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   int cg = (gather ? 1024 : 512) / ng;
   if (l > natural) cg = 32;
   if (!gather && tsize == 4 && l == 5) cg = 32;
-  // 1-KiB streamed rows (fp32 F = 256: a whole wave per row): 16 loads in flight over 32- / 64-edge groups (round-3 sweep:
+  // 1-KiB streamed rows (fp32 F = 256: a whole wave per row): 16 loads in flight over 32-edge groups (round-3 sweep:
   // -2..-4 % at 10 M edges, -10..-15 % at 0.3-1 M edges against 128-edge groups with 8 loads in flight)
   const bool wide_u16 = !gather && !atomic_flush && tsize == 4 && vec == 4 && l == 6;
-  if (wide_u16) cg = nnz > 2000000 ? 64 : 32;
+  if (wide_u16) cg = 32; // (64-edge groups above 2 M edges, the first form of this rule, re-measured 5-6 % slower at 10 M edges)
+  // SHORT runs on streamed fp32 rows of >= 256 B (average run of a few edges: molecules, road networks, meshes): the smallest
+  // groups, 16 edges.  tools/_ab sweep of the round, normal-distributed run lengths, 10 M / 2 M edges, auto vs 16-edge groups:
+  // average 1.5-2: F=64 +6..7 % / +3.5 %, F=128 +9 % / +7 %, F=256 +10 % / +6.5 %; average 4: +2 % / -1 %, +4.4 % / +3 %,
+  // +11 % / +2 %; average 6: 0 / -3 %, +2 % / +1 %, +6 % / 0; from ~10 on the larger groups win again.
+  if (!gather && !atomic_flush && tsize == 4 && vec == 4 && l >= 4 && l == natural) {
+    const int64_t k = K > 0 ? K : 1;
+    if ((l == 4 && 2 * nnz < 7 * k) || (l == 5 && nnz < 8 * k) || (l == 6 && nnz < 5 * k)) cg = 16;
+  }
   // launch-bound sizes: a lane group walks its cg edges in dependent batches of U row loads, so on a chip that the grid
   // does not fill (< ~400 tiles) shorter groups = more tiles finish sooner.  Measured on graphs of 15 k - 250 k edges
   // (graph replay, us per call): gws F=64 19.6 -> 12.4 / 21.6 -> 14.2, F=128 26.9 -> 11.6 / 29.0 -> 19.6, index_scatter
@@ -1891,6 +1899,14 @@ template <typename T, int RED, bool GATHER, int WMODE>
 int dispatch_reduce_mode(const SegParams &p, const Plan &P, hipStream_t st) {
   constexpr int MAXV = 16 / (int)sizeof(T);
   constexpr int NTP = GATHER ? 0 : 3;
+  if constexpr (!GATHER && WMODE == 0 && sizeof(T) == 4 && (RED == RED_MAX || RED == RED_MIN)) {
+    if (P.unroll == 16 && P.vec == MAXV) {   // 16 row loads in flight per lane, as the sum (the tile shape was chosen for it)
+      const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
+      dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED, 16>), grid, dim3(kThreads), L.bytes, st, p);
+      return GEOT_OK;
+    }
+  }
   if (P.vec == MAXV) launch_tile<T, MAXV, GATHER, WMODE, false, NTP, RED>(p, P, st);
   else if (MAXV >= 4 && P.vec == 2) launch_tile<T, 2, GATHER, WMODE, false, NTP, RED>(p, P, st);
   else if (P.vec == 1) launch_tile<T, 1, GATHER, WMODE, false, NTP, RED>(p, P, st);
