@@ -1825,18 +1825,24 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   const int ng = kThreads >> l;
   int cg = (gather ? 1024 : 512) / ng;
   if (l > natural) cg = 32;
-  if (!gather && tsize == 4 && l == 5) cg = 32;
+  if (!gather && vec == maxvec && l == 5) cg = 32; // 512-byte streamed rows, every dtype (bf16 F=256: +7..12 %, fp64 F=64: +3..6 % over 64-edge groups)
   // 1-KiB streamed rows (fp32 F = 256: a whole wave per row): 16 loads in flight over 32-edge groups (round-3 sweep:
   // -2..-4 % at 10 M edges, -10..-15 % at 0.3-1 M edges against 128-edge groups with 8 loads in flight)
   const bool wide_u16 = !gather && !atomic_flush && tsize == 4 && vec == 4 && l == 6;
+  const int64_t keys1 = K > 0 ? K : 1;
   if (wide_u16) cg = 32; // (64-edge groups above 2 M edges, the first form of this rule, re-measured 5-6 % slower at 10 M edges)
+  // ... the other dtypes' 1-KiB rows (8 loads in flight): 32-edge groups, 64 where runs are long (bf16 F=512 at 2-10 M edges:
+  // +11 % / +6 % at an average run of 10, +2..4 % at 50; fp64 F=128: +2 %) - the generic 128 only suited the fp32 kernel of round 1
+  else if (!gather && !atomic_flush && vec == maxvec && l == 6 && lanes <= 64) cg = nnz < 30 * keys1 ? 32 : 64;
   // SHORT runs on streamed fp32 rows of >= 256 B (average run of a few edges: molecules, road networks, meshes): the smallest
   // groups, 16 edges.  tools/_ab sweep of the round, normal-distributed run lengths, 10 M / 2 M edges, auto vs 16-edge groups:
   // average 1.5-2: F=64 +6..7 % / +3.5 %, F=128 +9 % / +7 %, F=256 +10 % / +6.5 %; average 4: +2 % / -1 %, +4.4 % / +3 %,
   // +11 % / +2 %; average 6: 0 / -3 %, +2 % / +1 %, +6 % / 0; from ~10 on the larger groups win again.
-  if (!gather && !atomic_flush && tsize == 4 && vec == 4 && l >= 4 && l == natural) {
-    const int64_t k = K > 0 ? K : 1;
-    if ((l == 4 && 2 * nnz < 7 * k) || (l == 5 && nnz < 8 * k) || (l == 6 && nnz < 5 * k)) cg = 16;
+  // The other dtypes (bf16 / f16 / fp64, 8 loads in flight): the same at 512-byte and 1-KiB rows (bf16 +8..16 %, fp64 +1..8 %);
+  // their 256-byte rows keep 32-edge groups (16-edge groups measured 15 % SLOWER there without the 16-load kernel).
+  if (!gather && !atomic_flush && vec == maxvec && l >= 4 && l == natural && lanes <= 64) {
+    const int64_t k = keys1;
+    if ((l == 4 && tsize == 4 && 2 * nnz < 7 * k) || (l == 5 && nnz < 8 * k) || (l == 6 && nnz < 5 * k)) cg = 16;
   }
   // launch-bound sizes: a lane group walks its cg edges in dependent batches of U row loads, so on a chip that the grid
   // does not fill (< ~400 tiles) shorter groups = more tiles finish sooner.  Measured on graphs of 15 k - 250 k edges
