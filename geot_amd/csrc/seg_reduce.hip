@@ -1705,6 +1705,7 @@ struct Tune {
 };
 Tune g_tune;
 std::atomic<int> g_unroll{0};  // 0 = rule, 8 / 16 = forced
+std::atomic<int> g_gather_grid{4096}; // make_plan: tiles a gathered call is cut into at least, where its size allows (0 = no such bound)
 std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
 std::atomic<int> g_nt_keys{0}; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
 std::atomic<int> g_hub{-1};    // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
@@ -1825,6 +1826,30 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   const int ng = kThreads >> l;
   int cg = (gather ? 1024 : 512) / ng;
   if (l > natural) cg = 32;
+  // Gathered rows: ~1024-edge tiles were chosen on uniform-random sources, where the row gathers miss every cache and the tile
+  // shape hardly matters.  On graphs with LOCALITY (sources near the destination: the rows a tile gathers are in the XCD's L2 if
+  // its neighbours in flight have just used them) and for multi-head weights it matters a lot (late round-3 sweep, 20 M / 2 M
+  // edges, sources within +-2000 rows: gws F=256 2.32 -> 1.73 ms, mh H=8 F=32 2.42 -> 1.81 ms, mh H=4 F=16 0.78 -> 0.57 ms; the
+  // same shapes on uniform-random sources: -3 .. +15 %).  Three bounds on the tile, each only ever shrinking it, 32-edge groups at least:
+  //  * the dst rows the ~160 tiles in flight per XCD cover, times the row size, stay within the XCD's 4 MiB L2 (the part of
+  //    the gather footprint the tile shape controls; the graph's own locality window comes on top);
+  //  * the per-edge LDS (keys, offsets, staged weights) stays within 20 KB: 5 workgroups per CU for every head count;
+  //  * fp32 rows: at least ~4096 tiles where the edge count allows - three rounds of tiles over the chip's ~1280 resident
+  //    workgroups (0.6-2 M edges with locality: +4..13 %; uniform-random sources: level).
+  if (gather && !atomic_flush && l == natural) {
+    const int64_t k = K > 0 ? K : 1;
+    const int64_t by_l2 = (int64_t)(((double)nnz / (double)k) * (double)((int64_t)4 << 20) / ((double)F * tsize * 160.0 * ng));
+    const int64_t by_lds = 20480 / (16 + 4 * (hw > 0 ? hw : 0)) / ng;
+    const int gg = g_gather_grid;
+    const int64_t by_grid = gg > 0 && tsize == 4 ? nnz / ((int64_t)ng * gg) : cg; // (16-bit storage: measured 7-15 % SLOWER with it at 1-2 M edges)
+    int64_t c = cg;
+    if (by_l2 < c) c = by_l2;
+    if (by_lds < c) c = by_lds;
+    if (by_grid < c) c = by_grid;
+    c = c / 16 * 16;
+    if (c < 32) c = 32;
+    if (c < cg) cg = (int)c;
+  }
   if (!gather && vec == maxvec && l == 5) cg = 32; // 512-byte streamed rows, every dtype (bf16 F=256: +7..12 %, fp64 F=64: +3..6 % over 64-edge groups)
   // 1-KiB streamed rows (fp32 F = 256: a whole wave per row): 16 loads in flight over 32-edge groups (round-3 sweep:
   // -2..-4 % at 10 M edges, -10..-15 % at 0.3-1 M edges against 128-edge groups with 8 loads in flight)
@@ -2613,6 +2638,7 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
 
 void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
+  if (name && std::string(name) == "gather_grid") g_gather_grid = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "handoff") g_handoff = value;
   if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
