@@ -1705,6 +1705,7 @@ struct Tune {
 };
 Tune g_tune;
 std::atomic<int> g_unroll{0};  // 0 = rule, 8 / 16 = forced
+std::atomic<int> g_sddmm_shift{-1};    // sddmm_coo_kernel: lanes per row = natural >> shift (each lane then walks 2^shift 16-byte pieces); -1 = by the rule
 std::atomic<int> g_gather_grid{4096}; // make_plan: tiles a gathered call is cut into at least, where its size allows (0 = no such bound)
 std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
 std::atomic<int> g_nt_keys{0}; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
@@ -2307,6 +2308,14 @@ int run_sddmm(const int64_t *si, const int64_t *di, const void *m1, const void *
   int vec = pick_row_vec<T>(F, m1, m2);
   int l = ceil_log2((F + vec - 1) / vec);
   if (l > 6) l = 6;
+  // One lane per 16-byte piece of the row (the gather kernels' layout) makes the dot product's cross-lane reduction the
+  // bottleneck: 5 shuffle steps per edge at 32 lanes per row, two edges per wave step.  Rows of 16 lanes get 8, wider rows a
+  // quarter of their lanes, each lane walking 2-4 pieces (tools/_ab sweep, 20 M / 2 M edges, fp32 and bf16, uniform-random and
+  // local sources: F=64 1.1-1.4x, F=128 1.2-1.8x, F=256 1.2-1.95x; rows of <= 8 lanes: unchanged, fewer lanes measured up to 30 % slower).
+  // (16-bit rows of 8 lanes: 4 lanes from ~8 M edges on, +15-25 %; at 2 M edges 9 % slower)
+  const int shift = g_sddmm_shift >= 0 ? (int)g_sddmm_shift : (l >= 5 ? 2 : (l == 4 ? 1 : (l == 3 && sizeof(T) == 2 && nnz >= 8000000 ? 1 : 0)));
+  l -= shift;
+  if (l < 2) l = 2;
   const int ng = kThreads >> l;
   int64_t chunk = (int64_t)ng * 64;                       // 64 edges per lane group and block
   int64_t blocks = (nnz + chunk - 1) / chunk;
@@ -2639,6 +2648,7 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
 void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "gather_grid") g_gather_grid = value;
+  if (name && std::string(name) == "sddmm_shift") g_sddmm_shift = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "handoff") g_handoff = value;
   if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
