@@ -114,7 +114,11 @@ def test_rewritten_model_is_trainable():
     ep = pattern_transform(model, (x, ei, w))
     ep.module()(x1, ei, w1).square().sum().backward()
     model(x2, ei, w2).square().sum().backward()
+    # (the gradients are sums of terms of both signs with magnitudes in the thousands: an element that cancels to ~0 carries the
+    #  absolute rounding error of those terms - ~2e-3 here, and the eager model's atomics add in a different order every run - so the
+    #  absolute tolerance scales with the tensor's magnitude; a fixed 1e-3 failed about one run in thirty)
     for name, a, b in (("d/dx", x1.grad, x2.grad), ("d/dw", w1.grad, w2.grad)):
         err = (a - b).abs()
         at = int(err.argmax())
-        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3), (name, float(err.max()), float(b.flatten()[at]), at, int((err > 1e-3 + 1e-3 * b.abs()).sum()))
+        atol = 1e-5 * float(b.abs().max())
+        assert torch.allclose(a, b, rtol=1e-3, atol=atol), (name, float(err.max()), float(b.flatten()[at]), at, int((err > atol + 1e-3 * b.abs()).sum()))
