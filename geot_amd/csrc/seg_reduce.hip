@@ -1841,7 +1841,9 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
     const int64_t k = K > 0 ? K : 1;
     const int64_t by_l2 = (int64_t)(((double)nnz / (double)k) * (double)((int64_t)4 << 20) / ((double)F * tsize * 160.0 * ng));
     // (runs of hundreds of edges - configs[3], Reddit scale, on the per-edge kernels - keep the large tile: 16.6 vs 17.4 ms there)
-    const int64_t by_lds = nnz >= 256 * k ? cg : 20480 / (16 + 4 * (hw > 0 ? hw : 0)) / ng;
+    // where that bound is mild anyway (>= 128-edge groups); 16 lanes per row with 4 heads of weights keep 32-edge groups: 0.62 -> 0.46 ms)
+    const int64_t lds_cg = 20480 / (16 + 4 * (hw > 0 ? hw : 0)) / ng;
+    const int64_t by_lds = nnz >= 256 * k && lds_cg >= 128 ? cg : lds_cg;
     const int gg = g_gather_grid;
     const int64_t by_grid = gg > 0 && tsize == 4 ? nnz / ((int64_t)ng * gg) : cg; // (16-bit storage: measured 7-15 % SLOWER with it at 1-2 M edges)
     int64_t c = cg;
