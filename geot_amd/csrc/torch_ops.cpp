@@ -68,7 +68,7 @@ struct Options {
 };
 Options g_opt;
 struct Stats {
-  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0, stale_products = 0, guard_checks = 0;
+  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0, stale_products = 0, guard_checks = 0, plan_trials = 0, plans_rejected = 0;
 };
 Stats g_stats;
 std::mutex g_mu; // guards the caches below (facts, transposed edge lists, slab plans)
@@ -621,6 +621,19 @@ struct SlabPlanHolder {
   at::Tensor w_planorder;
   Produced made, w_made; // events of Phase A / of the weight permutation (consumers on other streams wait for them)
   at::Tensor fp, w_fp;   // fingerprints of the edge list / of the weight those were made from (guard_store)
+  // Is the plan FASTER than the per-edge kernels on this graph?  The density rule that routes a graph here was calibrated on
+  // uniform-random sources.  A dense graph whose sources sit NEAR their destinations (nodes numbered by community) is another
+  // matter: its per-edge gathers hit in L2 anyway, and the plan's chip-wide slab walk makes waves wait for slabs they do not need
+  // - measured 3-20x SLOWER than the per-edge kernels (Reddit scale, sources within +-2000 rows: 48.8 vs 6.2 ms).  So the first
+  // call that would use a plan runs BOTH ways, timed with events on the call's stream, and the plan is kept only if it wins
+  // (per kind of operator).  0 undecided, 1 the plan, 2 the per-edge kernels (the plan's arrays are released then).
+  std::atomic<int> verdict[2] = {{0}, {0}}; // [0] the forward reductions, [1] SDDMM
+  float trial_ms[2][2] = {{0, 0}, {0, 0}};  // [kind][0 plan, 1 per-edge]
+  void release() { // (keeps the holder as the record of the decision)
+    keep.clear();
+    w_planorder = at::Tensor();
+    fp = w_fp = at::Tensor();
+  }
   int64_t bytes() const {
     int64_t b = nbytes_of(w_planorder);
     for (const at::Tensor &t : keep) b += nbytes_of(t);
@@ -894,7 +907,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
           it->rpg == rpg && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R)
         g_slab.splice(g_slab.begin(), g_slab, it);
         g_slab.front().plan->made.before_use(src, g_slab.front().plan->keep);
-        guard_check(g_slab.front().plan->fp, {&si, &di});
+        guard_check(g_slab.front().plan->fp, {&si, &di}); // (a rejected plan has released its fingerprint: the per-edge kernels read the caller's bytes)
         return g_slab.front().plan;
       }
     if (tl_capturing) return nullptr; // Phase A synchronises: never inside a capture (the per-edge kernels serve the call)
@@ -940,6 +953,54 @@ void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::
                            red, ws.data_ptr(), ws.numel(), stream_of(src)));
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.slab_calls;
+}
+
+// One operator call over a graph that has a plan: the plan's kernels or the per-edge kernels (SlabPlanHolder::verdict).
+// run_plan(o) / run_edges(o) enqueue the whole call into `o`.  kind: 0 forward reduction, 1 SDDMM.
+template <typename RunPlan, typename RunEdges>
+at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, at::Tensor o, const at::Tensor &on, RunPlan run_plan, RunEdges run_edges) {
+  int v = plan ? plan->verdict[kind].load() : 2;
+  if (plan && g_opt.slab_mode == 1) v = plan->keep.empty() ? 2 : 1; // forced: no trial (a released plan cannot serve)
+  if (v == 0 && tl_capturing) v = 2;                                // an undecided plan is not tried inside a capture (the trial waits)
+  if (v == 0) {
+    hipStream_t st = static_cast<hipStream_t>(stream_of(on));
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    for (hipEvent_t &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
+    auto destroy = [&]() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); };
+    at::Tensor o2 = at::empty_like(o);
+    try {
+      TORCH_CHECK(hipEventRecord(ev[0], st) == hipSuccess, "hipEventRecord failed");
+      run_plan(o);
+      TORCH_CHECK(hipEventRecord(ev[1], st) == hipSuccess, "hipEventRecord failed");
+      run_edges(o2);
+      TORCH_CHECK(hipEventRecord(ev[2], st) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipEventSynchronize(ev[2]) == hipSuccess, "hipEventSynchronize failed");
+      float t_plan = 0.f, t_edges = 0.f;
+      TORCH_CHECK(hipEventElapsedTime(&t_plan, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&t_edges, ev[1], ev[2]) == hipSuccess,
+                  "hipEventElapsedTime failed");
+      destroy();
+      plan->trial_ms[kind][0] = t_plan;
+      plan->trial_ms[kind][1] = t_edges;
+      const bool keep_plan = t_plan <= t_edges;
+      {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ++g_stats.plan_trials;
+        if (!keep_plan) ++g_stats.plans_rejected;
+        plan->verdict[kind] = keep_plan ? 1 : 2;
+        if (!keep_plan && kind == 0) { // what makes the forward lose makes the SDDMM lose: one decision, and the arrays go
+          plan->verdict[1] = 2;
+          plan->release();
+        }
+      }
+      return keep_plan ? o : o2;
+    } catch (...) {
+      destroy();
+      throw;
+    }
+  }
+  if (v == 1) run_plan(o);
+  else run_edges(o);
+  return o;
 }
 
 // ---- index_scatter -------------------------------------------------------------------------------------------------------------
@@ -1141,8 +1202,23 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
   const int64_t nnz = e.di.numel(), feat = x.size(1);
   auto launch = [&](int64_t rows) {
     at::Tensor o = at::empty({rows, feat}, x.options());
-    if (red != GEOT_REDUCE_PROD && !e.permuted) {      // dense graphs: sum / mean / max / min on the source-blocked kernel
-      if (auto plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1)) {
+    auto run_edges = [&](at::Tensor &o) {
+      auto &ws = workspace(x, geot_workspace_bytes(nnz, feat, rows, dt));
+      if (red == GEOT_REDUCE_SUM && has_w)
+        GEOT_CALL(geot_gather_weight_scatter(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows,
+                                             dt, ws.data_ptr(), ws.numel(), stream_of(x)));
+      else if (red == GEOT_REDUCE_SUM)
+        GEOT_CALL(geot_gather_scatter(index_ptr(e.si), index_ptr(e.di), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows, dt, ws.data_ptr(),
+                                      ws.numel(), stream_of(x)));
+      else
+        GEOT_CALL(geot_gather_reduce(index_ptr(e.si), index_ptr(e.di), has_w ? e.w.data_ptr() : nullptr, x.data_ptr(), o.data_ptr(), nnz, feat,
+                                     x.size(0), rows, dt, red, ws.data_ptr(), ws.numel(), stream_of(x)));
+    };
+    std::shared_ptr<SlabPlanHolder> plan;
+    if (red != GEOT_REDUCE_PROD && !e.permuted)        // dense graphs: sum / mean / max / min on the source-blocked kernel
+      plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1);
+    if (plan) {
+      auto run_plan = [&](at::Tensor &o) {
         const void *wptr = has_w ? e.w.data_ptr() : nullptr;
         int wmode = has_w ? 1 : 0;
         at::Tensor w_planorder;                        // (keeps the permuted copy alive across the launch)
@@ -1155,7 +1231,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
             guard_check(plan->w_fp, {&e.w});
           } else if (tl_capturing) {
             // (no new cache content during a capture)
-          } else if (plan->w_seen_valid && plan->w_seen == wk) { // the same weight content again: permute it once
+          } else if (plan->w_seen_valid && plan->w_seen == wk && plan->keep.size() > 2) { // the same weight content again: permute it once
             plan->w_planorder = e.w.index_select(0, plan->keep[2]);
             plan->w_fp = owned_product(e.w) ? at::Tensor() : guard_store({&e.w});
             plan->w_made.mark(x);
@@ -1172,19 +1248,10 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
           }
         }
         run_slab(*plan, wptr, wmode, x, o, 1, feat, red);
-        return o;
-      }
+      };
+      return plan_or_edges(plan, 0, o, x, run_plan, run_edges);
     }
-    auto &ws = workspace(x, geot_workspace_bytes(nnz, feat, rows, dt));
-    if (red == GEOT_REDUCE_SUM && has_w)
-      GEOT_CALL(geot_gather_weight_scatter(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows,
-                                           dt, ws.data_ptr(), ws.numel(), stream_of(x)));
-    else if (red == GEOT_REDUCE_SUM)
-      GEOT_CALL(geot_gather_scatter(index_ptr(e.si), index_ptr(e.di), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows, dt, ws.data_ptr(),
-                                    ws.numel(), stream_of(x)));
-    else
-      GEOT_CALL(geot_gather_reduce(index_ptr(e.si), index_ptr(e.di), has_w ? e.w.data_ptr() : nullptr, x.data_ptr(), o.data_ptr(), nnz, feat,
-                                   x.size(0), rows, dt, red, ws.data_ptr(), ws.numel(), stream_of(x)));
+    run_edges(o);
     return o;
   };
   if (rows_given >= 0) return launch(rows_given);
@@ -1231,19 +1298,24 @@ at::Tensor mh_spmm_common(const at::Tensor &si, const at::Tensor &di, const at::
   const int64_t heads = x.size(1), feat = x.size(2);
   auto launch = [&](int64_t rows) {
     at::Tensor o = at::empty({rows, heads, feat}, x.options());
+    auto run_edges = [&](at::Tensor &o) {
+      auto &ws = workspace(x, geot_mh_workspace_bytes(nnz, heads, feat, rows, dt));
+      GEOT_CALL(geot_mh_spmm(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, heads, feat, x.size(0), rows, layout,
+                             dt, ws.data_ptr(), ws.numel(), stream_of(x)));
+    };
     if (!e.permuted && (feat * x.element_size()) % 16 == 0 && heads <= 16) {
       // the source-blocked kernel reads weights through the edge permutation: edge-major [nnz, H] is one 16-byte read per
       // edge, head-major [H, nnz] would be H scattered 4-byte reads (H x 64-byte sectors) - transpose it once instead
       // (a streaming pass, ~0.6 ms at 115 M edges x 4 heads)
       if (auto plan = slab_plan_for(e.si, e.di, rows, x, 2, heads)) {
-        at::Tensor w_em = layout == GEOT_W_HEAD_MAJOR ? e.w.t().contiguous() : e.w;
-        run_slab(*plan, w_em.data_ptr(), 2, x, o, heads, feat);
-        return o;
+        auto run_plan = [&](at::Tensor &o) {
+          at::Tensor w_em = layout == GEOT_W_HEAD_MAJOR ? e.w.t().contiguous() : e.w;
+          run_slab(*plan, w_em.data_ptr(), 2, x, o, heads, feat);
+        };
+        return plan_or_edges(plan, 0, o, x, run_plan, run_edges);
       }
     }
-    auto &ws = workspace(x, geot_mh_workspace_bytes(nnz, heads, feat, rows, dt));
-    GEOT_CALL(geot_mh_spmm(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, heads, feat, x.size(0), rows, layout,
-                           dt, ws.data_ptr(), ws.numel(), stream_of(x)));
+    run_edges(o);
     return o;
   };
   if (rows_given >= 0) return launch(rows_given);
@@ -1270,6 +1342,10 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
   at::Tensor si = as_int64(si_in), di = as_int64(di_in);
   at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
   at::Tensor out = at::empty({di.size(0)}, m1.options());
+  auto run_edges = [&](at::Tensor &o) {
+    GEOT_CALL(geot_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), o.data_ptr(), di.size(0), m1.size(1), m1.size(0),
+                             m2.size(0), dtype_code(m1, "sddmm_coo"), stream_of(m1)));
+  };
   if (m1.scalar_type() != at::kDouble && m1.scalar_type() == m2.scalar_type() && di.numel() > 0 && m1.size(0) < ((int64_t)1 << 31)) {
     // a dense graph that has (or now earns) a source-blocked plan - the forward gather_weight_scatter's - and an
     // ascending dst_index (known from the facts): SDDMM over the plan, the gathered m2 rows re-used out of L2
@@ -1278,17 +1354,18 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
         (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(di.numel(), m1.size(0), m2.size(0), rowbytes, dtype_code(m1, "sddmm_coo")))) &&
         (tl_capturing || index_facts(di).ascending)) { // (under capture only an existing plan is used: built on an ascending di)
       if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 1, 1)) {
-        auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
-        GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), out.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
-                                  dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
-        std::lock_guard<std::mutex> lk(g_mu);
-        ++g_stats.slab_calls;
-        return out;
+        auto run_plan = [&](at::Tensor &o) {
+          auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
+          GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
+                                    dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
+          std::lock_guard<std::mutex> lk(g_mu);
+          ++g_stats.slab_calls;
+        };
+        return plan_or_edges(plan, 1, out, m1, run_plan, run_edges);
       }
     }
   }
-  GEOT_CALL(geot_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), out.data_ptr(), di.size(0), m1.size(1), m1.size(0),
-                           m2.size(0), dtype_code(m1, "sddmm_coo"), stream_of(m1)));
+  run_edges(out);
   return out;
 }
 
@@ -1640,7 +1717,7 @@ std::vector<int64_t> host_stats_op() {
   sweep_expired_locked();
   return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
           (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published, g_stats.alarms,
-          cache_bytes_locked(), g_stats.stale_products, g_stats.guard_checks};
+          cache_bytes_locked(), g_stats.stale_products, g_stats.guard_checks, g_stats.plan_trials, g_stats.plans_rejected};
 }
 
 // Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).

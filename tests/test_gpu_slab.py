@@ -103,13 +103,17 @@ def test_host_layer_routes_dense_graphs_on_the_second_call(geot, oracle, monkeyp
     from geot_amd import slab
     assert slab.worthwhile(nnz, nodes, nodes, H * Fh * 4)
     d_si, d_di, d_w, d_x = dev(si), dev(di), dev(w), dev(x)
-    built0, calls0 = ops.stats()["plans_built"], ops.stats()["slab_calls"]
+    built0, calls0, trials0, rejected0 = (ops.stats()[k] for k in ("plans_built", "slab_calls", "plan_trials", "plans_rejected"))
     a = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # first sighting: per-edge gather kernel
     assert ops.stats()["plans_built"] == built0
-    b = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # second: plan built, slab kernel
-    c = geot.mh_spmm(d_si, d_di, d_w, d_x)
-    assert ops.stats()["plans_built"] == built0 + 1 and ops.stats()["slab_calls"] == calls0 + 2
-    assert torch.equal(b, c) and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    b = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # second: plan built and TRIED against the per-edge kernels
+    c = geot.mh_spmm(d_si, d_di, d_w, d_x)                                # third: whichever was faster on this box
+    st = ops.stats()
+    assert st["plans_built"] == built0 + 1 and st["plan_trials"] == trials0 + 1
+    kept = st["plans_rejected"] == rejected0
+    assert st["slab_calls"] == calls0 + (2 if kept else 1)
+    assert torch.allclose(b, c, rtol=1e-5, atol=1e-5) and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert torch.equal(c, geot.mh_spmm(d_si, d_di, d_w, d_x))             # the decision stands: same kernels, same bits
     hi = oracle.mh_spmm(si, di, w, x, rows=nodes, acc64=True)
     close(b, hi, "routed mh_spmm")
     d_si[0] = (d_si[0] + 1) % nodes                                       # in-place edit: the plan must not be reused
@@ -522,3 +526,35 @@ def test_slab_sddmm_16bit_storage(geot, oracle, dtype, nodes, nnz, F):
     again = torch.empty_like(out)
     slab.slab_sddmm_out(plan, m1.cuda(), m2.cuda(), again)
     assert torch.equal(out, again)
+
+
+def test_a_plan_that_loses_to_the_per_edge_kernels_is_dropped(geot, oracle):
+    """The density rule that routes a graph to the source-blocked kernels was calibrated on uniform-random sources.  A dense graph
+    whose sources sit next to their destinations is served much faster by the per-edge kernels (its gathers hit in L2; the plan's
+    chip-wide slab walk only makes waves wait): the first call over a plan runs both and keeps the faster.  Results never change."""
+    from geot_amd import ops, slab
+    rng = np.random.default_rng(21)
+    nodes, nnz, F = 40_000, 12_000_000, 128
+    di = powerlaw_index(nnz, nodes, 4)
+    si = np.clip(di + rng.integers(-300, 301, nnz), 0, nodes - 1).astype(np.int64)     # sources within +-300 rows
+    w = rng.random(nnz, dtype=np.float32)
+    x = rng.random((nodes, F), dtype=np.float32)
+    assert slab.worthwhile(nnz, nodes, nodes, F * 4)
+    d_si, d_di, d_w, d_x = dev(si), dev(di), dev(w), dev(x)
+    ops.clear_caches()
+    st0 = ops.stats()
+    outs = [geot.gather_weight_scatter(d_si, d_di, d_w, d_x) for _ in range(4)]
+    st = ops.stats()
+    assert st["plans_built"] == st0["plans_built"] + 1 and st["plan_trials"] == st0["plan_trials"] + 1
+    assert st["plans_rejected"] == st0["plans_rejected"] + 1, "the per-edge kernels are several times faster on this graph"
+    assert st["slab_calls"] == st0["slab_calls"] + 1                       # the trial's one run over the plan
+    assert st["cache_bytes"] < 64 << 20                                    # the rejected plan's arrays (9 B per edge) are gone
+    hi = oracle.gather_weight_scatter(si, di, w, x, rows=nodes, acc64=True)
+    for o in outs:
+        close(o, hi, "local dense graph")
+    assert torch.equal(outs[2], outs[3])
+    # the decision covers the SDDMM over the same edge list, and a captured graph never tries an undecided plan
+    g = torch.rand(nodes, F, device="cuda")
+    calls = ops.stats()["slab_calls"]
+    torch.ops.geot.sddmm_coo_impl(d_si, d_di, g, d_x)
+    assert ops.stats()["slab_calls"] == calls and ops.stats()["plan_trials"] == st["plan_trials"]
