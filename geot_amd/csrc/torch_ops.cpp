@@ -629,12 +629,17 @@ struct SlabPlanHolder {
   // (per kind of operator).  0 undecided, 1 the plan, 2 the per-edge kernels (the plan's arrays are released then).
   std::atomic<int> verdict[2] = {{0}, {0}}; // [0] the forward reductions, [1] SDDMM
   float trial_ms[2][2] = {{0, 0}, {0, 0}};  // [kind][0 plan, 1 per-edge]
-  void release() { // (keeps the holder as the record of the decision)
-    keep.clear();
-    w_planorder = at::Tensor();
-    fp = w_fp = at::Tensor();
+  void release() { // (keeps the holder as the record of the decision; lock order everywhere: g_mu, then wmu)
+    std::vector<at::Tensor> gone;
+    {
+      std::lock_guard<std::mutex> lk(wmu);
+      gone.swap(keep);
+      w_planorder = at::Tensor();
+      fp = w_fp = at::Tensor();
+    }
   }
-  int64_t bytes() const {
+  int64_t bytes() {
+    std::lock_guard<std::mutex> lk(wmu);
     int64_t b = nbytes_of(w_planorder);
     for (const at::Tensor &t : keep) b += nbytes_of(t);
     return b;
@@ -1223,6 +1228,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
         int wmode = has_w ? 1 : 0;
         at::Tensor w_planorder;                        // (keeps the permuted copy alive across the launch)
         ContentKey wk;
+        const bool w_owned = has_w && owned_product(e.w); // (takes g_mu: before wmu)
         if (has_w && may_remember({&e.w}) && content_key(e.w, &wk)) {
           std::lock_guard<std::mutex> lk(plan->wmu);
           if (plan->w_planorder.defined() && plan->w_key == wk && plan->w_given && !plan->w_given->expired()) {
@@ -1233,7 +1239,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
             // (no new cache content during a capture)
           } else if (plan->w_seen_valid && plan->w_seen == wk && plan->keep.size() > 2) { // the same weight content again: permute it once
             plan->w_planorder = e.w.index_select(0, plan->keep[2]);
-            plan->w_fp = owned_product(e.w) ? at::Tensor() : guard_store({&e.w});
+            plan->w_fp = w_owned ? at::Tensor() : guard_store({&e.w});
             plan->w_made.mark(x);
             plan->w_key = wk;
             plan->w_given = weak_of(e.w);              // (weak: pins the address under this key, not the data)
