@@ -654,8 +654,10 @@ bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t ro
   const int64_t rpg = geot_slab_rows_per_group_dtype(1, 1, dtype); // (16-bit storage: fp32 accumulators, half the rows per group)
   const int64_t rounds = std::max<int64_t>(1, (out_rows + rpg * units - 1) / (rpg * units));
   // uses of a source row per XCD and round; measured (profiles/r02/bench_slab_density_rule.txt, 120 M edges): 10 -> 1.50x,
-  // 4.8 -> 1.34x, 2.8 -> 1.22x, 1.6 -> 1.09x, 0.8 -> 0.86x at 512-B rows; 8.8 -> 2.08x, 2.4 -> 1.62x, 1.0 -> 1.13x at 1 KiB
-  return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= 2.0;
+  // 4.8 -> 1.34x, 2.8 -> 1.22x, 1.6 -> 1.09x, 0.8 -> 0.86x at 512-B rows; 8.8 -> 2.08x, 2.4 -> 1.62x, 1.8 -> 1.43x (Reddit2: 23 M
+  // edges), 1.0 -> 1.13x at 1 KiB.  A graph routed here is only a CANDIDATE: its plan is tried against the per-edge kernels on
+  // first use (plan_or_edges), so the threshold for 1-KiB rows sits where the plan starts to win, not where it wins clearly.
+  return (double)nnz / rounds / 8.0 / (double)std::max<int64_t>(src_rows, 1) >= (rowbytes == 1024 ? 1.0 : 2.0);
 }
 
 // Phase A in ATen: the reference formulation of the plan (generic passes, one stable sort, a host loop over the virtual

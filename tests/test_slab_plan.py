@@ -91,6 +91,8 @@ def test_density_rule():
     assert not slab.worthwhile(123_718_280, 2_449_029, 2_449_029, 512)   # configs[2]: ogbn-products scale
     assert not slab.worthwhile(201_960_734, 13_882_494, 111_059_956, 512)  # configs[4] shard
     assert slab.worthwhile(120_000_000, 450_000, 450_000, 1024)          # measured 1.62x
+    assert slab.worthwhile(23_213_838, 232_965, 232_965, 1024)           # Reddit2 (the reference's benchmark/utils.py:41-43), H=4 F=64: 1.43x
+    assert not slab.worthwhile(100_000_000, 1_000_000, 1_000_000, 1024)  # measured 0.68x
     assert slab.worthwhile(120_000_000, 600_000, 600_000, 512)           # measured 1.22x
     assert not slab.worthwhile(120_000_000, 800_000, 800_000, 512)       # measured 1.09x: not worth a 1 GB plan
     assert not slab.worthwhile(100_000_000, 1_000_000, 1_000_000, 512)   # measured 0.86x
