@@ -256,7 +256,8 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   constexpr bool MEAN = RED == RED_MEAN;
   // the instantiations that can finish their straddling runs in-kernel ("hand-off", at the end of the kernel): streamed
   // rows, fp32 accumulators, whole 16-byte pieces per lane, no per-run counts
-  constexpr bool kHandoff = !GATHER && WMODE == 0 && !ATOMIC && !MEAN && std::is_same<A, float>::value && VEC % 4 == 0;
+  // (16-bit storage with mean: 140 VGPRs with the hand-off compiled in - 3 waves per SIMD instead of 4, measured 13-20 % slower: left out)
+  constexpr bool kHandoff = !GATHER && WMODE == 0 && !ATOMIC && std::is_same<A, float>::value && VEC % 4 == 0 && !(MEAN && sizeof(T) == 2);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   // hand-off: does a run that came in from the previous tile END in this tile?  (lane group 0 learns it at partial 0)
   bool ho_pending = false;
   int64_t ho_key = -1;
+  int64_t ho_cnt = 0; // (mean: the edges of that run inside this tile)
   A ho_head[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) ho_head[q] = red_ident<A, RED>();
@@ -541,14 +543,29 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
     const int cslot_id = (i == 0 && k == kprev_tile) ? 0 : ((at_end && k == knext_tile && k != kNoKey) ? 1 : -1); // (padding is no run)
     if constexpr (MEAN) {
-      if (cslot_id >= 0 && c == 0 && blockIdx.y == 0) p.ccnt[tile * 2 + cslot_id] = csum;
+      if (cslot_id >= 0 && c == 0 && blockIdx.y == 0) {
+        if (kHandoff && p.handoff) // (read by the tile in which the run ends, while this kernel runs: written through, like the carry rows)
+          __hip_atomic_store(&p.ccnt[tile * 2 + cslot_id], csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          p.ccnt[tile * 2 + cslot_id] = csum;
+      }
     }
     if constexpr (kHandoff) {
       if (p.handoff && cslot_id == 0) {
         ho_pending = !(at_end && k == knext_tile); // (a run that also leaves the tile passes through: the tile where it ends takes it)
-        ho_key = k;
+        if constexpr (MEAN) {
+          // (the mean kernel's merge loop is the register peak - counts ride along - and 4 more live registers cost a wave per
+          //  SIMD: the run's head is parked in LDS until the hand-off block - in partial slot 0, which only this lane group reads
+          //  and has just consumed: cslot_id == 0 happens at i == 0 only)
+          A *park = pL + c * VEC;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) ho_head[q] = sum[q];
+          for (int q = 0; q < VEC; ++q) park[q] = sum[q];
+          if (c == 0) cntL[0] = (int)csum; // (edges of this tile: fits)
+        } else {
+          ho_key = k;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) ho_head[q] = sum[q];
+        }
       }
     }
     if (!active) continue;
@@ -597,6 +614,13 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         const int64_t hf0 = (int64_t)cc * VEC < F ? (int64_t)cc * VEC : 0;
         // the tiles' partials meet in float64 and are rounded once: a hub over thousands of tiles is summed tile after tile here,
         // and a float32 running sum would lose ~(tiles) ulps on the way (two tiles: the same correctly rounded sum as a + b)
+        if constexpr (MEAN) { // (parked by this lane group during the merge; same lanes, no barrier needed beyond the one above)
+          const A *park = pL + cc * VEC;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) ho_head[q] = park[q];
+          ho_cnt = cntL[0];
+          ho_key = keysL[0];
+        }
         double hacc[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) hacc[q] = (double)ho_head[q];
@@ -627,6 +651,12 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
           const bool start_here = k < lpr && ((R >> k) & 1ull);
           const int take = start_here ? k + 1 : k; // >= 1
           for (int q0 = 0; q0 < take; q0 += 4) {
+            if constexpr (MEAN) { // the partial runs' edge counts (one word per tile and slot; every lane of the group reads the same ones)
+              for (int u = 0; u < 4 && q0 + u < take; ++u) {
+                const int q = q0 + u;
+                ho_cnt += __hip_atomic_load(&p.ccnt[(j - q) * 2 + (q < k ? 0 : 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
 #pragma unroll
             for (int v0 = 0; v0 < VEC; v0 += 4) {
               ho_f4 r[4];
@@ -651,6 +681,11 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
           if (!done && j < 0) ok = false; // (cannot happen: tile 0 is never single)
         }
         if (ok) {
+          if constexpr (MEAN) {
+            const double inv = 1.0 / (double)ho_cnt;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) hacc[q] *= inv;
+          }
 #pragma unroll
           for (int q = 0; q < VEC; ++q) ho_head[q] = (A)hacc[q];
           if (active && (uint64_t)ho_key < (uint64_t)K) store_vec<T, VEC, NTS>(dstf + ho_key * F, ho_head);
@@ -2094,7 +2129,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // 2.5-8 % at every size; rows of <= 128 bytes gain 2-5 % up to ~1 M edges and LOSE 2-16 % beyond (short tiles: the drain at
   // the end of every workgroup is a larger share of its life) - those keep the classic second pass.  `handoff` = 2 forces.
   const bool ho_pays = p.rowbytes >= 256 || nnz <= 2000000 || g_handoff == 2;
-  p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && red != RED_MEAN && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
+  const bool mean16 = red == RED_MEAN && sizeof(T) == 2; // (not compiled into the tile kernel: see kHandoff there)
+  p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && !mean16 && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
   p.ho_tries = g_handoff_tries;
   p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
   p.epoch = 0x6E07A5C300000000ull + (++epoch_counter & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)

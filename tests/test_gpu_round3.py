@@ -380,7 +380,21 @@ def test_handoff_results_with_data_that_changes_every_call(geot):
         mx = geot.index_scatter(0, src, t_index, "max", True)
         want = torch.zeros(K, F, device="cuda").scatter_reduce(0, t_index[:, None].expand(-1, F), src.float(), "amax", include_self=False)
         assert torch.equal(mx.float(), want), (name, "max")
-        del base, ref0, src, want, out, mx
+        # mean: the partial runs' edge counts travel with their rows (fp32 storage; 16-bit storage keeps the classic second pass)
+        counts = torch.bincount(t_index, minlength=K).clamp_min(1).double()[:, None]
+        for it in range(4):
+            src = (base * float(it + 1)).to(dtype)
+            want = _segment_sums(t_index, src.double(), K) / counts
+            mean = geot.index_scatter(0, src, t_index, "mean", True)
+            assert torch.allclose(mean.double(), want, rtol=tol, atol=1e-6 * (it + 1)), (name, "mean", it)
+        assert torch.equal(mean, geot.index_scatter(0, src, t_index, "mean", True)), (name, "mean not reproducible")
+        hip.set_option("handoff", 0)
+        try:
+            classic = geot.index_scatter(0, src, t_index, "mean", True)
+        finally:
+            hip.set_option("handoff", 1)
+        assert torch.allclose(mean.double(), classic.double(), rtol=tol, atol=1e-6 * (it + 1)), (name, "mean: classic second pass disagrees")
+        del base, ref0, src, want, out, mx, mean, classic
 
 
 def test_handoff_gives_up_gracefully_and_the_second_launch_finishes_the_call(geot):
@@ -392,11 +406,14 @@ def test_handoff_gives_up_gracefully_and_the_second_launch_finishes_the_call(geo
     t_index = dev(index)
     src = torch.rand(index.size, F, device="cuda")
     want = _segment_sums(t_index, src.double(), K)
+    want_mean = want / torch.bincount(t_index, minlength=K).clamp_min(1).double()[:, None]
     hip.set_option("handoff_tries", 0)
     try:
         for _ in range(6):
             out = geot.index_scatter(0, src, t_index, "sum", True)
             assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-6)
+            mean = geot.index_scatter(0, src, t_index, "mean", True)         # (deferred runs: the second launch divides by the counts)
+            assert torch.allclose(mean.double(), want_mean, rtol=1e-5, atol=1e-6)
     finally:
         hip.set_option("handoff_tries", 400000)
     out = geot.index_scatter(0, src, t_index, "sum", True)
