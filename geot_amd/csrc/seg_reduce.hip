@@ -1880,7 +1880,9 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
     const int64_t lds_cg = 20480 / (16 + 4 * (hw > 0 ? hw : 0)) / ng;
     const int64_t by_lds = nnz >= 256 * k && lds_cg >= 128 ? cg : lds_cg;
     const int gg = g_gather_grid;
-    const int64_t by_grid = gg > 0 && tsize == 4 ? nnz / ((int64_t)ng * gg) : cg; // (16-bit storage: measured 7-15 % SLOWER with it at 1-2 M edges)
+    // (16-bit storage: measured 7-15 % SLOWER with it at 1-2 M edges; runs of hundreds of edges: 12-17 % slower at 0.3-1 M edges - fewer,
+    //  longer groups mean fewer partials to merge, which is what such a call waits for)
+    const int64_t by_grid = gg > 0 && tsize == 4 && nnz < 128 * k ? nnz / ((int64_t)ng * gg) : cg;
     int64_t c = cg;
     if (by_l2 < c) c = by_l2;
     if (by_lds < c) c = by_lds;
