@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         for (int q = 0; q < VEC; ++q) sum[q] = red_op<A, RED>(sum[q], pL[(size_t)j * FB + c * VEC + q]);
         // a long run (hub segment): walk it in batches of kMB slots whose LDS reads are independent,
         // one round trip per batch instead of one per slot; partials are still added in edge order
-        constexpr int kMB = 8;
+        constexpr int kMB = VEC > 4 ? 4 : 8; // (8 elements per lane: half the batch, the same registers)
         for (++j; j < ne; j += kMB) {
           int64_t kk[kMB];
           A val[kMB][VEC];
@@ -1740,6 +1740,7 @@ struct Tune {
 };
 Tune g_tune;
 std::atomic<int> g_unroll{0};  // 0 = rule, 8 / 16 = forced
+std::atomic<int> g_lds_floor{-1};      // tile kernel, 16-bit storage: dynamic LDS asked for per workgroup at least (caps the workgroups per CU); -1 = by the rule
 std::atomic<int> g_sddmm_shift{-1};    // sddmm_coo_kernel: lanes per row = natural >> shift (each lane then walks 2^shift 16-byte pieces); -1 = by the rule
 std::atomic<int> g_gather_grid{4096}; // make_plan: tiles a gathered call is cut into at least, where its size allows (0 = no such bound)
 std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
@@ -1956,13 +1957,38 @@ Plan narrow_plan(int64_t nnz, int64_t F, int64_t K, bool lane_seq, bool gather =
 }
 
 
+// Dynamic LDS a tile-kernel launch asks for: the layout's bytes, or MORE - the only handle on the number of workgroups a CU
+// takes (160 KB of LDS per CU: 33 000 bytes -> 4 workgroups, 41 000 -> 3).  Streamed rows of >= 512 bytes run faster with
+// fewer tiles in flight (see g_lds_floor and make_plan's notes); everything else takes what fits.
+// Measured (tools/_ab sweep, 10 M / 2 M power-law edges, sum / mean / max; gains over "what fits"): fp32 rows of 512 B: 4 per CU
+// +1..2 %, 1 KiB: 3 per CU +3..6 %; bf16 512 B: 4 (+3.4 %), 1 KiB: 3 (+5 %), their means (classic second pass) one step
+// lower (+4..8 %); fp64 256 B: 4 (+1..4 %), 512 B: 3 (+4..6 %), 1 KiB: 2 (+7..10 %).  Narrower rows: every cap measured slower.
+// Fewer, longer streams reach the memory at once.  Only for grids that fill the chip several times over.
+// The GRADED shape too (fp32, 256-byte rows, sum, 16 loads in flight per lane, 19 532 tiles): 4 workgroups per CU instead of the
+// 5 that fit: 0.4690 vs 0.4744 ms (six alternating repetitions on one box, spread 0.001); 3 per CU: 0.4838.  Its max / mean
+// (8 loads in flight) lose 1-2 % with the cap and keep what fits; so do 2 M edges (3906 tiles: -3 %).
+inline size_t tile_lds(const SmemLayout &L, const SegParams &p, int64_t num_tiles, int tsize, bool gather, int red, int unroll = 8) {
+  int floor_bytes = g_lds_floor;
+  if (floor_bytes < 0) {
+    floor_bytes = 0;
+    if (!gather && num_tiles >= 4096) {
+      constexpr int kPerCu[4] = {0, 33000, 41000, 54000}; // what fits / 4 / 3 / 2 workgroups per CU
+      int step = p.rowbytes >= 1024 ? (red == RED_SUM ? 2 : 1) : (p.rowbytes >= 512 ? 1 : 0);
+      if (tsize == 8) step = p.rowbytes >= 1024 ? 3 : (p.rowbytes >= 512 ? 2 : (p.rowbytes >= 256 ? 1 : 0));
+      if (tsize == 2 && red == RED_MEAN && p.rowbytes >= 256 && step < 3) ++step;
+      if (tsize == 4 && p.rowbytes == 256 && unroll == 16 && red == RED_SUM && num_tiles >= 8192) step = 1;
+      floor_bytes = kPerCu[step];
+    }
+  }
+  return (size_t)floor_bytes > L.bytes ? (size_t)floor_bytes : L.bytes;
+}
+
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
 void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
   const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(typename AccOf<T>::type), GATHER, hw);
   dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
-  hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads),
-                     L.bytes, st, p);
+  hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), GATHER, RED), st, p);
 }
 
 // non-sum reductions, sorted index.  index_scatter: streamed operand -> nt loads + stores;
@@ -1975,7 +2001,7 @@ int dispatch_reduce_mode(const SegParams &p, const Plan &P, hipStream_t st) {
     if (P.unroll == 16 && P.vec == MAXV) {   // 16 row loads in flight per lane, as the sum (the tile shape was chosen for it)
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
-      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED, 16>), grid, dim3(kThreads), L.bytes, st, p);
+      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED, 16>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), false, RED, 16), st, p);
       return GEOT_OK;
     }
   }
@@ -2033,7 +2059,7 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
     if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 3) {   // 16 row loads in flight per lane
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
-      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED_SUM, 16>), grid, dim3(kThreads), L.bytes, st, p);
+      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED_SUM, 16>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), false, RED_SUM, 16), st, p);
       return GEOT_OK;
     }
   }
@@ -2041,7 +2067,7 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
     if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 0) {   // gather modes, default cache policy
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), true, WMODE);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
-      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, true, WMODE, false, 0, RED_SUM, 16>), grid, dim3(kThreads), L.bytes, st, p);
+      hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, true, WMODE, false, 0, RED_SUM, 16>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), true, RED_SUM), st, p);
       return GEOT_OK;
     }
   }
@@ -2690,6 +2716,7 @@ void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "unroll") g_unroll = value;
   if (name && std::string(name) == "gather_grid") g_gather_grid = value;
   if (name && std::string(name) == "sddmm_shift") g_sddmm_shift = value;
+  if (name && std::string(name) == "lds_floor") g_lds_floor = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "handoff") g_handoff = value;
   if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
