@@ -123,8 +123,12 @@ __device__ __forceinline__ void publish_word(const SegParams &p) {
 // the consumer loads only after its poll of the flag has matched).  16-byte forms; the load waits for its data in the same
 // asm statement, so the compiler never sees a register that is still in flight.
 typedef float ho_f4 __attribute__((ext_vector_type(4)));
+// HAZARD: a VMEM store of more than 8 bytes reads its data registers a few cycles after issue, and on gfx940+ a VALU write to
+// those registers needs 2 wait states behind it.  The compiler inserts them for its own stores; it cannot see into an asm
+// statement - and did, for the 16-bit mean kernel (two stores per lane), compute the second store's address INTO the first
+// store's data registers in the very next instruction: elements 0-1 of the lane's piece went out wrong.  Hence the s_nop here.
 __device__ __forceinline__ void ho_store16(float *p, const ho_f4 &v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void ho_load16x4(const float *p0, const float *p1, const float *p2, const float *p3, ho_f4 &a, ho_f4 &b, ho_f4 &c,
                                             ho_f4 &d) {
@@ -256,8 +260,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   constexpr bool MEAN = RED == RED_MEAN;
   // the instantiations that can finish their straddling runs in-kernel ("hand-off", at the end of the kernel): streamed
   // rows, fp32 accumulators, whole 16-byte pieces per lane, no per-run counts
-  // (16-bit storage with mean: 140 VGPRs with the hand-off compiled in - 3 waves per SIMD instead of 4, measured 13-20 % slower: left out)
-  constexpr bool kHandoff = !GATHER && WMODE == 0 && !ATOMIC && std::is_same<A, float>::value && VEC % 4 == 0 && !(MEAN && sizeof(T) == 2);
+  constexpr bool kHandoff = !GATHER && WMODE == 0 && !ATOMIC && std::is_same<A, float>::value && VEC % 4 == 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if constexpr (kHandoff) {
       if (p.handoff && cslot_id == 0) {
         ho_pending = !(at_end && k == knext_tile); // (a run that also leaves the tile passes through: the tile where it ends takes it)
-        if constexpr (MEAN) {
+        if constexpr (MEAN && sizeof(T) == 4) { // (fp32 storage; the 16-bit kernels have registers to spare)
           // (the mean kernel's merge loop is the register peak - counts ride along - and 4 more live registers cost a wave per
           //  SIMD: the run's head is parked in LDS until the hand-off block - in partial slot 0, which only this lane group reads
           //  and has just consumed: cslot_id == 0 happens at i == 0 only)
@@ -563,6 +566,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
           if (c == 0) cntL[0] = (int)csum; // (edges of this tile: fits)
         } else {
           ho_key = k;
+          if constexpr (MEAN) ho_cnt = csum;
 #pragma unroll
           for (int q = 0; q < VEC; ++q) ho_head[q] = sum[q];
         }
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
         const int64_t hf0 = (int64_t)cc * VEC < F ? (int64_t)cc * VEC : 0;
         // the tiles' partials meet in float64 and are rounded once: a hub over thousands of tiles is summed tile after tile here,
         // and a float32 running sum would lose ~(tiles) ulps on the way (two tiles: the same correctly rounded sum as a + b)
-        if constexpr (MEAN) { // (parked by this lane group during the merge; same lanes, no barrier needed beyond the one above)
+        if constexpr (MEAN && sizeof(T) == 4) { // (parked by this lane group during the merge; same lanes, no barrier needed beyond the one above)
           const A *park = pL + cc * VEC;
 #pragma unroll
           for (int q = 0; q < VEC; ++q) ho_head[q] = park[q];
@@ -1961,8 +1965,7 @@ Plan narrow_plan(int64_t nnz, int64_t F, int64_t K, bool lane_seq, bool gather =
 // takes (160 KB of LDS per CU: 33 000 bytes -> 4 workgroups, 41 000 -> 3).  Streamed rows of >= 512 bytes run faster with
 // fewer tiles in flight (see g_lds_floor and make_plan's notes); everything else takes what fits.
 // Measured (tools/_ab sweep, 10 M / 2 M power-law edges, sum / mean / max; gains over "what fits"): fp32 rows of 512 B: 4 per CU
-// +1..2 %, 1 KiB: 3 per CU +3..6 %; bf16 512 B: 4 (+3.4 %), 1 KiB: 3 (+5 %), their means (classic second pass) one step
-// lower (+4..8 %); fp64 256 B: 4 (+1..4 %), 512 B: 3 (+4..6 %), 1 KiB: 2 (+7..10 %).  Narrower rows: every cap measured slower.
+// +1..2 %, 1 KiB: 3 per CU +3..6 %; bf16 512 B: 4 (+3.4 %), 1 KiB: 3 (+5 %), fp64 256 B: 4 (+1..4 %), 512 B: 3 (+4..6 %), 1 KiB: 2 (+7..10 %).  Narrower rows: every cap measured slower.
 // Fewer, longer streams reach the memory at once.  Only for grids that fill the chip several times over.
 // The GRADED shape too (fp32, 256-byte rows, sum, 16 loads in flight per lane, 19 532 tiles): 4 workgroups per CU instead of the
 // 5 that fit: 0.4690 vs 0.4744 ms (six alternating repetitions on one box, spread 0.001); 3 per CU: 0.4838.  Its max / mean
@@ -1975,7 +1978,6 @@ inline size_t tile_lds(const SmemLayout &L, const SegParams &p, int64_t num_tile
       constexpr int kPerCu[4] = {0, 33000, 41000, 54000}; // what fits / 4 / 3 / 2 workgroups per CU
       int step = p.rowbytes >= 1024 ? (red == RED_SUM ? 2 : 1) : (p.rowbytes >= 512 ? 1 : 0);
       if (tsize == 8) step = p.rowbytes >= 1024 ? 3 : (p.rowbytes >= 512 ? 2 : (p.rowbytes >= 256 ? 1 : 0));
-      if (tsize == 2 && red == RED_MEAN && p.rowbytes >= 256 && step < 3) ++step;
       if (tsize == 4 && p.rowbytes == 256 && unroll == 16 && red == RED_SUM && num_tiles >= 8192) step = 1;
       floor_bytes = kPerCu[step];
     }
@@ -2157,8 +2159,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // 2.5-8 % at every size; rows of <= 128 bytes gain 2-5 % up to ~1 M edges and LOSE 2-16 % beyond (short tiles: the drain at
   // the end of every workgroup is a larger share of its life) - those keep the classic second pass.  `handoff` = 2 forces.
   const bool ho_pays = p.rowbytes >= 256 || nnz <= 2000000 || g_handoff == 2;
-  const bool mean16 = red == RED_MEAN && sizeof(T) == 2; // (not compiled into the tile kernel: see kHandoff there)
-  p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && !mean16 && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
+  p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
   p.ho_tries = g_handoff_tries;
   p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
   p.epoch = 0x6E07A5C300000000ull + (++epoch_counter & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)
