@@ -2158,7 +2158,10 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // Measured (tools/bench_handoff_ab.py: F = 16..256 x 1-10 M edges, fp32 / bf16, alternating modes on one box): rows of >= 256 bytes gain
   // 2.5-8 % at every size; rows of <= 128 bytes gain 2-5 % up to ~1 M edges and LOSE 2-16 % beyond (short tiles: the drain at
   // the end of every workgroup is a larger share of its life) - those keep the classic second pass.  `handoff` = 2 forces.
-  const bool ho_pays = p.rowbytes >= 256 || nnz <= 2000000 || g_handoff == 2;
+  // ... and not where such narrow rows come in runs of hundreds of edges above launch-bound sizes (2 M edges on 2 000-8 000 keys, F = 16 / 32:
+  // -7..-25 %: the walk back over a hub's tiles is not hidden by anything there).
+  const bool narrow_long = p.rowbytes <= 128 && nnz > 700000 && nnz >= 128 * (K > 0 ? K : 1);
+  const bool ho_pays = p.rowbytes >= 256 || (nnz <= 2000000 && !narrow_long) || g_handoff == 2;
   p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
   p.ho_tries = g_handoff_tries;
   p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
