@@ -329,7 +329,11 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
  * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
  * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
  * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
- * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free) */
+ * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free);
+ * "handoff_tries" = polls of a predecessor's flag before a run is left to the second launch (0: sample once);
+ * "lds_floor" = -1 | bytes: dynamic LDS a tile-kernel launch asks for at least - the cap on workgroups per CU
+ * (-1: the rule; 33000 -> 4, 41000 -> 3, 54000 -> 2 per CU); "gather_grid" = tiles a gathered fp32 call is cut into
+ * at least (4096; 0 off); "sddmm_shift" = -1 | n: lanes per row of the per-edge SDDMM = natural >> n (-1: the rule) */
 void geot_set_option(const char *name, int value);
 
 #ifdef __cplusplus
