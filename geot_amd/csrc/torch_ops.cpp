@@ -953,11 +953,39 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   return plan;
 }
 
+// The source-blocked kernels are PERSISTENT grids sized for the whole chip whose waves keep step with each other: two of them at once
+// (calls from several threads, each on its own stream) would take each other's CUs and wait for waves that are not running - bounded
+// waits, but the design's premise is gone, and a 1-in-25 hang of the box was seen with three of them in flight.  So they take turns on
+// the device: a launch waits (on its stream) for the event of the previous one, whichever stream that was on.  Not under capture.
+struct SlabTurn {
+  std::mutex mu;
+  std::map<int, hipEvent_t> last; // per device
+  template <typename Launch> void take(const at::Tensor &on, Launch launch) {
+    if (tl_capturing) {
+      launch();
+      return;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    hipStream_t st = static_cast<hipStream_t>(stream_of(on));
+    hipEvent_t &e = last[(int)on.device().index()];
+    if (e) {
+      TORCH_CHECK(hipStreamWaitEvent(st, e, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    } else {
+      TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    }
+    launch();
+    TORCH_CHECK(hipEventRecord(e, st) == hipSuccess, "hipEventRecord failed");
+  }
+};
+SlabTurn g_slab_turn;
+
 void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
               int red = GEOT_REDUCE_SUM) {
   auto &ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
-  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
-                           red, ws.data_ptr(), ws.numel(), stream_of(src)));
+  g_slab_turn.take(src, [&]() {
+    GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
+                             red, ws.data_ptr(), ws.numel(), stream_of(src)));
+  });
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.slab_calls;
 }
@@ -1364,8 +1392,10 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
       if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 1, 1)) {
         auto run_plan = [&](at::Tensor &o) {
           auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
-          GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
-                                    dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
+          g_slab_turn.take(m1, [&]() {
+            GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
+                                      dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
+          });
           std::lock_guard<std::mutex> lk(g_mu);
           ++g_stats.slab_calls;
         };
