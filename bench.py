@@ -105,6 +105,62 @@ def powerlaw_index(nnz, keys, seed, device):
     return idx
 
 
+def _mix64(e, seed):
+    """splitmix64-style hash of int64 edge numbers (wrapping int64 arithmetic), 63-bit non-negative result: edge e of the
+    global list gets the same source whatever rank generates it and however many ranks there are."""
+    m1, m2, m3 = 0x9E3779B97F4A7C15 - (1 << 64), 0xBF58476D1CE4E5B9 - (1 << 64), 0x94D049BB133111EB - (1 << 64)
+    x = e * m1 + seed
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * m2
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * m3
+    x = x ^ ((x >> 31) & 0x1FFFFFFFF)
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
+def global_list_shard(rows_global, nnz_target, src_nodes, world, rank, cuts, seed, device):
+    """Rank `rank`'s contiguous slice of ONE global dst-sorted power-law edge list, generated WITHOUT materialising the list:
+    every rank derives the same per-row edge counts from the same seed (w_k ~ rank^(-1/1.5), ranks randomly permuted,
+    randomised rounding of the expected count - rows_global values, cheap), cuts the edge range [0, nnz) like
+    geot_amd.sharding.equal_edge_cuts / segment_aligned_cuts would, and expands only its own rows; the source of edge e is a
+    hash of e.  Returns (dst_index_local, src_index, first_key, my_rows_upper, nnz_global, cut_edges):
+    dst_index_local = global key - first_key (what sharded_gather_scatter's key_offset expects)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    w = torch.arange(1, rows_global + 1, device=device, dtype=torch.float64) ** (-1.0 / 1.5)
+    w *= nnz_target / float(w.sum())
+    perm = torch.randperm(rows_global, generator=g, device=device)
+    counts = torch.floor(w[perm] + torch.rand(rows_global, generator=g, device=device, dtype=torch.float64)).to(torch.int64)
+    del w, perm
+    counts[-1].clamp_(min=1)                                  # the last row exists: rows = index[-1] + 1 = rows_global
+    ends = torch.cumsum(counts, 0)                            # ends[k] = first edge of row k + 1
+    nnz = int(ends[-1].item())
+    edges = [(nnz * r) // world for r in range(world + 1)]
+    if cuts == "aligned":                                     # move every cut to the next row start (no key shared by two ranks)
+        probe = torch.tensor(edges[1:-1], device=device, dtype=torch.int64)
+        k = torch.searchsorted(ends, probe, right=True)       # row holding edge e
+        starts = torch.where(k > 0, ends[(k - 1).clamp_(min=0)], torch.zeros_like(probe))
+        snapped = torch.where(starts == probe, probe, ends[k])
+        edges = [0] + [int(v) for v in snapped.tolist()] + [nnz]
+        for i in range(1, len(edges)):
+            edges[i] = max(edges[i], edges[i - 1])
+    e0, e1 = edges[rank], edges[rank + 1]
+    if e1 <= e0:
+        raise SystemExit(f"rank {rank}: empty shard (too few edges for {world} ranks)")
+    k0 = int(torch.searchsorted(ends, torch.tensor([e0], device=device), right=True).item())
+    k1 = int(torch.searchsorted(ends, torch.tensor([e1 - 1], device=device), right=True).item())
+    mine = counts[k0:k1 + 1].clone()
+    mine[0] = int(ends[k0].item()) - e0                       # the part of row k0 that lies in [e0, e1)
+    if k1 > k0:
+        mine[-1] = e1 - (int(ends[k1 - 1].item()))
+    else:
+        mine[0] = e1 - e0
+    del counts, ends
+    dst_local = torch.repeat_interleave(torch.arange(k1 - k0 + 1, device=device, dtype=torch.int64), mine, output_size=e1 - e0)
+    del mine
+    src_index = _mix64(torch.arange(e0, e1, device=device, dtype=torch.int64), seed + 1) % src_nodes
+    return dst_local, src_index, k0, k1 - k0 + 1, nnz, edges
+
+
 def algorithmic_bytes(nnz, feat, rows):
     """each src row and index read once, each dst row written once."""
     return nnz * (4 * feat + 8) + rows * 4 * feat
@@ -167,14 +223,15 @@ def device_ms(fn, iters, warmup=2):
     return a.elapsed_time(b) / iters
 
 
-SECONDARY = ("gws_cfg3", "gws_cfg3_local", "mh_spmm_cfg4", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16")
+SECONDARY = ("cfg1", "gws_cfg3", "gws_cfg3_local", "gws_cfg3_powerlaw_src", "mh_spmm_cfg4", "mh_spmm_cfg4_powerlaw_src",
+             "gws_cfg3_bf16", "mh_spmm_cfg4_bf16")
 
 
 def profiled(entry):
     """PMC-derived fabric traffic of a secondary workload's kernel, from the round's profiling session (committed under
     profiles/; tools/profile_round.sh + tools/derive_traffic.py) - a recorded measurement of the same kernel on the same
     workload, not a measurement of this run: labelled with its source."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "gather_kernels.json")
         try:
             k = json.load(open(f))["kernels"].get(entry)
@@ -201,27 +258,39 @@ def secondary(dev, scale=1.0, iters=5, only=None):
     want = set(only) if only else set(SECONDARY)
     res = {}
 
-    def gws(name, local, dtype):
+    def sources(kind, di, nodes, g):
+        """src_index of a stand-in graph: "uniform" = no structure at all (every row gather misses: the worst case); "local" =
+        within +-2000 rows of the destination (nodes numbered by community); "powerlaw" = SURVEY.md 8(d)'s "permuted endpoints":
+        src_index = dst_index[randperm(nnz)] - sources exactly as skewed as the destinations (the named graphs are symmetrised:
+        a hub is a hub on both sides), ids unordered."""
+        nnz = di.numel()
+        if kind == "local":
+            return (di + torch.randint(-2000, 2001, (nnz,), device=dev, generator=g)).clamp_(0, nodes - 1)
+        if kind == "powerlaw":
+            return di[torch.randperm(nnz, device=dev, generator=g)].contiguous()
+        return torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+
+    SRC_DESC = {"uniform": "uniform-random src", "local": "sources within +-2000 rows of the destination (uniform offset, clamped)",
+                "powerlaw": "src = a random permutation of the dst endpoints (as skewed as the destinations, ids unordered)"}
+
+    def gws(name, kind, dtype):
         nodes, nnz, F = int(2_449_029 * scale), int(123_718_280 * scale), 128
         esize = 4 if dtype == torch.float32 else 2
         di = powerlaw_index(nnz, nodes, 7, dev)
         g = torch.Generator(device=dev)
         g.manual_seed(8)
-        if local:
-            si = (di + torch.randint(-2000, 2001, (nnz,), device=dev, generator=g)).clamp_(0, nodes - 1)
-        else:
-            si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+        si = sources(kind, di, nodes, g)
         w = torch.rand(nnz, device=dev, generator=g).to(dtype)
         x = torch.rand(nodes, F, device=dev, generator=g).to(dtype)
         out = torch.empty(nodes, F, device=dev, dtype=dtype)
         ms = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), iters)
+        kernel = hip.last_kernel()
         op_ms = device_ms(lambda: geot.gather_weight_scatter(si, di, w, x), iters)
         uniq = int(torch.unique(si).numel())
         comp = nnz * (16 + esize) + uniq * esize * F + nodes * esize * F
-        src_desc = "sources within +-2000 rows of the destination (uniform offset, clamped)" if local else "uniform-random src"
-        entry = {"workload": f"gather_weight_scatter, power-law dst / {src_desc}, {nodes} nodes, {nnz} edges, feat={F}, "
+        entry = {"workload": f"gather_weight_scatter, power-law dst / {SRC_DESC[kind]}, {nodes} nodes, {nnz} edges, feat={F}, "
                              f"{str(dtype).split('.')[-1]}, int64 COO dst-sorted (stand-in of ogbn-products)",
-                 "kernel_ms": ms, "op_ms_with_row_rule": op_ms, "edges_per_s": nnz / ms * 1e3,
+                 "kernel": kernel, "kernel_ms": ms, "op_ms_with_row_rule": op_ms, "edges_per_s": nnz / ms * 1e3,
                  "compulsory_bytes": comp, "distinct_src_rows": uniq,
                  "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": comp / ms / 1e6 / HBM_PEAK_GBPS, **profiled(name)},
@@ -243,13 +312,13 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         del di, si, w, x, out
         torch.cuda.empty_cache()
 
-    def mh(name, dtype):
+    def mh(name, dtype, kind="uniform"):
         nodes, nnz, H, F = int(232_965 * scale), int(114_615_892 * scale), 4, 64
         esize = 4 if dtype == torch.float32 else 2
         di = powerlaw_index(nnz, nodes, 11, dev)
         g = torch.Generator(device=dev)
         g.manual_seed(12)
-        si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+        si = sources(kind, di, nodes, g)
         w = torch.rand(nnz, H, device=dev, generator=g).to(dtype)
         x = torch.rand(nodes, H, F, device=dev, generator=g).to(dtype)
         out = torch.empty(nodes, H, F, device=dev, dtype=dtype)
@@ -273,6 +342,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         # edge list) and then served by the source-blocked kernel (csrc/seg_slab.hip); device time, steady state
         st0 = ops.stats()
         ms = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters, warmup=3)
+        kernel = hip.last_kernel()
         st1 = ops.stats()
         # the same with the content guard off: what the fingerprint re-check of the remembered plan costs (csrc/seg_guard.hip)
         guard_was = ops.set_option("content_guard", 0)
@@ -284,15 +354,14 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         slab_used = st1["slab_calls"] > st0["slab_calls"]
         uniq = int(torch.unique(si).numel())
         comp = nnz * (16 + esize * H) + uniq * esize * H * F + nodes * esize * H * F
-        tname = "float" if dtype == torch.float32 else "bf16"
         res[name] = {
-            "workload": f"mh_spmm, power-law dst / uniform-random src, {nodes} nodes, {nnz} edges, heads={H} feat={F}, "
+            "workload": f"mh_spmm, power-law dst / {SRC_DESC[kind]}, {nodes} nodes, {nnz} edges, heads={H} feat={F}, "
                         f"{str(dtype).split('.')[-1]} (stand-in of Reddit)",
             "kernel_ms": ms,
             "content_guard": "on: every call re-reads both index arrays and compares their fingerprint with the plan's (kernel_ms includes it)",
             "kernel_ms_without_content_guard": ms_unguarded,
-            "kernel": f"seg_slab_kernel<{tname}, 2, {'true' if H * F * esize == 1024 else 'false'}, sum> (+ memset, combine)" if slab_used
-                      else f"seg_tile_kernel<{tname}, ..., true, 2, ...>",
+            "kernel": kernel + (" (+ memset, combine)" if slab_used else ""),     # what the operator launched (geot_last_kernel)
+            "plan_trial_ms": {"plan": st1["trial_plan_us"] / 1e3, "per_edge": st1["trial_edges_us"] / 1e3} if st1["plan_trials"] > st0["plan_trials"] else None,
             "source_blocked_path": slab_used,
             "phase_a": "device builder csrc/seg_plan.hip; wall ms of one build on an idle stream, synchronised before and after",
             "phase_a_ms_once_per_edge_list": phase_a[0] if phase_a else None,          # the first plan this process builds
@@ -309,14 +378,91 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         ops.clear_caches()
         torch.cuda.empty_cache()
 
+    def cfg1(name):
+        """BASELINE.json configs[0]: the reference's own CPU-runnable case (test/test_index_scatter.py scaled to 100 k x 32 ->
+        10 k segments; SURVEY.md 8(d) generator).  Launch-bound on the GPU: microseconds per call AS DISPATCHED (the drop-in
+        operator: read-back of index[-1], allocation, two launches), the kernel alone, and the reference's CPU kernel on the
+        same inputs."""
+        nnz, K, F = 100_000, 10_000, 32
+        g = torch.Generator(device=dev)
+        g.manual_seed(0)
+        index = torch.randint(0, K, (nnz,), device=dev, generator=g).sort().values.contiguous()
+        index[-1] = K - 1
+        g.manual_seed(1)
+        src = torch.rand(nnz, F, device=dev, generator=g)
+        for _ in range(20):
+            out = geot.index_scatter(0, src, index, "sum", True)
+        torch.cuda.synchronize()
+        n = 300
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = geot.index_scatter(0, src, index, "sum", True)
+        torch.cuda.synchronize()
+        wall_us = (time.perf_counter() - t0) / n * 1e6
+        hip.profile_enable(True)
+        hip.profile_reset()
+        for _ in range(50):
+            out = geot.index_scatter(0, src, index, "sum", True)
+        torch.cuda.synchronize()
+        prof = hip.profile_read()
+        hip.profile_enable(False)
+        kernel = hip.last_kernel()
+        k_us = prof["main_ms"] / max(prof["calls"], 1) * 1e3
+        f_us = prof["fixup_ms"] / max(prof["calls"], 1) * 1e3
+        alg = algorithmic_bytes(nnz, F, K)
+        entry = {"workload": "index_scatter dim=0 sum, sorted, 100k src rows x feat=32 -> 10k dst segments, fp32, int64 index (BASELINE.json configs[0])",
+                 "us_per_call_as_dispatched": wall_us, "calls_timed": n,
+                 "kernel": kernel, "kernel_us": k_us, "fixup_kernel_us": f_us, "edges_per_s": nnz / wall_us * 1e6,
+                 "algorithmic_bytes": alg,
+                 "roofline": {"bound": "hbm", "achieved": alg / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": alg / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                              "traffic_source": None, "note": "launch-bound: 391 tiles on 256 CUs; the call is host + launch latency"}}
+        try:
+            from oracle import api as oracle, ref
+            idx, s_np = index.cpu().numpy(), src.cpu().numpy()
+            cores = os.cpu_count() or 1
+
+            def best(fn, reps=5):
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                return min(ts)
+            cb = {"unit": "us per call", "sample": "the full configs[0] workload, best of 5 calls", "host_cores": cores}
+            if ref.available(omp=True):
+                t, nthr = min((best(lambda n=n: ref.index_scatter_cpu(idx, s_np, omp=True, threads=n, rows=K)), n)
+                              for n in sorted({min(cores, 16), min(cores, 64), 1}))
+                cb.update(value=t * 1e6, cores=nthr, kind="reference",
+                          note="reference csrc/cpu/index_scatter_cpu.cpp compiled in place with -fopenmp, best thread count of {1, 16, 64}")
+                if ref.available(omp=False):
+                    cb["reference_as_shipped_serial_us"] = best(lambda: ref.index_scatter_cpu(idx, s_np, omp=False, rows=K)) * 1e6
+            else:
+                t = best(lambda: oracle.index_scatter_3pass(idx, s_np, "sum", threads=min(cores, 16), rows=K))
+                cb.update(value=t * 1e6, cores=min(cores, 16), kind="port")
+            got = out.cpu().numpy()
+            hi = oracle.index_scatter(idx, s_np, acc64=True)
+            entry["max_rel_err_vs_oracle_f64"] = float(abs(got - hi).max() / abs(hi).max())
+            entry["cpu_baseline"] = cb
+            entry["speedup_vs_cpu_reference"] = cb["value"] / wall_us
+        except Exception as e:
+            entry["cpu_baseline"] = {"error": repr(e)}
+        res[name] = entry
+
+    if "cfg1" in want:
+        cfg1("cfg1")
     if "gws_cfg3" in want:
-        gws("gws_cfg3", False, torch.float32)
+        gws("gws_cfg3", "uniform", torch.float32)
     if "gws_cfg3_local" in want:
-        gws("gws_cfg3_local", True, torch.float32)
+        gws("gws_cfg3_local", "local", torch.float32)
+    if "gws_cfg3_powerlaw_src" in want:
+        gws("gws_cfg3_powerlaw_src", "powerlaw", torch.float32)
     if "mh_spmm_cfg4" in want:
         mh("mh_spmm_cfg4", torch.float32)
+    if "mh_spmm_cfg4_powerlaw_src" in want:
+        mh("mh_spmm_cfg4_powerlaw_src", torch.float32, "powerlaw")
     if "gws_cfg3_bf16" in want:
-        gws("gws_cfg3_bf16", False, torch.bfloat16)
+        gws("gws_cfg3_bf16", "uniform", torch.bfloat16)
     if "mh_spmm_cfg4_bf16" in want:
         mh("mh_spmm_cfg4_bf16", torch.bfloat16)
     return res
@@ -368,7 +514,6 @@ def main():
         else:
             def step():
                 return geot.index_scatter(0, src, index, "sum", True)
-        kernel = "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"
         coll = "RCCL" if backend == "nccl" else backend
         workload = ("index_scatter sorted sum, power-law 10M edges -> 1M nodes, feat=64 (BASELINE.json configs[1])"
                     + (f" per GPU, neighbouring shards share their boundary key, boundary rows exchanged by a {coll} {args.collective}" if distributed else ""))
@@ -377,26 +522,32 @@ def main():
                      "geot.index_scatter(0, src, index, 'sum', True): read-back of index[-1] + alloc + tile kernel + fix-up kernel")
         metric = METRIC
     else:
+        # BASELINE.json configs[4]: ONE global dst-sorted edge list cut into `world` contiguous edge ranges (global_list_shard).
+        #   weak (default): every GPU holds 1/8 of the configuration's edges and dst rows - the list covers world/8 of the dst
+        #                   rows, 8 ranks = the full 1.6 B edges; src (all nodes) replicated;
+        #   --strong:       the full configuration (x --scale) at every N, cut into N.
         nodes_all, feat = int(CFG5_NODES * args.scale), CFG5_FEAT
-        nnz, rows = int(CFG5_EDGES * args.scale) // 8, nodes_all // 8
-        index = powerlaw_index(nnz, rows, seed=13 + rank, device=dev)
+        share = 8 if args.strong else world
+        rows_global = max(world, nodes_all * share // 8)
+        nnz_target = int(CFG5_EDGES * args.scale) * share // 8
+        index, src_index, first_key, rows, nnz_global, cut_edges = global_list_shard(
+            rows_global, nnz_target, nodes_all, world, rank, args.cuts, seed=13, device=dev)
+        nnz = index.numel()
         gen = torch.Generator(device=dev)
-        gen.manual_seed(14 + rank)
-        src_index = torch.randint(0, nodes_all, (nnz,), device=dev, generator=gen)
         gen.manual_seed(15)                                                # src is REPLICATED: same seed on every rank
         src = torch.rand(nodes_all, feat, device=dev, generator=gen)
         uniq = int(torch.unique(src_index).numel())
         alg = nnz * 16 + uniq * 4 * feat + rows * 4 * feat                 # compulsory bytes
-        key_offset = rank * (rows - 1) if args.cuts == "equal" else rank * rows
+        key_offset = first_key
         if distributed:
             def step(collective=args.collective):
                 return sharding.sharded_gather_scatter(src_index, index, src, key_offset=key_offset, timing=timing, collective=collective)[0]
         else:
             def step():
                 return geot.gather_scatter(src_index, index, src)
-        kernel = "seg_tile_kernel<float, 4, true, 0, false, 0, 3, 8>"
-        workload = (f"gather_scatter, papers100M-scale synthetic, feat={feat}: per GPU {nnz} edges -> {rows} dst rows, "
-                    f"src {nodes_all} x {feat} fp32 replicated (BASELINE.json configs[4]; 8 ranks = the full 1.6 B edges)")
+        workload = (f"gather_scatter, papers100M-scale synthetic, feat={feat}: one global dst-sorted list of {nnz_global} edges -> "
+                    f"{rows_global} dst rows cut into {world} edge ranges ({args.cuts} cuts), rank 0 holds {nnz} edges / {rows} rows; "
+                    f"src {nodes_all} x {feat} fp32 replicated (BASELINE.json configs[4]; 8 ranks weak = the full 1.6 B edges)")
         step_desc = "geot.gather_scatter(src_index, dst_index, src)" + (" via sharding.sharded_gather_scatter" if distributed else "")
         metric = "aggregated edges/sec, gather_scatter feat=128, edge-sharded, src replicated"
 
@@ -438,7 +589,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    edges_per_s = world * nnz * args.steps / elapsed
+    total_edges = world * nnz
+    if args.workload == "cfg5":
+        total_edges = nnz_global                      # (the shards of one list differ by an edge or by a row's tail)
+    edges_per_s = total_edges * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: HIP events around the tile kernel, K more steps -------
     hip.profile_enable(True)
@@ -448,6 +602,7 @@ def main():
     torch.cuda.synchronize(dev)
     prof = hip.profile_read()
     hip.profile_enable(False)
+    kernel = hip.last_kernel()                        # what the launcher picked for this call (geot_last_kernel), not a literal
     box = hip.profile_box(src if args.workload == "cfg2" else src[: 20_000_000])   # this box's own read ceiling, now
     main_ms = prof["main_ms"] / max(prof["calls"], 1)
     fix_ms = prof["fixup_ms"] / max(prof["calls"], 1)

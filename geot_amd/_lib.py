@@ -37,7 +37,7 @@ SYMBOLS = [
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm",
     "geot_slab_plan_scratch_bytes", "geot_slab_plan_rows", "geot_slab_plan_groups", "geot_slab_plan_edges",
-    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option",
+    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option", "geot_last_kernel",
 ]
 
 class SlabPlan(ctypes.Structure):

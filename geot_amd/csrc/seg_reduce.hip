@@ -1781,6 +1781,21 @@ int fail(int code, const std::string &msg) {
   return code;
 }
 
+// name of the dominant kernel of the calling thread's last call, as rocprofv3 prints it (geot_last_kernel)
+thread_local std::string t_last_kernel;
+template <typename T> constexpr const char *type_name() {
+  if constexpr (std::is_same<T, float>::value) return "float";
+  else if constexpr (std::is_same<T, double>::value) return "double";
+  else if constexpr (std::is_same<T, half_t>::value) return "_Float16";
+  else return "__bf16";
+}
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED, int U> void note_tile_kernel() {
+  char buf[160];
+  std::snprintf(buf, sizeof buf, "seg_tile_kernel<%s, %d, %s, %d, %s, %d, %d, %d>", type_name<T>(), VEC, GATHER ? "true" : "false", WMODE,
+                ATOMIC ? "true" : "false", NT, RED, U);
+  t_last_kernel = buf;
+}
+
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
     hipError_t _e = (expr);                                                                    \
@@ -1990,6 +2005,7 @@ void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
   const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(typename AccOf<T>::type), GATHER, hw);
   dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+  note_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED, kU>();
   hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), GATHER, RED), st, p);
 }
 
@@ -2003,6 +2019,7 @@ int dispatch_reduce_mode(const SegParams &p, const Plan &P, hipStream_t st) {
     if (P.unroll == 16 && P.vec == MAXV) {   // 16 row loads in flight per lane, as the sum (the tile shape was chosen for it)
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+      note_tile_kernel<T, MAXV, false, 0, false, 3, RED, 16>();
       hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED, 16>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), false, RED, 16), st, p);
       return GEOT_OK;
     }
@@ -2061,6 +2078,7 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
     if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 3) {   // 16 row loads in flight per lane
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+      note_tile_kernel<T, MAXV, false, 0, false, 3, RED_SUM, 16>();
       hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, false, 0, false, 3, RED_SUM, 16>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), false, RED_SUM, 16), st, p);
       return GEOT_OK;
     }
@@ -2069,6 +2087,7 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
     if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 0) {   // gather modes, default cache policy
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), true, WMODE);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+      note_tile_kernel<T, MAXV, true, WMODE, false, 0, RED_SUM, 16>();
       hipLaunchKernelGGL((seg_tile_kernel<T, MAXV, true, WMODE, false, 0, RED_SUM, 16>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), true, RED_SUM), st, p);
       return GEOT_OK;
     }
@@ -2233,6 +2252,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
         int64_t blocks = (nnz + 4095) / 4096;                  // >= 4096 edges per block, <= 4 blocks per CU
         if (blocks > 1024) blocks = 1024;
         if (blocks < 1) blocks = 1;
+        t_last_kernel = std::string("seg_lds_bin_kernel<") + type_name<T>() + ">";
         if constexpr (sizeof(T) >= 4)
           hipLaunchKernelGGL((seg_lds_bin_kernel<T>), dim3((unsigned)blocks), dim3(kThreads), tab_bytes, st,
                              dst_index, static_cast<const T *>(src), static_cast<T *>(dst), nnz, F, K, l);
@@ -2246,6 +2266,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
         if (lane_seq) {
           const dim3 grid((unsigned)P.num_tiles), blk(kThreads);
           const bool e8 = lane_seq_edges(F) == 8;
+          t_last_kernel = "seg_lane_kernel<" + std::to_string((int)F) + ", " + std::to_string(mode == 0 ? (e8 ? 8 : 4) : (F <= 4 ? 8 : 4)) + ", " +
+                          std::to_string(red) + ", " + std::to_string(mode) + ">";
 #define GEOT_LANE_F(RED_)                                                                                          \
   switch ((int)F) {                                                                                                \
   case 1: if (e8) hipLaunchKernelGGL((seg_lane_kernel<1, 8, RED_>), grid, blk, 0, st, p); else hipLaunchKernelGGL((seg_lane_kernel<1, 4, RED_>), grid, blk, 0, st, p); break; \
@@ -2293,6 +2315,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
           narrow = true;
         } else if (narrow_path) {
           const dim3 grid((unsigned)P.num_tiles), blk(kThreads);
+          t_last_kernel = "seg_narrow_kernel<" + std::to_string((int)F) + ", " + std::to_string(scan_steps(F)) + ">";
           switch ((int)F) {
           case 1: hipLaunchKernelGGL((seg_narrow_kernel<1, 8>), grid, blk, 0, st, p); break;
           case 2: hipLaunchKernelGGL((seg_narrow_kernel<2, 8>), grid, blk, 0, st, p); break;
@@ -2433,6 +2456,8 @@ int run_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nn
 extern "C" {
 
 int geot_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+void geot_internal_note_kernel(const char *name) { t_last_kernel = name ? name : ""; }
+const char *geot_last_kernel(void) { return t_last_kernel.c_str(); }
 
 int geot_abi_version(void) { return GEOT_ABI_VERSION; }
 

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
+#include <mutex>
 #include <string>
 
 #include "geot_hip.h"
@@ -56,6 +58,8 @@ struct SlabParams {
 };
 constexpr int kProgSlots = 512;
 constexpr int kProgIdle = 0x7f7f7f7f;
+constexpr int kSyncTries = 640;  // polls of one wait (8 loads + s_sleep 16 each, ~1.5 us: ~1 ms; a slab step is ~50-100 us)
+constexpr int kSyncGiveUp = 4;   // waits that ran out in a row before a wave stops keeping step (see slab_sync)
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
@@ -64,6 +68,9 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 // 4 floats or 8 halves, i.e. NV = 1 or 2 float4 accumulators per lane.
 typedef _Float16 half_t;
 typedef __bf16 bf16_t;
+template <typename T> constexpr const char *slab_tname() { // (as rocprofv3 spells the template argument)
+  return sizeof(T) == 4 ? "float" : (__is_same(T, _Float16) ? "_Float16" : "__bf16");
+}
 template <typename T> struct SlabVec { static constexpr int VEC = 16 / (int)sizeof(T), NV = VEC / 4; };
 
 template <typename T> __device__ __forceinline__ void slab_unpack(const f4_t &raw, f4_t (&m)[SlabVec<T>::NV]) {
@@ -173,12 +180,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   }
   int published = -1;
   int known_min = -1;                         // a lower bound of the slowest wave's step (steps only grow)
+  int timeouts = 0;                           // consecutive waits that ran out (wave-uniform)
   auto slab_sync = [&](int step) {            // wave-uniform
     if (my_slot < 0 || step <= published) return;
     published = step;
     if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
     if (known_min + p.window >= step) return; // the last poll already allows this step: no memory round trip
-    for (int tries = 0; tries < 2048; ++tries) {
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
       int m = kProgIdle;
 #pragma unroll
       for (int q = 0; q < kProgSlots / 64; ++q) {
@@ -191,8 +200,22 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         m = other < m ? other : m;
       }
       known_min = m;
-      if (m + p.window >= step) break;
+      if (m + p.window >= step) {
+        ok = true;
+        break;
+      }
       __builtin_amdgcn_s_sleep(16);
+    }
+    // Bounded in AGGREGATE too: a wait is ~1 ms at most, and a wave whose waits run out kSyncGiveUp times in a row stops
+    // keeping step for the rest of the launch (it withdraws its progress word, so nobody waits for it either).  That is
+    // the situation of a grid that does not have the chip to itself - another persistent grid of this process, of another
+    // process, or a replayed graph on a second stream holds the CUs its slowest waves would run on: lockstep has nothing to
+    // offer there, and without this rule thousands of steps x a timed-out wait each would look like a hang.  Timing only:
+    // the result never depends on the lockstep.
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
     }
   };
 
@@ -396,13 +419,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
     xprog = p.prog + xcc * kProgSlots;
     if (slot >= 0 && slot < kProgSlots) my_slot = slot;
   }
-  int published = -1, known_min = -1;
-  auto slab_sync = [&](int step) {
+  int published = -1, known_min = -1, timeouts = 0;
+  auto slab_sync = [&](int step) {              // (as in seg_slab_kernel: every wait bounded, and bounded in aggregate)
     if (my_slot < 0 || step <= published) return;
     published = step;
     if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
     if (known_min + p.window >= step) return;
-    for (int tries = 0; tries < 2048; ++tries) {
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
       int m = kProgIdle;
 #pragma unroll
       for (int q = 0; q < kProgSlots / 64; ++q) {
@@ -415,8 +439,16 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
         m = other < m ? other : m;
       }
       known_min = m;
-      if (m + p.window >= step) break;
+      if (m + p.window >= step) {
+        ok = true;
+        break;
+      }
       __builtin_amdgcn_s_sleep(16);
+    }
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
     }
   };
 
@@ -556,12 +588,49 @@ __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p
   }
 }
 
+extern "C" int g_slab_turn;
+// The persistent grids are sized for the whole chip and keep step per XCD: two of them at once take each other's CUs and
+// lockstep has nothing to offer (the kernels stay correct and bounded - slab_sync gives up - but both run slower than one
+// after the other).  So the launches of this process take turns per device, whichever stream, thread or entry point (the
+// torch plugin, ctypes, a C caller) they come from: a launch waits, on ITS stream, for the event of the previous one.
+// An optimisation, not a safety net: a stream that is being captured skips it (an event recorded outside a capture cannot
+// be waited for inside one; replayed graphs on two streams may overlap), and so does another process on the same GPU.
+struct SlabTurn {
+  std::mutex mu;
+  std::map<int, hipEvent_t> last; // per device
+  template <typename Launch> int take(hipStream_t st, Launch launch) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+    if (!g_slab_turn || cs != hipStreamCaptureStatusNone) return launch();
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return launch();
+    }
+    hipEvent_t &e = last[dev];
+    if (e) {
+      if (hipStreamWaitEvent(st, e, 0) != hipSuccess) (void)hipGetLastError();
+    } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      e = nullptr;
+      return launch();
+    }
+    const int rc = launch();
+    if (hipEventRecord(e, st) != hipSuccess) (void)hipGetLastError();
+    return rc;
+  }
+};
+SlabTurn g_turn;
+
 } // namespace
 
 extern "C" {
 
 constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
 int g_slab_window = 2;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
+
+int g_slab_turn = 1;    // "slab_turn": 1 = the persistent grids of this process take turns on a device (see SlabTurn), 0 = launch freely
 
 int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
 
@@ -684,6 +753,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     const bool combine = plan->n_split > 0;
 #define GEOT_SLAB_LAUNCH(T_, W, RED_)                                                                         \
   do {                                                                                                        \
+    geot_internal_note_kernel((std::string("seg_slab_kernel<") + slab_tname<T_>() + ", " #W ", " + (wave_row ? "true" : "false") + ", " + std::to_string((int)RED_) + ">").c_str()); \
     if (wave_row) hipLaunchKernelGGL((seg_slab_kernel<T_, W, true, RED_>), grid, blk, lds, st, p);            \
     else hipLaunchKernelGGL((seg_slab_kernel<T_, W, false, RED_>), grid, blk, lds, st, p);                    \
     if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, RED_>), cgrid, blk, 0, st, p);               \
@@ -702,14 +772,17 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   case 2: GEOT_SLAB_LAUNCH(T_, 2, GEOT_REDUCE_SUM); break;                                                    \
   default: GEOT_SLAB_LAUNCH(T_, 3, GEOT_REDUCE_SUM); break;                                                   \
   }
-    if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
-    else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
-    else { GEOT_SLAB_MODE(bf16_t) }
+    const int rc = g_turn.take(st, [&]() -> int {
+      if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
+      else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
+      else { GEOT_SLAB_MODE(bf16_t) }
+      const hipError_t le = hipGetLastError();
+      return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
+    });
 #undef GEOT_SLAB_MODE
 #undef GEOT_SLAB_RED
 #undef GEOT_SLAB_LAUNCH
-    e = hipGetLastError();
-    if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
+    if (rc != GEOT_OK) return rc;
   }
   return GEOT_OK;
 }
@@ -764,17 +837,20 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
     if (lpr_log2 == 6) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, true>), grid, blk, lds, st, p);          \
     else hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, false>), grid, blk, lds, st, p);                       \
   } while (0)
-  if (dtype == GEOT_F32) GEOT_SLAB_SDDMM(float);
-  else if (dtype == GEOT_F16) GEOT_SLAB_SDDMM(half_t);
-  else GEOT_SLAB_SDDMM(bf16_t);
+  const int rc = g_turn.take(st, [&]() -> int {
+    if (dtype == GEOT_F32) GEOT_SLAB_SDDMM(float);
+    else if (dtype == GEOT_F16) GEOT_SLAB_SDDMM(half_t);
+    else GEOT_SLAB_SDDMM(bf16_t);
+    const hipError_t le = hipGetLastError();
+    return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
+  });
 #undef GEOT_SLAB_SDDMM
-  e = hipGetLastError();
-  if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
-  return GEOT_OK;
+  return rc;
 }
 
 void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_window") g_slab_window = value;
+  if (name && std::string(name) == "slab_turn") g_slab_turn = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 

@@ -26,6 +26,7 @@
 #include <torch/library.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -55,6 +56,7 @@ struct Options {
   int64_t cache_mb = 0;      // GEOT_CACHE_MB: byte budget of all cached artefacts together (0 = 1/8 of the device's memory)
   int slab_builder = 0;      // Phase A: 0 = the device builder (csrc/seg_plan.hip), 1 = the ATen formulation (CPU tensors always; cross-check)
   int content_guard = 1;     // GEOT_CONTENT_GUARD: every use of a remembered product re-reads the tensors it was derived from (fingerprint)
+  int guard_side_stream = 1; // the fingerprint kernels run on a side stream beside the call's kernels (0: in line, in front of them)
   Options() {
     if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;
     if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
@@ -68,7 +70,7 @@ struct Options {
 };
 Options g_opt;
 struct Stats {
-  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0, stale_products = 0, guard_checks = 0, plan_trials = 0, plans_rejected = 0;
+  int64_t probes = 0, row_mismatches = 0, sorts = 0, transposes = 0, plans_built = 0, slab_calls = 0, plan_us = 0, published = 0, alarms = 0, stale_products = 0, guard_checks = 0, plan_trials = 0, plans_rejected = 0, trial_plan_us = 0, trial_edges_us = 0;
 };
 Stats g_stats;
 std::mutex g_mu; // guards the caches below (facts, transposed edge lists, slab plans)
@@ -254,9 +256,9 @@ bool guardable(std::initializer_list<const at::Tensor *> ts) {
 // may this call look a product of these tensors up / remember one?
 bool may_remember(std::initializer_list<const at::Tensor *> ts) { return g_opt.trust_version && (!guard_on() || guardable(ts)); }
 
-at::Tensor &guard_scratch(const at::Tensor &like) { // per (device, stream): the kernel's ticket and per-workgroup sums
+at::Tensor &guard_scratch(const at::Tensor &like, void *stream) { // per (device, stream): the kernel's ticket and per-workgroup sums
   static thread_local std::map<std::pair<int, void *>, at::Tensor> sc;
-  auto &t = sc[{(int)like.device().index(), stream_of(like)}];
+  auto &t = sc[{(int)like.device().index(), stream}];
   if (!t.defined()) t = at::zeros({(int64_t)geot_content_fingerprint_scratch_bytes()}, like.options().dtype(at::kByte));
   return t;
 }
@@ -277,45 +279,106 @@ void guard_drain() {
   tl_pending.clear();
 }
 
-void launch_fingerprint(std::initializer_list<const at::Tensor *> ts, at::Tensor &fp, bool compare, int64_t *slot, int64_t seq) {
+void launch_fingerprint(const std::vector<at::Tensor> &ts, at::Tensor &fp, bool compare, int64_t *slot, int64_t seq, void *stream) {
   const void *bufs[4];
   size_t bytes[4];
   int n = 0;
-  const at::Tensor *first = nullptr;
-  for (const at::Tensor *t : ts) {
+  for (const at::Tensor &t : ts) {
     TORCH_CHECK(n < 4, "guard: at most four tensors per product");
-    if (!first) first = t;
-    bufs[n] = t->data_ptr();
-    bytes[n] = (size_t)t->numel() * (size_t)t->element_size();
+    bufs[n] = t.data_ptr();
+    bytes[n] = (size_t)t.numel() * (size_t)t.element_size();
     ++n;
   }
   GEOT_CALL(geot_content_fingerprint(bufs, bytes, n, reinterpret_cast<unsigned long long *>(fp.data_ptr<int64_t>()), compare ? 1 : 0, slot, seq,
-                                     guard_scratch(*first).data_ptr(), stream_of(*first)));
+                                     guard_scratch(ts.front(), stream).data_ptr(), stream));
 }
 
-// fingerprint of `ts` as they are now, for a product that is being made from them (undefined when the guard is off)
+std::vector<at::Tensor> tensors_of(std::initializer_list<const at::Tensor *> ts) {
+  std::vector<at::Tensor> v;
+  for (const at::Tensor *t : ts) v.push_back(*t);
+  return v;
+}
+
+// fingerprint of `ts` as they are now, for a product that is being made from them (undefined when the guard is off); on the
+// call's stream, behind whatever produced the tensors
 at::Tensor guard_store(std::initializer_list<const at::Tensor *> ts) {
   if (!guard_on() || !guardable(ts)) return at::Tensor();
   at::Tensor fp = at::empty({2}, (*ts.begin())->options().dtype(at::kLong));
-  launch_fingerprint(ts, fp, false, nullptr, 0);
+  launch_fingerprint(tensors_of(ts), fp, false, nullptr, 0, stream_of(**ts.begin()));
   return fp;
 }
 
-// a remembered product is about to be used: are `ts` still the bytes it was made from?  (answered at guard_settle)
+// A remembered product is about to be used: are `ts` still the bytes it was made from?  Called from inside the cache lookups,
+// i.e. with g_mu (or a plan's wmu) HELD: it only notes the question.  guard_flush - run by the GuardFlush object at the top of
+// every function that looks a product up, after the locks are gone - launches the fingerprint kernels; guard_settle reads the answers.
+struct GuardRequest {
+  at::Tensor fp;
+  std::vector<at::Tensor> ts;
+};
+thread_local std::vector<GuardRequest> tl_requests;
+
 void guard_check(const at::Tensor &fp, std::initializer_list<const at::Tensor *> ts) {
   if (!guard_on() || !fp.defined() || !guardable(ts)) return;
   const std::pair<const void *, const void *> what{fp.data_ptr(), (*ts.begin())->data_ptr()};
   for (const auto &a : tl_asked)
     if (a == what) return;
   tl_asked.push_back(what);
-  if ((int)tl_pending.size() >= kGuardSlots) guard_drain();
-  Slot &s = slot_for((*ts.begin())->device().index());
-  int64_t *slot = s.host + 8 + 2 * (s.guard_next++ % kGuardSlots);
-  const int64_t seq = ++s.seq;
-  at::Tensor f = fp;
-  launch_fingerprint(ts, f, true, slot, seq);
-  tl_pending.push_back(PendingVerdict{slot, seq, stream_of(**ts.begin())});
+  tl_requests.push_back(GuardRequest{fp, tensors_of(ts)});
 }
+
+// The fingerprint kernels run on a SIDE stream (one per thread and device, from torch's pool): they wait for an event recorded
+// on the call's stream at this point - everything that may have written the tensors is in front of it - and then read
+// BESIDE the call's own kernels instead of in front of them (8-16 streamed bytes per edge: +4 % on a 115 M-edge mh_spmm when
+// they ran in line).  Nothing downstream depends on them until guard_settle looks at the verdicts, and the operator does not
+// return before it has: the tensors they read are the caller's arguments, alive until then.
+struct GuardSide {
+  void *stream = nullptr;
+  hipEvent_t entry = nullptr;
+};
+GuardSide &guard_side(int device) {
+  static thread_local std::map<int, GuardSide> sides;
+  GuardSide &g = sides[device];
+  if (!g.stream) {
+    g.stream = c10::hip::getStreamFromPoolMasqueradingAsCUDA(/*isHighPriority=*/false, (c10::DeviceIndex)device).stream();
+    TORCH_CHECK(hipEventCreateWithFlags(&g.entry, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+  }
+  return g;
+}
+
+void guard_flush() {
+  if (tl_requests.empty()) return;
+  std::vector<GuardRequest> reqs;
+  reqs.swap(tl_requests);
+  for (GuardRequest &r : reqs) {
+    const at::Tensor &first = r.ts.front();
+    const int device = (int)first.device().index();
+    if ((int)tl_pending.size() >= kGuardSlots) guard_drain();
+    Slot &s = slot_for(device);
+    int64_t *slot = s.host + 8 + 2 * (s.guard_next++ % kGuardSlots);
+    const int64_t seq = ++s.seq;
+    void *main_stream = stream_of(first);
+    void *stream = main_stream;
+    if (g_opt.guard_side_stream) {
+      GuardSide &side = guard_side(device);
+      (void)guard_scratch(first, side.stream); // (zero-filled on the call's stream the first time: in front of the event below)
+      TORCH_CHECK(hipEventRecord(side.entry, static_cast<hipStream_t>(main_stream)) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(side.stream), side.entry, 0) == hipSuccess, "hipStreamWaitEvent failed");
+      stream = side.stream;
+    }
+    launch_fingerprint(r.ts, r.fp, true, slot, seq, stream);
+    tl_pending.push_back(PendingVerdict{slot, seq, stream});
+  }
+}
+struct GuardFlush { // declare FIRST in a function that looks products up: its destructor runs after the function's lock_guards'
+  ~GuardFlush() {
+    try {
+      guard_flush();
+    } catch (...) {
+      tl_requests.clear();
+      tl_guard_tripped = true; // (a question that could not be asked counts as a changed content: the call is repeated from the caller's bytes)
+    }
+  }
+};
 
 void clear_all_caches_locked();
 // true: every product this operator call used was made from the bytes the tensors hold now
@@ -464,6 +527,7 @@ std::pair<at::Tensor, at::Tensor> stable_sort_index(const at::Tensor &index, int
 
 // (keys ascending, perm) of an index with descents
 std::pair<at::Tensor, at::Tensor> sorted_form(const at::Tensor &index, int64_t kmin, int64_t kmax) {
+  const GuardFlush flush_questions_;
   ContentKey k;
   const bool keyed = may_remember({&index}) && content_key(index, &k);
   if (keyed) {
@@ -507,6 +571,7 @@ struct WidenedEntry {
 std::list<WidenedEntry> g_widened;
 
 at::Tensor as_int64(const at::Tensor &t) {
+  const GuardFlush flush_questions_;
   if (t.scalar_type() == at::kLong) return t.contiguous();
   ContentKey k;
   const bool keyed = may_remember({&t}) && content_key(t, &k);
@@ -628,7 +693,9 @@ struct SlabPlanHolder {
   // call that would use a plan runs BOTH ways, timed with events on the call's stream, and the plan is kept only if it wins
   // (per kind of operator).  0 undecided, 1 the plan, 2 the per-edge kernels (the plan's arrays are released then).
   std::atomic<int> verdict[2] = {{0}, {0}}; // [0] the forward reductions, [1] SDDMM
-  float trial_ms[2][2] = {{0, 0}, {0, 0}};  // [kind][0 plan, 1 per-edge]
+  float trial_ms[2][2] = {{0, 0}, {0, 0}};  // [kind][0 plan, 1 per-edge]: best of the timed repetitions
+  std::mutex trial_mu;                       // one trial at a time per plan; a thread that finds it taken serves its call per edge
+  std::atomic<int> uses_since_trial[2] = {{0}, {0}}, trials_done[2] = {{0}, {0}};
   void release() { // (keeps the holder as the record of the decision; lock order everywhere: g_mu, then wmu)
     std::vector<at::Tensor> gone;
     {
@@ -637,6 +704,22 @@ struct SlabPlanHolder {
       w_planorder = at::Tensor();
       fp = w_fp = at::Tensor();
     }
+    // `gone` dies here: a launch in flight on another thread holds its own references (pinned()) and has told the allocator
+    // which stream reads them (launched_on), so the memory is not handed out again under a running kernel
+  }
+  // the arrays a launch is about to read through the raw pointers of `plan` (empty: released)
+  std::vector<at::Tensor> pinned() {
+    std::lock_guard<std::mutex> lk(wmu);
+    return keep;
+  }
+  // after the launch: the arrays were allocated on the stream that built the plan; a launch on another stream is recorded with
+  // the caching allocator AFTER it is enqueued (a block freed later is then only re-used behind this launch)
+  void launched_on(const at::Tensor &on, const std::vector<at::Tensor> &arrays) const {
+    if (tl_capturing) return;
+    const auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(on.device().index());
+    if (cur.stream() == made.stream) return;
+    for (const at::Tensor &t : arrays)
+      if (t.defined() && t.is_cuda()) c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(t.storage().data_ptr(), cur);
   }
   int64_t bytes() {
     std::lock_guard<std::mutex> lk(wmu);
@@ -893,6 +976,7 @@ std::list<std::pair<ContentKey, ContentKey>> g_sightings; // edge lists seen onc
 
 std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Tensor &di, int64_t rows, const at::Tensor &src,
                                               int wmode, int64_t heads) {
+  const GuardFlush flush_questions_;
   const bool f32 = src.scalar_type() == at::kFloat;
   if (g_opt.slab_mode < 0 || rows < 1 || !(f32 || src.scalar_type() == at::kHalf || src.scalar_type() == at::kBFloat16)) return nullptr;
   const int dt = dtype_code(src, "slab");
@@ -953,88 +1037,109 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   return plan;
 }
 
-// The source-blocked kernels are PERSISTENT grids sized for the whole chip whose waves keep step with each other: two of them at once
-// (calls from several threads, each on its own stream) would take each other's CUs and wait for waves that are not running - bounded
-// waits, but the design's premise is gone, and a 1-in-25 hang of the box was seen with three of them in flight.  So they take turns on
-// the device: a launch waits (on its stream) for the event of the previous one, whichever stream that was on.  Not under capture.
-struct SlabTurn {
-  std::mutex mu;
-  std::map<int, hipEvent_t> last; // per device
-  template <typename Launch> void take(const at::Tensor &on, Launch launch) {
-    if (tl_capturing) {
-      launch();
-      return;
-    }
-    std::lock_guard<std::mutex> lk(mu);
-    hipStream_t st = static_cast<hipStream_t>(stream_of(on));
-    hipEvent_t &e = last[(int)on.device().index()];
-    if (e) {
-      TORCH_CHECK(hipStreamWaitEvent(st, e, 0) == hipSuccess, "hipStreamWaitEvent failed");
-    } else {
-      TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
-    }
-    launch();
-    TORCH_CHECK(hipEventRecord(e, st) == hipSuccess, "hipEventRecord failed");
-  }
-};
-SlabTurn g_slab_turn;
-
-void run_slab(const SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
+// (the persistent grids of a process take turns on a device INSIDE the library - geot_slab_spmm / geot_slab_sddmm, seg_slab.hip
+// "SlabTurn" - so every caller of the C ABI gets it, not only this plugin)
+// false: the plan's arrays have been released (a trial on another thread rejected it) - the caller runs the per-edge kernels
+bool run_slab(SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
               int red = GEOT_REDUCE_SUM) {
+  const std::vector<at::Tensor> pinned = H.pinned(); // this launch's own references: a release() meanwhile cannot free under the kernel
+  if (pinned.empty()) return false;
   auto &ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
-  g_slab_turn.take(src, [&]() {
-    GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
-                             red, ws.data_ptr(), ws.numel(), stream_of(src)));
-  });
+  GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
+                           red, ws.data_ptr(), ws.numel(), stream_of(src)));
+  H.launched_on(src, pinned);
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.slab_calls;
+  return true;
 }
 
 // One operator call over a graph that has a plan: the plan's kernels or the per-edge kernels (SlabPlanHolder::verdict).
-// run_plan(o) / run_edges(o) enqueue the whole call into `o`.  kind: 0 forward reduction, 1 SDDMM.
+// run_plan(o) / run_edges(o) enqueue the whole call into `o`; run_plan returns false when the plan's arrays are gone (released by
+// a trial on another thread) - the per-edge kernels then serve the call.  kind: 0 forward reduction, 1 SDDMM.
+//
+// The TRIAL (first use of an undecided plan): both ways are run once UNTIMED first - the first launch of a kernel loads its
+// code object, the workspace is allocated, a head-major weight is transposed, a static weight is not in plan order yet: none of
+// that may decide a permanent verdict - and then kTrialReps alternating repetitions are timed with events on the call's stream;
+// the best time of each side decides.  One trial at a time per plan (trial_mu): a thread that finds a trial in progress serves
+// its call with the per-edge kernels and leaves the decision to the trying thread.  A plan that loses CLEARLY (> 10 %) is
+// released; one that loses narrowly keeps its arrays and is tried once more after kRetrialAfter further calls.
+constexpr int kTrialReps = 2, kRetrialAfter = 256;
 template <typename RunPlan, typename RunEdges>
 at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, at::Tensor o, const at::Tensor &on, RunPlan run_plan, RunEdges run_edges) {
   int v = plan ? plan->verdict[kind].load() : 2;
-  if (plan && g_opt.slab_mode == 1) v = plan->keep.empty() ? 2 : 1; // forced: no trial (a released plan cannot serve)
+  if (plan && g_opt.slab_mode == 1) v = 1;                          // forced: no trial (a released plan falls through to the per-edge kernels)
+  if (v == 2 && plan && g_opt.slab_mode == 0 && !tl_capturing && plan->trials_done[kind].load() == 1 &&
+      ++plan->uses_since_trial[kind] >= kRetrialAfter && !plan->pinned().empty())
+    v = 0;                                                          // a narrow loss is looked at once more
   if (v == 0 && tl_capturing) v = 2;                                // an undecided plan is not tried inside a capture (the trial waits)
   if (v == 0) {
-    hipStream_t st = static_cast<hipStream_t>(stream_of(on));
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    for (hipEvent_t &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
-    auto destroy = [&]() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); };
-    at::Tensor o2 = at::empty_like(o);
-    try {
-      TORCH_CHECK(hipEventRecord(ev[0], st) == hipSuccess, "hipEventRecord failed");
-      run_plan(o);
-      TORCH_CHECK(hipEventRecord(ev[1], st) == hipSuccess, "hipEventRecord failed");
-      run_edges(o2);
-      TORCH_CHECK(hipEventRecord(ev[2], st) == hipSuccess, "hipEventRecord failed");
-      TORCH_CHECK(hipEventSynchronize(ev[2]) == hipSuccess, "hipEventSynchronize failed");
-      float t_plan = 0.f, t_edges = 0.f;
-      TORCH_CHECK(hipEventElapsedTime(&t_plan, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&t_edges, ev[1], ev[2]) == hipSuccess,
-                  "hipEventElapsedTime failed");
-      destroy();
-      plan->trial_ms[kind][0] = t_plan;
-      plan->trial_ms[kind][1] = t_edges;
-      const bool keep_plan = t_plan <= t_edges;
-      {
-        std::lock_guard<std::mutex> lk(g_mu);
-        ++g_stats.plan_trials;
-        if (!keep_plan) ++g_stats.plans_rejected;
-        plan->verdict[kind] = keep_plan ? 1 : 2;
-        if (!keep_plan && kind == 0) { // what makes the forward lose makes the SDDMM lose: one decision, and the arrays go
-          plan->verdict[1] = 2;
-          plan->release();
+    std::unique_lock<std::mutex> trying(plan->trial_mu, std::try_to_lock);
+    if (!trying.owns_lock()) v = 2;                                 // another thread is trying this plan right now
+    else if (plan->verdict[kind].load() != 0 && plan->uses_since_trial[kind].load() < kRetrialAfter) v = plan->verdict[kind].load(); // decided meanwhile
+    else {
+      hipStream_t st = static_cast<hipStream_t>(stream_of(on));
+      constexpr int kEv = 2 * kTrialReps + 1;
+      hipEvent_t ev[kEv] = {};
+      for (hipEvent_t &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
+      auto destroy = [&]() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); };
+      at::Tensor o2 = at::empty_like(o);
+      try {
+        bool plan_ok = run_plan(o);                                 // untimed: warms both paths
+        run_edges(o2);
+        TORCH_CHECK(hipEventRecord(ev[0], st) == hipSuccess, "hipEventRecord failed");
+        for (int r = 0; r < kTrialReps && plan_ok; ++r) {
+          plan_ok = run_plan(o);
+          TORCH_CHECK(hipEventRecord(ev[2 * r + 1], st) == hipSuccess, "hipEventRecord failed");
+          run_edges(o2);
+          TORCH_CHECK(hipEventRecord(ev[2 * r + 2], st) == hipSuccess, "hipEventRecord failed");
         }
+        if (!plan_ok) {                                             // (released under our feet: cannot happen while we hold trial_mu, but stay safe)
+          destroy();
+          run_edges(o);
+          return o;
+        }
+        TORCH_CHECK(hipEventSynchronize(ev[kEv - 1]) == hipSuccess, "hipEventSynchronize failed");
+        float t_plan = 1e30f, t_edges = 1e30f;
+        for (int r = 0; r < kTrialReps; ++r) {
+          float a = 0.f, b = 0.f;
+          TORCH_CHECK(hipEventElapsedTime(&a, ev[2 * r], ev[2 * r + 1]) == hipSuccess && hipEventElapsedTime(&b, ev[2 * r + 1], ev[2 * r + 2]) == hipSuccess,
+                      "hipEventElapsedTime failed");
+          t_plan = std::min(t_plan, a);
+          t_edges = std::min(t_edges, b);
+        }
+        destroy();
+        plan->trial_ms[kind][0] = t_plan;
+        plan->trial_ms[kind][1] = t_edges;
+        const bool keep_plan = t_plan <= t_edges;
+        const bool clear_loss = t_plan > 1.1f * t_edges;
+        {
+          std::lock_guard<std::mutex> lk(g_mu);
+          ++g_stats.plan_trials;
+          if (!keep_plan) ++g_stats.plans_rejected;
+          g_stats.trial_plan_us = (int64_t)(t_plan * 1e3f);
+          g_stats.trial_edges_us = (int64_t)(t_edges * 1e3f);
+          plan->verdict[kind] = keep_plan ? 1 : 2;
+          plan->uses_since_trial[kind] = 0;
+          ++plan->trials_done[kind];
+          // what makes the forward lose clearly makes the SDDMM lose: one decision, and the arrays go - unless the SDDMM has
+          // already WON a trial of its own (then its launches keep the arrays they are reading)
+          if (clear_loss && kind == 0 && plan->verdict[1].load() != 1) {
+            plan->verdict[1] = 2;
+            plan->trials_done[0] = plan->trials_done[1] = 2;        // (no arrays, no second look)
+            plan->release();
+          } else if (clear_loss) {
+            plan->trials_done[kind] = 2;
+          }
+        }
+        return keep_plan ? o : o2;
+      } catch (...) {
+        destroy();
+        throw;
       }
-      return keep_plan ? o : o2;
-    } catch (...) {
-      destroy();
-      throw;
     }
   }
-  if (v == 1) run_plan(o);
-  else run_edges(o);
+  if (v == 1 && run_plan(o)) return o;
+  run_edges(o);
   return o;
 }
 
@@ -1253,7 +1358,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
     if (red != GEOT_REDUCE_PROD && !e.permuted)        // dense graphs: sum / mean / max / min on the source-blocked kernel
       plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1);
     if (plan) {
-      auto run_plan = [&](at::Tensor &o) {
+      auto run_plan = [&](at::Tensor &o) -> bool {
         const void *wptr = has_w ? e.w.data_ptr() : nullptr;
         int wmode = has_w ? 1 : 0;
         at::Tensor w_planorder;                        // (keeps the permuted copy alive across the launch)
@@ -1283,7 +1388,8 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
             wmode = 4;
           }
         }
-        run_slab(*plan, wptr, wmode, x, o, 1, feat, red);
+        guard_flush(); // (the question about the weight, asked under wmu: launched now, in front of the plan's kernels)
+        return run_slab(*plan, wptr, wmode, x, o, 1, feat, red);
       };
       return plan_or_edges(plan, 0, o, x, run_plan, run_edges);
     }
@@ -1344,9 +1450,9 @@ at::Tensor mh_spmm_common(const at::Tensor &si, const at::Tensor &di, const at::
       // edge, head-major [H, nnz] would be H scattered 4-byte reads (H x 64-byte sectors) - transpose it once instead
       // (a streaming pass, ~0.6 ms at 115 M edges x 4 heads)
       if (auto plan = slab_plan_for(e.si, e.di, rows, x, 2, heads)) {
-        auto run_plan = [&](at::Tensor &o) {
+        auto run_plan = [&](at::Tensor &o) -> bool {
           at::Tensor w_em = layout == GEOT_W_HEAD_MAJOR ? e.w.t().contiguous() : e.w;
-          run_slab(*plan, w_em.data_ptr(), 2, x, o, heads, feat);
+          return run_slab(*plan, w_em.data_ptr(), 2, x, o, heads, feat);
         };
         return plan_or_edges(plan, 0, o, x, run_plan, run_edges);
       }
@@ -1390,14 +1496,16 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
         (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(di.numel(), m1.size(0), m2.size(0), rowbytes, dtype_code(m1, "sddmm_coo")))) &&
         (tl_capturing || index_facts(di).ascending)) { // (under capture only an existing plan is used: built on an ascending di)
       if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 1, 1)) {
-        auto run_plan = [&](at::Tensor &o) {
+        auto run_plan = [&](at::Tensor &o) -> bool {
+          const std::vector<at::Tensor> pinned = plan->pinned();
+          if (pinned.empty()) return false;
           auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
-          g_slab_turn.take(m1, [&]() {
-            GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
-                                      dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
-          });
+          GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
+                                    dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
+          plan->launched_on(m1, pinned);
           std::lock_guard<std::mutex> lk(g_mu);
           ++g_stats.slab_calls;
+          return true;
         };
         return plan_or_edges(plan, 1, out, m1, run_plan, run_edges);
       }
@@ -1419,6 +1527,7 @@ struct ExpandedEntry {
 std::list<ExpandedEntry> g_expanded;
 
 at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
+  const GuardFlush flush_questions_;
   ContentKey k;
   const bool keyed = may_remember({&indptr}) && content_key(indptr, &k);
   if (keyed) {
@@ -1517,6 +1626,7 @@ bool owned_product(const at::Tensor &t) {
 }
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tensor &si, const at::Tensor &di) {
+  const GuardFlush flush_questions_;
   require_gpu("transpose_edges", {&si, &di});
   GEOT_DEVICE_GUARD(si);
   ContentKey k1, k2;
@@ -1552,6 +1662,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> transpose_edges_op(const at::Tens
 }
 
 at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, const at::Tensor &weight) {
+  const GuardFlush flush_questions_;
   require_gpu("transposed_weight", {&si, &di, &weight});
   TORCH_CHECK(weight.dim() >= 1 && weight.size(0) == si.size(0), "weight must have one entry per edge");
   GEOT_DEVICE_GUARD(si);
@@ -1675,6 +1786,12 @@ void clear_all_caches_locked() {
 }
 
 bool guard_settle() {
+  try {
+    guard_flush(); // (normally empty: every lookup flushed its own question)
+  } catch (...) {
+    tl_requests.clear();
+    tl_guard_tripped = true;
+  }
   const size_t asked = tl_asked.size();
   tl_asked.clear();
   guard_drain();
@@ -1731,6 +1848,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "publish_rows") p = &g_opt.publish_rows;
   else if (name == "slab_builder") p = &g_opt.slab_builder;
   else if (name == "content_guard") p = &g_opt.content_guard;
+  else if (name == "guard_side_stream") p = &g_opt.guard_side_stream;
   else if (name == "clear_caches") {
     clear_all_caches_locked();
     return 0;
@@ -1755,7 +1873,8 @@ std::vector<int64_t> host_stats_op() {
   sweep_expired_locked();
   return {g_stats.probes, g_stats.row_mismatches, g_stats.sorts, g_stats.transposes, g_stats.plans_built, g_stats.slab_calls, g_stats.plan_us,
           (int64_t)g_facts.size(), (int64_t)g_transposed.size(), (int64_t)g_slab.size(), g_stats.published, g_stats.alarms,
-          cache_bytes_locked(), g_stats.stale_products, g_stats.guard_checks, g_stats.plan_trials, g_stats.plans_rejected};
+          cache_bytes_locked(), g_stats.stale_products, g_stats.guard_checks, g_stats.plan_trials, g_stats.plans_rejected,
+          g_stats.trial_plan_us, g_stats.trial_edges_us};
 }
 
 // Phase A of the source-blocked kernel as an op (works on CPU tensors too: the tests emulate the kernel on its output).

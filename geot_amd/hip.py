@@ -321,6 +321,14 @@ def profile_read() -> dict:
     return {"main_ms": a.value, "fixup_ms": b.value, "aux_ms": c.value, "calls": n.value}
 
 
+def last_kernel() -> str:
+    """Name of the dominant kernel this thread's last call launched, as rocprofv3 prints it (geot_last_kernel)."""
+    L = _lib.load()
+    L.geot_last_kernel.restype = ctypes.c_char_p
+    L.geot_last_kernel.argtypes = []
+    return (L.geot_last_kernel() or b"").decode()
+
+
 def profile_box(buf: torch.Tensor, iters: int = 5) -> dict:
     """Read ceiling (pure nt 16-B-per-lane read of `buf`) and shader clock of THIS box, now."""
     dev = _require_gpu(buf)

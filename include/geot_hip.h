@@ -312,6 +312,11 @@ void geot_profile_reset(void);
 /* main = tile kernel, fixup = carry/gap kernel, aux = memsets; *_calls = launches counted */
 int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls);
 
+/* Name of the dominant kernel the calling thread's LAST operator call launched, spelled as rocprofv3 prints it
+ * (e.g. "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"): bench.py labels its roofline with what the launcher
+ * picked instead of a literal.  Valid until the thread's next call; "" before the first. */
+const char *geot_last_kernel(void);
+
 /* What this box can do right now (bench.py reports it next to the roofline: devices of the pool differ by a few
  * per cent): best-of-`iters` bandwidth of a pure non-temporal 16-B-per-lane read of `buf` (device memory, `bytes`
  * long), and the shader clock a busy wave sees (MHz; s_memtime ticks per 100 MHz s_memrealtime tick).

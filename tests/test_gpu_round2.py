@@ -447,6 +447,12 @@ def test_bench_launches_its_own_ranks():
             assert r["scaling"] == "strong" and r["config"]["nnz_per_gpu"] == 1_250_000 and r["boundary_exchange_ms"] > 0
         elif "--strong" in extra:                                           # aligned cuts: no data-path collective at all
             assert r["scaling"] == "strong" and r["boundary_exchange_ms"] is None and r["config"]["nnz_per_gpu"] == 5_000_000
+        elif "cfg5" in extra:
+            # one global list cut at nnz / 2: the cut may fall on a row start, and then there is nothing to exchange (world 8, seven
+            # cuts, always has a shared key: tests/test_gpu_world8.py)
+            assert r["scaling"] == "weak" and r["collective"] == "all_gather"
+            both = r["boundary_exchange_ms_by_collective"]
+            assert (both["all_gather"] is None) == (both["reduce_scatter"] is None) == (r["boundary_exchange_ms"] is None)
         else:
             assert r["scaling"] == "weak" and r["boundary_exchange_ms"] is not None and r["boundary_exchange_ms"] > 0
             both = r["boundary_exchange_ms_by_collective"]                 # the first SCALE run needs no code change: both forms timed

@@ -306,3 +306,30 @@ def test_cut_helpers():
     assert cuts[0] == 0 and cuts[-1] == 10 and idx[cuts[1] - 1] != idx[cuts[1]]
     cuts = sharding.segment_aligned_cuts(torch.zeros(8, dtype=torch.int64), 4)          # one hub: later shards empty
     assert cuts == [0, 8, 8, 8, 8]
+
+
+@pytest.mark.parametrize("cuts", ["equal", "aligned"])
+def test_bench_global_list_shards_concatenate_to_one_list_whatever_the_world(cuts):
+    """bench.py --workload cfg5 (BASELINE.json configs[4]) cuts ONE global dst-sorted list into the ranks' edge ranges without
+    any rank materialising it: the shards of world 1 / 2 / 3 / 8 concatenate to the same list (same keys, same sources), the
+    cuts are equal_edge_cuts' (or snapped to row starts: no key shared by two ranks), local keys start at 0."""
+    import bench
+    from geot_amd import sharding
+    ref = None
+    for world in (1, 2, 3, 8):
+        parts = [bench.global_list_shard(5000, 60000, 7000, world, r, cuts, 13, "cpu") for r in range(world)]
+        nnz, edges = parts[0][4], parts[0][5]
+        full = torch.cat([p[0] + p[2] for p in parts])
+        si = torch.cat([p[1] for p in parts])
+        assert full.numel() == nnz and bool((full[1:] >= full[:-1]).all()) and int(full[-1]) == 4999
+        assert 0 <= int(si.min()) and int(si.max()) < 7000
+        if ref is None:
+            ref = (full, si)
+        assert torch.equal(full, ref[0]) and torch.equal(si, ref[1])
+        for r, p in enumerate(parts):
+            assert p[0].numel() == edges[r + 1] - edges[r] and int(p[0][0]) == 0 and int(p[0][-1]) == p[3] - 1
+        if cuts == "equal":
+            assert edges == sharding.equal_edge_cuts(nnz, world)
+        else:
+            assert edges == sharding.segment_aligned_cuts(full, world)
+            assert all(int(a[0][-1]) + a[2] != b[2] for a, b in zip(parts, parts[1:]))

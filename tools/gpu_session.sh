@@ -1,16 +1,17 @@
 #!/bin/bash
-# GPU session driver (round 3; logs under gpurun_out/r03): `gpurun --timeout 3300 -- bash tools/gpu_session.sh [steps...]`
+# GPU session driver (round 4; logs under gpurun_out/r04): `gpurun --timeout 3300 -- bash tools/gpu_session.sh [steps...]`
 # Each step writes its log under gpurun_out/r02/ and is bounded by its own timeout.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-O=gpurun_out/r03
+O=gpurun_out/r04
 mkdir -p $O
 steps="${@:-tests bench kexp unsorted soak}"
 for s in $steps; do
   echo "=== $s $(date +%T)"
   case $s in
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
+    w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
     ab)       timeout 600 python3 tools/ab_libs.py geot_amd/libgeot_hip.so tools/_ab/libgeot_r02.so > $O/ab_libs.txt 2>&1; echo "rc=$?"; cat $O/ab_libs.txt ;;
     tests2)   timeout 1500 python3 -m pytest tests/test_gpu_round2.py -m gpu -x -q > $O/pytest_round2.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_round2.log ;;
