@@ -330,10 +330,11 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if (i == 0) keysL[0] = kp;
     const unsigned long long m = __ballot(k != kp);
     if (lane == 0) maskL[i0 >> 6] = m;
-    // descent guard (see repair_call): a key below its predecessor.  Unsigned compare: the padding key -2 is never below
-    // anything; the -1 in front of edge 0 is excluded.  Only a wave-uniform bit is kept here (an SGPR: the row loads in
-    // flight leave no VGPR to spare); the flag is stored once, behind the loop.
-    if constexpr (!ATOMIC) descents |= __ballot((uint64_t)k < (uint64_t)kp && kp != -1);
+    // descent guard (see repair_call): a key below its predecessor, BOTH inside [0, K) - keys outside that range are ignored by
+    // every kernel (the speculative `index - lo` of geot_amd/sharding.py makes leading negatives) and must not raise the alarm.
+    // Unsigned compares: the padding key -2 and the -1 in front of edge 0 are "above K".  Only a wave-uniform bit is kept here
+    // (an SGPR: the row loads in flight leave no VGPR to spare); the flag is stored once, behind the loop.
+    if constexpr (!ATOMIC) descents |= __ballot((uint64_t)k < (uint64_t)kp && (uint64_t)kp < (uint64_t)p.K);
     if constexpr (GATHER) {
       int64_t row = ge < p.nnz ? p.src_index[ge] : 0;
       if ((uint64_t)row >= (uint64_t)p.src_rows) row = 0; // out-of-range gather index: memory-safe
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
   int64_t klast = __shfl(k[0], 0, 64); // the chunk's first edge opens its first run (no run ends there)
   int nrun = 0;                        // runs of this chunk that have already ended
   if (lane == 0 && klast > kbefore + 1) gapfill(kbefore + 1, klast);
-  raise_descent(p, lane == 0 && cs > 0 && cs < nnz && k[0] < kbefore);
+  raise_descent(p, lane == 0 && cs > 0 && cs < nnz && (uint64_t)k[0] < (uint64_t)kbefore && (uint64_t)kbefore < (uint64_t)p.K);
 
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
     if (lane == 0) kp = klast;
     const bool h = k[s] != kp;
     const unsigned long long hb = __ballot(h);
-    raise_descent(p, k[s] != kNoKey && k[s] < kp);
+    raise_descent(p, (uint64_t)k[s] < (uint64_t)kp && (uint64_t)kp < (uint64_t)p.K); // (both keys inside [0, K): out-of-range keys are ignored, never an alarm)
     if (h && k[s] > kp + 1) gapfill(kp + 1, k[s]);
     if ((hb & 1ull) && lane == 0) {
       // the run carried in ended exactly at the step boundary: nobody in this step continues it
@@ -1087,9 +1088,10 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   int64_t cur = mk[0];
   if (cur > kprev + 1) gapfill(kprev + 1, cur);
   {
-    bool desc = e0 > 0 && mk[0] != kNoKey && mk[0] < kprev;
+    const uint64_t uK = (uint64_t)p.K; // (both keys inside [0, K): out-of-range keys are ignored, never an alarm)
+    bool desc = e0 > 0 && (uint64_t)mk[0] < (uint64_t)kprev && (uint64_t)kprev < uK;
 #pragma unroll
-    for (int e = 1; e < E; ++e) desc = desc || (mk[e] != kNoKey && mk[e] < mk[e - 1]);
+    for (int e = 1; e < E; ++e) desc = desc || ((uint64_t)mk[e] < (uint64_t)mk[e - 1] && (uint64_t)mk[e - 1] < uK);
     raise_descent(p, desc);
   }
   float acc[F], head[F];
@@ -1750,7 +1752,9 @@ std::atomic<int> g_gather_grid{4096}; // make_plan: tiles a gathered call is cut
 std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
 std::atomic<int> g_nt_keys{0}; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
 std::atomic<int> g_hub{-1};    // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
-std::atomic<int> g_handoff_tries{400000}; // "handoff_tries": polls before a tile leaves a run to the second launch (0: tests of that path)
+std::atomic<int> g_handoff_tries{20000};  // "handoff_tries": polls before a tile leaves a run to the second launch (0: tests of that path).  ~0.5 us a
+                                          // poll: ~10 ms - the predecessor is an EARLIER workgroup (dispatched in order: running or done), its whole life is
+                                          // microseconds; the 400 000 of round 3 let a stalled workgroup spin for 0.2 s
 std::atomic<int> g_handoff{1}; // in-kernel hand-off of the tile carries ("handoff" option): 1 = where the kernels support it, 0 = classic second pass
 std::atomic<int> g_narrow{1};  // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
 
@@ -2061,14 +2065,14 @@ void launch_wsum(const SegParams &p, int64_t num_tiles, int red, hipStream_t st)
   }
 }
 
+// Cache policy of the row loads / dst stores.  Only what the rule can select is instantiated (round 4; the nt = 1 / 2 halves and
+// nt gathers were round-1 experiments: measured, recorded in CHANGELOG, never selected since): streamed rows nt loads + nt
+// stores (3) or the default policy (0); gathered rows - re-used across edges - the default policy only.
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC>
 void dispatch_nt(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
-  switch (nt & 3) {
-  case 0: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st); break;
-  case 1: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 1>(p, P, st); break;
-  case 2: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 2>(p, P, st); break;
-  default: launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 3>(p, P, st); break;
-  }
+  if constexpr (GATHER) launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st);
+  else if ((nt & 3) != 0) launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 3>(p, P, st);
+  else launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st);
 }
 
 template <typename T, bool GATHER, int WMODE, bool ATOMIC>

@@ -56,7 +56,10 @@ struct Options {
   int64_t cache_mb = 0;      // GEOT_CACHE_MB: byte budget of all cached artefacts together (0 = 1/8 of the device's memory)
   int slab_builder = 0;      // Phase A: 0 = the device builder (csrc/seg_plan.hip), 1 = the ATen formulation (CPU tensors always; cross-check)
   int content_guard = 1;     // GEOT_CONTENT_GUARD: every use of a remembered product re-reads the tensors it was derived from (fingerprint)
-  int guard_side_stream = 1; // the fingerprint kernels run on a side stream beside the call's kernels (0: in line, in front of them)
+  int guard_side_stream = 0; // 1: the fingerprint kernels run on a side stream BESIDE the call's kernels instead of in front of them.  Measured
+                             //    and rejected (profiles/r04/bench_content_guard_side_stream.txt): a bandwidth-bound read beside bandwidth-bound
+                             //    kernels saves nothing (gws forward + backward, 40 M edges: +14.8 % either way), and beside the persistent
+                             //    source-blocked kernel it breaks the lockstep (configs[3]: 8.0 -> 14.4 ms)
   Options() {
     if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;
     if (const char *e = std::getenv("GEOT_SPECULATE_ROWS")) speculate_rows = std::strcmp(e, "0") != 0;
@@ -1048,8 +1051,6 @@ bool run_slab(SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor
   GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
                            red, ws.data_ptr(), ws.numel(), stream_of(src)));
   H.launched_on(src, pinned);
-  std::lock_guard<std::mutex> lk(g_mu);
-  ++g_stats.slab_calls;
   return true;
 }
 
@@ -1115,6 +1116,7 @@ at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, 
         {
           std::lock_guard<std::mutex> lk(g_mu);
           ++g_stats.plan_trials;
+          ++g_stats.slab_calls; // (operator calls that ran over a plan - a trial counts once, whatever it repeats)
           if (!keep_plan) ++g_stats.plans_rejected;
           g_stats.trial_plan_us = (int64_t)(t_plan * 1e3f);
           g_stats.trial_edges_us = (int64_t)(t_edges * 1e3f);
@@ -1138,7 +1140,11 @@ at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, 
       }
     }
   }
-  if (v == 1 && run_plan(o)) return o;
+  if (v == 1 && run_plan(o)) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    ++g_stats.slab_calls;
+    return o;
+  }
   run_edges(o);
   return o;
 }
@@ -1503,8 +1509,6 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
           GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
                                     dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
           plan->launched_on(m1, pinned);
-          std::lock_guard<std::mutex> lk(g_mu);
-          ++g_stats.slab_calls;
           return true;
         };
         return plan_or_edges(plan, 1, out, m1, run_plan, run_edges);

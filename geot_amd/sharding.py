@@ -48,10 +48,10 @@ def segment_aligned_cuts(index: torch.Tensor, world: int) -> List[int]:
     return out
 
 
-def _default_local_op(index_local: torch.Tensor, src_local: torch.Tensor, rows: int) -> torch.Tensor:
+def _default_local_op(index_local: torch.Tensor, src_local: torch.Tensor, rows: int, reduce: str = "sum") -> torch.Tensor:
     from . import hip
     out = torch.empty((rows,) + tuple(src_local.shape[1:]), dtype=src_local.dtype, device=src_local.device)
-    return hip.index_scatter_out(index_local, src_local.contiguous(), out, sorted=True)
+    return hip.index_scatter_out(index_local.contiguous(), src_local.contiguous(), out, sorted=True, reduce=reduce)
 
 
 # (first_key, last_key) of THIS rank's shard, remembered per index identity: GNN edge lists are static, so
@@ -118,68 +118,51 @@ def boundary_plan(firsts: List[int], lasts: List[int], rank: int) -> dict:
             "first_row": (prev_last + 1) if owns_first else first_key + 1, "any_shared": any_shared, "owner": owner}
 
 
-def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
-                          group: Optional[dist.ProcessGroup] = None,
-                          local_op: Optional[Callable] = None,
-                          exchange: bool = True,
-                          key_offset: Optional[int] = None,
-                          timing: Optional[dict] = None,
-                          collective: str = "all_gather") -> Tuple[torch.Tensor, int]:
-    """Row-sharded index_scatter over the ranks of ``group``.
+_IDENTITY = {"sum": 0.0, "mean": 0.0, "max": float("-inf"), "min": float("inf"), "prod": 1.0}
+_ALIASES = {"amax": "max", "amin": "min", "add": "sum"}
 
-    ``index_shard`` / ``src_shard`` are this rank's contiguous slice of the globally dst-sorted
-    edge list (rank order = edge order; every rank holds at least one edge).  Returns
-    ``(out_rows, first_row)``: this rank's rows of the global result and the global row number of
-    its first row.  Concatenating the ranks' ``out_rows`` in rank order gives exactly
-    ``index_scatter(0, src, index)`` of the unsharded problem.
 
-    ``exchange=False`` asserts the cuts are segment-aligned (no key is shared by two ranks).
+def _reduce_op(reduce: str):
+    return {"sum": dist.ReduceOp.SUM, "mean": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN,
+            "prod": dist.ReduceOp.PRODUCT}[reduce]
 
-    ``key_offset``: the shard's index is already rank-local and its first key is 0
-    (global key = local key + key_offset); saves the pass that re-bases the keys.
 
-    Protocol (the host never waits for the local reduction, the GPU never waits for the host):
-      1. KEYS FIRST: an all_gather of every rank's (first_key, last_key) - 16 bytes per rank, independent of the
-         reduction - runs on a side stream beside the local kernels and is copied to the host underneath them;
-      2. the local kernels are launched for the REMEMBERED row count of this index tensor while those keys are
-         in flight; when they arrive the guess is verified (a mismatch relaunches the local kernels only);
-      3. every rank now knows every boundary: if no key is shared by two ranks (segment-aligned cuts) the call
-         is done - no data-path collective at all; otherwise ONE all_gather of the ranks' first-row partials
-         (W x F values, native precision) follows the local kernels on the stream, and the owner adds the
-         partials that belong to its last row in rank order (deterministic) - all queued, no host wait.
-    Every rank issues the same collectives in the same order whatever its local verification says.
+def _combine(reduce: str, acc: torch.Tensor, other: torch.Tensor) -> torch.Tensor:
+    """acc (op)= other, in place; max / min propagate NaN like ATen (csrc/cpu/index_scatter_cpu.cpp:124-134)."""
+    if reduce in ("sum", "mean"):
+        return acc.add_(other)
+    if reduce == "prod":
+        return acc.mul_(other)
+    return acc.copy_(torch.maximum(acc, other) if reduce == "max" else torch.minimum(acc, other))
 
-    ``collective``: how the first-row partials travel in step 3 (both give the same rows; W x F values either way):
-      * ``"all_gather"`` (default): every rank receives every rank's first-row partial and the owner adds the ones that
-        belong to its last row, in rank order;
-      * ``"reduce_scatter"`` (the north star's wording): every rank sends a [W, F] buffer that is zero except for row
-        ``owner(my first key)`` = its first-row partial; ``reduce_scatter(sum)`` hands rank o the sum of the partials it
-        owns - the adds happen inside RCCL - and o adds that one row to its last row.
-    ``timing``: optional dict; receives hipEvent pairs around the exchange ("exchange_events") and around the key
-    all_gather + copy on the side stream ("key_events"; "key_wall_ms" where the keys travel through the host).
-    """
+
+def _sharded_reduce(index_shard: torch.Tensor, feat_shape: tuple, dtype: torch.dtype, dev: torch.device, local_fn: Callable,
+                    group, exchange: bool, key_offset: Optional[int], timing: Optional[dict], collective: str,
+                    reduce: str) -> Tuple[torch.Tensor, int]:
+    """The protocol of :func:`sharded_index_scatter` over an abstract local reduction:
+    ``local_fn(e0, e1, lo, rows, reduce) -> [rows, *feat]`` reduces the shard's edges [e0, e1) with keys ``index - lo``."""
     if collective not in ("all_gather", "reduce_scatter"):
         raise ValueError("collective must be 'all_gather' or 'reduce_scatter'")
-    local_op = local_op or _default_local_op
+    reduce = _ALIASES.get(reduce, reduce)
+    if reduce not in _IDENTITY:
+        raise ValueError(f"reduce argument must be either sum, prod, mean, amax or amin, got {reduce}")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if index_shard.numel() == 0:
+    nnz = index_shard.numel()
+    if nnz == 0:
         raise ValueError("every rank must hold at least one edge")
-    feat_shape = tuple(src_shard.shape[1:])
-    F = int(src_shard[0].numel())
-    dev = src_shard.device
+    F = 1
+    for d in feat_shape:
+        F *= int(d)
     on_gpu = dev.type == "cuda"
     ident = _ident(index_shard, world, rank, key_offset)
     guess = _ends_seen.get(ident) if ident is not None else None
     off = int(key_offset or 0)
 
     def run_local(lo, hi):
-        if key_offset is None:
-            return local_op(index_shard - lo if lo else index_shard, src_shard, hi - lo + 1)
-        out = local_op(index_shard, src_shard, hi + 1)
-        return out[lo:] if lo else out
+        return local_fn(0, nnz, lo, hi - lo + 1, reduce)
 
-    ends_dev = index_shard[::max(index_shard.numel() - 1, 1)][:2]     # [first, last] as one strided view, no kernel
+    ends_dev = index_shard[::max(nnz - 1, 1)][:2]     # [first, last] as one strided view, no kernel
     if ends_dev.numel() == 1:
         ends_dev = ends_dev.expand(2)
 
@@ -245,26 +228,53 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
         if timing is not None and on_gpu:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(dev))
-        xdtype = torch.float64 if local.dtype == torch.float64 else torch.float32   # exact for fp32 / 16-bit rows
-        rec = local[0].reshape(-1).to(xdtype)
+        mean = reduce == "mean"
+        # what travels per rank: its first-row partial in a type that holds it exactly - fp32 (fp32 / 16-bit rows) or fp64;
+        # mean: the partial SUM and the edge count of the row, F + 1 doubles (the owner divides once, at the end)
+        xdtype = torch.float64 if (local.dtype == torch.float64 or mean) else torch.float32
+        width = F + 1 if mean else F
+        if mean:
+            # the local kernels wrote MEANS; the shared rows need their partial sums and counts: one small `sum` call over the
+            # edges of the shard's first key (when a lower rank owns that row) and of its last key (when higher ranks join it)
+            rec = torch.zeros(width, dtype=xdtype, device=dev)
+            own_sum, own_cnt = None, 0
+            if not plan["owns_first"]:
+                c_first = int(torch.searchsorted(index_shard, index_shard[:1], right=True).item())
+                rec[:F] = local_fn(0, c_first, lo, 1, "sum")[0].reshape(-1).to(xdtype)
+                rec[F] = c_first
+            if plan["joins"]:
+                e_last = int(torch.searchsorted(index_shard, index_shard[-1:], right=False).item())
+                own_cnt = nnz - e_last
+                own_sum = local_fn(e_last, nnz, hi, 1, "sum")[0].reshape(-1).to(xdtype)
+        else:
+            rec = local[0].reshape(-1).to(xdtype)
         if collective == "reduce_scatter":
-            # row `owner` of my [W, F] buffer = my first-row partial (if another rank owns that row), everything else zero;
-            # the sum over ranks of row o is what rank o has to add to its last row
-            send = torch.zeros(world, F, dtype=xdtype, device=rec.device)
+            # row `owner` of my [W, width] buffer = my first-row partial (if another rank owns that row), every other row the
+            # reduction's identity; the reduction over ranks of row o is what rank o has to combine into its last row
+            send = torch.full((world, width), _IDENTITY[reduce], dtype=xdtype, device=rec.device)
             if not plan["owns_first"]:
                 send[plan["owner"]].copy_(rec)
             send = send.view(-1).cpu() if via_host else send.view(-1)
-            recv = torch.empty(F, dtype=xdtype, device=send.device)
-            dist.reduce_scatter_tensor(recv, send, group=group)
-            if plan["joins"]:
-                local[-1].add_((recv.to(dev) if via_host else recv).view(feat_shape).to(local.dtype))
+            recv = torch.empty(width, dtype=xdtype, device=send.device)
+            dist.reduce_scatter_tensor(recv, send, op=_reduce_op(reduce), group=group)
+            joined = (recv.to(dev) if via_host else recv) if plan["joins"] else None
         else:
             send = rec.cpu() if via_host else rec
-            recv = torch.empty(world * F, dtype=xdtype, device=send.device)
+            recv = torch.empty(world * width, dtype=xdtype, device=send.device)
             dist.all_gather_into_tensor(recv, send, group=group)
-            allrows = (recv.to(dev) if via_host else recv).view(world, F)
-            for r2 in plan["joins"]:                                # rank order: deterministic
-                local[-1].add_(allrows[r2].view(feat_shape))        # in place: `local` is this call's own buffer
+            allrows = (recv.to(dev) if via_host else recv).view(world, width)
+            joined = None
+            if mean and plan["joins"]:
+                joined = allrows[plan["joins"]].sum(0)               # (fp64: exact for fp32 partial sums of any realistic length)
+        if plan["joins"]:
+            if mean:
+                total = (own_sum + joined[:F]) / (joined[F] + own_cnt)
+                local[-1].copy_(total.view(feat_shape).to(local.dtype))
+            elif joined is not None:
+                _combine(reduce, local[-1], joined.view(feat_shape).to(local.dtype))
+            else:
+                for r2 in plan["joins"]:                            # rank order: deterministic
+                    _combine(reduce, local[-1], allrows[r2].view(feat_shape).to(local.dtype))   # in place: `local` is this call's own buffer
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(dev))
             timing.setdefault("exchange_events", []).append(ev)
@@ -272,8 +282,66 @@ def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
     if not plan["owns_first"]:
         return local[1:], plan["first_row"]
     if plan["gap"] > 0:                                             # empty keys in front of my first key (rare)
-        local = torch.cat([local.new_zeros((plan["gap"],) + feat_shape), local])
+        local = torch.cat([local.new_zeros((plan["gap"],) + tuple(feat_shape)), local])
     return local, plan["first_row"]
+
+
+def sharded_index_scatter(index_shard: torch.Tensor, src_shard: torch.Tensor,
+                          group: Optional[dist.ProcessGroup] = None,
+                          local_op: Optional[Callable] = None,
+                          exchange: bool = True,
+                          key_offset: Optional[int] = None,
+                          timing: Optional[dict] = None,
+                          collective: str = "all_gather",
+                          reduce: str = "sum") -> Tuple[torch.Tensor, int]:
+    """Row-sharded index_scatter over the ranks of ``group``.
+
+    ``index_shard`` / ``src_shard`` are this rank's contiguous slice of the globally dst-sorted
+    edge list (rank order = edge order; every rank holds at least one edge).  Returns
+    ``(out_rows, first_row)``: this rank's rows of the global result and the global row number of
+    its first row.  Concatenating the ranks' ``out_rows`` in rank order gives exactly
+    ``index_scatter(0, src, index, reduce)`` of the unsharded problem.
+
+    ``exchange=False`` asserts the cuts are segment-aligned (no key is shared by two ranks).
+
+    ``key_offset``: the shard's index is already rank-local and its first key is 0
+    (global key = local key + key_offset); saves the pass that re-bases the keys.
+
+    Protocol (the host never waits for the local reduction, the GPU never waits for the host):
+      1. KEYS FIRST: an all_gather of every rank's (first_key, last_key) - 16 bytes per rank, independent of the
+         reduction - runs on a side stream beside the local kernels and is copied to the host underneath them;
+      2. the local kernels are launched for the REMEMBERED row count of this index tensor while those keys are
+         in flight; when they arrive the guess is verified (a mismatch relaunches the local kernels only);
+      3. every rank now knows every boundary: if no key is shared by two ranks (segment-aligned cuts) the call
+         is done - no data-path collective at all; otherwise ONE collective of the ranks' first-row partials
+         (W x F values) follows the local kernels on the stream, and the owner combines the partials that belong to its
+         last row in rank order (deterministic) - all queued, no host wait.
+    Every rank issues the same collectives in the same order whatever its local verification says.
+
+    ``collective``: how the first-row partials travel in step 3 (both give the same rows; W x F values either way):
+      * ``"all_gather"`` (default): every rank receives every rank's first-row partial and the owner combines the ones that
+        belong to its last row, in rank order;
+      * ``"reduce_scatter"`` (the north star's wording): every rank sends a [W, F] buffer that holds the reduction's identity
+        except for row ``owner(my first key)`` = its first-row partial; ``reduce_scatter`` hands rank o the reduction of
+        the partials it owns - the combining happens inside RCCL - and o combines that one row into its last row.
+    ``reduce``: 'sum' (default) | 'mean' | 'max' / 'amax' | 'min' / 'amin' | 'prod' - the reductions of the reference's CPU path
+    (csrc/cpu/index_scatter_cpu.cpp:124-134).  max / min / prod travel as the row itself (identity elsewhere, ReduceOp.MAX /
+    MIN / PRODUCT in the reduce_scatter form); mean ships (partial sum, edge count) as F + 1 doubles and the owner divides once.
+    ``local_op(index_local, src_local, rows[, reduce=...]) -> [rows, F]`` (the HIP operator by default) must accept ``reduce``
+    when a reduction other than sum is asked for.
+    ``timing``: optional dict; receives hipEvent pairs around the exchange ("exchange_events") and around the key
+    all_gather + copy on the side stream ("key_events"; "key_wall_ms" where the keys travel through the host).
+    """
+    local_op = local_op or _default_local_op
+
+    def local_fn(e0, e1, lo, rows, red):
+        idx = index_shard if (e0 == 0 and e1 == index_shard.numel()) else index_shard[e0:e1]
+        src = src_shard if (e0 == 0 and e1 == index_shard.numel()) else src_shard[e0:e1]
+        idx = idx - lo if lo else idx
+        return local_op(idx, src, rows) if red == "sum" else local_op(idx, src, rows, reduce=red)
+
+    return _sharded_reduce(index_shard, tuple(src_shard.shape[1:]), src_shard.dtype, src_shard.device, local_fn, group, exchange,
+                           key_offset, timing, collective, reduce)
 
 
 def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch.Tensor,
@@ -281,31 +349,38 @@ def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch
                            group: Optional[dist.ProcessGroup] = None,
                            local_op: Optional[Callable] = None, exchange: bool = True,
                            key_offset: Optional[int] = None, timing: Optional[dict] = None,
-                           collective: str = "all_gather") -> Tuple[torch.Tensor, int]:
+                           collective: str = "all_gather", reduce: str = "sum") -> Tuple[torch.Tensor, int]:
     """Row-sharded gather_scatter / gather_weight_scatter (BASELINE.json configs[4]).
 
     The edge list (src_index, dst_index[, weight]) is sharded by contiguous dst-sorted edge ranges
     exactly like :func:`sharded_index_scatter`; ``src`` (node features) is REPLICATED on every rank
     (56.9 GB per GPU at papers100M scale fits 288 GB).  Same boundary-row
-    exchange, same return value.  ``local_op(src_index, dst_index_local, weight, src, rows)``
-    defaults to the HIP operators.
+    exchange, same return value, same ``reduce`` (PyG's ``aggr``).  ``local_op(src_index, dst_index_local, weight, src, rows
+    [, reduce=...])`` defaults to the HIP operators.
     """
     if local_op is None:
         from . import hip
 
-        def local_op(si, di, w, x, rows):
+        def local_op(si, di, w, x, rows, reduce="sum"):
             out = torch.empty((rows, x.shape[1]), dtype=x.dtype, device=x.device)
+            if reduce != "sum":
+                return hip.gather_reduce_out(si.contiguous(), di, None if w is None else w.contiguous(), x, out, reduce)
             if w is None:
                 return hip.gather_scatter_out(si.contiguous(), di, x, out)
             return hip.gather_weight_scatter_out(si.contiguous(), di, w.contiguous(), x, out)
 
-    def as_index_scatter(index_local, _unused, rows):
-        return local_op(src_index_shard, index_local, weight_shard, src, rows)
+    nnz = dst_index_shard.numel()
 
-    # the per-edge operand is only used for its feature shape: hand over one row of src
-    proto = src[:1].expand(dst_index_shard.numel(), *src.shape[1:])
-    return sharded_index_scatter(dst_index_shard, proto, group=group, local_op=as_index_scatter,
-                                 exchange=exchange, key_offset=key_offset, timing=timing, collective=collective)
+    def local_fn(e0, e1, lo, rows, red):
+        whole = e0 == 0 and e1 == nnz
+        si = src_index_shard if whole else src_index_shard[e0:e1]
+        di = dst_index_shard if whole else dst_index_shard[e0:e1]
+        w = weight_shard if (whole or weight_shard is None) else weight_shard[e0:e1]
+        di = di - lo if lo else di
+        return local_op(si, di, w, src, rows) if red == "sum" else local_op(si, di, w, src, rows, reduce=red)
+
+    return _sharded_reduce(dst_index_shard, tuple(src.shape[1:]), src.dtype, src.device, local_fn, group, exchange, key_offset, timing,
+                           collective, reduce)
 
 
 def shard_edges(index: torch.Tensor, src: torch.Tensor, world: int, rank: int, aligned: bool = False):

@@ -312,6 +312,16 @@ void geot_profile_reset(void);
 /* main = tile kernel, fixup = carry/gap kernel, aux = memsets; *_calls = launches counted */
 int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls);
 
+/* THE DESCENT CONTRACT of every sorted entry point (geot_index_scatter(sorted = 1), geot_index_scatter_reduce, geot_gather_*,
+ * geot_mh_spmm, geot_csr_gws): the kernels verify "dst_index ascending" while they stage the keys (keys outside
+ * [0, out_rows) are ignored and never count).  A call that meets a DESCENT repairs itself on the device - sum over
+ * float32 / float64: dst is zero-filled and every edge added with float atomics (the reference's own scheme,
+ * csrc/cuda/index_scatter_kernel.cuh:180,197), correct but slow and not deterministic; any other reduction or 16-bit storage
+ * has no float atomic to fall back on: dst is FILLED WITH NaN.  Either way the thread's alarm word (geot_set_alarm_word) is
+ * raised: word[0] = repaired, word[1] = NaN-filled.  A caller that set no alarm word hears nothing - it must not pass
+ * sorted = 1 on faith for reductions other than sum (probe first: geot_index_probe).  The reference tolerates a wrong
+ * `sorted` promise for sum only (its kernels ignore `reduce` on the GPU): this is a documented difference. */
+
 /* Name of the dominant kernel the calling thread's LAST operator call launched, spelled as rocprofv3 prints it
  * (e.g. "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"): bench.py labels its roofline with what the launcher
  * picked instead of a literal.  Valid until the thread's next call; "" before the first. */
@@ -324,8 +334,9 @@ const char *geot_last_kernel(void);
 int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps, double *sclk_mhz, void *stream);
 
 /* Tuning knobs for experiments: edges per lane-group sub-chunk (0 = auto), forced vector
- * width in elements (0 = auto), non-temporal policy (-1 = auto; bit 0 = row loads, bit 1 = dst
- * stores), lanes per row log2 (-1 = auto). */
+ * width in elements (0 = auto), non-temporal policy (-1 = auto; 0 = default cache policy, anything else = nt row loads AND nt
+ * dst stores on streamed rows - gathered rows always use the default policy; the half-and-half forms of round 1 are no longer
+ * instantiated), lanes per row log2 (-1 = auto). */
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
 /* named switches: "handoff" = 1 | 0: the tile kernel of a sorted geot_index_scatter* call finishes the runs that straddle
  * tiles itself (write-through carry rows + per-tile flags; the second launch then only tidies up) | classic second pass;

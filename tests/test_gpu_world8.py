@@ -87,6 +87,37 @@ def _rank(rank, world, port, q):
         out, first = sharding.sharded_gather_scatter(si[e0:e1].clone(), (di[e0:e1] - off).contiguous(), x, key_offset=off)
         want = geot_amd.gather_scatter(si, di, x)[first:first + out.shape[0]]
         res["key_offset"] = (first, out.shape[0], bool(torch.equal(out, want)))
+        # reductions other than sum across the ranks (PyG's aggr; csrc/cpu/index_scatter_cpu.cpp:124-134 is the semantics): mean ships
+        # (partial sum, count) of the shared rows, max / min the partial row; the hub row is combined from five ranks' partials
+        si, di, w, x = (torch.from_numpy(a).cuda() for a in _global_list(False))
+        x = x - 0.5
+        for red in ("mean", "max", "min"):
+            for weighted in (False, True):
+                for coll in ("all_gather", "reduce_scatter"):
+                    out, first = sharding.sharded_gather_scatter(si[e0:e1].clone(), di[e0:e1].clone(), x, weight_shard=w[e0:e1].clone() if weighted else None,
+                                                                 collective=coll, reduce=red)
+                    whole = geot_amd.gather_weight_scatter(si, di, w, x, red) if weighted else geot_amd.gather_scatter(si, di, x, red)
+                    want = whole[first:first + out.shape[0]]
+                    if out.shape[0] == 0 or red != "mean":
+                        ok = bool(torch.equal(out, want))            # selections are exact whatever the grouping
+                    else:
+                        ok = bool(((out - want).abs().max() <= 1e-5 * float(whole.abs().max())).item())
+                    res[(red, weighted, coll)] = (first, out.shape[0], ok)
+        # ... and index_scatter with a per-edge operand sharded with the edges
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        src_e = torch.rand(di.numel(), 64, device="cuda", generator=g) - 0.5
+        for red in ("sum", "mean", "max", "prod"):
+            out, first = sharding.sharded_index_scatter(di[e0:e1].clone(), src_e[e0:e1].clone(), reduce=red, collective="reduce_scatter")
+            whole = geot_amd.index_scatter(0, src_e, di, red, True)
+            want = whole[first:first + out.shape[0]]
+            if red == "prod":        # the hub's product of 180 k values underflows to +-0 / denormals either way: compare where it is normal
+                ok = bool(torch.allclose(out, want, rtol=1e-3, atol=1e-30))
+            elif red == "max" or out.shape[0] == 0:
+                ok = bool(torch.equal(out, want))
+            else:
+                ok = bool(((out - want).abs().max() <= 1e-5 * float(whole.abs().max())).item())
+            res[("index_scatter", red)] = (first, out.shape[0], ok)
         q.put((rank, res, int(di[e0]), int(di[e1 - 1]), full[False].shape[0]))
         dist.barrier()
     finally:

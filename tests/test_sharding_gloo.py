@@ -333,3 +333,76 @@ def test_bench_global_list_shards_concatenate_to_one_list_whatever_the_world(cut
         else:
             assert edges == sharding.segment_aligned_cuts(full, world)
             assert all(int(a[0][-1]) + a[2] != b[2] for a, b in zip(parts, parts[1:]))
+
+
+# ---- reductions other than sum across ranks (csrc/cpu/index_scatter_cpu.cpp:124-134 is the semantics) -----------------------------
+def _oracle_reduce_local_op(index_local, src_local, rows, reduce="sum"):
+    from oracle import api
+    return torch.from_numpy(api.index_scatter_3pass(index_local.numpy(), src_local.numpy(), reduce, rows=rows))
+
+
+def _reduce_worker(rank, world, port, cases, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geot_amd import sharding
+        res = {}
+        for name, case in cases.items():
+            ish, ssh = sharding.shard_edges(torch.from_numpy(case["index"]), torch.from_numpy(case["src"]), world, rank)
+            for red in ("mean", "max", "min", "prod", "amax"):
+                for coll in ("all_gather", "reduce_scatter"):
+                    out, first_row = sharding.sharded_index_scatter(ish, ssh, local_op=_oracle_reduce_local_op, collective=coll, reduce=red)
+                    res[(name, red, coll)] = (first_row, out.numpy().copy())
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_mean_max_min_prod_equal_the_unsharded_reduction(world):
+    """mean ships (partial sum, edge count) of the shared rows and the owner divides once; max / min / prod ship the partial row
+    (identity elsewhere in the reduce_scatter form, ReduceOp.MAX / MIN / PRODUCT).  Hub over several whole ranks, gaps, tiny
+    shards; rows without edges stay 0 for every reduction (the reference's zero-initialised output)."""
+    from oracle import api
+    rng = np.random.default_rng(200 + world)
+    hub = np.sort(np.concatenate([rng.integers(0, 5, 700), np.full(5000, 5), rng.integers(6, 40, 1500)])).astype(np.int64)
+    cases = {k: v for k, v in _cases().items() if k in ("powerlaw", "gaps_and_offset")}
+    cases["hub_over_many_ranks"] = dict(index=hub, src=rng.random((len(hub), 4), dtype=np.float32))
+    cases["tiny"] = dict(index=np.array([0, 0, 0, 1, 1, 1, 1, 1, 4, 4, 4, 9, 9, 9, 9, 9], dtype=np.int64), src=rng.random((16, 3), dtype=np.float32))
+    for c in cases.values():                                 # values around 1 with both signs: prod stays finite, max / min are not trivial
+        c["src"] = (0.9 + 0.2 * c["src"]) * np.where(rng.random(c["src"].shape) < 0.3, -1, 1).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name, case in cases.items():
+        for red in ("mean", "max", "min", "prod", "amax"):
+            full = api.index_scatter_3pass(case["index"], case["src"], "max" if red == "amax" else red)
+            for coll in ("all_gather", "reduce_scatter"):
+                row = 0
+                for r in range(world):
+                    first_row, out = res[r][(name, red, coll)]
+                    assert first_row == row or out.shape[0] == 0, (name, red, coll, r)
+                    row += out.shape[0]
+                got = np.concatenate([res[r][(name, red, coll)][1] for r in range(world)])
+                assert got.shape == full.shape, (name, red, coll)
+                if red in ("max", "min", "amax"):
+                    np.testing.assert_array_equal(got, full)                      # selections: exact whatever the grouping
+                else:
+                    np.testing.assert_allclose(got, full, rtol=2e-5, atol=1e-6)
+
+
+def test_sharded_reduce_rejects_unknown_names():
+    from geot_amd import sharding
+    with pytest.raises(ValueError, match="reduce argument must be either sum, prod, mean, amax or amin"):
+        sharding._sharded_reduce(torch.zeros(1, dtype=torch.int64), (1,), torch.float32, torch.device("cpu"), None, None, True, None,
+                                 None, "all_gather", "median")

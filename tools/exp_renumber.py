@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Experiment: fewer bytes for gathers on UNORDERED graphs by a one-time node renumbering.
+
+The per-edge gather kernels serve a graph with locality (sources near their destinations: node ids numbered by community) at
+3.4 ms / 1.05x compulsory traffic at configs[2] size, and the same edge count with unordered ids at 9.6 ms / 13.5x.  Real
+datasets ship unordered.  If a device-built order brings community members together, a call can run as
+
+    x_perm = gather_rows(x, order)                  # 2 x |x| bytes streamed
+    y_perm = gws(new_src, new_dst_sorted, w_perm, x_perm)
+    y      = gather_rows(y_perm, rank)              # 2 x |y| bytes streamed
+
+Stand-in (the judge's): a block-model graph at configs[2] size - communities of 2-20 k nodes, 90 % of a node's edges inside
+its community, ids randomly permuted.  Orders tried: (a) the true community order (the ceiling), (b) label propagation on the
+device (synchronous "most frequent neighbour label", a few sweeps, sort-based), (c) min-neighbour-label sweeps.
+
+    python tools/exp_renumber.py [--scale 1.0] [--sweeps 4]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import device_ms  # noqa: E402
+import geot_amd as geot  # noqa: E402
+from geot_amd import hip  # noqa: E402
+
+
+def block_model(nodes, nnz, intra, dev, seed=3, powerlaw=True):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    # community sizes uniform in [2000, 20000]
+    sizes = []
+    left = nodes
+    gs = torch.Generator()
+    gs.manual_seed(seed)
+    while left > 0:
+        s = int(torch.randint(2000, 20001, (1,), generator=gs).item())
+        s = min(s, left)
+        sizes.append(s)
+        left -= s
+    sizes_t = torch.tensor(sizes, device=dev)
+    starts = torch.cumsum(sizes_t, 0) - sizes_t
+    comm = torch.repeat_interleave(torch.arange(len(sizes), device=dev), sizes_t)       # community of node (ordered ids)
+    if powerlaw:
+        w = torch.arange(1, nodes + 1, device=dev, dtype=torch.float64) ** (-1.0 / 1.5)
+        cdf = torch.cumsum(w, 0)
+        pr = torch.randperm(nodes, generator=g, device=dev)
+        u = torch.rand(nnz, generator=g, device=dev, dtype=torch.float64) * cdf[-1]
+        dst = pr[torch.searchsorted(cdf, u).clamp_(max=nodes - 1)]
+        del w, cdf, u
+    else:
+        dst = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    c = comm[dst]
+    inside = torch.rand(nnz, device=dev, generator=g) < intra
+    src_in = starts[c] + (torch.rand(nnz, device=dev, generator=g) * sizes_t[c]).long().clamp_(max=nodes - 1)
+    src_out = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    src = torch.where(inside, src_in, src_out)
+    del c, inside, src_in, src_out
+    shuffle = torch.randperm(nodes, generator=g, device=dev)                               # ordered id -> shipped id
+    dst_s, src_s = shuffle[dst], shuffle[src]
+    order = torch.argsort(dst_s, stable=True)
+    truth = torch.empty(nodes, dtype=torch.int64, device=dev)
+    truth[shuffle] = torch.arange(nodes, device=dev)                                       # shipped id -> ordered id (the ceiling's rank)
+    return src_s[order].contiguous(), dst_s[order].contiguous(), truth, len(sizes)
+
+
+def lpa(si, di, nodes, sweeps, dev):
+    """Synchronous label propagation, sort-based: label[d] <- the most frequent label among d's in-neighbours (ties: larger label)."""
+    label = torch.arange(nodes, device=dev)
+    bits = max(1, (nodes - 1).bit_length())
+    for _ in range(sweeps):
+        key = (di << bits) | label[si]
+        key = torch.sort(key).values
+        uniq, cnt = torch.unique_consecutive(key, return_counts=True)
+        d = uniq >> bits
+        score = (cnt << bits) | (uniq & ((1 << bits) - 1))
+        best = torch.zeros(nodes, dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, d, score, reduce="amax", include_self=True)
+        new = torch.where(best > 0, best & ((1 << bits) - 1), label)
+        changed = int((new != label).sum().item())
+        label = new
+        if changed == 0:
+            break
+    return label
+
+
+def min_label(si, di, nodes, sweeps, dev):
+    label = torch.arange(nodes, device=dev)
+    for _ in range(sweeps):
+        new = label.clone()
+        new.scatter_reduce_(0, di, label[si], reduce="amin", include_self=True)
+        label = new
+    return label
+
+
+def run_renumbered(name, rank, si, di, w, x, y_ref, nodes, iters=5):
+    """rank[node] = new id.  One-time: renumber + re-sort the edge list; per call: permute x in, gws, permute y out."""
+    dev = x.device
+    t0 = time.perf_counter()
+    order = torch.argsort(rank)                       # new id -> old id
+    nd, ns = rank[di], rank[si]
+    eperm = torch.argsort(nd, stable=True)
+    nd_s, ns_s = nd[eperm].contiguous(), ns[eperm].contiguous()
+    torch.cuda.synchronize()
+    t_once = (time.perf_counter() - t0) * 1e3
+    xp = torch.empty_like(x)
+    yp = torch.empty_like(x)
+    y = torch.empty_like(x)
+    wp = w[eperm].contiguous()                        # static weight: permuted once
+    k_ms = device_ms(lambda: hip.gather_weight_scatter_out(ns_s, nd_s, wp, xp, yp), iters)
+
+    def whole(dynamic_w):
+        hip.gather_rows_out(order, x, xp)
+        ww = w[eperm] if dynamic_w else wp
+        hip.gather_weight_scatter_out(ns_s, nd_s, ww, xp, yp)
+        hip.gather_rows_out(rank, yp, y)
+    ms_static = device_ms(lambda: whole(False), iters)
+    ms_dyn = device_ms(lambda: whole(True), iters)
+    whole(False)
+    err = float(((y - y_ref).abs().max() / y_ref.abs().max()).item())
+    print(f"  {name:34s} kernel {k_ms:7.3f} ms   call incl. x/y permutes {ms_static:7.3f} ms (static w) {ms_dyn:7.3f} ms (w permuted per call)   "
+          f"one-time renumber+sort {t_once:7.1f} ms   max rel diff {err:.1e}", flush=True)
+    return ms_static
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--sweeps", type=int, default=4)
+    ap.add_argument("--intra", type=float, default=0.9)
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    nodes, nnz, F = int(2_449_029 * a.scale), int(123_718_280 * a.scale), 128
+    print(hip.build_info())
+    si, di, truth, ncomm = block_model(nodes, nnz, a.intra, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    w = torch.rand(nnz, device=dev, generator=g)
+    x = torch.rand(nodes, F, device=dev, generator=g)
+    y_ref = torch.empty_like(x)
+    base = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, y_ref), 5)
+    print(f"block model: {nodes} nodes, {nnz} edges, {ncomm} communities of 2-20 k nodes, {a.intra:.0%} intra-community edges, ids shuffled, F={F}")
+    print(f"  as shipped (unordered ids)         kernel {base:7.3f} ms", flush=True)
+    res = {"shipped": base}
+    res["truth"] = run_renumbered("true community order (ceiling)", truth, si, di, w, x, y_ref, nodes)
+    for sweeps in sorted({a.sweeps, 8, 12}):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lab = lpa(si, di, nodes, sweeps, dev)
+        rank = torch.empty(nodes, dtype=torch.int64, device=dev)
+        rank[torch.argsort(lab, stable=True)] = torch.arange(nodes, device=dev)
+        torch.cuda.synchronize()
+        t_lpa = (time.perf_counter() - t0) * 1e3
+        nlab = int(torch.unique(lab).numel())
+        print(f"  label propagation, {sweeps} sweeps: {t_lpa:.0f} ms on the device (torch ops), {nlab} labels left")
+        res[f"lpa{sweeps}"] = run_renumbered(f"label propagation x{sweeps}", rank, si, di, w, x, y_ref, nodes)
+    for sweeps in (2, 3):
+        lab = min_label(si, di, nodes, sweeps, dev)
+        rank = torch.empty(nodes, dtype=torch.int64, device=dev)
+        rank[torch.argsort(lab, stable=True)] = torch.arange(nodes, device=dev)
+        res[f"min{sweeps}"] = run_renumbered(f"min-neighbour label x{sweeps}", rank, si, di, w, x, y_ref, nodes)
+    print({k: round(v, 3) for k, v in res.items()}, "speedup of the best device-built order (call incl. permutes):",
+          round(base / min(v for k, v in res.items() if k not in ("shipped", "truth")), 2))
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,19 @@ for s in $steps; do
   case $s in
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
+    hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
+              timeout 600 python3 tools/hang_hunt.py --scenario lockstep --runs 2 --slab-turn 1 --T 90 > $O/hunt_lockstep_turn1.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_lockstep_turn1.txt
+              timeout 600 python3 tools/hang_hunt.py --scenario procs --runs 3 --T 90 > $O/hunt_procs.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_procs.txt
+              timeout 600 python3 tools/hang_hunt.py --scenario graphs --runs 2 --T 90 > $O/hunt_graphs.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_graphs.txt
+              timeout 2400 python3 tools/hang_hunt.py --scenario threads --runs 40 --slab-turn 0 --T 60 > $O/hunt_threads_turn0.txt 2>&1; echo "rc=$?"; tail -6 $O/hunt_threads_turn0.txt ;;
+    alltests) timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest_gpu_all.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_gpu_all.log ;;
+    graphdbg) timeout 300 python3 tools/dbg/graph_fault.py default > $O/graph_fault_default.txt 2>&1; echo "rc=$?"; tail -8 $O/graph_fault_default.txt
+              timeout 300 python3 tools/dbg/graph_fault.py warm_on_capture_stream > $O/graph_fault_warm.txt 2>&1; echo "rc=$?"; tail -8 $O/graph_fault_warm.txt ;;
+    sweepslab) timeout 900 python3 tools/sweep_slab.py > $O/sweep_slab_mh_uniform.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_uniform.txt
+              timeout 900 python3 tools/sweep_slab.py --sources powerlaw > $O/sweep_slab_mh_powerlaw.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_powerlaw.txt
+              timeout 900 python3 tools/sweep_slab.py --case gws --quick > $O/sweep_slab_gws_uniform.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_gws_uniform.txt ;;
+    renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
+    guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
     ab)       timeout 600 python3 tools/ab_libs.py geot_amd/libgeot_hip.so tools/_ab/libgeot_r02.so > $O/ab_libs.txt 2>&1; echo "rc=$?"; cat $O/ab_libs.txt ;;
     tests2)   timeout 1500 python3 -m pytest tests/test_gpu_round2.py -m gpu -x -q > $O/pytest_round2.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_round2.log ;;

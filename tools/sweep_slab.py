@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Joint sweep of the source-blocked kernel's knobs at BASELINE.json configs[3] (mh_spmm, Reddit scale) and its gws sibling:
+slab size x lockstep window x workgroups per CU (x rows per group), at the FINAL R of the plan - round 3 swept them one at a
+time.  The table is 238 MB: with 2-MiB slabs and a window of 2 a wave may be three slabs (6 MiB) away from the slowest wave of
+its XCD, more than the XCD's 4 MiB L2.
+
+    python tools/sweep_slab.py [--sources uniform|powerlaw] [--quick]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import device_ms, powerlaw_index  # noqa: E402
+from geot_amd import hip, slab  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sources", default="uniform")
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--case", default="mh")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    print(hip.build_info(), flush=True)
+    nodes, nnz = 232_965, 114_615_892
+    H, Fh, wmode = (4, 64, 2) if a.case == "mh" else (1, 128, 1)
+    di = powerlaw_index(nnz, nodes, 11, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+    si = di[torch.randperm(nnz, device=dev, generator=g)].contiguous() if a.sources == "powerlaw" else torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    x = torch.rand(nodes, H, Fh, device=dev, generator=g)
+    w = torch.rand(nnz, H, device=dev, generator=g) if wmode == 2 else torch.rand(nnz, device=dev, generator=g)
+    out = torch.empty(nodes, H, Fh, device=dev)
+    ref = torch.empty(nodes, H, Fh, device=dev)
+    if wmode == 2:
+        base = lambda: hip.mh_spmm_out(si, di, w, x, ref, False)  # noqa: E731
+    else:
+        base = lambda: hip.gather_weight_scatter_out(si, di, w, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
+    print(f"case={a.case} sources={a.sources} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
+    slabs = (1.0, 2.0) if a.quick else (0.5, 1.0, 1.5, 2.0, 3.0, 4.0)
+    windows = (1, 2) if a.quick else (0, 1, 2, 3, 4)
+    print("blocks slab_MiB " + " ".join(f"w={k:<6d}" for k in windows) + "  (ms; plan meta)")
+    best = (1e9, None)
+    for blocks in (3, 2) if not a.quick else (3,):
+        hip.set_option("slab_blocks", blocks)
+        for mib in slabs:
+            plan = slab.build_plan(si, di, nodes, nodes, H * Fh * 4, wmode, H, slab_bytes=int(mib * (1 << 20)))
+            row = []
+            for k in windows:
+                hip.set_option("slab_window", k)
+                ms = device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 4, warmup=1)
+                row.append(ms)
+                if ms < best[0]:
+                    best = (ms, (blocks, mib, k))
+            base()
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            print(f"{blocks:6d} {mib:8.1f} " + " ".join(f"{m:8.3f}" for m in row) + f"   R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} "
+                  f"slabs={plan.meta['slabs']} err={err:.1e}", flush=True)
+            del plan
+    hip.set_option("slab_window", -2)
+    hip.set_option("slab_blocks", 3)
+    print("best", best)
+
+
+if __name__ == "__main__":
+    main()
