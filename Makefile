@@ -25,15 +25,10 @@ tools/kbench: tools/kbench.cpp $(LIB) include/geot_hip.h
 	  -Wl,-rpath,'$$ORIGIN/../geot_amd' -o $@
 
 # the PyTorch dispatcher plugin over the C ABI (the host side of the drop-in): geot_amd/_C.so
-TORCH_DIR := $(shell python3 -c "import os,torch;print(os.path.dirname(torch.__file__))")
-CXXABI    := $(shell python3 -c "import torch;print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")
 shim: geot_amd/_C.so
-geot_amd/_C.so: geot_amd/csrc/torch_ops.cpp $(LIB) include/geot_hip.h
-	g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=$(CXXABI) \
-	  -Iinclude -I$(TORCH_DIR)/include -I$(TORCH_DIR)/include/torch/csrc/api/include -I/opt/rocm/include \
-	  geot_amd/csrc/torch_ops.cpp -o $@ -Lgeot_amd -lgeot_hip -L$(TORCH_DIR)/lib -ltorch -ltorch_cpu -ltorch_hip -lc10 -lc10_hip -L/opt/rocm/lib -lamdhip64 \
-	  -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(TORCH_DIR)/lib
-	python3 geot_amd/_lib.py stamp-plugin
+# (geot_amd/_lib.py holds the recipe: g++ -c csrc/torch_ops.cpp csrc/host_*.cpp side by side, one link against libtorch + libgeot_hip)
+geot_amd/_C.so: geot_amd/csrc/torch_ops.cpp geot_amd/csrc/host_state.cpp geot_amd/csrc/host_cache.cpp geot_amd/csrc/host_plan.cpp geot_amd/csrc/host.h $(LIB) include/geot_hip.h
+	python3 geot_amd/_lib.py plugin
 
 oracle:
 	$(MAKE) -C oracle oracle

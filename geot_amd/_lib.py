@@ -19,9 +19,10 @@ SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "c
            os.path.join(_HERE, "csrc", "seg_guard.hip")]
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
-PLUGIN_SOURCE = os.path.join(_HERE, "csrc", "torch_ops.cpp")
+PLUGIN_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("torch_ops.cpp", "host_state.cpp", "host_cache.cpp", "host_plan.cpp")]
+PLUGIN_HEADER = os.path.join(_HERE, "csrc", "host.h")
 LIB_INPUTS = SOURCES + [HEADER, os.path.join(_HERE, "csrc", "internal.h")]
-PLUGIN_INPUTS = [PLUGIN_SOURCE, HEADER]
+PLUGIN_INPUTS = PLUGIN_SOURCES + [PLUGIN_HEADER, HEADER]
 
 GEOT_OK = 0
 GEOT_F32, GEOT_F64, GEOT_F16, GEOT_BF16 = 0, 1, 2, 3
@@ -137,14 +138,37 @@ def plugin_needs_build() -> bool:
 
 
 def build_plugin(force: bool = False, verbose: bool = False) -> str:
-    """g++ build of geot_amd/_C.so against the installed torch (no GPU needed; ~30 s).  Same recipe as `make shim`."""
+    """g++ build of geot_amd/_C.so against the installed torch (no GPU needed): one object per source (csrc/torch_ops.cpp +
+    csrc/host_*.cpp, compiled side by side, ~40 s), one link.  Same recipe as `make shim`."""
     if force or plugin_needs_build():
         import torch
+        from concurrent.futures import ThreadPoolExecutor
         tdir = os.path.dirname(torch.__file__)
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
-               f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", os.path.join(_ROOT, "include"),
-               "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
-               "-I", "/opt/rocm/include", PLUGIN_SOURCE, "-o", PLUGIN_PATH, "-L", _HERE, "-lgeot_hip",
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        flags = ["-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+                 f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", os.path.join(_ROOT, "include"),
+                 "-I", os.path.join(tdir, "include"), "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+                 "-I", "/opt/rocm/include"]
+        shared = [PLUGIN_HEADER, HEADER]
+        todo, objs = [], []
+        for src in PLUGIN_SOURCES:
+            obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [src] + shared) or not os.path.exists(obj + ".srchash"):
+                todo.append((src, obj))
+
+        def compile_one(job):
+            src, obj = job
+            cmd = ["g++", *flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            with open(obj + ".srchash", "w") as f:
+                f.write(_digest([src] + shared) + "\n")
+
+        with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, todo))
+        cmd = ["g++", "-shared", "-fPIC", *objs, "-o", PLUGIN_PATH, "-L", _HERE, "-lgeot_hip",
                "-L", os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
                "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{os.path.join(tdir, 'lib')}"]
         if verbose:

@@ -54,6 +54,8 @@ struct SlabParams {
   int slab_shift;       // slab = source row >> slab_shift
   int n_slabs;
   int window;           // a wave may be at most `window` slabs ahead of the slowest wave of its XCD; < 0: no sync
+  int far;              // ... but a slowest wave MORE than `far` steps behind is not waited for: nothing it reads can still be shared
+  int nt_plan;          // experiment: non-temporal loads of the plan's edge fields and of the weights (read once per launch)
   int w_in_plan_order;  // WMODE 1: weight[] is indexed by plan position (a static weight permuted once), not by edge id
 };
 constexpr int kProgSlots = 512;
@@ -154,8 +156,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   T *dst = static_cast<T *>(p.dst);
   const int h = WMODE >= 2 ? (c * VEC) / p.Fh : 0;
   typedef T t4_t __attribute__((ext_vector_type(4)));
+  const bool ntp = p.nt_plan != 0;
   auto load_w4 = [&](int64_t pe) { // the 4 head weights of an edge (edge-major layout, H == 4) as floats: one 16- / 8-byte read
-    const t4_t x = *reinterpret_cast<const t4_t *>(weight + pe * 4);
+    const t4_t x = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + pe * 4)) : *reinterpret_cast<const t4_t *>(weight + pe * 4);
     return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
   };
   const uint32_t rb = p.rowbytes;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         m = other < m ? other : m;
       }
       known_min = m;
-      if (m + p.window >= step) {
+      if (m + p.window >= step || step - m > p.far) {
         ok = true;
         break;
       }
@@ -271,10 +274,10 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       // next chunk's fields: in flight underneath this chunk's rows
       const bool nvalid = off + lpr + c < len;
       const int64_t ne = e0 + off + lpr + c;
-      const int n_src = nvalid ? P.e_src[ne] : 0;
-      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      const int n_src = nvalid ? (ntp ? __builtin_nontemporal_load(P.e_src + ne) : P.e_src[ne]) : 0;
+      const int n_dl = nvalid ? (int)(ntp ? __builtin_nontemporal_load(P.e_dl + ne) : P.e_dl[ne]) : 255;
       int64_t n_pe = 0;
-      if constexpr (WMODE != 0) n_pe = nvalid ? (int64_t)P.e_perm[ne] : 0;
+      if constexpr (WMODE != 0) n_pe = nvalid ? (int64_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne]) : 0;
       f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
       float wn1 = 0.f;
 
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
         m = other < m ? other : m;
       }
       known_min = m;
-      if (m + p.window >= step) {
+      if (m + p.window >= step || step - m > p.far) {
         ok = true;
         break;
       }
@@ -630,6 +633,13 @@ extern "C" {
 constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
 int g_slab_window = 2;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
 
+// "slab_far": the lockstep exists so that the waves of an XCD read the SAME slab at about the same time.  A wave whose slab is far
+// from the slowest wave's shares nothing with it whatever it does - the case of a graph with LOCALITY (sources near their
+// destinations: every group lives in its own few slabs, the groups in flight are spread over the whole table), where waiting
+// for the slowest wave serialised the chip (Reddit scale, sources within +-2000 rows: 48.7 ms against 6.2 ms per edge, r03).
+// Such a wave does not wait.  On graphs without locality all waves sweep the table together and never get that far apart.
+int g_slab_far = 12;
+int g_slab_nt = 0;      // "slab_nt": experiment, see SlabParams::nt_plan
 int g_slab_turn = 1;    // "slab_turn": 1 = the persistent grids of this process take turns on a device (see SlabTurn), 0 = launch freely
 
 int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
@@ -726,6 +736,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.slab_shift = plan->slab_shift;
   p.n_slabs = plan->n_slabs;
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (lpr_log2 == 6 ? 2 : 1) : g_slab_window) : -1;
+  p.far = g_slab_far;
+  p.nt_plan = g_slab_nt;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
   p.src_rows = src_rows;
   p.K = out_rows;
@@ -811,6 +823,8 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
   p.src = mat_2;
   p.dst = out;
   p.carry = nullptr;
+  p.far = g_slab_far;
+  p.nt_plan = g_slab_nt;
   p.w_in_plan_order = 0;
   p.src_rows = rows_2;
   p.K = rows_1;
@@ -851,6 +865,8 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
 void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_window") g_slab_window = value;
   if (name && std::string(name) == "slab_turn") g_slab_turn = value != 0;
+  if (name && std::string(name) == "slab_far" && value >= 0) g_slab_far = value;
+  if (name && std::string(name) == "slab_nt") g_slab_nt = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 

@@ -126,7 +126,7 @@ def clear_caches() -> None:
 def stats() -> dict:
     names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans",
              "published", "alarms", "cache_bytes", "stale_products", "guard_checks", "plan_trials", "plans_rejected",
-             "trial_plan_us", "trial_edges_us")
+             "trial_plan_us", "trial_edges_us", "plans_declined", "last_coverage_permille")
     return dict(zip(names, torch.ops.geot._host_stats()))
 
 

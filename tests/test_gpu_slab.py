@@ -528,7 +528,7 @@ def test_slab_sddmm_16bit_storage(geot, oracle, dtype, nodes, nnz, F):
     assert torch.equal(out, again)
 
 
-def test_a_plan_that_loses_to_the_per_edge_kernels_is_dropped(geot, oracle):
+def test_a_plan_that_loses_to_the_per_edge_kernels_is_dropped(geot, oracle, request):
     """The density rule that routes a graph to the source-blocked kernels was calibrated on uniform-random sources.  A dense graph
     whose sources sit next to their destinations is served much faster by the per-edge kernels (its gathers hit in L2; the plan's
     chip-wide slab walk only makes waves wait): the first call over a plan runs both and keeps the faster.  Results never change."""
@@ -541,6 +541,20 @@ def test_a_plan_that_loses_to_the_per_edge_kernels_is_dropped(geot, oracle):
     x = rng.random((nodes, F), dtype=np.float32)
     assert slab.worthwhile(nnz, nodes, nodes, F * 4)
     d_si, d_di, d_w, d_x = dev(si), dev(di), dev(w), dev(x)
+    hi = oracle.gather_weight_scatter(si, di, w, x, rows=nodes, acc64=True)
+    # (1) the routing itself notices the locality - the groups of this graph touch a few per cent of the source slabs - and never
+    #     builds a plan: no Phase A, no trial, the per-edge kernels from the first call on
+    ops.clear_caches()
+    st0 = ops.stats()
+    outs = [geot.gather_weight_scatter(d_si, d_di, d_w, d_x) for _ in range(3)]
+    st = ops.stats()
+    assert st["plans_declined"] == st0["plans_declined"] + 1 and st["plans_built"] == st0["plans_built"] and st["plan_trials"] == st0["plan_trials"]
+    assert st["last_coverage_permille"] < 200 and st["slab_calls"] == st0["slab_calls"]
+    for o in outs:
+        close(o, hi, "local dense graph, declined by the coverage probe")
+    # (2) with the probe off the plan is built, TRIED on its first use, loses and is dropped
+    old_cov = ops.set_option("slab_min_coverage_pct", 0)
+    request.addfinalizer(lambda: ops.set_option("slab_min_coverage_pct", old_cov))
     ops.clear_caches()
     st0 = ops.stats()
     outs = [geot.gather_weight_scatter(d_si, d_di, d_w, d_x) for _ in range(4)]
@@ -549,7 +563,6 @@ def test_a_plan_that_loses_to_the_per_edge_kernels_is_dropped(geot, oracle):
     assert st["plans_rejected"] == st0["plans_rejected"] + 1, "the per-edge kernels are several times faster on this graph"
     assert st["slab_calls"] == st0["slab_calls"] + 1                       # the trial's one run over the plan
     assert st["cache_bytes"] < 64 << 20                                    # the rejected plan's arrays (9 B per edge) are gone
-    hi = oracle.gather_weight_scatter(si, di, w, x, rows=nodes, acc64=True)
     for o in outs:
         close(o, hi, "local dense graph")
     assert torch.equal(outs[2], outs[3])

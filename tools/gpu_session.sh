@@ -23,6 +23,13 @@ for s in $steps; do
     sweepslab) timeout 900 python3 tools/sweep_slab.py > $O/sweep_slab_mh_uniform.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_uniform.txt
               timeout 900 python3 tools/sweep_slab.py --sources powerlaw > $O/sweep_slab_mh_powerlaw.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_powerlaw.txt
               timeout 900 python3 tools/sweep_slab.py --case gws --quick > $O/sweep_slab_gws_uniform.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_gws_uniform.txt ;;
+    slabab)   timeout 600 python3 tools/sweep_slab.py --ab slab_nt=0,1 > $O/slab_ab_nt.txt 2>&1; echo "rc=$?"; cat $O/slab_ab_nt.txt
+              timeout 600 python3 tools/sweep_slab.py --ab slab_far=2,6,12,1000000 > $O/slab_ab_far.txt 2>&1; echo "rc=$?"; cat $O/slab_ab_far.txt
+              timeout 600 python3 tools/sweep_slab.py --case gws --ab slab_nt=0,1 > $O/slab_ab_nt_gws.txt 2>&1; echo "rc=$?"; cat $O/slab_ab_nt_gws.txt ;;
+    locality) timeout 1500 python3 tools/bench_slab_locality.py > $O/slab_vs_per_edge_by_locality.txt 2>&1; echo "rc=$?"; cat $O/slab_vs_per_edge_by_locality.txt ;;
+    newtests) timeout 1500 python3 -m pytest tests/test_gpu_slab.py tests/test_reorder.py tests/test_gpu_guard.py tests/test_gpu_round3.py -m gpu -q > $O/pytest_new.log 2>&1; echo "rc=$?"; tail -12 $O/pytest_new.log ;;
+    hunt2)    timeout 600 python3 tools/hang_hunt.py --scenario graphs --runs 3 --T 90 > $O/hunt_graphs2.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_graphs2.txt
+              timeout 2400 python3 tools/hang_hunt.py --scenario threads --runs 200 --slab-turn 0 --T 60 > $O/hunt_threads200_turn0.txt 2>&1; echo "rc=$?"; tail -3 $O/hunt_threads200_turn0.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;

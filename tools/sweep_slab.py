@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--sources", default="uniform")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--case", default="mh")
+    ap.add_argument("--ab", default="", help="A/B of one library option at the default plan: NAME=v0,v1 (e.g. slab_nt=0,1 or slab_far=4,12,1000000)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     print(hip.build_info(), flush=True)
@@ -41,6 +42,17 @@ def main():
     else:
         base = lambda: hip.gather_weight_scatter_out(si, di, w, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
     print(f"case={a.case} sources={a.sources} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
+    if a.ab:
+        name, vals = a.ab.split("=")
+        vals = [int(v) for v in vals.split(",")]
+        plan = slab.build_plan(si, di, nodes, nodes, H * Fh * 4, wmode, H)
+        for rep in range(3):
+            row = []
+            for v in vals:
+                hip.set_option(name, v)
+                row.append(device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 5, warmup=1))
+            print(f"{name}: " + "  ".join(f"{v}: {m:.3f} ms" for v, m in zip(vals, row)), flush=True)
+        return
     slabs = (1.0, 2.0) if a.quick else (0.5, 1.0, 1.5, 2.0, 3.0, 4.0)
     windows = (1, 2) if a.quick else (0, 1, 2, 3, 4)
     print("blocks slab_MiB " + " ".join(f"w={k:<6d}" for k in windows) + "  (ms; plan meta)")
