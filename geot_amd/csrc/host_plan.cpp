@@ -267,6 +267,7 @@ double slab_source_coverage(const at::Tensor &si, int64_t src_rows, int64_t rowb
 std::list<SlabEntry> g_slab;
 std::list<std::pair<ContentKey, ContentKey>> g_sightings; // edge lists seen once (no tensors held)
 std::list<std::pair<ContentKey, ContentKey>> g_declined;  // edge lists with locality (slab_source_coverage): per-edge kernels, no plan
+std::list<std::pair<ContentKey, ContentKey>> g_building;  // edge lists whose plan a thread is building right now (the others keep the per-edge kernels)
 
 std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Tensor &di, int64_t rows, const at::Tensor &src,
                                               int wmode, int64_t heads) {
@@ -299,6 +300,10 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
     if (g_opt.slab_mode != 1) { // first sighting of this edge list: only remember it - a one-shot call never pays for Phase A
       for (auto &dc : g_declined)
         if (dc.first == k1 && dc.second == k2) return nullptr;
+    }
+    for (auto &bd : g_building) // one builder per edge list: Phase A takes milliseconds and ~80 bytes per edge of transient memory
+      if (bd.first == k1 && bd.second == k2) return nullptr;
+    if (g_opt.slab_mode != 1) {
       bool seen = false;
       for (auto &sg : g_sightings) seen |= (sg.first == k1 && sg.second == k2);
       if (!seen) {
@@ -307,7 +312,15 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
         return nullptr;
       }
     }
+    g_building.emplace_back(k1, k2); // this thread probes / builds; concurrent callers keep the per-edge kernels until the plan is there
   }
+  struct Building { // (leaves the list however this function is left)
+    const ContentKey &a, &b;
+    ~Building() {
+      std::lock_guard<std::mutex> lk(g_mu);
+      g_building.remove_if([&](const std::pair<ContentKey, ContentKey> &x) { return x.first == a && x.second == b; });
+    }
+  } building{k1, k2};
   if (g_opt.slab_mode != 1 && g_opt.slab_min_coverage_pct > 0 && si.is_cuda()) { // a graph with locality keeps the per-edge kernels (and pays neither Phase A nor a trial)
     const int64_t units = (int64_t)geot_slab_units() * (1024 / std::max<int64_t>(rowbytes, 16));
     const int64_t rounds = std::max<int64_t>(1, (rows + rpg * units - 1) / (rpg * units));

@@ -1394,7 +1394,46 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
     repair_call<T, RED>(p);
     return;
   }
-  const bool first = valid && (m & 1) && !(mp & 2);
+  // Hand-off runs that the tile kernel gave up waiting for (`deferred`): redone HERE exactly as the tile kernel would have done them
+  // - the tile in which a straddling run ENDS walks back over its predecessors, nearest first, the partial rows meet in float64
+  // and are rounded once - so a call gives the same BITS whether a flag was seen in time or not (timing must never decide a
+  // result; round 3 redid them the classic way: fp32 adds in another association, last-ulp differences between two calls).
+  // Sequential per run (a hub over thousands of tiles is walked by one lane group): this is the rare path.
+  const bool ho_redo = p.handoff && deferred != 0ull;
+  if constexpr (std::is_same<A, float>::value) {
+    if (ho_redo && valid && (m & 1) && !(m & 2)) {
+      const int64_t kend = m >> 2;
+      for (int64_t fb = 0; fb < F; fb += (int64_t)lpr * J) {
+        double acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int64_t f = fb + (int64_t)j * lpr + c;
+          acc[j] = f < F ? (double)carry[(t * 2) * F + f] : 0.0;
+        }
+        int64_t cnt = 0;
+        if constexpr (MEAN) cnt = p.ccnt[t * 2];
+        for (int64_t jt = t - 1; jt >= 0; --jt) {
+          const bool single = (p.meta[jt] & 2) != 0;
+          const int64_t row = (jt * 2 + (single ? 0 : 1)) * F;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int64_t f = fb + (int64_t)j * lpr + c;
+            if (f < F) acc[j] = red_op<double, RED>((double)carry[row + f], acc[j]);
+          }
+          if constexpr (MEAN) cnt += p.ccnt[jt * 2 + (single ? 0 : 1)];
+          if (!single) break; // the tile in which the run starts
+        }
+        double inv = 1.0;
+        if constexpr (MEAN) inv = 1.0 / (double)cnt;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int64_t f = fb + (int64_t)j * lpr + c;
+          if (f < F && (uint64_t)kend < (uint64_t)p.K) dst[kend * F + f] = (T)(A)(MEAN ? acc[j] * inv : acc[j]);
+        }
+      }
+    }
+  }
+  const bool first = !ho_redo && valid && (m & 1) && !(mp & 2);
   const int64_t k = m >> 2;
   if (first && !(m & 2)) {
     A inv_div = A(1);

@@ -1,0 +1,205 @@
+"""Round-4 cases (`-m gpu`).
+
+* hand-off runs that the tile kernel gave up waiting for are redone by the second launch with the SAME bits (float64 meeting,
+  nearest tile first): `handoff_tries = 0` against the normal mode, bitwise - timing never decides a result;
+* the descent guard ignores keys outside [0, K): leading negatives (the speculative `index - lo` of geot_amd/sharding.py) are
+  skipped like every out-of-range key and raise no alarm;
+* the plan trial is safe under threads: three threads on ONE dense graph, automatic routing - one trial, right results;
+* `geot_last_kernel`: the roofline label of bench.py is what the launcher picked;
+* the source-blocked kernel beside another persistent grid: two streams through the C ABI with the library's turn-taking off -
+  both finish, both right (waits bounded in aggregate).
+
+Reference semantics: dst[index[e]] (op)= src[e] (csrc/util/check.cuh:78-87), reductions of csrc/cpu/index_scatter_cpu.cpp:124-134.
+"""
+import sys
+import threading
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, powerlaw_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def geot():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import geot_amd
+    return geot_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _hub_index(nnz, keys, seed):
+    """Power-law keys plus one hub that spans hundreds of tiles and a second one of a few tiles."""
+    rng = np.random.default_rng(seed)
+    idx = powerlaw_index(nnz, keys, seed)
+    big = np.full(nnz // 5, keys // 3)
+    small = np.full(3000, keys // 2)
+    out = np.sort(np.concatenate([idx[: nnz - big.size - small.size], big, small])).astype(np.int64)
+    out[-1] = keys - 1
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+def test_deferred_handoff_runs_get_the_same_bits(geot, dtype, reduce):
+    from geot_amd import hip
+    nnz, K, F = 1_500_000, 40_000, 64 if dtype == torch.float32 else 128      # rows of 256 bytes: the hand-off's shapes
+    index = dev(_hub_index(nnz, K, 3))
+    g = torch.Generator(device="cuda").manual_seed(7)
+    src = (torch.rand(nnz, F, device="cuda", generator=g) - 0.3).to(dtype)
+    normal = geot.index_scatter(0, src, index, reduce, True)
+    assert torch.equal(normal, geot.index_scatter(0, src, index, reduce, True))             # run-to-run bit-equality
+    hip.set_option("handoff_tries", 0)
+    try:
+        for _ in range(4):                                                                    # whatever mix of in-kernel and deferred runs a call produces
+            deferred = geot.index_scatter(0, src, index, reduce, True)
+            assert torch.equal(deferred, normal), (dtype, reduce)
+    finally:
+        hip.set_option("handoff_tries", 20000)
+    hip.set_option("handoff", 0)                                                              # the classic second pass: same sums within rounding
+    try:
+        classic = geot.index_scatter(0, src, index, reduce, True)
+    finally:
+        hip.set_option("handoff", 1)
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+    scale = float(normal.float().abs().max())
+    assert float((classic.float() - normal.float()).abs().max()) <= tol * scale
+
+
+def test_keys_outside_the_row_range_are_ignored_and_raise_no_alarm(geot, oracle):
+    """C ABI, sorted = 1: negatives in front (ascending as signed numbers), then valid keys, then keys >= K.  The kernels skip
+    what lies outside [0, K) - and the descent guard must not read "-3 followed by 0" (an unsigned compare) as a descent."""
+    from geot_amd import hip, ops
+    rng = np.random.default_rng(5)
+    K, F = 700, 64
+    valid = np.sort(rng.integers(0, K, 60_000)).astype(np.int64)
+    index = np.concatenate([np.arange(-500, 0, dtype=np.int64).repeat(3), valid, np.arange(K, K + 40, dtype=np.int64).repeat(5)])
+    src = rng.random((index.size, F), dtype=np.float32)
+    t_index, t_src = dev(index), dev(src)
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", message="geot")                                      # a repair would warn at the next operator call
+        geot.index_scatter(0, torch.rand(8, 4, device="cuda"), torch.arange(8, device="cuda"))   # (sets this thread's alarm word)
+        alarms = ops.stats()["alarms"]
+        for red in ("sum", "max"):
+            out = torch.full((K, F), float("nan"), device="cuda")
+            hip.index_scatter_out(t_index, t_src, out, sorted=True, reduce=red)
+            torch.cuda.synchronize()
+            inside = (index >= 0) & (index < K)
+            hi = oracle.index_scatter_3pass(index[inside], src[inside], red, rows=K)
+            got = out.cpu().numpy()
+            assert not np.isnan(got).any()
+            np.testing.assert_allclose(got, hi, rtol=1e-5, atol=1e-6)
+        geot.index_scatter(0, torch.rand(8, 4, device="cuda"), torch.arange(8, device="cuda"))   # (would raise / warn here)
+        assert ops.stats()["alarms"] == alarms
+
+
+def test_three_threads_one_dense_graph_one_trial(geot, oracle):
+    """Automatic routing on a graph the density rule sends to the source-blocked kernel: three threads, each on its own stream,
+    call the operator on the SAME edge list at once.  One of them builds the plan and tries it; the others serve their calls
+    with the per-edge kernels meanwhile; nobody reads freed plan arrays; every result is right."""
+    from geot_amd import ops
+    rng = np.random.default_rng(11)
+    nodes, nnz, F = 30_000, 9_000_000, 128
+    di = powerlaw_index(nnz, nodes, 6)
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    w = rng.random(nnz, dtype=np.float32)
+    x = rng.random((nodes, F), dtype=np.float32)
+    hi = oracle.gather_weight_scatter(si, di, w, x, rows=nodes, acc64=True)
+    t_si, t_di, t_w, t_x = dev(si), dev(di), dev(w), dev(x)
+    old = ops.set_option("slab_mode", "auto")
+    ops.clear_caches()
+    st0 = ops.stats()
+    errors, bound = [], 1e-5 * float(np.abs(hi).max())
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for it in range(8):
+                    got = geot.gather_weight_scatter(t_si, t_di, t_w, t_x)
+                    err = float(np.abs(got.cpu().numpy() - hi).max())
+                    if not err <= bound:
+                        errors.append((k, it, err))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    try:
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        ops.set_option("slab_mode", old)
+    st = ops.stats()
+    assert not errors, errors[:3]
+    assert st["plan_trials"] - st0["plan_trials"] <= 1 and st["plans_built"] - st0["plans_built"] <= 1     # one builder, one trial
+    ops.clear_caches()
+
+
+def test_last_kernel_names_what_the_launcher_picked(geot):
+    from geot_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(1)
+    index = torch.randint(0, 50_000, (2_000_000,), device="cuda", generator=g).sort().values
+    src = torch.rand(2_000_000, 64, device="cuda", generator=g)
+    geot.index_scatter(0, src, index, "sum", True)
+    assert hip.last_kernel() == "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"      # the graded configuration's kernel
+    geot.index_scatter(0, src, index, "max", True)
+    assert hip.last_kernel().startswith("seg_tile_kernel<float, 4, false, 0, false, 3, 0,")
+    geot.index_scatter(0, src[:, :4].contiguous(), index, "sum", True)
+    assert hip.last_kernel().startswith("seg_lane_kernel<4,")
+    x = torch.rand(50_000, 128, device="cuda", generator=g)
+    si = torch.randint(0, 50_000, (2_000_000,), device="cuda", generator=g)
+    geot.gather_scatter(si, index, x.bfloat16())
+    assert hip.last_kernel().startswith("seg_tile_kernel<__bf16, 8, true, 0, false, 0, 3,")
+
+
+def test_two_persistent_grids_at_once_finish_and_agree(geot):
+    """geot_slab_spmm from two threads / streams with the library's turn-taking OFF: the two whole-chip grids share the CUs, the
+    lockstep of each meets waves that are not running - every wait is bounded, a wave that keeps timing out stops keeping step,
+    both launches finish and both results are right."""
+    from geot_amd import hip, slab
+    nodes, nnz, H, F = 60_000, 12_000_000, 4, 64
+    results, errors = {}, []
+
+    def one(seed):
+        try:
+            g = torch.Generator(device="cuda").manual_seed(seed)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                di = torch.randint(0, nodes, (nnz,), device="cuda", generator=g).sort().values
+                di[-1] = nodes - 1
+                si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+                w = torch.rand(nnz, H, device="cuda", generator=g)
+                x = torch.rand(nodes, H, F, device="cuda", generator=g)
+                plan = slab.build_plan(si, di, nodes, nodes, H * F * 4, 2, H)
+                assert plan.meta["slabs"] > 8                                   # the lockstep is on
+                out, ref = torch.empty(nodes, H, F, device="cuda"), torch.empty(nodes, H, F, device="cuda")
+                hip.mh_spmm_out(si, di, w, x, ref, False)
+                for _ in range(12):
+                    slab.slab_spmm_out(plan, w, 2, x, out, H, F)
+                s.synchronize()
+                results[seed] = float(((out - ref).abs().max() / ref.abs().max()).item())
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    hip.set_option("slab_turn", 0)
+    try:
+        threads = [threading.Thread(target=one, args=(s,)) for s in (1, 2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in threads), "a persistent grid did not finish"
+    finally:
+        hip.set_option("slab_turn", 1)
+    assert not errors, errors
+    assert all(e < 1e-5 for e in results.values()) and len(results) == 2, results

@@ -63,7 +63,7 @@ def test_renumbered_operators_equal_the_direct_ones_forward_and_backward():
     nodes, nnz, F, H = 60_000, 2_400_000, 64, 4
     si, di, truth, _ = block_model(nodes, nnz, 0.9, 3, device="cuda")
     g = reorder.renumber(si, di, nodes)
-    assert g is not None and g.locality_after > g.locality_before + 0.5 and g.rows == nodes
+    assert g is not None and g.locality_after > 0.9 and g.locality_after > g.locality_before + 0.4 and g.rows == nodes   # (60 k nodes: the 16 k-row window already covers half of a shuffled graph)
     gen = torch.Generator(device="cuda").manual_seed(4)
     x = torch.rand(nodes, F, device="cuda", generator=gen)
     w = torch.rand(nnz, device="cuda", generator=gen)

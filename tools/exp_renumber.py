@@ -24,48 +24,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import device_ms  # noqa: E402
+from bench import block_model, device_ms  # noqa: E402
 import geot_amd as geot  # noqa: E402
 from geot_amd import hip  # noqa: E402
-
-
-def block_model(nodes, nnz, intra, dev, seed=3, powerlaw=True):
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    # community sizes uniform in [2000, 20000]
-    sizes = []
-    left = nodes
-    gs = torch.Generator()
-    gs.manual_seed(seed)
-    while left > 0:
-        s = int(torch.randint(2000, 20001, (1,), generator=gs).item())
-        s = min(s, left)
-        sizes.append(s)
-        left -= s
-    sizes_t = torch.tensor(sizes, device=dev)
-    starts = torch.cumsum(sizes_t, 0) - sizes_t
-    comm = torch.repeat_interleave(torch.arange(len(sizes), device=dev), sizes_t)       # community of node (ordered ids)
-    if powerlaw:
-        w = torch.arange(1, nodes + 1, device=dev, dtype=torch.float64) ** (-1.0 / 1.5)
-        cdf = torch.cumsum(w, 0)
-        pr = torch.randperm(nodes, generator=g, device=dev)
-        u = torch.rand(nnz, generator=g, device=dev, dtype=torch.float64) * cdf[-1]
-        dst = pr[torch.searchsorted(cdf, u).clamp_(max=nodes - 1)]
-        del w, cdf, u
-    else:
-        dst = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
-    c = comm[dst]
-    inside = torch.rand(nnz, device=dev, generator=g) < intra
-    src_in = starts[c] + (torch.rand(nnz, device=dev, generator=g) * sizes_t[c]).long().clamp_(max=nodes - 1)
-    src_out = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
-    src = torch.where(inside, src_in, src_out)
-    del c, inside, src_in, src_out
-    shuffle = torch.randperm(nodes, generator=g, device=dev)                               # ordered id -> shipped id
-    dst_s, src_s = shuffle[dst], shuffle[src]
-    order = torch.argsort(dst_s, stable=True)
-    truth = torch.empty(nodes, dtype=torch.int64, device=dev)
-    truth[shuffle] = torch.arange(nodes, device=dev)                                       # shipped id -> ordered id (the ceiling's rank)
-    return src_s[order].contiguous(), dst_s[order].contiguous(), truth, len(sizes)
 
 
 def lpa(si, di, nodes, sweeps, dev):

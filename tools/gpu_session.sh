@@ -30,6 +30,9 @@ for s in $steps; do
     newtests) timeout 1500 python3 -m pytest tests/test_gpu_slab.py tests/test_reorder.py tests/test_gpu_guard.py tests/test_gpu_round3.py -m gpu -q > $O/pytest_new.log 2>&1; echo "rc=$?"; tail -12 $O/pytest_new.log ;;
     hunt2)    timeout 600 python3 tools/hang_hunt.py --scenario graphs --runs 3 --T 90 > $O/hunt_graphs2.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_graphs2.txt
               timeout 2400 python3 tools/hang_hunt.py --scenario threads --runs 200 --slab-turn 0 --T 60 > $O/hunt_threads200_turn0.txt 2>&1; echo "rc=$?"; tail -3 $O/hunt_threads200_turn0.txt ;;
+    r4tests)  timeout 1500 python3 -m pytest tests/test_gpu_round4.py tests/test_reorder.py tests/test_gpu_slab.py -m gpu -q > $O/pytest_r4.log 2>&1; echo "rc=$?"; tail -12 $O/pytest_r4.log ;;
+    stressho) timeout 2400 python3 tools/stress_handoff.py --matrix --calls 1000 > $O/stress_handoff_matrix.txt 2>&1; echo "rc=$?"; cat $O/stress_handoff_matrix.txt ;;
+    hunt3)    timeout 600 python3 tools/hang_hunt.py --scenario graphs --runs 3 --T 90 > $O/hunt_graphs3.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_graphs3.txt; grep -h RES $O/hunt/graphs_turn1_guard1_always_00*.log ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
