@@ -487,7 +487,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             entry["cpu_baseline"] = {"error": repr(e)}
         res[name] = entry
 
-    def blockmodel(name):
+    def blockmodel(name, mode="both"):        # mode "asis" / "renum": one half only (profiling passes: per-kernel averages stay pure)
         """configs[2]'s size on a graph that HAS community structure but ships with shuffled ids (what public datasets look like;
         VERDICT r03 item 4): the operator as it is, rocSPARSE's best, and geot_amd.reorder - a one-time device-built node order
         (label propagation), then per call: permute x in, the same kernels on the renumbered list, permute y out."""
@@ -499,7 +499,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         w = torch.rand(nnz, device=dev, generator=g)
         x = torch.rand(nodes, F, device=dev, generator=g)
         out = torch.empty(nodes, F, device=dev)
-        ms = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), iters)
+        ms = device_ms(lambda: hip.gather_weight_scatter_out(si, di, w, x, out), iters) if mode != "renum" else float("nan")
         kernel = hip.last_kernel()
         uniq = int(torch.unique(si).numel())
         comp = nnz * 20 + uniq * 4 * F + nodes * 4 * F
@@ -509,6 +509,8 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                  "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": comp / ms / 1e6 / HBM_PEAK_GBPS, **profiled(name)}}
         try:
+            if mode != "both":
+                raise RuntimeError("comparator skipped in a profiling pass")
             from tools import rocsparse
             best, table, y = rocsparse.best_csr_spmm(di, si, w, x, nodes, iters=max(2, iters // 2), algs=("csr_nnz_split", "csr_merge_path"))
             entry.update(rocsparse_best_ms=best["ms"], rocsparse_best_algorithm=best["algorithm"], speedup_vs_rocsparse_best=best["ms"] / ms)
@@ -517,7 +519,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             entry["rocsparse_error"] = repr(e)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rg = reorder.renumber(si, di, nodes)
+        rg = reorder.renumber(si, di, nodes) if mode != "asis" else None
         torch.cuda.synchronize()
         once_ms = (time.perf_counter() - t0) * 1e3
         if rg is None:
@@ -525,12 +527,15 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         else:
             w_new = rg.edge_values(w)
             ms_static = device_ms(lambda: rg.gather_weight_scatter(w_new, x, in_new_order=True), iters)
-            ms_dyn = device_ms(lambda: rg.gather_weight_scatter(w, x), iters)
+            ms_dyn = device_ms(lambda: rg.gather_weight_scatter(w, x), iters) if mode == "both" else None
             y = rg.gather_weight_scatter(w_new, x, in_new_order=True)
-            hip.gather_weight_scatter_out(si, di, w, x, out)
-            ceiling = reorder.RenumberedGraph(si, di, nodes, truth)
-            w_c = ceiling.edge_values(w)
-            ms_ceiling = device_ms(lambda: ceiling.gather_weight_scatter(w_c, x, in_new_order=True), iters)
+            ms_ceiling = None
+            if mode == "both":
+                hip.gather_weight_scatter_out(si, di, w, x, out)
+                ceiling = reorder.RenumberedGraph(si, di, nodes, truth)
+                w_c = ceiling.edge_values(w)
+                ms_ceiling = device_ms(lambda: ceiling.gather_weight_scatter(w_c, x, in_new_order=True), iters)
+                del ceiling, w_c
             entry["renumbered"] = {
                 "what": "geot_amd.reorder.renumber: label propagation on the device, then per call rows of x permuted in, the same "
                         "kernels on the renumbered + re-sorted edge list, rows of y permuted back (both permutations inside the timings)",
@@ -539,9 +544,9 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                 "one_time_ms_label_propagation_and_renumbering": once_ms,
                 "edges_within_16k_rows_before": rg.locality_before, "edges_within_16k_rows_after": rg.locality_after,
                 "speedup_vs_as_shipped": ms / ms_static, "calls_to_amortise_the_one_time_cost": once_ms / max(ms - ms_static, 1e-9),
-                "max_rel_diff_vs_as_shipped": float(((y - out).abs().max() / out.abs().max()).item()),
+                "max_rel_diff_vs_as_shipped": float(((y - out).abs().max() / out.abs().max()).item()) if mode == "both" else None,
                 "roofline_frac_on_compulsory_bytes": comp / ms_static / 1e6 / HBM_PEAK_GBPS}
-            del ceiling, w_c, w_new, y
+            del w_new, y
         res[name] = entry
         del si, di, truth, w, x, out, rg
         torch.cuda.empty_cache()
@@ -556,6 +561,10 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         gws("gws_cfg3_powerlaw_src", "powerlaw", torch.float32)
     if "gws_cfg3_blockmodel" in want:
         blockmodel("gws_cfg3_blockmodel")
+    if "gws_cfg3_blockmodel_asis" in want:                    # (profiling passes only: not in SECONDARY)
+        blockmodel("gws_cfg3_blockmodel_asis", "asis")
+    if "gws_cfg3_blockmodel_renum" in want:
+        blockmodel("gws_cfg3_blockmodel_renum", "renum")
     if "mh_spmm_cfg4" in want:
         mh("mh_spmm_cfg4", torch.float32)
     if "mh_spmm_cfg4_powerlaw_src" in want:
@@ -565,6 +574,79 @@ def secondary(dev, scale=1.0, iters=5, only=None):
     if "mh_spmm_cfg4_bf16" in want:
         mh("mh_spmm_cfg4_bf16", torch.bfloat16)
     return res
+
+
+def cfg5_leg(world, rank, dev, scale, steps, warmup, cuts="equal", collective="all_gather"):
+    """BASELINE.json configs[4] as a bounded extra leg of the default line (every N: the SCALE run then carries the gather_scatter
+    numbers at 1 / 2 / 4 / 8 GPUs without a flag): weak scaling - every GPU holds 1/8 of the configuration's edges and dst rows
+    (8 ranks = the full 1.6 B edges), src replicated (56.9 GB).  All ranks call this; the result is meaningful on rank 0."""
+    import torch
+    import geot_amd as geot
+    from geot_amd import hip, sharding
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+    nodes_all, feat = int(CFG5_NODES * scale), CFG5_FEAT
+    rows_global = max(world, nodes_all * world // 8)
+    nnz_target = int(CFG5_EDGES * scale) * world // 8
+    setup_error = None
+    try:
+        index, src_index, first_key, rows, nnz_global, _ = global_list_shard(rows_global, nnz_target, nodes_all, world, rank, cuts, seed=13, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(15)
+        src = torch.rand(nodes_all, feat, device=dev, generator=gen)
+    except BaseException as e:  # noqa: BLE001  (SystemExit of an empty shard included)
+        setup_error = repr(e)
+    if distributed:             # every rank steps or none does: a rank that failed to set up must not leave the others in a collective
+        ok = torch.tensor([0 if setup_error else 1], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"cfg5 leg skipped on every rank: set-up failed on some rank (this rank: {setup_error})")
+    elif setup_error:
+        raise RuntimeError(setup_error)
+    timing = {}
+    if distributed:
+        def step():
+            return sharding.sharded_gather_scatter(src_index, index, src, key_offset=first_key, timing=timing, collective=collective)[0]
+    else:
+        def step():
+            return geot.gather_scatter(src_index, index, src)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        step()
+    sync_all()
+    timing.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ev = timing.get("exchange_events")
+    exchange_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel = hip.last_kernel()
+    ms = device_ms(lambda: hip.gather_scatter_out(src_index, index, src, torch.empty(rows, feat, device=dev)), 3, warmup=1)
+    uniq = int(torch.unique(src_index).numel())
+    comp = index.numel() * 16 + uniq * 4 * feat + rows * 4 * feat
+    out = {"workload": f"gather_scatter, papers100M-scale synthetic (BASELINE.json configs[4]), feat={feat}: ONE global dst-sorted list of "
+                       f"{nnz_global} edges -> {rows_global} dst rows cut into {world} edge ranges ({cuts} cuts); this rank {index.numel()} edges -> "
+                       f"{rows} rows; src {nodes_all} x {feat} fp32 replicated ({nodes_all * feat * 4 / 1e9:.1f} GB per GPU); 8 ranks = the full 1.6 B edges",
+           "scaling": "weak", "n_gpus": world, "steps": steps, "value": nnz_global * steps / elapsed, "unit": "edges/s",
+           "ms_per_step": elapsed / steps * 1e3, "boundary_exchange_ms": exchange_ms, "collective": collective if distributed else None,
+           "kernel": kernel, "kernel_ms_rank0": ms, "compulsory_bytes_rank0": comp,
+           "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": comp / ms / 1e6 / HBM_PEAK_GBPS,
+                        "traffic": None, "traffic_source": None}}
+    del index, src_index, src
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -754,6 +836,20 @@ def main():
                 res["secondary"] = secondary(dev, scale=args.scale, only=[x for x in args.only_secondary.split(",") if x] or None)
             except Exception as e:
                 res["secondary"] = {"error": repr(e)}
+    # configs[4] rides along at every N (bounded: a few steps), so the driver's 1 / 2 / 4 / 8 runs report it without a flag
+    want_cfg5 = args.workload == "cfg2" and not args.no_secondary and (not args.only_secondary or "cfg5" in args.only_secondary.split(","))
+    if want_cfg5:
+        index = src = out = None
+        torch.cuda.empty_cache()
+        # (test ranks that SHARE one GPU over a gloo rendezvous cannot each hold the 56.9 GB source table: a hundredth of it there)
+        leg_scale = args.scale if (not distributed or backend == "nccl") else min(args.scale, 0.01)
+        try:
+            leg = cfg5_leg(world, rank, dev, leg_scale, steps=max(2, min(args.steps, 8)), warmup=2, cuts=args.cuts, collective=args.collective)
+        except Exception as e:
+            leg = {"error": repr(e)}
+        if rank == 0:
+            res.setdefault("secondary", {})["gather_scatter_cfg5"] = leg
+    if rank == 0:
         print(json.dumps(res))
     if distributed:
         dist.barrier()

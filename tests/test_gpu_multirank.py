@@ -25,6 +25,8 @@ def test_bench_two_ranks_one_gpu():
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 1e9 and r["unit"] == "edges/s"
     assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
+    leg = r["secondary"]["gather_scatter_cfg5"]                       # configs[4] rides along at every N (a hundredth of it where ranks share a GPU)
+    assert "error" not in leg and leg["n_gpus"] == 2 and leg["value"] > 1e8 and leg["scaling"] == "weak"
 
 
 def _rank(rank, world, port, q):
@@ -141,3 +143,13 @@ def test_bench_json_contract_single_gpu():
     cb = r["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["unit"] == "edges/s" and cb["cores"] >= 1 and cb["value"] > 1e6
     assert r["value"] > 1e9 and abs(r["value"] - 10_000_000 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    # BASELINE.json's other configs ride along as `secondary`: configs[0], configs[2] (four stand-ins), configs[3] (two), configs[4]'s shard
+    sec = r["secondary"]
+    for name in ("cfg1", "gws_cfg3", "gws_cfg3_local", "gws_cfg3_powerlaw_src", "gws_cfg3_blockmodel", "mh_spmm_cfg4", "mh_spmm_cfg4_powerlaw_src",
+                 "gather_scatter_cfg5"):
+        assert name in sec and "error" not in sec[name], (name, sec.get(name))
+        assert 0 < sec[name]["roofline"]["frac"] < 1 and "traffic_source" in sec[name]["roofline"]
+    assert sec["cfg1"]["us_per_call_as_dispatched"] < 100 and sec["cfg1"]["cpu_baseline"]["value"] > 0
+    assert sec["gather_scatter_cfg5"]["n_gpus"] == 1 and sec["gather_scatter_cfg5"]["value"] > 1e9
+    assert sec["gws_cfg3_blockmodel"]["renumbered"]["speedup_vs_as_shipped"] > 1.2
+    assert r["roofline"]["kernel"] == "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"       # from the library (geot_last_kernel)

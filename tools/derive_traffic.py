@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_round")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 COPY_BYTES = 2_684_354_560            # tools/kbench copy: 160 Mi float4 elements
@@ -127,6 +127,11 @@ WORKLOADS = {
                  ("/rocsparse csr_merge_path", r"csrmmnt_merge_path_main_kernel"), ("/rocsparse csr_row_split", r"csrmmnt_row_split")],
     "gws_cfg3_local": [("", r"seg_tile_kernel<float, 4, true, 1,"), ("/rocsparse csr_nnz_split", r"csrmmnt_nnz_split_main_kernel"),
                        ("/rocsparse csr_merge_path", r"csrmmnt_merge_path_main_kernel")],
+    "gws_cfg3_powerlaw_src": [("", r"seg_tile_kernel<float, 4, true, 1,"), ("/rocsparse csr_nnz_split", r"csrmmnt_nnz_split_main_kernel"),
+                              ("/rocsparse csr_merge_path", r"csrmmnt_merge_path_main_kernel")],
+    "gws_cfg3_blockmodel_asis": [("", r"seg_tile_kernel<float, 4, true, 1,")],
+    "gws_cfg3_blockmodel_renum": [("", r"seg_tile_kernel<float, 4, true, 1,"), ("/gather_rows (x in, y out)", r"gather_rows_kernel<float")],
+    "mh_spmm_cfg4_powerlaw_src": [("", r"seg_slab_kernel<float, 2, true,"), ("/per-edge [nnz,H]", r"seg_tile_kernel<float, 4, true, 2,")],
     "mh_spmm_cfg4": [("", r"seg_slab_kernel<float, 2, true,"), ("/per-edge [nnz,H]", r"seg_tile_kernel<float, 4, true, 2,"),
                      ("/per-edge [H,nnz]", r"seg_tile_kernel<float, 4, true, 3,"), ("/phase A edge keys", r"plan_edge_keys_kernel"),
                      ("/phase A edge out", r"plan_edge_out_kernel")],
@@ -173,6 +178,8 @@ for w, wanted in WORKLOADS.items():
             if "fabric_bytes_per_launch" in g:
                 g["traffic_over_compulsory"] = g["fabric_bytes_per_launch"] / comp
         gather[w + suffix] = g
+if "gws_cfg3_blockmodel_asis" in gather:                # bench.py's entry `gws_cfg3_blockmodel` quotes the as-shipped kernel
+    gather["gws_cfg3_blockmodel"] = dict(gather["gws_cfg3_blockmodel_asis"])
 json.dump({"method": "one rocprofv3 pass set per workload (tools/profile_round.sh: bench.py --only-secondary <workload>): --kernel-trace "
                      "--stats for the times, one --pmc counter per pass for the bytes; FETCH_SIZE doubled (gfx950, 16-B-per-lane reads); "
                      "counters in KB",

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--sources", default="uniform")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--case", default="mh")
+    ap.add_argument("--coalesced", action="store_true", help="sources sorted inside every dst row (what torch_geometric's coalesce() / a CSR leaves)")
     ap.add_argument("--ab", default="", help="A/B of one library option at the default plan: NAME=v0,v1 (e.g. slab_nt=0,1 or slab_far=4,12,1000000)")
     a = ap.parse_args()
     dev = torch.device("cuda")
@@ -33,6 +34,8 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(12)
     si = di[torch.randperm(nnz, device=dev, generator=g)].contiguous() if a.sources == "powerlaw" else torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    if a.coalesced:
+        si = (torch.sort(di * nodes + si).values % nodes).contiguous()
     x = torch.rand(nodes, H, Fh, device=dev, generator=g)
     w = torch.rand(nnz, H, device=dev, generator=g) if wmode == 2 else torch.rand(nnz, device=dev, generator=g)
     out = torch.empty(nodes, H, Fh, device=dev)
@@ -41,7 +44,7 @@ def main():
         base = lambda: hip.mh_spmm_out(si, di, w, x, ref, False)  # noqa: E731
     else:
         base = lambda: hip.gather_weight_scatter_out(si, di, w, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
-    print(f"case={a.case} sources={a.sources} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
+    print(f"case={a.case} sources={a.sources} coalesced={a.coalesced} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
     if a.ab:
         name, vals = a.ab.split("=")
         vals = [int(v) for v in vals.split(",")]
