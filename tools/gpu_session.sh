@@ -33,6 +33,11 @@ for s in $steps; do
     r4tests)  timeout 1500 python3 -m pytest tests/test_gpu_round4.py tests/test_reorder.py tests/test_gpu_slab.py -m gpu -q > $O/pytest_r4.log 2>&1; echo "rc=$?"; tail -12 $O/pytest_r4.log ;;
     stressho) timeout 2400 python3 tools/stress_handoff.py --matrix --calls 1000 > $O/stress_handoff_matrix.txt 2>&1; echo "rc=$?"; cat $O/stress_handoff_matrix.txt ;;
     hunt3)    timeout 600 python3 tools/hang_hunt.py --scenario graphs --runs 3 --T 90 > $O/hunt_graphs3.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_graphs3.txt; grep -h RES $O/hunt/graphs_turn1_guard1_always_00*.log ;;
+    coalesced) timeout 600 python3 tools/sweep_slab.py --coalesced --ab slab_nt=0,0 > $O/slab_coalesced_mh.txt 2>&1; echo "rc=$?"; cat $O/slab_coalesced_mh.txt
+              timeout 600 python3 tools/sweep_slab.py --ab slab_nt=0,0 > $O/slab_uncoalesced_mh.txt 2>&1; echo "rc=$?"; cat $O/slab_uncoalesced_mh.txt ;;
+    soak4)    for seed in 61 62 63; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -3 $O/soak_seed$seed.log
+              done ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
