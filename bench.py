@@ -262,7 +262,7 @@ def device_ms(fn, iters, warmup=2):
 
 
 SECONDARY = ("cfg1", "gws_cfg3", "gws_cfg3_local", "gws_cfg3_powerlaw_src", "gws_cfg3_blockmodel", "mh_spmm_cfg4",
-             "mh_spmm_cfg4_powerlaw_src", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16")
+             "mh_spmm_cfg4_powerlaw_src", "mh_spmm_cfg4_coalesced", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16")
 
 
 def profiled(entry):
@@ -350,13 +350,15 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         del di, si, w, x, out
         torch.cuda.empty_cache()
 
-    def mh(name, dtype, kind="uniform"):
+    def mh(name, dtype, kind="uniform", coalesced=False):
         nodes, nnz, H, F = int(232_965 * scale), int(114_615_892 * scale), 4, 64
         esize = 4 if dtype == torch.float32 else 2
         di = powerlaw_index(nnz, nodes, 11, dev)
         g = torch.Generator(device=dev)
         g.manual_seed(12)
         si = sources(kind, di, nodes, g)
+        if coalesced:       # sources ascending inside every dst row: what a CSR / torch_geometric's coalesce() / a stable sort by dst leaves
+            si = (torch.sort(di * nodes + si).values % nodes).contiguous()
         w = torch.rand(nnz, H, device=dev, generator=g).to(dtype)
         x = torch.rand(nodes, H, F, device=dev, generator=g).to(dtype)
         out = torch.empty(nodes, H, F, device=dev, dtype=dtype)
@@ -393,7 +395,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         uniq = int(torch.unique(si).numel())
         comp = nnz * (16 + esize * H) + uniq * esize * H * F + nodes * esize * H * F
         res[name] = {
-            "workload": f"mh_spmm, power-law dst / {SRC_DESC[kind]}, {nodes} nodes, {nnz} edges, heads={H} feat={F}, "
+            "workload": f"mh_spmm, power-law dst / {SRC_DESC[kind]}{', ascending inside every dst row (coalesced COO)' if coalesced else ''}, {nodes} nodes, {nnz} edges, heads={H} feat={F}, "
                         f"{str(dtype).split('.')[-1]} (stand-in of Reddit)",
             "kernel_ms": ms,
             "content_guard": "on: every call re-reads both index arrays and compares their fingerprint with the plan's (kernel_ms includes it)",
@@ -569,6 +571,8 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         mh("mh_spmm_cfg4", torch.float32)
     if "mh_spmm_cfg4_powerlaw_src" in want:
         mh("mh_spmm_cfg4_powerlaw_src", torch.float32, "powerlaw")
+    if "mh_spmm_cfg4_coalesced" in want:
+        mh("mh_spmm_cfg4_coalesced", torch.float32, "uniform", coalesced=True)
     if "gws_cfg3_bf16" in want:
         gws("gws_cfg3_bf16", "uniform", torch.bfloat16)
     if "mh_spmm_cfg4_bf16" in want:

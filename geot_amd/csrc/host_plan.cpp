@@ -45,7 +45,10 @@ std::shared_ptr<SlabPlanHolder> slab_build_aten(const at::Tensor &src_index, con
   const int64_t V = nv_row.sum().item<int64_t>();
   at::Tensor v_row = at::repeat_interleave(nv_row, c10::optional<int64_t>(V)); // dst row of every virtual row
   at::Tensor v_piece = at::arange(V, lopt) - vstart.index_select(0, v_row);
-  at::Tensor v_cnt = at::clamp_max(counts.index_select(0, v_row) - v_piece * cap, cap);
+  // (a split row's edges go to its pieces interleaved - edge j to piece j % nv - so that every piece samples the row's whole source
+  //  range also when the sources are sorted inside the row; see plan_vrows_kernel in seg_plan.hip)
+  at::Tensor nv_of_v = nv_row.index_select(0, v_row), cnt_of_v = counts.index_select(0, v_row);
+  at::Tensor v_cnt = at::div(cnt_of_v, nv_of_v, "floor") + v_piece.lt(at::remainder(cnt_of_v, nv_of_v)).to(at::kLong);
   // groups: greedy over consecutive virtual rows, <= R rows and <= budget edges
   at::Tensor v_cnt_h = v_cnt.cpu();
   const int64_t *vc = v_cnt_h.data_ptr<int64_t>();
@@ -82,7 +85,7 @@ std::shared_ptr<SlabPlanHolder> slab_build_aten(const at::Tensor &src_index, con
   at::Tensor pos_t = to_dev(pos_of_group, at::kLong);
   // per edge: virtual row, group position, slab, row in group -> one stable sort
   at::Tensor e_id = at::arange(nnz, lopt);
-  at::Tensor vrow_e = vstart.index_select(0, dst_index) + at::div(e_id - rowptr.index_select(0, dst_index), cap, "floor");
+  at::Tensor vrow_e = vstart.index_select(0, dst_index) + at::remainder(e_id - rowptr.index_select(0, dst_index), nv_row.index_select(0, dst_index).clamp_min(1));
   e_id = at::Tensor();
   at::Tensor gid_e = group_of_vrow.index_select(0, vrow_e);
   at::Tensor dl_e = vrow_e - start_of_group.index_select(0, gid_e);
@@ -246,7 +249,7 @@ constexpr int64_t kSlabBytes = 2 << 20; // measured (profiles/r02/bench_slab.txt
 // against what uniform sources would touch.  Uniform / power-law sources: ~1.0; sources within +-100 000 of 233 k rows: 0.86
 // (plan and per-edge kernels level - the trial decides); +-20 000: 0.18, +-2 000: 0.03 (declined here: no Phase A, no trial).
 // One small read-back, once per edge list.
-double slab_source_coverage(const at::Tensor &si, int64_t src_rows, int64_t rowbytes, int64_t block_edges) {
+double slab_source_coverage(const at::Tensor &si, const at::Tensor &di, int64_t src_rows, int64_t rowbytes, int64_t block_edges) {
   const int64_t nnz = si.numel();
   int64_t slab_rows = 1;
   while (2 * slab_rows * rowbytes <= kSlabBytes) slab_rows *= 2;
@@ -255,7 +258,16 @@ double slab_source_coverage(const at::Tensor &si, int64_t src_rows, int64_t rowb
   if (n_slabs < 8 || nnz < 4 * B * L) return 1.0;
   const auto lopt = si.options();
   at::Tensor starts = at::arange(B, lopt) * ((nnz - L) / B);
-  at::Tensor idx = (starts.unsqueeze(1) + at::arange(L, lopt).unsqueeze(0)).flatten();
+  // a block that falls inside a row of more than L edges (a hub) is spread over that whole row, as Phase A's interleaved pieces are:
+  // on a list whose sources ascend inside every row, L CONSECUTIVE edges of a hub would cover one narrow source range and read
+  // as locality the graph does not have
+  at::Tensor key = di.index_select(0, starts);
+  at::Tensor lo = at::searchsorted(di, key, /*out_int32=*/false, /*right=*/false), hi = at::searchsorted(di, key, false, true);
+  at::Tensor len = hi - lo;
+  at::Tensor hub = len.gt(L);
+  at::Tensor base = at::where(hub, lo, starts).unsqueeze(1);
+  at::Tensor step = at::where(hub, len.to(at::kDouble) / (double)L, at::ones_like(len).to(at::kDouble)).unsqueeze(1);
+  at::Tensor idx = (base + (at::arange(L, lopt).to(at::kDouble).unsqueeze(0) * step).floor().to(at::kLong)).clamp_max(nnz - 1).flatten();
   at::Tensor slabs = at::div(si.index_select(0, idx), slab_rows, "floor").view({B, L});
   at::Tensor sorted = std::get<0>(slabs.sort(1));
   at::Tensor distinct = sorted.slice(1, 1, L).ne(sorted.slice(1, 0, L - 1)).sum(1) + 1;
@@ -324,7 +336,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   if (g_opt.slab_mode != 1 && g_opt.slab_min_coverage_pct > 0 && si.is_cuda()) { // a graph with locality keeps the per-edge kernels (and pays neither Phase A nor a trial)
     const int64_t units = (int64_t)geot_slab_units() * (1024 / std::max<int64_t>(rowbytes, 16));
     const int64_t rounds = std::max<int64_t>(1, (rows + rpg * units - 1) / (rpg * units));
-    const double cover = slab_source_coverage(si, src.size(0), rowbytes, nnz / (rounds * units));
+    const double cover = slab_source_coverage(si, di, src.size(0), rowbytes, nnz / (rounds * units));
     std::lock_guard<std::mutex> lk(g_mu);
     g_stats.last_coverage_permille = (int64_t)(cover * 1000.0);
     if (cover * 100.0 < (double)g_opt.slab_min_coverage_pct) {

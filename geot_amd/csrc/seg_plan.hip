@@ -136,10 +136,14 @@ __global__ __launch_bounds__(kThreads) void plan_vrows_kernel(const int32_t *__r
   const int nv = (c + cap - 1) / cap;
   const Tri ex = tri_ex[r];
   const bool split = nv > 1;
+  // A row above `cap` edges is split into nv virtual rows by INTERLEAVING: edge j of the row goes to piece j % nv.  (Rounds 2-3 cut
+  // contiguous ranges: on an edge list whose sources are SORTED inside every dst row - what a CSR / torch_geometric's coalesce()
+  // leaves - each piece then covered one narrow source range, i.e. a few slabs, the groups made of hub pieces had all their
+  // edges in a few steps of the sweep, and the lockstep waited for them: configs[3]'s stand-in with sorted sources ran 19.4 ms
+  // instead of 8.0.  Interleaved pieces sample the whole row.)
   for (int p = 0; p < nv; ++p) {
     const int64_t v = (int64_t)ex.nv + p;
-    const int rest = c - p * cap;
-    v_cnt[v] = rest < cap ? rest : cap;
+    v_cnt[v] = c / nv + (p < c % nv ? 1 : 0);
     v_row[v] = (int32_t)r;
     v_total[v] = c;
     v_out[v] = split ? -((int64_t)ex.pieces + p + 1) : r;
@@ -230,7 +234,9 @@ __global__ __launch_bounds__(kThreads) void plan_edge_keys_kernel(const int64_t 
   d = d < 0 ? 0 : (d >= out_rows ? out_rows - 1 : d);               // (checked by stage 1; clamped all the same)
   int64_t off = e - (int64_t)rowptr[d];
   off = off < 0 ? 0 : off;
-  int64_t vrow = (int64_t)tri_ex[d].nv + (uint32_t)off / cap;
+  const uint32_t cnt = (uint32_t)row_count(rowptr, d);
+  const uint32_t nv = cnt > cap ? (cnt + cap - 1) / cap : 1;        // (plan_vrows_kernel's split: edge j of a row goes to piece j % nv)
+  int64_t vrow = (int64_t)tri_ex[d].nv + (uint32_t)off % nv;
   vrow = vrow >= V ? V - 1 : vrow;                                   // (only for an index that is not ascending after all)
   const int32_t gid = gidinc[vrow] - 1;
   const uint32_t dl = (uint32_t)(vrow - starts[gid]);
