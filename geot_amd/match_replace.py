@@ -19,7 +19,7 @@ with these guarantees the reference's pass does not give:
   ``max(row) + 2`` rows (SURVEY.md quirk Q9);
 * ``index_add`` is order-independent, the atomic-free kernels want ``row`` (the index_add index) ascending.
   PyG-style ``edge_index`` sorted by destination satisfies it and runs at full speed; any other order is
-  still CORRECT: the ``geot::*_rows`` ops probe ``row`` once per content (``index_facts`` in geot_amd/csrc/torch_ops.cpp)
+  still CORRECT: the ``geot::*_rows`` ops probe ``row`` once per content (``index_facts`` in geot_amd/csrc/host_cache.cpp)
   and reduce over its stable sort when it has descents.  ``sort_edges=True`` makes the pass insert that sort
   into the graph instead (useful when the exported program is to run somewhere the cache does not live).
 """

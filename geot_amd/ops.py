@@ -95,7 +95,7 @@ def _aggr_kind(reduce: str) -> str:
     return "sum" if reduce == "add" else get_reduction_enum(reduce)
 
 
-# ---- host-layer switches and counters (geot_amd/csrc/torch_ops.cpp) -----------------------------------------------
+# ---- host-layer switches and counters (geot_amd/csrc/host_state.cpp, host_cache.cpp) -----------------------------------------------
 _KEEP = -(2 ** 63)
 _UNSORTED = {"auto": 0, "sort": 1, "atomic": 2}
 _SLAB = {"never": -1, "auto": 0, "always": 1}

@@ -45,7 +45,7 @@ def worthwhile(nnz: int, out_rows: int, src_rows: int, rowbytes: int) -> bool:
     """Is the graph dense enough for L2 re-use?  Per round the chip holds R x units output rows; each XCD then reads
     (edges of the round / 8) rows out of a table of src_rows: below ~4 uses per row and round the sweep through L2
     costs more than it saves (configs[2], ogbn-products scale, has 0.1; configs[3], Reddit scale, 7).  The rule lives in
-    the host layer (csrc/torch_ops.cpp slab_worthwhile)."""
+    the host layer (csrc/host_plan.cpp slab_worthwhile)."""
     return bool(torch.ops.geot._slab_worthwhile(nnz, out_rows, src_rows, rowbytes))
 
 

@@ -1,4 +1,4 @@
-"""Content guard of the remembered products (`-m gpu`; csrc/seg_guard.hip, "content guard" in csrc/torch_ops.cpp).
+"""Content guard of the remembered products (`-m gpu`; csrc/seg_guard.hip, "content guard" in csrc/host_cache.cpp).
 
 The reference keeps nothing between calls: every call reads the caller's tensors (csrc/gather_scatter.cpp:25-34,
 geot/gather_scatter.py:30-33 re-sorts on every backward call), so its result always follows the bytes it is handed.  The host

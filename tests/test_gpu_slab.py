@@ -382,7 +382,7 @@ def test_backward_computes_only_what_autograd_asks_for(geot):
 ])
 def test_device_plan_builder_is_bit_identical_to_the_aten_formulation(geot, nodes, nnz, rowbytes, wmode, heads, R, units, slab_bytes):
     """Phase A as device code (csrc/seg_plan.hip: row pointers by binary search, one scan of (virtual rows, split, carry
-    slots), greedy grouping by pointer doubling, two radix sorts) against the ATen formulation it replaced (torch_ops.cpp
+    slots), greedy grouping by pointer doubling, two radix sorts) against the ATen formulation it replaced (host_plan.cpp
     slab_build_aten, whose arrays the numpy emulation of tests/test_slab_plan.py validates): every array and scalar equal."""
     from geot_amd import ops, slab
     rng = np.random.default_rng(nodes + R)

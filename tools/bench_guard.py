@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What the content guard costs (csrc/seg_guard.hip; "content guard" in csrc/torch_ops.cpp).
+"""What the content guard costs (csrc/seg_guard.hip; "content guard" in csrc/host_cache.cpp).
 
 1. the fingerprint kernel alone on two int64 index arrays of E edges (HIP events, streamed bytes / time);
 2. operators that use a remembered product, content_guard on / off alternating in ONE process on one box:
