@@ -158,8 +158,10 @@ void enforce_cache_budget_locked(); // (defined behind the caches; call with g_m
 void sweep_expired_locked();
 
 
-// one zero-initialised workspace per (device, stream), grown on demand (the ABI: one stream at a time per workspace)
-at::Tensor &workspace(const at::Tensor &like, size_t bytes);
+// one zero-initialised workspace per (device, stream), grown on demand (the ABI: one stream at a time per workspace).  Under graph
+// capture a workspace that is not there yet (or too small) is made for THIS call only and not kept: memory of a graph's private pool
+// must not outlive the graph in a thread-local cache (exit-order crashes), and the captured memset re-zeroes it on every replay
+at::Tensor workspace(const at::Tensor &like, size_t bytes);
 void clear_all_caches_locked();
 int64_t cache_bytes_locked();
 

@@ -377,7 +377,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
 bool run_slab(SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat, int red) {
   const std::vector<at::Tensor> pinned = H.pinned(); // this launch's own references: a release() meanwhile cannot free under the kernel
   if (pinned.empty()) return false;
-  auto &ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
+  const at::Tensor ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
   GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
                            red, ws.data_ptr(), ws.numel(), stream_of(src)));
   H.launched_on(src, pinned);

@@ -45,9 +45,15 @@ void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqu
 
 
 // one zero-initialised workspace per (device, stream), grown on demand (the ABI: one stream at a time per workspace)
-at::Tensor &workspace(const at::Tensor &like, size_t bytes) {
+at::Tensor workspace(const at::Tensor &like, size_t bytes) {
   static thread_local std::map<std::pair<int, void *>, at::Tensor> ws;
-  auto &w = ws[{(int)like.device().index(), stream_of(like)}];
+  const std::pair<int, void *> key{(int)like.device().index(), stream_of(like)};
+  if (tl_capturing) {
+    auto it = ws.find(key);
+    if (it != ws.end() && it->second.defined() && (size_t)it->second.numel() >= bytes) return it->second;   // made before the capture (warm-up on this stream)
+    return at::zeros({(int64_t)std::max<size_t>(bytes, 1 << 20)}, like.options().dtype(at::kByte));          // this call's own; not kept
+  }
+  auto &w = ws[key];
   if (!w.defined() || (size_t)w.numel() < bytes)
     w = at::zeros({(int64_t)std::max<size_t>(bytes, 1 << 20)}, like.options().dtype(at::kByte));
   return w;

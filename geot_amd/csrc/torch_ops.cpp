@@ -217,7 +217,7 @@ at::Tensor index_scatter_op(const int64_t dim, const at::Tensor &index_in, const
   at::Tensor out = with_row_rule(index, f.rows, !f.cached, [&](int64_t rows) {
     shape[0] = rows;
     at::Tensor o = at::empty(shape, moved.options());
-    auto &ws = workspace(src, geot_workspace_bytes(nnz, feat, rows, dt));
+    const at::Tensor ws = workspace(src, geot_workspace_bytes(nnz, feat, rows, dt));
     if (f.ascending) {
       if (red == GEOT_REDUCE_SUM)
         GEOT_CALL(geot_index_scatter(index_ptr(index), moved.data_ptr(), o.data_ptr(), nnz, feat, rows, dt, 1, ws.data_ptr(), ws.numel(), stream_of(src)));
@@ -392,7 +392,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
   auto launch = [&](int64_t rows) {
     at::Tensor o = at::empty({rows, feat}, x.options());
     auto run_edges = [&](at::Tensor &o) {
-      auto &ws = workspace(x, geot_workspace_bytes(nnz, feat, rows, dt));
+      const at::Tensor ws = workspace(x, geot_workspace_bytes(nnz, feat, rows, dt));
       if (red == GEOT_REDUCE_SUM && has_w)
         GEOT_CALL(geot_gather_weight_scatter(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, feat, x.size(0), rows,
                                              dt, ws.data_ptr(), ws.numel(), stream_of(x)));
@@ -490,7 +490,7 @@ at::Tensor mh_spmm_common(const at::Tensor &si, const at::Tensor &di, const at::
   auto launch = [&](int64_t rows) {
     at::Tensor o = at::empty({rows, heads, feat}, x.options());
     auto run_edges = [&](at::Tensor &o) {
-      auto &ws = workspace(x, geot_mh_workspace_bytes(nnz, heads, feat, rows, dt));
+      const at::Tensor ws = workspace(x, geot_mh_workspace_bytes(nnz, heads, feat, rows, dt));
       GEOT_CALL(geot_mh_spmm(index_ptr(e.si), index_ptr(e.di), e.w.data_ptr(), x.data_ptr(), o.data_ptr(), nnz, heads, feat, x.size(0), rows, layout,
                              dt, ws.data_ptr(), ws.numel(), stream_of(x)));
     };
@@ -548,7 +548,7 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
         auto run_plan = [&](at::Tensor &o) -> bool {
           const std::vector<at::Tensor> pinned = plan->pinned();
           if (pinned.empty()) return false;
-          auto &ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
+          const at::Tensor ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, m1.size(1)));
           GEOT_CALL(geot_slab_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), m1.size(1), m1.size(0), m2.size(0),
                                     dtype_code(m1, "sddmm_coo"), ws.data_ptr(), ws.numel(), stream_of(m1)));
           plan->launched_on(m1, pinned);
@@ -583,7 +583,7 @@ at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in,
   const int64_t rows = indptr.size(0), nnz = indices.size(0), feat = src.size(1);
   at::Tensor out = at::empty({rows, feat}, src.options());
   const int dt = dtype_code(src, "csr_gws");
-  auto &ws = workspace(src, geot_csr_workspace_bytes(nnz, feat, rows, dt));
+  const at::Tensor ws = workspace(src, geot_csr_workspace_bytes(nnz, feat, rows, dt));
   GEOT_CALL(geot_csr_gws(index_ptr(indptr), index_ptr(indices), weight.data_ptr(), src.data_ptr(), out.data_ptr(), rows - 1, nnz, feat, src.size(0),
                          rows, dt, ws.data_ptr(), ws.numel(), stream_of(src)));
   return out;

@@ -83,13 +83,15 @@ class _on_device:
 
 
 def workspace(dev: torch.device, nbytes: int, stream: Optional[int] = None) -> torch.Tensor:
-    """Cached scratch for the current stream; zero-initialised once (control words), reused after."""
+    """Cached scratch for the current stream; zero-initialised once (control words), reused after.  Under graph capture a scratch that
+    is not there yet is made for this call only and not kept (memory of a graph's private pool must not outlive the graph in a cache)."""
     stream = _stream_handle(dev) if stream is None else stream
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _workspaces[key] = ws
+        if not torch.cuda.is_current_stream_capturing():
+            _workspaces[key] = ws
     return ws
 
 

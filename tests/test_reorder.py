@@ -56,6 +56,29 @@ def test_rank_orders_by_label_then_id_and_directed_mode_runs():
     assert reorder.edge_locality(si[:0], di[:0]) == 1.0
 
 
+def test_renumber_accepts_structure_and_declines_its_absence():
+    """The one-time part runs on any device (torch ops): a shuffled block model is renumbered (most edges end up within an
+    L2-sized window of their destination, the new list is dst-sorted, the permutations are inverse to each other); a graph with
+    uniform-random sources has nothing to find and is declined - the two permutations per call would be pure overhead."""
+    from geot_amd import reorder
+    nodes, nnz = 40_000, 1_200_000
+    si, di, truth, _ = block_model(nodes, nnz, 0.8, 7)
+    g = reorder.renumber(si, di, nodes)
+    assert g is not None and g.rows == nodes and g.locality_after > 0.9 and g.locality_after - g.locality_before >= 0.25
+    assert bool((g.dst_index[1:] >= g.dst_index[:-1]).all())
+    assert torch.equal(g.order[g.rank], torch.arange(nodes)) and torch.equal(g.rank[g.order], torch.arange(nodes))
+    assert torch.equal(g.dst_index, g.rank[di][g.edge_perm]) and torch.equal(g.src_index, g.rank[si][g.edge_perm])
+    w = torch.rand(nnz)
+    assert torch.equal(g.edge_values(w), w[g.edge_perm])
+    gen = torch.Generator().manual_seed(1)
+    di_r = torch.randint(0, nodes, (nnz,), generator=gen).sort().values
+    di_r[-1] = nodes - 1
+    si_r = torch.randint(0, nodes, (nnz,), generator=gen)
+    assert reorder.renumber(si_r, di_r, nodes) is None
+    with pytest.raises(ValueError, match="int64 permutation"):
+        reorder.RenumberedGraph(si, di, nodes, torch.arange(nodes - 1))
+
+
 @pytest.mark.gpu
 def test_renumbered_operators_equal_the_direct_ones_forward_and_backward():
     import geot_amd as geot

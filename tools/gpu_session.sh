@@ -39,6 +39,16 @@ for s in $steps; do
                 timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -3 $O/soak_seed$seed.log
               done ;;
     trainstep) timeout 900 python3 tools/bench_train_step.py > $O/bench_train_step.txt 2>&1; echo "rc=$?"; cat $O/bench_train_step.txt ;;
+    longrun)  for seed in 64 65 66 67; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-200
+              done
+              timeout 900 python3 tools/hang_hunt.py --scenario lockstep --runs 30 --slab-turn 0 --T 90 > $O/hunt_lockstep30_turn0.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_lockstep30_turn0.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario procs --runs 20 --T 90 > $O/hunt_procs20.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_procs20.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 20 --T 90 > $O/hunt_graphs20.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_graphs20.txt ;;
+    shardover) timeout 600 python3 tools/bench_sharded_overhead.py > $O/bench_sharded_overhead.txt 2>&1; echo "rc=$?"; cat $O/bench_sharded_overhead.txt ;;
+    graphs20) timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 20 --T 90 > $O/hunt_graphs20b.txt 2>&1; echo "rc=$?"; grep -c "rc=0" $O/hunt_graphs20b.txt; tail -2 $O/hunt_graphs20b.txt
+              timeout 900 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_round3.py tests/test_gpu_round2.py -m gpu -q -k "graph or captur" > $O/pytest_graphs.log 2>&1; echo "rc=$?"; tail -3 $O/pytest_graphs.log ;;
+    exitctl)  timeout 1200 python3 tools/dbg/graph_exit_control.py > $O/graph_exit_control.txt 2>&1; echo "rc=$?"; cat $O/graph_exit_control.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
