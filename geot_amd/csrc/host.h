@@ -297,7 +297,7 @@ struct SlabEntry {
   WeakStorage w1, w2; // the edge list the plan was built from (weak: the plan goes when the edge list dies)
   std::shared_ptr<SlabPlanHolder> plan;
 };
-extern std::list<SlabEntry> g_slab;
+extern std::list<SlabEntry> &g_slab;
 extern std::list<std::pair<ContentKey, ContentKey>> g_sightings, g_declined;
 bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes, int dtype = GEOT_F32);
 std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Tensor &di, int64_t rows, const at::Tensor &src, int wmode,

@@ -168,7 +168,9 @@ struct Facts {
   Produced made;         // ... and the event of that sort
   at::Tensor sort_fp;    // ... and the fingerprint of the index it sorted (guard_store)
 };
-std::list<Facts> g_facts; // most recent first, <= 16 entries
+// (the caches are never destroyed: at process exit their tensors would be freed by static destructors, after graphs / streams /
+//  the allocator may already be half gone - an exit-time SIGSEGV was seen with captured graphs alive; the OS takes the memory back)
+std::list<Facts> &g_facts = *new std::list<Facts>; // most recent first, <= 16 entries
 constexpr size_t kFactsMax = 16, kSortedKeep = 4;
 
 
@@ -307,7 +309,7 @@ struct WidenedEntry {
   Produced made;
   at::Tensor fp; // fingerprint of the narrow tensor (guard_store)
 };
-std::list<WidenedEntry> g_widened;
+std::list<WidenedEntry> &g_widened = *new std::list<WidenedEntry>;
 
 at::Tensor as_int64(const at::Tensor &t) {
   const GuardFlush flush_questions_;
@@ -346,7 +348,7 @@ struct ExpandedEntry {
   Produced made;
   at::Tensor fp; // fingerprint of the row pointers (guard_store)
 };
-std::list<ExpandedEntry> g_expanded;
+std::list<ExpandedEntry> &g_expanded = *new std::list<ExpandedEntry>;
 
 at::Tensor expand_indptr(const at::Tensor &indptr, int64_t nnz) {
   const GuardFlush flush_questions_;
@@ -394,7 +396,7 @@ struct TransposedEntry {
   at::Tensor fp, w_fp; // fingerprints of the edge list / of the weight (guard_store)
   int64_t bytes() const { return nbytes_of(perm) + nbytes_of(si_sorted) + nbytes_of(di_perm) + nbytes_of(w_perm); }
 };
-std::list<TransposedEntry> g_transposed;
+std::list<TransposedEntry> &g_transposed = *new std::list<TransposedEntry>;
 
 bool owned_product(const at::Tensor &t) {
   if (!t.defined() || !t.has_storage()) return false;

@@ -276,7 +276,7 @@ double slab_source_coverage(const at::Tensor &si, const at::Tensor &di, int64_t 
   return mean / std::max(expect, 1.0);
 }
 
-std::list<SlabEntry> g_slab;
+std::list<SlabEntry> &g_slab = *new std::list<SlabEntry>; // (never destroyed: see g_facts)
 std::list<std::pair<ContentKey, ContentKey>> g_sightings; // edge lists seen once (no tensors held)
 std::list<std::pair<ContentKey, ContentKey>> g_declined;  // edge lists with locality (slab_source_coverage): per-edge kernels, no plan
 std::list<std::pair<ContentKey, ContentKey>> g_building;  // edge lists whose plan a thread is building right now (the others keep the per-edge kernels)

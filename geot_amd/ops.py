@@ -123,6 +123,22 @@ def clear_caches() -> None:
     torch.ops.geot._host_option("clear_caches", 0)
 
 
+def _at_exit() -> None:
+    """Drop what the host layer remembers while torch is still whole: tensors freed by static destructors at process exit - after
+    captured graphs, streams or the allocator may be half gone - were seen to crash the exit (SIGSEGV with two CUDAGraphs alive)."""
+    try:
+        clear_caches()
+        from . import hip
+        hip.release_workspaces()
+    except Exception:  # noqa: BLE001  (interpreter shutdown: nothing left to do)
+        pass
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_at_exit)
+
+
 def stats() -> dict:
     names = ("probes", "row_mismatches", "sorts", "transposes", "plans_built", "slab_calls", "plan_us", "facts", "transposed", "plans",
              "published", "alarms", "cache_bytes", "stale_products", "guard_checks", "plan_trials", "plans_rejected",

@@ -18,8 +18,6 @@ for s in $steps; do
               timeout 600 python3 tools/hang_hunt.py --scenario graphs --runs 2 --T 90 > $O/hunt_graphs.txt 2>&1; echo "rc=$?"; tail -4 $O/hunt_graphs.txt
               timeout 2400 python3 tools/hang_hunt.py --scenario threads --runs 40 --slab-turn 0 --T 60 > $O/hunt_threads_turn0.txt 2>&1; echo "rc=$?"; tail -6 $O/hunt_threads_turn0.txt ;;
     alltests) timeout 2400 python3 -m pytest tests -m gpu -q > $O/pytest_gpu_all.log 2>&1; echo "rc=$?"; tail -15 $O/pytest_gpu_all.log ;;
-    graphdbg) timeout 300 python3 tools/dbg/graph_fault.py default > $O/graph_fault_default.txt 2>&1; echo "rc=$?"; tail -8 $O/graph_fault_default.txt
-              timeout 300 python3 tools/dbg/graph_fault.py warm_on_capture_stream > $O/graph_fault_warm.txt 2>&1; echo "rc=$?"; tail -8 $O/graph_fault_warm.txt ;;
     sweepslab) timeout 900 python3 tools/sweep_slab.py > $O/sweep_slab_mh_uniform.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_uniform.txt
               timeout 900 python3 tools/sweep_slab.py --sources powerlaw > $O/sweep_slab_mh_powerlaw.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_powerlaw.txt
               timeout 900 python3 tools/sweep_slab.py --case gws --quick > $O/sweep_slab_gws_uniform.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_gws_uniform.txt ;;
@@ -48,7 +46,6 @@ for s in $steps; do
     shardover) timeout 600 python3 tools/bench_sharded_overhead.py > $O/bench_sharded_overhead.txt 2>&1; echo "rc=$?"; cat $O/bench_sharded_overhead.txt ;;
     graphs20) timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 20 --T 90 > $O/hunt_graphs20b.txt 2>&1; echo "rc=$?"; grep -c "rc=0" $O/hunt_graphs20b.txt; tail -2 $O/hunt_graphs20b.txt
               timeout 900 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_round3.py tests/test_gpu_round2.py -m gpu -q -k "graph or captur" > $O/pytest_graphs.log 2>&1; echo "rc=$?"; tail -3 $O/pytest_graphs.log ;;
-    exitctl)  timeout 1200 python3 tools/dbg/graph_exit_control.py > $O/graph_exit_control.txt 2>&1; echo "rc=$?"; cat $O/graph_exit_control.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
