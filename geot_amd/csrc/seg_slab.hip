@@ -631,7 +631,11 @@ SlabTurn g_turn;
 extern "C" {
 
 constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
-int g_slab_window = 2;  // experiment knob ("slab_window" of geot_set_option): -1 = no synchronisation
+// "slab_window": how many slabs a wave may run ahead of the slowest wave of its XCD; -2 = the rule, -1 = no synchronisation.
+// The rule (round-4 sweeps, profiles/r04/sweep_slab_*.txt, slab_window_*.txt, configs[3]'s graph): 2 everywhere (1-KiB rows 7.46 vs
+// 7.73 ms; 512-B rows without weights 3.52 vs 3.61; multi-head bf16 6.11 vs 6.23) except a per-edge weight on rows below 1 KiB,
+// where 1 is better (fp32 F=128 4.71 vs 4.93 ms, bf16 F=128 3.35 vs 3.49 ms)
+int g_slab_window = -2;
 
 // "slab_far": the lockstep exists so that the waves of an XCD read the SAME slab at about the same time.  A wave whose slab is far
 // from the slowest wave's shares nothing with it whatever it does - the case of a graph with LOCALITY (sources near their
@@ -735,7 +739,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.carry = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + kSyncBytes);
   p.slab_shift = plan->slab_shift;
   p.n_slabs = plan->n_slabs;
-  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (lpr_log2 == 6 ? 2 : 1) : g_slab_window) : -1;
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? ((weight_mode == 1 && lpr_log2 < 6) ? 1 : 2) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
@@ -838,7 +842,7 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
   p.prog_cnt = p.prog + 8 * kProgSlots;
   p.slab_shift = plan->slab_shift;
   p.n_slabs = plan->n_slabs;
-  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (lpr_log2 == 6 ? 2 : 1) : g_slab_window) : -1;
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? 2 : g_slab_window) : -1;
   hipError_t e = hipSuccess;
   if (p.window >= 0) {
     e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);

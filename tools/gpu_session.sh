@@ -46,6 +46,10 @@ for s in $steps; do
     shardover) timeout 600 python3 tools/bench_sharded_overhead.py > $O/bench_sharded_overhead.txt 2>&1; echo "rc=$?"; cat $O/bench_sharded_overhead.txt ;;
     graphs20) timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 20 --T 90 > $O/hunt_graphs20b.txt 2>&1; echo "rc=$?"; grep -c "rc=0" $O/hunt_graphs20b.txt; tail -2 $O/hunt_graphs20b.txt
               timeout 900 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_round3.py tests/test_gpu_round2.py -m gpu -q -k "graph or captur" > $O/pytest_graphs.log 2>&1; echo "rc=$?"; tail -3 $O/pytest_graphs.log ;;
+    sweep16)  timeout 900 python3 tools/sweep_slab.py --dtype bfloat16 > $O/sweep_slab_mh_bf16.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_mh_bf16.txt
+              timeout 900 python3 tools/sweep_slab.py --case gws > $O/sweep_slab_gws_f32_full.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_gws_f32_full.txt ;;
+    sweepw)   for c in gs64 gs128 gws256; do timeout 600 python3 tools/sweep_slab.py --case $c --ab slab_window=1,2,3 > $O/slab_window_$c.txt 2>&1; echo "rc=$?"; cat $O/slab_window_$c.txt; done
+              timeout 600 python3 tools/sweep_slab.py --case gws --dtype bfloat16 --ab slab_window=1,2,3 > $O/slab_window_gws_bf16.txt 2>&1; cat $O/slab_window_gws_bf16.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;

@@ -23,32 +23,39 @@ def main():
     ap.add_argument("--sources", default="uniform")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--case", default="mh")
+    ap.add_argument("--dtype", default="float32")
     ap.add_argument("--coalesced", action="store_true", help="sources sorted inside every dst row (what torch_geometric's coalesce() / a CSR leaves)")
     ap.add_argument("--ab", default="", help="A/B of one library option at the default plan: NAME=v0,v1 (e.g. slab_nt=0,1 or slab_far=4,12,1000000)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     print(hip.build_info(), flush=True)
     nodes, nnz = 232_965, 114_615_892
-    H, Fh, wmode = (4, 64, 2) if a.case == "mh" else (1, 128, 1)
+    H, Fh, wmode = {"mh": (4, 64, 2), "gws": (1, 128, 1), "gs64": (1, 64, 0), "gs128": (1, 128, 0), "gws256": (1, 256, 1)}[a.case]
     di = powerlaw_index(nnz, nodes, 11, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(12)
     si = di[torch.randperm(nnz, device=dev, generator=g)].contiguous() if a.sources == "powerlaw" else torch.randint(0, nodes, (nnz,), device=dev, generator=g)
     if a.coalesced:
         si = (torch.sort(di * nodes + si).values % nodes).contiguous()
-    x = torch.rand(nodes, H, Fh, device=dev, generator=g)
-    w = torch.rand(nnz, H, device=dev, generator=g) if wmode == 2 else torch.rand(nnz, device=dev, generator=g)
-    out = torch.empty(nodes, H, Fh, device=dev)
-    ref = torch.empty(nodes, H, Fh, device=dev)
+    dt = getattr(torch, a.dtype)
+    esz = 2 if dt != torch.float32 else 4
+    x = torch.rand(nodes, H, Fh, device=dev, generator=g).to(dt)
+    w = (torch.rand(nnz, H, device=dev, generator=g) if wmode == 2 else torch.rand(nnz, device=dev, generator=g)).to(dt)
+    if wmode == 0:
+        w = None
+    out = torch.empty(nodes, H, Fh, device=dev, dtype=dt)
+    ref = torch.empty(nodes, H, Fh, device=dev, dtype=dt)
     if wmode == 2:
         base = lambda: hip.mh_spmm_out(si, di, w, x, ref, False)  # noqa: E731
-    else:
+    elif wmode == 1:
         base = lambda: hip.gather_weight_scatter_out(si, di, w, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
-    print(f"case={a.case} sources={a.sources} coalesced={a.coalesced} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
+    else:
+        base = lambda: hip.gather_scatter_out(si, di, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
+    print(f"case={a.case} dtype={a.dtype} sources={a.sources} coalesced={a.coalesced} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
     if a.ab:
         name, vals = a.ab.split("=")
         vals = [int(v) for v in vals.split(",")]
-        plan = slab.build_plan(si, di, nodes, nodes, H * Fh * 4, wmode, H)
+        plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, rows_per_group=slab.rows_per_group(wmode, H, dt))
         for rep in range(3):
             row = []
             for v in vals:
@@ -63,7 +70,7 @@ def main():
     for blocks in (3, 2) if not a.quick else (3,):
         hip.set_option("slab_blocks", blocks)
         for mib in slabs:
-            plan = slab.build_plan(si, di, nodes, nodes, H * Fh * 4, wmode, H, slab_bytes=int(mib * (1 << 20)))
+            plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, slab_bytes=int(mib * (1 << 20)), rows_per_group=slab.rows_per_group(wmode, H, dt))
             row = []
             for k in windows:
                 hip.set_option("slab_window", k)
@@ -72,7 +79,7 @@ def main():
                 if ms < best[0]:
                     best = (ms, (blocks, mib, k))
             base()
-            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            err = ((out.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
             print(f"{blocks:6d} {mib:8.1f} " + " ".join(f"{m:8.3f}" for m in row) + f"   R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} "
                   f"slabs={plan.meta['slabs']} err={err:.1e}", flush=True)
             del plan
