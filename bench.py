@@ -553,30 +553,28 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         del si, di, truth, w, x, out, rg
         torch.cuda.empty_cache()
 
-    if "cfg1" in want:
-        cfg1("cfg1")
-    if "gws_cfg3" in want:
-        gws("gws_cfg3", "uniform", torch.float32)
-    if "gws_cfg3_local" in want:
-        gws("gws_cfg3_local", "local", torch.float32)
-    if "gws_cfg3_powerlaw_src" in want:
-        gws("gws_cfg3_powerlaw_src", "powerlaw", torch.float32)
-    if "gws_cfg3_blockmodel" in want:
-        blockmodel("gws_cfg3_blockmodel")
-    if "gws_cfg3_blockmodel_asis" in want:                    # (profiling passes only: not in SECONDARY)
-        blockmodel("gws_cfg3_blockmodel_asis", "asis")
-    if "gws_cfg3_blockmodel_renum" in want:
-        blockmodel("gws_cfg3_blockmodel_renum", "renum")
-    if "mh_spmm_cfg4" in want:
-        mh("mh_spmm_cfg4", torch.float32)
-    if "mh_spmm_cfg4_powerlaw_src" in want:
-        mh("mh_spmm_cfg4_powerlaw_src", torch.float32, "powerlaw")
-    if "mh_spmm_cfg4_coalesced" in want:
-        mh("mh_spmm_cfg4_coalesced", torch.float32, "uniform", coalesced=True)
-    if "gws_cfg3_bf16" in want:
-        gws("gws_cfg3_bf16", "uniform", torch.bfloat16)
-    if "mh_spmm_cfg4_bf16" in want:
-        mh("mh_spmm_cfg4_bf16", torch.bfloat16)
+    # one entry failing (out of memory on a smaller device, a comparator that does not load) must not take the others with it
+    plan = [("cfg1", lambda n: cfg1(n)),
+            ("gws_cfg3", lambda n: gws(n, "uniform", torch.float32)),
+            ("gws_cfg3_local", lambda n: gws(n, "local", torch.float32)),
+            ("gws_cfg3_powerlaw_src", lambda n: gws(n, "powerlaw", torch.float32)),
+            ("gws_cfg3_blockmodel", lambda n: blockmodel(n)),
+            ("gws_cfg3_blockmodel_asis", lambda n: blockmodel(n, "asis")),        # (profiling passes only: not in SECONDARY)
+            ("gws_cfg3_blockmodel_renum", lambda n: blockmodel(n, "renum")),
+            ("mh_spmm_cfg4", lambda n: mh(n, torch.float32)),
+            ("mh_spmm_cfg4_powerlaw_src", lambda n: mh(n, torch.float32, "powerlaw")),
+            ("mh_spmm_cfg4_coalesced", lambda n: mh(n, torch.float32, "uniform", coalesced=True)),
+            ("gws_cfg3_bf16", lambda n: gws(n, "uniform", torch.bfloat16)),
+            ("mh_spmm_cfg4_bf16", lambda n: mh(n, torch.bfloat16))]
+    for name, run in plan:
+        if name not in want:
+            continue
+        try:
+            run(name)
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"error": repr(e)}
+            ops.clear_caches()
+            torch.cuda.empty_cache()
     return res
 
 

@@ -50,6 +50,13 @@ for s in $steps; do
               timeout 900 python3 tools/sweep_slab.py --case gws > $O/sweep_slab_gws_f32_full.txt 2>&1; echo "rc=$?"; cat $O/sweep_slab_gws_f32_full.txt ;;
     sweepw)   for c in gs64 gs128 gws256; do timeout 600 python3 tools/sweep_slab.py --case $c --ab slab_window=1,2,3 > $O/slab_window_$c.txt 2>&1; echo "rc=$?"; cat $O/slab_window_$c.txt; done
               timeout 600 python3 tools/sweep_slab.py --case gws --dtype bfloat16 --ab slab_window=1,2,3 > $O/slab_window_gws_bf16.txt 2>&1; cat $O/slab_window_gws_bf16.txt ;;
+    driverbench) ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err ) 2> $O/bench_driver_cmd.time; echo "rc=$?"; cat $O/bench_driver_cmd.time; head -c 600 $O/bench_driver_cmd.json; echo
+              timeout 900 python3 -m pytest tests/test_gpu_multirank.py -m gpu -q > $O/pytest_multirank.log 2>&1; echo "rc=$?"; tail -3 $O/pytest_multirank.log ;;
+    evidence) for seed in 68 69 70 71 72 73; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-120
+              done
+              timeout 2400 python3 tools/hang_hunt.py --scenario threads --runs 150 --slab-turn 1 --T 60 > $O/hunt_threads150_turn1.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_threads150_turn1.txt
+              timeout 1200 python3 tools/stress_handoff.py --calls 3000 > $O/stress_handoff_3000.txt 2>&1; echo "rc=$?"; tail -2 $O/stress_handoff_3000.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
