@@ -226,7 +226,11 @@ int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *
  *                    row inside the group, original edge number (for the weights)
  *   g_begin[p]       first edge of the group at position p (n_groups + 1 entries); g_vrow0 / g_nv its rows
  *   v_out[v]         >= 0: the dst row of virtual row v;  < 0: -(carry slot + 1) for a piece of a split hub row
- *   c_row/c_first/c_count  the split rows: dst row, first carry slot, number of slots                          */
+ *   c_row/c_first/c_count  the split rows: dst row, first carry slot, number of slots
+ * A row above `cap` edges is split by INTERLEAVING (edge j of the row belongs to piece j mod nv): every piece samples the row's
+ * whole source range, also on an edge list whose sources ascend inside every row (a CSR, coalesce(), any transposed list) -
+ * contiguous pieces there put a hub's groups into a few steps of the sweep and the lockstep waits for them (2.4x at configs[3]).
+ * A plan made by other means must do the same.                                                                */
 typedef struct geot_slab_plan {
   const int32_t *e_src;
   const uint8_t *e_dl;
@@ -346,6 +350,9 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
  * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
  * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
  * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free);
+ * "slab_far" = n: a slowest wave more than n steps behind is not waited for (12); "slab_turn" = 1 | 0: the persistent
+ * source-blocked grids of this process take turns per device (a launch waits on its stream for the event of the previous one;
+ * skipped on a capturing stream); "slab_nt" = 0 | 1: experiment, non-temporal loads of the plan's streams;
  * "handoff_tries" = polls of a predecessor's flag before a run is left to the second launch (0: sample once);
  * "lds_floor" = -1 | bytes: dynamic LDS a tile-kernel launch asks for at least - the cap on workgroups per CU
  * (-1: the rule; 33000 -> 4, 41000 -> 3, 54000 -> 2 per CU); "gather_grid" = tiles a gathered fp32 call is cut into
