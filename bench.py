@@ -538,7 +538,21 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                 w_c = ceiling.edge_values(w)
                 ms_ceiling = device_ms(lambda: ceiling.gather_weight_scatter(w_c, x, in_new_order=True), iters)
                 del ceiling, w_c
+            fair = {}
+            if mode == "both":          # the comparator on the SAME renumbered matrix (kernel against kernel, permutations outside both)
+                try:
+                    from tools import rocsparse
+                    xp, yp = rg.rows_in(x), torch.empty_like(x)
+                    k_ms = device_ms(lambda: hip.gather_weight_scatter_out(rg.src_index, rg.dst_index, w_new, xp, yp), iters)
+                    best, _, yr = rocsparse.best_csr_spmm(rg.dst_index, rg.src_index, w_new, xp, nodes, iters=max(2, iters // 2),
+                                                          algs=("csr_nnz_split", "csr_merge_path"))
+                    fair = {"kernel_ms_on_the_renumbered_list": k_ms, "rocsparse_best_ms_on_the_renumbered_matrix": best["ms"],
+                            "speedup_vs_rocsparse_on_the_renumbered_matrix": best["ms"] / k_ms}
+                    del xp, yp, yr
+                except Exception as e:  # noqa: BLE001
+                    fair = {"rocsparse_error": repr(e)}
             entry["renumbered"] = {
+                **fair,
                 "what": "geot_amd.reorder.renumber: label propagation on the device, then per call rows of x permuted in, the same "
                         "kernels on the renumbered + re-sorted edge list, rows of y permuted back (both permutations inside the timings)",
                 "call_ms_static_weight": ms_static, "call_ms_weight_permuted_per_call": ms_dyn,

@@ -564,7 +564,10 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
-// split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row)
+// split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row).  The pieces meet in FLOAT64 and are
+// rounded once: a hub of 300 k edges is thousands of pieces, and with interleaved pieces (Phase A) they can all be nearly EQUAL
+// (two distinct source rows: every piece samples both in proportion) - adding thousands of equal fp32 values to a growing fp32
+// sum rounds the same way every time (2e-5 relative seen in the soak, over the 1e-5 bar); in float64 the drift is gone.
 template <typename T, int RED>
 __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p) {
   constexpr int VEC = SlabVec<T>::VEC, NV = SlabVec<T>::NV;
@@ -578,14 +581,30 @@ __global__ __launch_bounds__(kThreads) void seg_slab_combine_kernel(SlabParams p
     const int n = P.c_count[s];
     constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
     f4_t acc[NV];
+    if constexpr (RED == GEOT_REDUCE_SUM || RED == GEOT_REDUCE_MEAN) {
+      double dacc[NV][4];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) acc[q] = f4_t{kIdent, kIdent, kIdent, kIdent};
-    for (int i = 0; i < n; ++i)
+      for (int q = 0; q < NV; ++q)
 #pragma unroll
-      for (int q = 0; q < NV; ++q) slab_acc<RED>(acc[q], *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * VEC + 4 * q));
-    if constexpr (RED == GEOT_REDUCE_MEAN) {
+        for (int e = 0; e < 4; ++e) dacc[q][e] = 0.0;
+      for (int i = 0; i < n; ++i)
 #pragma unroll
-      for (int q = 0; q < NV; ++q) acc[q] = acc[q] / (float)P.c_total[s];
+        for (int q = 0; q < NV; ++q) {
+          const f4_t m = *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * VEC + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dacc[q][e] += (double)m[e];
+        }
+      const double inv = RED == GEOT_REDUCE_MEAN ? 1.0 / (double)P.c_total[s] : 1.0;
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = (float)(RED == GEOT_REDUCE_MEAN ? dacc[q][e] * inv : dacc[q][e]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = f4_t{kIdent, kIdent, kIdent, kIdent};
+      for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) slab_acc<RED>(acc[q], *reinterpret_cast<const f4_t *>(p.carry + (first + i) * p.F + c * VEC + 4 * q));
     }
     if (row >= 0 && row < p.K) *reinterpret_cast<f4_t *>(static_cast<T *>(p.dst) + row * p.F + c * VEC) = slab_pack<T>(acc);
   }

@@ -187,6 +187,13 @@ def main():
                     ok = out.shape == ref.shape and np.array_equal(out, ref)
         if not ok:
             print("MISMATCH", tag, flush=True)
+            try:        # where and by how much (sum cases keep `hi` / `mag`)
+                ratio = np.abs(out - hi) / (2e-5 * mag + 1e-30)
+                r, c = np.unravel_index(np.argmax(ratio), ratio.shape)
+                print(f"  worst: row {r} col {c}: got {out[r, c]!r} want {hi[r, c]!r} |diff| / bound = {ratio[r, c]:.3g}; rows over the bound: "
+                      f"{np.unique(np.nonzero(ratio > 1)[0])[:10]}, nodes {x.shape[0] if 'x' in dir() else '-'}, stats {geot.ops.stats()}", flush=True)
+            except Exception as e:  # noqa: BLE001
+                print("  (no detail:", repr(e), ")", flush=True)
             sys.exit(1)
         if it % 20 == 0:
             print("ok", tag, flush=True)
