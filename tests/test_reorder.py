@@ -101,6 +101,11 @@ def test_renumbered_operators_equal_the_direct_ones_forward_and_backward():
     wh = torch.rand(nnz, H, device="cuda", generator=gen)
     want_h = geot.mh_spmm(si, di, wh, xh)
     assert float((g.mh_spmm(wh, xh) - want_h).abs().max()) <= 1e-5 * float(want_h.abs().max())
+    # two layers that STAY in the new order: one permutation in, one out
+    h_new = g.gather_weight_scatter_new_order(w_new, g.rows_in(x))
+    y2 = g.rows_out(g.gather_weight_scatter_new_order(w_new, h_new))
+    want2 = geot.gather_weight_scatter(si, di, w, want)
+    assert float((y2 - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
     # gradients: d/dx and d/dweight through the permutations and geot's own autograd formulas
     xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)

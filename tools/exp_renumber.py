@@ -119,6 +119,23 @@ def main():
         nlab = int(torch.unique(lab).numel())
         print(f"  label propagation, {sweeps} sweeps: {t_lpa:.0f} ms on the device (torch ops), {nlab} labels left")
         res[f"lpa{sweeps}"] = run_renumbered(f"label propagation x{sweeps}", rank, si, di, w, x, y_ref, nodes)
+    # a TRAINING step per layer (forward + d/dsrc + d/dweight through autograd), as shipped vs a model that stays in the new order
+    from geot_amd import reorder
+    rg = reorder.renumber(si, di, nodes)
+    if rg is not None:
+        cot = torch.rand(nodes, F, device=dev, generator=g)
+
+        def step(fn, xx, ww):
+            xx.grad = None
+            ww.grad = None
+            fn(ww, xx).backward(cot)
+        xs, ws = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        t_ship = device_ms(lambda: step(lambda ww, xx: geot.gather_weight_scatter(si, di, ww, xx), xs, ws), 5, warmup=3)
+        xn, wn = rg.rows_in(x).detach().requires_grad_(True), rg.edge_values(w).detach().requires_grad_(True)
+        t_new = device_ms(lambda: step(lambda ww, xx: rg.gather_weight_scatter_new_order(ww, xx), xn, wn), 5, warmup=3)
+        print(f"  training step of one layer (forward + d/dsrc + d/dweight): as shipped {t_ship:.3f} ms, staying in the new order {t_new:.3f} ms "
+              f"({t_ship / t_new:.2f}x)", flush=True)
+        del xs, ws, xn, wn, cot
     for sweeps in (2, 3):
         lab = min_label(si, di, nodes, sweeps, dev)
         rank = torch.empty(nodes, dtype=torch.int64, device=dev)
