@@ -252,3 +252,33 @@ def test_sources_sorted_inside_every_row_do_not_skew_the_hub_pieces(geot):
     finally:
         ops.set_option("slab_mode", old)
         ops.clear_caches()
+
+
+@pytest.mark.parametrize("F", [66, 130, 301, 602])
+def test_rows_that_are_not_whole_vectors_are_padded_where_the_edges_dominate(geot, oracle, F):
+    """F = 602 (Reddit's raw features), 130, odd widths: the gather operators pad the node table to whole 16-byte vectors when
+    nnz >= 16 x nodes, run the full-width kernels and cut the pad columns off - same values, same shape, contiguous, gradients too."""
+    rng = np.random.default_rng(F)
+    nodes, nnz = 3_000, 120_000
+    di = np.sort(rng.integers(0, nodes, nnz)).astype(np.int64)
+    di[-1] = nodes - 1
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    w = rng.random(nnz, dtype=np.float32)
+    x = rng.standard_normal((nodes, F)).astype(np.float32)
+    t_si, t_di, t_w = dev(si), dev(di), dev(w)
+    t_x = dev(x).requires_grad_(True)
+    y = geot.gather_weight_scatter(t_si, t_di, t_w, t_x)
+    assert y.shape == (nodes, F) and y.is_contiguous()
+    hi = oracle.gather_weight_scatter(si, di, w, x, rows=nodes, acc64=True)
+    mag = oracle.gather_weight_scatter(si, di, w, np.abs(x), rows=nodes, acc64=True)
+    assert np.all(np.abs(y.detach().cpu().numpy() - hi) <= 1e-5 * mag + 1e-30)
+    y.sum().backward()
+    want = np.zeros((nodes, F), np.float64)
+    np.add.at(want, si, np.broadcast_to(w[:, None].astype(np.float64), (nnz, F)))
+    assert t_x.grad.shape == (nodes, F) and np.allclose(t_x.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+    for red in ("max", "mean"):
+        got = geot.gather_scatter(t_si, t_di, t_x.detach(), red).cpu().numpy()
+        ref = oracle.index_scatter_3pass(di, x[si], red, rows=nodes)
+        assert got.shape == ref.shape and np.allclose(got, ref, rtol=2e-5, atol=2e-6)
+    half = geot.gather_scatter(t_si, t_di, t_x.detach().to(torch.bfloat16))          # 16-bit rows: whole vectors are 8 elements
+    assert half.shape == (nodes, F) and torch.allclose(half.float(), geot.gather_scatter(t_si, t_di, t_x.detach().to(torch.bfloat16).float()), rtol=2e-2, atol=2e-2)
