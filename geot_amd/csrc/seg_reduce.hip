@@ -236,8 +236,14 @@ __host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec,
 
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // NT   : bit 0 non-temporal row loads, bit 1 non-temporal dst stores
-template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM, int U = kU>
-__global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
+// RAG ("ragged"): rows that are NOT whole vectors (F = 601 / 602 floats; rows and bases then sit on 4- or 8-byte boundaries).  gfx950
+// serves 16-byte global accesses at 4-byte alignment at ~0.9 of the aligned rate, 4-byte accesses at half of it (tools/kexp3.hip,
+// profiles/r04/kexp3_misaligned_vectors.txt), so such rows keep the full-width lanes: the row's LAST lane owns fewer than VEC
+// elements; it works on the columns [F - VEC, F) instead - a whole vector that ends with the row, overlapping its neighbour's
+// columns - and every global store of it skips the first `shift` = VEC - (its own elements) entries.  Nothing is ever read or
+// written outside a row.  Its LDS partials and accumulators simply carry the overlap along.  No in-kernel hand-off for such rows.
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED, int U, bool RAG>
+__device__ __forceinline__ void seg_tile_body(const SegParams &p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using A = typename AccOf<T>::type; // accumulator / LDS / carry type
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   constexpr bool MEAN = RED == RED_MEAN;
   // the instantiations that can finish their straddling runs in-kernel ("hand-off", at the end of the kernel): streamed
   // rows, fp32 accumulators, whole 16-byte pieces per lane, no per-run counts
-  constexpr bool kHandoff = !GATHER && WMODE == 0 && !ATOMIC && std::is_same<A, float>::value && VEC % 4 == 0;
+  constexpr bool kHandoff = !RAG && !GATHER && WMODE == 0 && !ATOMIC && std::is_same<A, float>::value && VEC % 4 == 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -289,7 +295,9 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   const int c = tid & (lpr - 1);   // lane in group
   const int64_t f0 = (int64_t)blockIdx.y * FB + (int64_t)c * VEC;
   const bool active = f0 < F;      // false only in the last feature block of a ragged F
-  const int64_t f0c = active ? f0 : 0; // loads of inactive lanes are clamped, never predicated
+  // (RAG) the row's last lane: `shift` leading entries of its vector belong to its neighbour
+  const int shift = (RAG && active && f0 + VEC > F) ? (int)(f0 + VEC - F) : 0;
+  const int64_t f0c = active ? f0 - shift : 0; // loads of inactive lanes are clamped, never predicated
   const int gs = g * cg;
 
   // streamed operand: tile base is wave-uniform, the lane adds a 32-bit byte offset
@@ -368,6 +376,11 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
   }
 
   T *dstf = dst + f0c;
+  auto put = [&](T *q, const A (&val)[VEC]) { // a dst row's VEC entries of this lane (RAG: the row's last lane stores only its own)
+    if (!RAG || shift == 0) store_vec<T, VEC, NTS>(q, val);
+    else
+      for (int i = shift; i < VEC; ++i) q[i] = (T)val[i];
+  };
   auto gapfill = [&](int64_t lo, int64_t hi) {
     if (hi <= lo || lo < 0 || hi > K) return; // also rejects the padding key and unsorted input
     const int64_t cnt = hi - lo;
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
           asm volatile("" : "+v"(t)); // (made here, on the rare path: a hoisted zero vector would sit in VEC registers across the whole walk)
           z[i] = t;
         }
-        for (int64_t r = lo; r < hi; ++r) store_vec<T, VEC, NTS>(dstf + r * F, z);
+        for (int64_t r = lo; r < hi; ++r) put(dstf + r * F, z);
       }
     } else if (c == 0 && blockIdx.y == 0) {
       const unsigned long long slot = atomicAdd(&p.ctrl[0], 1ull);
@@ -419,7 +432,8 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
           if constexpr (sizeof(T) >= 4) { // float atomics exist for fp32 / fp64 only
             if (active && (uint64_t)cur < (uint64_t)K) {
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+              for (int i = 0; i < VEC; ++i)
+                if (!RAG || i >= shift) atomicAdd(dstf + cur * F + i, acc[i]);
             }
           }
         } else {
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
 #pragma unroll
               for (int i = 0; i < VEC; ++i) acc[i] = acc[i] / A(cnt);
             }
-            store_vec<T, VEC, NTS>(dstf + cur * F, acc);
+            put(dstf + cur * F, acc);
           }
           if (knew > cur + 1) gapfill(cur + 1, knew);
         }
@@ -464,7 +478,8 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     if constexpr (sizeof(T) >= 4) {
       if (active && (uint64_t)cur < (uint64_t)K) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) atomicAdd(dstf + cur * F + i, acc[i]);
+        for (int i = 0; i < VEC; ++i)
+          if (!RAG || i >= shift) atomicAdd(dstf + cur * F + i, acc[i]);
       }
     }
     return;
@@ -574,7 +589,12 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       }
     }
     if (!active) continue;
-    A *cslot = static_cast<A *>(p.carry) + (tile * 2) * F + f0;
+    A *cslot = static_cast<A *>(p.carry) + (tile * 2) * F + f0c;
+    auto put_carry = [&](A *q, const A (&val)[VEC]) {
+      if (!RAG || shift == 0) store_vec<A, VEC>(q, val);
+      else
+        for (int i = shift; i < VEC; ++i) q[i] = val[i];
+    };
     if constexpr (kHandoff) {
       if (p.handoff && cslot_id >= 0) { // write-through: another workgroup reads this row while the kernel runs
         float *cs = reinterpret_cast<float *>(cslot + (cslot_id == 1 ? F : 0));
@@ -585,16 +605,16 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
     }
     if (cslot_id == 0) {
       // continues a run that started in an earlier tile: slot 0, added by seg_fixup_kernel
-      store_vec<A, VEC>(cslot, sum);
+      put_carry(cslot, sum);
     } else if (cslot_id == 1) {
       // starts here and continues into the next tile: slot 1; seg_fixup_kernel writes the row
-      store_vec<A, VEC>(cslot + F, sum);
+      put_carry(cslot + F, sum);
     } else if ((uint64_t)k < (uint64_t)K) {
       if constexpr (MEAN) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) sum[q] = sum[q] / A(csum);
       }
-      store_vec<T, VEC, NTS>(dstf + k * F, sum);
+      put(dstf + k * F, sum);
     }
   }
 
@@ -700,6 +720,16 @@ __global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
       }
     }
   }
+}
+
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM, int U = kU>
+__global__ __launch_bounds__(kThreads) void seg_tile_kernel(SegParams p) {
+  seg_tile_body<T, VEC, GATHER, WMODE, ATOMIC, NT, RED, U, false>(p);
+}
+// rows that are not whole vectors (see seg_tile_body, RAG)
+template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int RED = RED_SUM>
+__global__ __launch_bounds__(kThreads) void seg_tile_rag_kernel(SegParams p) {
+  seg_tile_body<T, VEC, GATHER, WMODE, ATOMIC, NT, RED, kU, true>(p);
 }
 
 // Tile bookkeeping + merge of the 2*NW wave partials of the narrow-row kernels (same rules as seg_tile_kernel:
@@ -1795,6 +1825,7 @@ std::atomic<int> g_handoff_tries{20000};  // "handoff_tries": polls before a til
                                           // poll: ~10 ms - the predecessor is an EARLIER workgroup (dispatched in order: running or done), its whole life is
                                           // microseconds; the 400 000 of round 3 let a stalled workgroup spin for 0.2 s
 std::atomic<int> g_handoff{1}; // in-kernel hand-off of the tile carries ("handoff" option): 1 = where the kernels support it, 0 = classic second pass
+std::atomic<int> g_ragged{1};  // "ragged": 1 = rows that are not whole 16-byte vectors keep full-width lanes (seg_tile_rag_kernel), 0 = the 8- / 4-byte-per-lane kernels
 std::atomic<int> g_narrow{1};  // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
 
 struct Prof {
@@ -1848,6 +1879,7 @@ template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC, int NT, int 
 
 struct Plan {
   int vec, lpr_log2, cg, te, unroll;
+  bool ragged; // rows are not whole vectors (or not on 16-byte boundaries): seg_tile_rag_kernel
   int64_t num_tiles, nfb;
   size_t meta_off, cnt_off, carry_off, list_off, wsum_off, wcnt_off, wflag_off, flag_off, total; // ctrl block sits at offset 0
   int64_t gap_cap;
@@ -1885,7 +1917,7 @@ constexpr int scan_steps(int64_t F) { return F <= 2 ? 8 : 4; }      // S of seg_
 // vec_unit: the feature granule that must stay inside one vector (F, or F per head for mh_spmm)
 // hw: weights staged in LDS per edge (0, 1 or H); gather: src offsets staged in LDS
 Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, bool aligned16,
-               bool gather, int hw, bool atomic_flush = false, int asize = 0) {
+               bool gather, int hw, bool atomic_flush = false, int asize = 0, bool aligned4 = false) {
   if (asize == 0) asize = tsize < 4 ? 4 : tsize; // accumulator size: fp32 for the 16-bit storage types
   Plan P;
   const int maxvec = 16 / tsize; // 16 B per lane
@@ -1893,11 +1925,20 @@ Plan make_plan(int64_t nnz, int64_t F, int64_t vec_unit, int64_t K, int tsize, b
   // atomic flushes want one element per lane: a lane group then adds LPR*4 contiguous bytes per
   // instruction (256 B at F>=64), the only shape that reaches the chip's float-atomic rate
   // (measured 2x over the 16-B-per-lane layout, whose atomics stride by 16 B)
-  if (aligned16 && !atomic_flush) {
-    if (vec_unit % maxvec == 0) vec = maxvec;
-    else if (maxvec >= 4 && vec_unit % 2 == 0) vec = 2;
+  P.ragged = false;
+  if (!atomic_flush) {
+    if (aligned16 && vec_unit % maxvec == 0) vec = maxvec;
+    else if (g_ragged && vec_unit == F && F >= maxvec && (F * tsize) % 4 == 0 && aligned4) {
+      // rows that are not whole 16-byte vectors, or operands off the 16-byte grid: full-width lanes all the same (seg_tile_body, RAG)
+      vec = maxvec;
+      P.ragged = true;
+    }   // (anything else - a head width that is not a whole vector, operands off the 4-byte grid - takes one element per lane; the
+        //  8-byte-per-lane instantiations of rounds 1-3 are gone: the ragged lanes cover their cases at twice the rate)
   }
-  if (g_tune.vec > 0 && g_tune.vec <= vec && vec_unit % g_tune.vec == 0) vec = g_tune.vec;
+  if (g_tune.vec > 0 && g_tune.vec <= vec && vec_unit % g_tune.vec == 0) {
+    if (g_tune.vec != vec) P.ragged = false;
+    vec = g_tune.vec;
+  }
   P.vec = vec;
   const int64_t lanes = (F + vec - 1) / vec;
   int l = ceil_log2(lanes);
@@ -2048,6 +2089,16 @@ void launch_tile(const SegParams &p, const Plan &P, hipStream_t st) {
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : (int)p.H);
   const SmemLayout L = smem_layout(P.lpr_log2, P.cg, VEC, (int)sizeof(typename AccOf<T>::type), GATHER, hw);
   dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
+  if constexpr (VEC == 16 / (int)sizeof(T) && WMODE <= 1) {
+    if (P.ragged) { // rows that are not whole vectors: full-width lanes, the row's last lane overlaps its neighbour (seg_tile_body, RAG)
+      note_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED, kU>();
+      t_last_kernel.replace(0, 15, "seg_tile_rag_kernel");
+      t_last_kernel.erase(t_last_kernel.rfind(','));   // (the ragged kernel has no U parameter)
+      t_last_kernel += ">";
+      hipLaunchKernelGGL((seg_tile_rag_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), GATHER, RED), st, p);
+      return;
+    }
+  }
   note_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED, kU>();
   hipLaunchKernelGGL((seg_tile_kernel<T, VEC, GATHER, WMODE, ATOMIC, NT, RED>), grid, dim3(kThreads), tile_lds(L, p, P.num_tiles, (int)sizeof(T), GATHER, RED), st, p);
 }
@@ -2059,7 +2110,7 @@ int dispatch_reduce_mode(const SegParams &p, const Plan &P, hipStream_t st) {
   constexpr int MAXV = 16 / (int)sizeof(T);
   constexpr int NTP = GATHER ? 0 : 3;
   if constexpr (!GATHER && WMODE == 0 && sizeof(T) == 4 && (RED == RED_MAX || RED == RED_MIN)) {
-    if (P.unroll == 16 && P.vec == MAXV) {   // 16 row loads in flight per lane, as the sum (the tile shape was chosen for it)
+    if (P.unroll == 16 && P.vec == MAXV && !P.ragged) {   // 16 row loads in flight per lane, as the sum (the tile shape was chosen for it)
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
       note_tile_kernel<T, MAXV, false, 0, false, 3, RED, 16>();
@@ -2068,7 +2119,6 @@ int dispatch_reduce_mode(const SegParams &p, const Plan &P, hipStream_t st) {
     }
   }
   if (P.vec == MAXV) launch_tile<T, MAXV, GATHER, WMODE, false, NTP, RED>(p, P, st);
-  else if (MAXV >= 4 && P.vec == 2) launch_tile<T, 2, GATHER, WMODE, false, NTP, RED>(p, P, st);
   else if (P.vec == 1) launch_tile<T, 1, GATHER, WMODE, false, NTP, RED>(p, P, st);
   else return fail(GEOT_EINVAL, "internal: bad vector width");
   return GEOT_OK;
@@ -2118,7 +2168,7 @@ template <typename T, bool GATHER, int WMODE, bool ATOMIC>
 int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
   constexpr int MAXV = 16 / (int)sizeof(T);
   if constexpr (!GATHER && WMODE == 0 && !ATOMIC && sizeof(T) == 4) {
-    if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 3) {   // 16 row loads in flight per lane
+    if (P.unroll == 16 && P.vec == MAXV && !P.ragged && (nt & 3) == 3) {   // 16 row loads in flight per lane
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), false, 0);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
       note_tile_kernel<T, MAXV, false, 0, false, 3, RED_SUM, 16>();
@@ -2127,7 +2177,7 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
     }
   }
   if constexpr (GATHER && WMODE <= 1 && !ATOMIC && sizeof(T) == 4) {
-    if (P.unroll == 16 && P.vec == MAXV && (nt & 3) == 0) {   // gather modes, default cache policy
+    if (P.unroll == 16 && P.vec == MAXV && !P.ragged && (nt & 3) == 0) {   // gather modes, default cache policy
       const SmemLayout L = smem_layout(P.lpr_log2, P.cg, MAXV, (int)sizeof(T), true, WMODE);
       dim3 grid((unsigned)P.num_tiles, (unsigned)P.nfb, 1);
       note_tile_kernel<T, MAXV, true, WMODE, false, 0, RED_SUM, 16>();
@@ -2136,7 +2186,6 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
     }
   }
   if (P.vec == MAXV) dispatch_nt<T, MAXV, GATHER, WMODE, ATOMIC>(p, P, st, nt);
-  else if (MAXV >= 4 && P.vec == 2) dispatch_nt<T, 2, GATHER, WMODE, ATOMIC>(p, P, st, nt);
   else if (P.vec == 1) dispatch_nt<T, 1, GATHER, WMODE, ATOMIC>(p, P, st, nt);
   else return fail(GEOT_EINVAL, "internal: bad vector width");
   return GEOT_OK;
@@ -2172,7 +2221,8 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   const bool al = is_aligned16(src) && is_aligned16(dst) && is_aligned16(ws);
   const int hw = mode <= 1 ? 0 : (mode == 2 ? 1 : (int)H);
   if (hw > 64) return fail(GEOT_EUNSUPPORTED, "more than 64 heads");
-  Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted);
+  const bool al4 = mode <= 2 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0; // (multi-head weights: a vector must stay inside one head - no ragged lanes)
+  Plan P = make_plan(nnz, F, mode >= 3 ? Fh : F, K, (int)sizeof(T), al, mode >= 1, hw, !sorted, 0, al4);
   // narrow fp32 rows: lane-sequential kernel (sum / max / min / prod; needs a 16-B aligned src), or the
   // lane-per-edge scan kernel (sum only; option "narrow" = 2, and the fallback for an unaligned src)
   const bool narrow_ok = std::is_same<T, float>::value && mode <= 2 && sorted && F <= kNarrowMaxF && g_narrow &&
@@ -2224,7 +2274,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // -7..-25 %: the walk back over a hub's tiles is not hidden by anything there).
   const bool narrow_long = p.rowbytes <= 128 && nnz > 700000 && nnz >= 128 * (K > 0 ? K : 1);
   const bool ho_pays = p.rowbytes >= 256 || (nnz <= 2000000 && !narrow_long) || g_handoff == 2;
-  p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && acc_f32 && P.vec % 4 == 0 && P.nfb == 1 && nnz > 0) ? 1 : 0;
+  p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && acc_f32 && P.vec % 4 == 0 && !P.ragged && P.nfb == 1 && nnz > 0) ? 1 : 0;
   p.ho_tries = g_handoff_tries;
   p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
   p.epoch = 0x6E07A5C300000000ull + (++epoch_counter & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)
@@ -2513,9 +2563,9 @@ const char *geot_build_info(void) { return "libgeot_hip gfx950 (CDNA4) built " _
 static size_t plan_bytes(int64_t nnz, int64_t feat, int64_t vec_unit, int64_t out_rows, int tsize, bool gather,
                          int hw) {
   size_t best = 0;
-  for (int aligned = 0; aligned < 2; ++aligned)
+  for (int aligned = 0; aligned < 3; ++aligned) // every shape the operands' alignment can lead to: off the grid, 4-byte (ragged lanes), 16-byte
     for (int atomic_flush = 0; atomic_flush < (gather ? 1 : 2); ++atomic_flush) {
-      const Plan P = make_plan(nnz, feat, vec_unit, out_rows, tsize, aligned != 0, gather, hw, atomic_flush != 0);
+      const Plan P = make_plan(nnz, feat, vec_unit, out_rows, tsize, aligned == 2, gather, hw, atomic_flush != 0, 0, aligned >= 1);
       if (P.total > best) best = P.total;
     }
   return best;
@@ -2791,6 +2841,7 @@ void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "lds_floor") g_lds_floor = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "handoff") g_handoff = value;
+  if (name && std::string(name) == "ragged") g_ragged = value != 0;
   if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
   if (name && std::string(name) == "hub") g_hub = value;
   if (name && std::string(name) == "lane_e") g_lane_e = value;

@@ -388,18 +388,14 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
   GEOT_DEVICE_GUARD(src);
   at::Tensor x = src.contiguous();
   Edges e = dst_ordered(si, di, weight, 0);
-  // Rows that are not whole 16-byte vectors (Reddit's raw features: F = 602; Cora 1433; F = 130) run the 8- / 4-byte-per-lane kernels,
-  // and a width just above a power of two wastes a whole second feature block: 20-39 % fewer bytes per second
-  // (profiles/r04/bench_odd_feat.txt: F = 602 5.65 vs 608 7.02 TB/s; 130 4.40 vs 128 7.21).  Where the edges dominate - the node
-  // table is small next to nnz rows gathered - the table is padded to the next multiple of 16 bytes once per call (one streaming
-  // pass over N rows), the full-width kernels run, and the result's pad columns are cut off (one pass over K rows).
-  // Measured, operator against the kernel as is (23 M edges on 233 k nodes): F = 601 11.8 -> 9.7 ms, 602 9.9 -> 8.6 (padded to 608: rows of
-  // >= 1 KiB go to whole 64-byte lines), 130 2.77 -> 2.15; F = 66 would LOSE (1.18 -> 1.27: even widths below 512 bytes keep the
-  // 8-byte-per-lane kernel).
+  // Rows that are not whole 16-byte vectors (Reddit's raw features: F = 602; Cora 1433; F = 130) run the ragged-lane kernels
+  // (seg_tile_rag_kernel: 16-byte accesses off the 16-byte grid, ~0.85-0.9 of the aligned rate).  For WIDE rows (>= 1 KiB) whose edges
+  // dominate the node table, padding the table to whole 64-byte lines once per call (one streaming pass over N rows in, one over K rows
+  // out) is still a little faster: F = 601 9.25 -> 8.65 ms, 602 9.46 -> 8.69 ms at 23 M edges on 233 k nodes (profiles/r04/bench_odd_feat.txt);
+  // narrower rows keep the ragged kernel as it is (F = 130: 2.02 ms against 2.18 padded).
   const int64_t feat_given = x.size(1), esize = (int64_t)x.element_size(), lane_elems = 16 / esize;
-  const int64_t unit = feat_given * esize >= 1024 ? 64 / esize : lane_elems;
-  const bool pad = x.dim() == 2 && feat_given > lane_elems && feat_given % lane_elems != 0 && (feat_given % 2 == 1 || feat_given * esize >= 512) &&
-                   e.di.numel() >= 16 * std::max<int64_t>(x.size(0), 1);
+  const int64_t unit = 64 / esize;
+  const bool pad = x.dim() == 2 && feat_given % lane_elems != 0 && feat_given * esize >= 1024 && e.di.numel() >= 16 * std::max<int64_t>(x.size(0), 1);
   if (pad) x = at::constant_pad_nd(x, {0, (unit - feat_given % unit) % unit}, 0);
   const int64_t nnz = e.di.numel(), feat = x.size(1);
   auto launch = [&](int64_t rows) {

@@ -256,7 +256,7 @@ def test_sources_sorted_inside_every_row_do_not_skew_the_hub_pieces(geot):
 
 @pytest.mark.parametrize("F", [66, 130, 301, 602])
 def test_rows_that_are_not_whole_vectors_are_padded_where_the_edges_dominate(geot, oracle, F):
-    """F = 602 (Reddit's raw features), 130, odd widths: the gather operators pad the node table to whole 16-byte vectors when
+    """F = 602 (Reddit's raw features), 130, odd widths: ragged-lane kernels, and for rows of >= 1 KiB the gather operators pad the node table when
     nnz >= 16 x nodes, run the full-width kernels and cut the pad columns off - same values, same shape, contiguous, gradients too."""
     rng = np.random.default_rng(F)
     nodes, nnz = 3_000, 120_000
