@@ -64,6 +64,7 @@ for s in $steps; do
     soakrag)  for seed in 81 82 83; do
                 timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-160
               done ;;
+    warmstate) timeout 600 python3 tools/bench_warm_state.py > $O/bench_warm_state.txt 2>&1; echo "rc=$?"; cat $O/bench_warm_state.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
