@@ -7,7 +7,8 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC -Iinclude -Wno-unused-value
 
 LIB = geot_amd/libgeot_hip.so
-SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip geot_amd/csrc/seg_plan.hip \
+SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_reduce_f32.hip geot_amd/csrc/seg_reduce_f64.hip geot_amd/csrc/seg_reduce_f16.hip \
+      geot_amd/csrc/seg_reduce_bf16.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip geot_amd/csrc/seg_plan.hip \
       geot_amd/csrc/seg_guard.hip
 
 .PHONY: all lib tools shim oracle ref clean

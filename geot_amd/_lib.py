@@ -14,9 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
-SOURCES = [os.path.join(_HERE, "csrc", "seg_reduce.hip"), os.path.join(_HERE, "csrc", "seg_slab.hip"),
-           os.path.join(_HERE, "csrc", "seg_sort.hip"), os.path.join(_HERE, "csrc", "seg_plan.hip"),
-           os.path.join(_HERE, "csrc", "seg_guard.hip")]
+# (the longest compiles first; seg_reduce_<type>.hip are seg_reduce.hip's kernels of one storage type each - they #include it)
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("seg_reduce_f32.hip", "seg_plan.hip", "seg_reduce_f16.hip", "seg_reduce_bf16.hip",
+                                                     "seg_reduce_f64.hip", "seg_slab.hip", "seg_reduce.hip", "seg_sort.hip",
+                                                     "seg_guard.hip")]
+SEG_REDUCE = os.path.join(_HERE, "csrc", "seg_reduce.hip")
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
 PLUGIN_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("torch_ops.cpp", "host_state.cpp", "host_cache.cpp", "host_plan.cpp")]
@@ -102,16 +104,20 @@ HIPFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-
 
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     """Cross-compile the HIP library for gfx950 in-tree (works without a GPU).  One object per source, the stale ones compiled
-    side by side (seg_reduce.hip alone is ~3 minutes: all the instantiations of the tile kernel), then one link."""
+    side by side (the tile kernel's instantiations are one object per storage type: the longest, fp32, ~1 minute), then one link."""
     if force or needs_build():
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(OBJ_DIR, exist_ok=True)
         shared = LIB_INPUTS[len(SOURCES):]
         todo, objs = [], []
+        def inputs(src):
+            part = os.path.basename(src).startswith("seg_reduce_")
+            return [src] + ([SEG_REDUCE] if part else []) + shared
+
         for src in SOURCES:
             obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
             objs.append(obj)
-            if force or _stale(obj, [src] + shared) or not os.path.exists(obj + ".srchash"):
+            if force or _stale(obj, inputs(src)) or not os.path.exists(obj + ".srchash"):
                 todo.append((src, obj))
 
         def compile_one(job):
@@ -121,9 +127,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             with open(obj + ".srchash", "w") as f:
-                f.write(_digest([src] + shared) + "\n")
+                f.write(_digest(inputs(src)) + "\n")
 
-        with ThreadPoolExecutor(max_workers=jobs or min(4, os.cpu_count() or 1)) as pool:
+        with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as pool:
             list(pool.map(compile_one, todo))
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
         if verbose:

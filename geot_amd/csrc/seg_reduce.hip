@@ -43,6 +43,19 @@
 #include "geot_hip.h"
 #include "internal.h"
 
+// Build: one storage type's instantiations of the tile kernel per object.  seg_reduce_{f32,f64,f16,bf16}.hip include this file
+// with GEOT_SEG_PART = 1..4 and keep run_segment_op<T> of their type (geot_seg::run_part_*); this file by itself (part 0)
+// holds the state, the C ABI and the small kernels.  The objects compile side by side (one of them alone took 1 min 40 s).
+// GEOT_HEADLINE_ONLY (tools/isa.sh: seconds) keeps everything in one object.
+#ifndef GEOT_SEG_PART
+#define GEOT_SEG_PART 0
+#endif
+#if defined(GEOT_HEADLINE_ONLY)
+#define GEOT_SEG_SPLIT 0
+#else
+#define GEOT_SEG_SPLIT 1
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -1673,6 +1686,7 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
   }
 }
 
+#if GEOT_SEG_PART == 0 // (the small kernels: part 0 only)
 // Row rule + precondition probe in one pass over the index: out[0] = index[nnz-1] (the reference's
 // index[-1].item() read, csrc/index_scatter.cpp:30), out[1] += number of descents index[i] > index[i+1]
 // found (0 <=> ascending, the precondition of the atomic-free kernels).  out[1] is zeroed by the launcher.
@@ -1801,11 +1815,21 @@ __global__ void box_clock_kernel(unsigned long long *out, int spins) {
     out[2] = (unsigned long long)x;
   }
 }
+#endif // GEOT_SEG_PART == 0
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-thread_local std::string g_err;
+} // namespace
+
+// State shared by the objects made of this file: defined by part 0, declared by the others.
+namespace geot_seg {
+#if GEOT_SEG_PART
+#define GEOT_SHARED(type, name, ...) extern type name;
+#else
+#define GEOT_SHARED(type, name, ...) type name __VA_ARGS__;
+#endif
+GEOT_SHARED(thread_local std::string, g_err)
 
 // Experiment knobs (geot_tune / geot_set_option): process-wide, relaxed atomics - a call reads each of them once or
 // twice while it plans; flipping one while calls are in flight on other threads changes which (equally correct)
@@ -1813,20 +1837,25 @@ thread_local std::string g_err;
 struct Tune {
   std::atomic<int> cg{0}, vec{0}, nt{-1}, lpr_log2{-1};
 };
-Tune g_tune;
-std::atomic<int> g_unroll{0};  // 0 = rule, 8 / 16 = forced
-std::atomic<int> g_lds_floor{-1};      // tile kernel, 16-bit storage: dynamic LDS asked for per workgroup at least (caps the workgroups per CU); -1 = by the rule
-std::atomic<int> g_sddmm_shift{-1};    // sddmm_coo_kernel: lanes per row = natural >> shift (each lane then walks 2^shift 16-byte pieces); -1 = by the rule
-std::atomic<int> g_gather_grid{4096}; // make_plan: tiles a gathered call is cut into at least, where its size allows (0 = no such bound)
-std::atomic<int> g_xcd{1};     // XCD-aware tile mapping for the gather modes
-std::atomic<int> g_nt_keys{0}; // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
-std::atomic<int> g_hub{-1};    // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
-std::atomic<int> g_handoff_tries{20000};  // "handoff_tries": polls before a tile leaves a run to the second launch (0: tests of that path).  ~0.5 us a
+GEOT_SHARED(Tune, g_tune)
+GEOT_SHARED(std::atomic<int>, g_unroll, {0})       // 0 = rule, 8 / 16 = forced
+GEOT_SHARED(std::atomic<int>, g_lds_floor, {-1})   // tile kernel, 16-bit storage: dynamic LDS asked for per workgroup at least (caps the workgroups per CU); -1 = by the rule
+GEOT_SHARED(std::atomic<int>, g_sddmm_shift, {-1}) // sddmm_coo_kernel: lanes per row = natural >> shift (each lane then walks 2^shift 16-byte pieces); -1 = by the rule
+GEOT_SHARED(std::atomic<int>, g_gather_grid, {4096}) // make_plan: tiles a gathered call is cut into at least, where its size allows (0 = no such bound)
+GEOT_SHARED(std::atomic<int>, g_xcd, {1})          // XCD-aware tile mapping for the gather modes
+GEOT_SHARED(std::atomic<int>, g_nt_keys, {0})      // nt key loads: measured neutral (within the +-4 % process-to-process noise), off
+GEOT_SHARED(std::atomic<int>, g_hub, {-1})         // window sums for hub chains: -1 = by the nnz / K rule, 0 = never, 1 = whenever there are > 64 tiles
+GEOT_SHARED(std::atomic<int>, g_handoff_tries, {20000}) // "handoff_tries": polls before a tile leaves a run to the second launch (0: tests of that path).  ~0.5 us a
                                           // poll: ~10 ms - the predecessor is an EARLIER workgroup (dispatched in order: running or done), its whole life is
                                           // microseconds; the 400 000 of round 3 let a stalled workgroup spin for 0.2 s
-std::atomic<int> g_handoff{1}; // in-kernel hand-off of the tile carries ("handoff" option): 1 = where the kernels support it, 0 = classic second pass
-std::atomic<int> g_ragged{1};  // "ragged": 1 = rows that are not whole 16-byte vectors keep full-width lanes (seg_tile_rag_kernel), 0 = the 8- / 4-byte-per-lane kernels
-std::atomic<int> g_narrow{1};  // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
+GEOT_SHARED(std::atomic<int>, g_handoff, {1})      // in-kernel hand-off of the tile carries ("handoff" option): 1 = where the kernels support it, 0 = classic second pass
+GEOT_SHARED(std::atomic<int>, g_ragged, {1})       // "ragged": 1 = rows that are not whole 16-byte vectors keep full-width lanes (seg_tile_rag_kernel), 0 = the 8- / 4-byte-per-lane kernels
+GEOT_SHARED(std::atomic<int>, g_narrow, {1})       // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
+GEOT_SHARED(std::atomic<int>, g_lane_e, {0})       // experiment: 4 | 8 forces E of seg_lane_kernel where that instantiation exists (F <= 4)
+// Tag of a call's hand-off flags: one counter for every storage type (calls of all types share a stream's workspace).  The second
+// launch lowers the flags after every call (seg_fixup_kernel), so between calls they stand at zero; the tag keeps a call apart from
+// whatever an interrupted call may have left behind
+GEOT_SHARED(std::atomic<unsigned long long>, g_epoch, {0})
 
 struct Prof {
   bool on = false;
@@ -1837,7 +1866,25 @@ struct Prof {
   double main_ms = 0, fix_ms = 0, aux_ms = 0;
   int64_t calls = 0;
 };
-Prof g_prof;
+GEOT_SHARED(Prof, g_prof)
+
+// name of the dominant kernel of the calling thread's last call, as rocprofv3 prints it (geot_last_kernel)
+GEOT_SHARED(thread_local std::string, t_last_kernel)
+
+// one-shot request of the calling thread (geot_publish_word): consumed by the next segment op it launches
+struct PublishRequest {
+  bool armed = false;
+  const int64_t *src = nullptr;
+  int64_t *dst = nullptr;
+  int64_t seq = 0;
+};
+GEOT_SHARED(thread_local PublishRequest, t_pub)
+GEOT_SHARED(thread_local int64_t *, t_alarm, = nullptr) // geot_set_alarm_word: sticky, per calling thread
+#undef GEOT_SHARED
+} // namespace geot_seg
+
+namespace {
+using namespace geot_seg;
 
 hipEvent_t prof_event() {
   if (!g_prof.pool.empty()) {
@@ -1855,8 +1902,6 @@ int fail(int code, const std::string &msg) {
   return code;
 }
 
-// name of the dominant kernel of the calling thread's last call, as rocprofv3 prints it (geot_last_kernel)
-thread_local std::string t_last_kernel;
 template <typename T> constexpr const char *type_name() {
   if constexpr (std::is_same<T, float>::value) return "float";
   else if constexpr (std::is_same<T, double>::value) return "double";
@@ -1910,7 +1955,6 @@ inline void layout_workspace(Plan &P, int64_t F, int asize) {
   P.total = P.flag_off + up256(nt * sizeof(unsigned long long)); // hand-off flags, one per tile
 }
 
-std::atomic<int> g_lane_e{0}; // experiment: 4 | 8 forces E of seg_lane_kernel where that instantiation exists (F <= 4)
 inline int lane_seq_edges(int64_t F) { return F <= 4 ? (g_lane_e == 4 ? 4 : 8) : 4; }  // E of seg_lane_kernel<F, E>
 constexpr int scan_steps(int64_t F) { return F <= 2 ? 8 : 4; }      // S of seg_narrow_kernel<F, S>
 
@@ -2194,16 +2238,6 @@ int dispatch_vec(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
 inline bool is_aligned16(const void *a) { return ((uintptr_t)a & 15) == 0; }
 
 // mode: 0 index_scatter, 1 gather_scatter, 2 gather_weight_scatter, 3 mh edge-major, 4 mh head-major
-// one-shot request of the calling thread (geot_publish_word): consumed by the next segment op it launches
-struct PublishRequest {
-  bool armed = false;
-  const int64_t *src = nullptr;
-  int64_t *dst = nullptr;
-  int64_t seq = 0;
-};
-thread_local PublishRequest t_pub;
-thread_local int64_t *t_alarm = nullptr; // geot_set_alarm_word: sticky, per calling thread
-
 template <typename T>
 int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_t *dst_index,
                    const void *weight, const void *src, void *dst, int64_t nnz, int64_t F,
@@ -2265,7 +2299,6 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // Hand-off mode: the tile kernel finishes the straddling runs itself and the second launch only tidies up (seg_tile_kernel,
   // "hand-off"; -3.5 % per call at the graded configuration).  Streamed rows with fp32 accumulators in whole 16-byte pieces,
   // one feature block, no per-run counts; the few-key regime keeps the window sums and the classic second pass.
-  static std::atomic<unsigned long long> epoch_counter{0};
   const bool acc_f32 = std::is_same<typename AccOf<T>::type, float>::value;
   // Measured (tools/bench_handoff_ab.py: F = 16..256 x 1-10 M edges, fp32 / bf16, alternating modes on one box): rows of >= 256 bytes gain
   // 2.5-8 % at every size; rows of <= 128 bytes gain 2-5 % up to ~1 M edges and LOSE 2-16 % beyond (short tiles: the drain at
@@ -2277,7 +2310,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && acc_f32 && P.vec % 4 == 0 && !P.ragged && P.nfb == 1 && nnz > 0) ? 1 : 0;
   p.ho_tries = g_handoff_tries;
   p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
-  p.epoch = 0x6E07A5C300000000ull + (++epoch_counter & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)
+  p.epoch = 0x6E07A5C300000000ull + (++g_epoch & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)
   // a pending geot_publish_word is consumed by the first kernel of this call if that kernel is one of the three that
   // publish (tile / lane / narrow kernel; not the LDS-bin kernel of the unsorted atomic path)
   const bool lds_bin = !sorted && (size_t)K * (size_t)F * sizeof(T) <= 48 * 1024 && g_tune.lpr_log2 != 7;
@@ -2462,18 +2495,49 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
 #endif
 }
 
+#define GEOT_SEG_ARGS                                                                                                   \
+  int mode, bool sorted, const int64_t *si, const int64_t *di, const void *w, const void *src, void *dst, int64_t nnz,  \
+      int64_t F, int64_t H, int64_t src_rows, int64_t K, void *ws, size_t wsb, hipStream_t st, int red
+#define GEOT_SEG_PASS mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red
+
+#if GEOT_SEG_PART
+} // namespace
+namespace geot_seg {
+#if GEOT_SEG_PART == 1
+int run_part_f32(GEOT_SEG_ARGS) { return run_segment_op<float>(GEOT_SEG_PASS); }
+#elif GEOT_SEG_PART == 2
+int run_part_f64(GEOT_SEG_ARGS) { return run_segment_op<double>(GEOT_SEG_PASS); }
+#elif GEOT_SEG_PART == 3
+int run_part_f16(GEOT_SEG_ARGS) { return run_segment_op<half_t>(GEOT_SEG_PASS); }
+#else
+int run_part_bf16(GEOT_SEG_ARGS) { return run_segment_op<bf16_t>(GEOT_SEG_PASS); }
+#endif
+} // namespace geot_seg
+#else // part 0: the state, the small kernels' launchers, the C ABI
+#if GEOT_SEG_SPLIT
+} // namespace
+namespace geot_seg {
+int run_part_f32(GEOT_SEG_ARGS);
+int run_part_f64(GEOT_SEG_ARGS);
+int run_part_f16(GEOT_SEG_ARGS);
+int run_part_bf16(GEOT_SEG_ARGS);
+} // namespace geot_seg
+namespace {
+#else
+int run_part_f32(GEOT_SEG_ARGS) { return run_segment_op<float>(GEOT_SEG_PASS); }
+int run_part_f64(GEOT_SEG_ARGS) { return run_segment_op<double>(GEOT_SEG_PASS); }
+int run_part_f16(GEOT_SEG_ARGS) { return run_segment_op<half_t>(GEOT_SEG_PASS); }
+int run_part_bf16(GEOT_SEG_ARGS) { return run_segment_op<bf16_t>(GEOT_SEG_PASS); }
+#endif
+
 int run_typed(int dtype, int mode, bool sorted, const int64_t *si, const int64_t *di,
               const void *w, const void *src, void *dst, int64_t nnz, int64_t F, int64_t H,
               int64_t src_rows, int64_t K, void *ws, size_t wsb, void *stream, int red = RED_SUM) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == GEOT_F32)
-    return run_segment_op<float>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
-  if (dtype == GEOT_F64)
-    return run_segment_op<double>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
-  if (dtype == GEOT_F16)
-    return run_segment_op<half_t>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
-  if (dtype == GEOT_BF16)
-    return run_segment_op<bf16_t>(mode, sorted, si, di, w, src, dst, nnz, F, H, src_rows, K, ws, wsb, st, red);
+  if (dtype == GEOT_F32) return run_part_f32(GEOT_SEG_PASS);
+  if (dtype == GEOT_F64) return run_part_f64(GEOT_SEG_PASS);
+  if (dtype == GEOT_F16) return run_part_f16(GEOT_SEG_PASS);
+  if (dtype == GEOT_BF16) return run_part_bf16(GEOT_SEG_PASS);
   return fail(GEOT_EINVAL, "dtype must be GEOT_F32, GEOT_F64, GEOT_F16 or GEOT_BF16");
 }
 
@@ -2858,3 +2922,4 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {
 }
 
 } // extern "C"
+#endif // GEOT_SEG_PART == 0

@@ -282,3 +282,4 @@ def test_rows_that_are_not_whole_vectors_are_padded_where_the_edges_dominate(geo
         assert got.shape == ref.shape and np.allclose(got, ref, rtol=2e-5, atol=2e-6)
     half = geot.gather_scatter(t_si, t_di, t_x.detach().to(torch.bfloat16))          # 16-bit rows: whole vectors are 8 elements
     assert half.shape == (nodes, F) and torch.allclose(half.float(), geot.gather_scatter(t_si, t_di, t_x.detach().to(torch.bfloat16).float()), rtol=2e-2, atol=2e-2)
+

@@ -60,11 +60,13 @@ for s in $steps; do
     soak72)   timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed 72 > $O/soak_seed72b.log 2>&1; echo "rc=$?"; tail -4 $O/soak_seed72b.log | cut -c1-900 ;;
     oddfeat)  timeout 900 python3 tools/bench_odd_feat.py > $O/bench_odd_feat.txt 2>&1; echo "rc=$?"; cat $O/bench_odd_feat.txt ;;
     kexp3)    timeout 600 ./tools/kexp3 > $O/kexp3_misaligned_vectors.txt 2>&1; echo "rc=$?"; cat $O/kexp3_misaligned_vectors.txt ;;
+    absplit)  timeout 600 python3 tools/ab_libs.py geot_amd/libgeot_hip.so tools/_ab/libgeot_before_split.so > $O/ab_libs_split.txt 2>&1; echo "rc=$?"; cat $O/ab_libs_split.txt ;;
     abrag)    timeout 600 python3 tools/ab_libs.py geot_amd/libgeot_hip.so tools/_ab/libgeot_before_rag.so > $O/ab_libs_rag.txt 2>&1; echo "rc=$?"; cat $O/ab_libs_rag.txt ;;
     soakrag)  for seed in 81 82 83; do
                 timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-160
               done ;;
     warmstate) timeout 600 python3 tools/bench_warm_state.py > $O/bench_warm_state.txt 2>&1; echo "rc=$?"; cat $O/bench_warm_state.txt ;;
+    epoch) timeout 600 python3 tools/repro_epoch.py > $O/repro_epoch.txt 2>&1; echo "rc=$?"; tail -8 $O/repro_epoch.txt ;;
     renumber) timeout 1200 python3 tools/exp_renumber.py > $O/exp_renumber.txt 2>&1; echo "rc=$?"; cat $O/exp_renumber.txt ;;
     guardcost) timeout 900 python3 tools/bench_guard.py > $O/bench_content_guard.txt 2>&1; echo "rc=$?"; cat $O/bench_content_guard.txt ;;
     r3)       timeout 1200 python3 -m pytest tests/test_gpu_round3.py tests/test_plugin_registration.py -m gpu -q --durations=12 > $O/pytest_r3.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r3.log ;;
