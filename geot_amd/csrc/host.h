@@ -50,6 +50,7 @@ struct Options {
   int64_t cache_mb = 0;      // GEOT_CACHE_MB: byte budget of all cached artefacts together (0 = 1/8 of the device's memory)
   int slab_builder = 0;      // Phase A: 0 = the device builder (csrc/seg_plan.hip), 1 = the ATen formulation (CPU tensors always; cross-check)
   int content_guard = 1;     // GEOT_CONTENT_GUARD: every use of a remembered product re-reads the tensors it was derived from (fingerprint)
+  int slab_bytes = 0;        // slab size of new plans in bytes (0 = by the rule, host_plan.cpp slab_bytes_rule)
   int slab_min_coverage_pct = 50; // graphs whose groups touch less than this share of the source slabs keep the per-edge kernels (slab_source_coverage; 0: no probe)
   Options() {
     if (const char *e = std::getenv("GEOT_PUBLISH_ROWS")) publish_rows = std::strcmp(e, "0") != 0;

@@ -608,6 +608,7 @@ int64_t host_option_op(c10::string_view name, int64_t value) {
   else if (name == "slab_builder") p = &g_opt.slab_builder;
   else if (name == "content_guard") p = &g_opt.content_guard;
   else if (name == "slab_min_coverage_pct") p = &g_opt.slab_min_coverage_pct;
+  else if (name == "slab_bytes") p = &g_opt.slab_bytes;
   else if (name == "clear_caches") {
     clear_all_caches_locked();
     return 0;

@@ -241,6 +241,11 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
 }
 
 constexpr int64_t kSlabBytes = 2 << 20; // measured (profiles/r02/bench_slab.txt; jointly with window and workgroups per CU: profiles/r04/sweep_slab_*.txt)
+// ... and 1 MiB (with a window of 3 slabs, seg_slab.hip) under multi-head weights, since the row loop got its scalar bases (round 4,
+// profiles/r04/sweep_slab_*_v2.txt: mh fp32 7.21 vs 7.37 ms, mh bf16 5.64 vs 5.81).  Plans of one weight or none stay at 2 MiB: rows
+// of 256 / 512 bytes are within 1.5 % of their best there, and at 1 KiB the forward would gain 2 % (gws F=256 6.63 vs 6.76) where the
+// SDDMM of its backward, which runs over the same plan, loses 4 % (8.21 vs 7.90)
+int64_t slab_bytes_rule(int64_t rowbytes, int wmode) { return g_opt.slab_bytes > 0 ? g_opt.slab_bytes : (wmode >= 2 ? kSlabBytes / 2 : kSlabBytes); }
 
 // Does the graph have LOCALITY?  The source-blocked kernel pays off when the groups in flight sweep the WHOLE source table together;
 // on a graph whose sources sit near their destinations every group lives in its own few slabs, the per-edge kernels serve it out of
@@ -291,7 +296,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   // rows of 256 / 512 / 1024 bytes; 128-byte rows run too but were measured slower than the per-edge kernels (DESIGN.md
   // section 3.1d): only when the path is forced
   if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024 && !(rowbytes == 128 && g_opt.slab_mode == 1)) || nnz == 0 ||
-      nnz >= ((int64_t)1 << 31))
+      nnz >= ((int64_t)1 << 31) || src.size(0) * rowbytes > ((int64_t)1 << 32))   // (32-bit row offsets in the kernel: a table of at most 4 GiB)
     return nullptr;
   if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes, dt)) return nullptr;
   ContentKey k1, k2;
@@ -351,7 +356,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   const auto t0 = std::chrono::steady_clock::now();
   std::shared_ptr<SlabPlanHolder> plan;
   try {
-    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, kSlabBytes, rpg, 0);
+    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, slab_bytes_rule(rowbytes, wmode), rpg, 0);
   } catch (const c10::Error &) {
     // Phase A needs ~80 bytes per edge of transient memory and keeps 9: if that does not fit, the per-edge kernels serve
     // the call (and every later one: the sighting is forgotten, a later call may try again)
@@ -391,7 +396,7 @@ std::vector<at::Tensor> slab_plan_op(const at::Tensor &si, const at::Tensor &di,
                                      int64_t weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group, int64_t units) {
   TORCH_CHECK(si.dim() == 1 && di.dim() == 1 && si.numel() == di.numel(), "slab_plan: 1-D edge lists of equal length");
   auto H = slab_build(si.contiguous(), di.contiguous(), rows, src_rows, rowbytes, (int)weight_mode, heads,
-                      slab_bytes > 0 ? slab_bytes : kSlabBytes, rows_per_group, units);
+                      slab_bytes > 0 ? slab_bytes : slab_bytes_rule(rowbytes, (int)weight_mode), rows_per_group, units);
   std::vector<at::Tensor> out = H->keep;
   at::Tensor sc = at::empty({13}, at::TensorOptions().dtype(at::kLong));
   int64_t *s = sc.data_ptr<int64_t>();

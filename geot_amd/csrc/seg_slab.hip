@@ -35,7 +35,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kU = 8; // row loads in flight per lane
+constexpr int kU = 8; // row loads in flight per lane (16: measured 4-35 % slower, r04)
 
 struct SlabParams {
   geot_slab_plan plan;
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     const t4_t x = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + pe * 4)) : *reinterpret_cast<const t4_t *>(weight + pe * 4);
     return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
   };
-  const uint32_t rb = p.rowbytes;
   const uint32_t src_rows = (uint32_t)p.src_rows;
+  const int rsh = WAVE_ROW ? 10 : 4 + p.lpr_log2;   // log2(row bytes)
+  const uint32_t c16 = (uint32_t)c * 16u;
 
   // ---- loose lockstep inside an XCD -------------------------------------------------------------------------------
   // The natural lockstep (same start, same work) drifts like a random walk: with ~6000 edges per group the waves of an
@@ -230,9 +231,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     // serpentine over the size-sorted groups: no unit is always handed the larger group of its round
     const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
     const bool has = pos < P.n_groups;
-    const int64_t e0 = has ? P.g_begin[pos] : 0;
-    const int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
-    const int nv = has ? P.g_nv[pos] : 0;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    if constexpr (WAVE_ROW) { // one unit per wave: tell the compiler (scalar loop bounds, scalar row bases, scalar row switches)
+      e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+      len = __builtin_amdgcn_readfirstlane(len);
+      nv = __builtin_amdgcn_readfirstlane(nv);
+    }
     for (int l = 0; l < R; ++l)
 #pragma unroll
       for (int q = 0; q < NV; ++q) accV[((size_t)l * lpr + c) * NV + q] = f4_t{kIdent, kIdent, kIdent, kIdent};
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     {
       const bool valid = c < len;
       my_src = valid ? P.e_src[e0 + c] : 0;
+      if ((uint32_t)my_src >= src_rows) my_src = 0;   // (checked once per edge, here, not in the row loop)
       my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
       if constexpr (WMODE != 0) {
         const int64_t pe = valid ? (int64_t)P.e_perm[e0 + c] : 0;
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       // next chunk's fields: in flight underneath this chunk's rows
       const bool nvalid = off + lpr + c < len;
       const int64_t ne = e0 + off + lpr + c;
-      const int n_src = nvalid ? (ntp ? __builtin_nontemporal_load(P.e_src + ne) : P.e_src[ne]) : 0;
+      int n_src = nvalid ? (ntp ? __builtin_nontemporal_load(P.e_src + ne) : P.e_src[ne]) : 0;
+      if ((uint32_t)n_src >= src_rows) n_src = 0;
       const int n_dl = nvalid ? (int)(ntp ? __builtin_nontemporal_load(P.e_dl + ne) : P.e_dl[ne]) : 255;
       int64_t n_pe = 0;
       if constexpr (WMODE != 0) n_pe = nvalid ? (int64_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne]) : 0;
@@ -293,20 +301,22 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         f4_t v[kU];
         int dls[kU];
         float ws[kU];
+        // Slots behind the unit's last edge need no test here: their lane holds row 0 and dl = 255 (set where the fields were
+        // loaded), the weight read stays inside the staging buffer, and what they add goes to the row that is never written
+        // back.  The row's byte offset is a 32-bit shift (rows are 128 B .. 1 KiB, the table is below 4 GiB - geot_slab_spmm
+        // checks): scalar base + 32-bit lane offset, no 64-bit multiply per edge.
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const bool ok = b + u < n_here;
-          int row;
+          uint32_t row;
           if constexpr (WAVE_ROW) {
-            row = __builtin_amdgcn_readlane(my_src, b + u);
-            dls[u] = ok ? __builtin_amdgcn_readlane(my_dl, b + u) : 255;
+            row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
+            dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
           } else {
-            row = __shfl(my_src, b + u, lpr);
-            dls[u] = ok ? __shfl(my_dl, b + u, lpr) : 255;
+            row = (uint32_t)__shfl(my_src, b + u, lpr);
+            dls[u] = __shfl(my_dl, b + u, lpr);
           }
-          if (!ok || (uint32_t)row >= src_rows) row = 0;
-          if constexpr (WMODE != 0) ws[u] = ok ? wcur[(b + u) * hw + h] : 0.f;
-          v[u] = *reinterpret_cast<const f4_t *>(src + (int64_t)row * rb + c * 16);
+          if constexpr (WMODE != 0) ws[u] = wcur[(b + u) * hw + h];
+          v[u] = *reinterpret_cast<const f4_t *>(src + (size_t)((row << rsh) + c16));
         }
         if constexpr (WMODE != 0) {
           if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
@@ -409,8 +419,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   const char *m2 = static_cast<const char *>(p.src);
   const T *m1 = static_cast<const T *>(p.weight);           // (the dst-side matrix travels in the `weight` slot)
   T *out = static_cast<T *>(p.dst);
-  const uint32_t rb = p.rowbytes;
   const uint32_t src_rows = (uint32_t)p.src_rows;
+  const int rsh = WAVE_ROW ? 10 : 4 + p.lpr_log2;   // log2(row bytes)
+  const uint32_t c16 = (uint32_t)c * 16u;
 
   int my_slot = -1;
   int *xprog = nullptr;
@@ -458,9 +469,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   for (int r = 0; r < p.rounds; ++r) {
     const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
     const bool has = pos < P.n_groups;
-    const int64_t e0 = has ? P.g_begin[pos] : 0;
-    const int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
-    const int nv = has ? P.g_nv[pos] : 0;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    if constexpr (WAVE_ROW) { // (as in seg_slab_kernel: one unit per wave - scalar bounds, bases and row switches)
+      e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+      len = __builtin_amdgcn_readfirstlane(len);
+      nv = __builtin_amdgcn_readfirstlane(nv);
+    }
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
     for (int l = 0; l < nv; ++l) {                       // the group's m1 rows (pieces of a split hub share their row)
       const int64_t row = P.v_row[v0 + l];
@@ -484,13 +500,15 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
       my_src = valid ? P.e_src[e0 + c] : 0;
       my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
       my_pe = valid ? P.e_perm[e0 + c] : 0;
+      if ((uint32_t)my_src >= src_rows) { my_src = 0; my_dl = 255; }   // out-of-range source: the dot is 0 (checked once per edge, here)
     }
     for (int off = 0; off < maxlen; off += lpr) {
       const bool nvalid = off + lpr + c < len;
       const int64_t ne = e0 + off + lpr + c;
-      const int n_src = nvalid ? P.e_src[ne] : 0;
-      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      int n_src = nvalid ? P.e_src[ne] : 0;
+      int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
       const int n_pe = nvalid ? P.e_perm[ne] : 0;
+      if ((uint32_t)n_src >= src_rows) { n_src = 0; n_dl = 255; }
       const int n_here = len - off;
       int n_max = maxlen - off;
       n_max = n_max < lpr ? n_max : lpr;
@@ -503,18 +521,16 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
         f4_t v[kU];
         int dls[kU];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          const bool ok = b + u < n_here;
-          int row;
+        for (int u = 0; u < kU; ++u) {           // (slots behind the unit's last edge hold row 0 and dl = 255: the dot is 0; 32-bit row offsets)
+          uint32_t row;
           if constexpr (WAVE_ROW) {
-            row = __builtin_amdgcn_readlane(my_src, b + u);
-            dls[u] = ok ? __builtin_amdgcn_readlane(my_dl, b + u) : 255;
+            row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
+            dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
           } else {
-            row = __shfl(my_src, b + u, lpr);
-            dls[u] = ok ? __shfl(my_dl, b + u, lpr) : 255;
+            row = (uint32_t)__shfl(my_src, b + u, lpr);
+            dls[u] = __shfl(my_dl, b + u, lpr);
           }
-          if (!ok || (uint32_t)row >= src_rows) { row = 0; dls[u] = 255; }   // no edge / out-of-range source: the dot is 0
-          v[u] = *reinterpret_cast<const f4_t *>(m2 + (int64_t)row * rb + c * 16);
+          v[u] = *reinterpret_cast<const f4_t *>(m2 + (size_t)((row << rsh) + c16));
         }
         float pd[kU];
 #pragma unroll
@@ -651,9 +667,9 @@ extern "C" {
 
 constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // progress words + slot counters
 // "slab_window": how many slabs a wave may run ahead of the slowest wave of its XCD; -2 = the rule, -1 = no synchronisation.
-// The rule (round-4 sweeps, profiles/r04/sweep_slab_*.txt, slab_window_*.txt, configs[3]'s graph): 2 everywhere (1-KiB rows 7.46 vs
-// 7.73 ms; 512-B rows without weights 3.52 vs 3.61; multi-head bf16 6.11 vs 6.23) except a per-edge weight on rows below 1 KiB,
-// where 1 is better (fp32 F=128 4.71 vs 4.93 ms, bf16 F=128 3.35 vs 3.49 ms)
+// The rule (round-4 sweeps, profiles/r04/sweep_slab_*.txt, slab_window_*.txt, configs[3]'s graph), for 2-MiB slabs: 2 everywhere
+// (512-B rows without weights 3.14 vs 3.17 ms) except a per-edge weight on rows below 1 KiB, where 1 is better (fp32 F=128 4.50 vs
+// 4.75 ms, bf16 F=128 3.20 vs 3.36 ms); 1-MiB slabs (multi-head weights: the host's slab_bytes_rule): 3
 int g_slab_window = -2;
 
 // "slab_far": the lockstep exists so that the waves of an XCD read the SAME slab at about the same time.  A wave whose slab is far
@@ -736,6 +752,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
   if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: rows of 128, 256, 512 or 1024 bytes only");
   if (feat % vec != 0 && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of 16 bytes");
+  if (src_rows < 0 || (uint64_t)src_rows * (uint64_t)rowbytes > ((uint64_t)1 << 32))
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: source table of at most 4 GiB (32-bit row offsets; the kernel is for tables a slab sweep can cover)");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
   const int64_t waves = plan->units / (64 >> lpr_log2);
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
@@ -758,7 +776,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.carry = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + kSyncBytes);
   p.slab_shift = plan->slab_shift;
   p.n_slabs = plan->n_slabs;
-  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? ((weight_mode == 1 && lpr_log2 < 6) ? 1 : 2) : g_slab_window) : -1;
+  // (slabs of <= 1 MiB - the host's choice under multi-head weights - keep step within 3 slabs)
+  const bool small_slabs = ((int64_t)rowbytes << plan->slab_shift) <= ((int64_t)1 << 20);
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : ((weight_mode == 1 && lpr_log2 < 6) ? 1 : 2)) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
@@ -834,6 +854,8 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
     if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
   if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: rows of 256, 512 or 1024 bytes only");
   if ((((uintptr_t)mat_1) | ((uintptr_t)mat_2) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 16-byte aligned operands");
+  if (rows_2 < 0 || (uint64_t)rows_2 * (uint64_t)rowbytes > ((uint64_t)1 << 32))
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: mat_2 of at most 4 GiB (32-bit row offsets)");
   const int64_t waves = plan->units / (64 >> lpr_log2);
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
   if (plan->units % (64 >> lpr_log2) != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)

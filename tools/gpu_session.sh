@@ -62,6 +62,32 @@ for s in $steps; do
     kexp3)    timeout 600 ./tools/kexp3 > $O/kexp3_misaligned_vectors.txt 2>&1; echo "rc=$?"; cat $O/kexp3_misaligned_vectors.txt ;;
     absplit)  timeout 600 python3 tools/ab_libs.py geot_amd/libgeot_hip.so tools/_ab/libgeot_before_split.so > $O/ab_libs_split.txt 2>&1; echo "rc=$?"; cat $O/ab_libs_split.txt ;;
     abrag)    timeout 600 python3 tools/ab_libs.py geot_amd/libgeot_hip.so tools/_ab/libgeot_before_rag.so > $O/ab_libs_rag.txt 2>&1; echo "rc=$?"; cat $O/ab_libs_rag.txt ;;
+    pmcslab)  bash tools/pmc_slab_grid.sh float32 $O/pmc_slab_float32 2:0,2:1,2:2,2:3,1:1,1:2,1:4,4:0,4:1 2>&1 | tail -14
+              bash tools/pmc_slab_grid.sh bfloat16 $O/pmc_slab_bfloat16 2:1,2:2,2:3,1:2,1:4,4:0,4:1 2>&1 | tail -12
+              bash tools/pmc_slab_grid.sh float32 $O/pmc_slab_float32_coalesced 2:1,2:2 --coalesced 2>&1 | tail -6
+              bash tools/pmc_slab_grid.sh bfloat16 $O/pmc_slab_bfloat16_coalesced 2:1,2:2 --coalesced 2>&1 | tail -6 ;;
+    slabcases) for spec in "mh float32" "mh bfloat16" "gws float32" "gws bfloat16" "gs128 float32" "gs64 float32" "gws256 float32" "mh float16"; do
+                set -- $spec
+                timeout 600 python3 tools/sweep_slab.py --case $1 --dtype $2 --ab slab_window=-2,-2 2>&1 | grep -v amdgpu.ids | tail -4
+              done > $O/slab_cases.txt 2>&1; cat $O/slab_cases.txt ;;
+    slabsweep) timeout 900 python3 tools/sweep_slab.py --case mh 2>&1 | grep -v amdgpu.ids > $O/sweep_slab_mh_f32_v2.txt; cat $O/sweep_slab_mh_f32_v2.txt
+               timeout 900 python3 tools/sweep_slab.py --case mh --dtype bfloat16 2>&1 | grep -v amdgpu.ids > $O/sweep_slab_mh_bf16_v2.txt; cat $O/sweep_slab_mh_bf16_v2.txt ;;
+    slabsweep2) for spec in "gws float32" "gws bfloat16" "gs128 float32" "gs64 float32" "gws256 float32" "gs128 bfloat16"; do
+                 set -- $spec
+                 timeout 900 python3 tools/sweep_slab.py --case $1 --dtype $2 2>&1 | grep -v amdgpu.ids > $O/sweep_slab_$1_$2_v2.txt; cat $O/sweep_slab_$1_$2_v2.txt | head -9
+               done ;;
+    slabsweep3) for spec in "sddmm256 float32" "sddmm128 float32" "sddmm256 bfloat16"; do
+                 set -- $spec
+                 timeout 900 python3 tools/sweep_slab.py --case $1 --dtype $2 2>&1 | grep -v amdgpu.ids > $O/sweep_slab_$1_$2_v2.txt; cat $O/sweep_slab_$1_$2_v2.txt | head -9
+               done ;;
+    benchmh)  timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --only-secondary mh_spmm_cfg4,mh_spmm_cfg4_powerlaw_src,mh_spmm_cfg4_coalesced,mh_spmm_cfg4_bf16 > $O/bench_mh.json 2> $O/bench_mh.err; echo "rc=$?"; python3 -c "
+import json; d=json.load(open('$O/bench_mh.json'))
+for k,v in d['secondary'].items(): print(k, {a:b for a,b in v.items() if a in ('kernel_ms','kernel','error','kernel_ms_without_content_guard')})" ;;
+    slabtests) timeout 1200 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_round4.py tests/test_gpu_guard.py -x -q -m gpu 2>&1 | tail -5 ;;
+    pmcsq)    bash tools/pmc_slab_sq.sh $O/pmc_slab_sq 2>&1 | tail -30 ;;
+    soakfinal) for seed in 101 102 103 104 105 106 107 108; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-160
+              done ;;
     soakrag)  for seed in 81 82 83; do
                 timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-160
               done ;;

@@ -25,12 +25,16 @@ def main():
     ap.add_argument("--case", default="mh")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--coalesced", action="store_true", help="sources sorted inside every dst row (what torch_geometric's coalesce() / a CSR leaves)")
+    ap.add_argument("--seq", default="", help="fixed sequence for a PMC pass: 'MiB:window,MiB:window,...' - two launches of the slab kernel per "
+                    "setting, nothing else of that name launched (tools/pmc_slab_grid.sh maps the dispatches back)")
     ap.add_argument("--ab", default="", help="A/B of one library option at the default plan: NAME=v0,v1 (e.g. slab_nt=0,1 or slab_far=4,12,1000000)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     print(hip.build_info(), flush=True)
     nodes, nnz = 232_965, 114_615_892
-    H, Fh, wmode = {"mh": (4, 64, 2), "gws": (1, 128, 1), "gs64": (1, 64, 0), "gs128": (1, 128, 0), "gws256": (1, 256, 1)}[a.case]
+    sddmm = a.case.startswith("sddmm")                   # d/dweight of gather_weight_scatter over the forward's plan (weight_mode 1)
+    H, Fh, wmode = {"mh": (4, 64, 2), "gws": (1, 128, 1), "gs64": (1, 64, 0), "gs128": (1, 128, 0), "gws256": (1, 256, 1),
+                    "sddmm128": (1, 128, 1), "sddmm256": (1, 256, 1)}[a.case]
     di = powerlaw_index(nnz, nodes, 11, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(12)
@@ -45,12 +49,29 @@ def main():
         w = None
     out = torch.empty(nodes, H, Fh, device=dev, dtype=dt)
     ref = torch.empty(nodes, H, Fh, device=dev, dtype=dt)
-    if wmode == 2:
+    if sddmm:
+        m1 = torch.rand(nodes, Fh, device=dev, generator=g).to(dt)
+        eo, eref = torch.empty(nnz, device=dev, dtype=dt), torch.empty(nnz, device=dev, dtype=dt)
+        base = lambda: hip.sddmm_coo_out(si, di, m1, x.view(nodes, Fh), eref)  # noqa: E731
+    elif wmode == 2:
         base = lambda: hip.mh_spmm_out(si, di, w, x, ref, False)  # noqa: E731
     elif wmode == 1:
         base = lambda: hip.gather_weight_scatter_out(si, di, w, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
     else:
         base = lambda: hip.gather_scatter_out(si, di, x.view(nodes, Fh), ref.view(nodes, Fh))  # noqa: E731
+    if a.seq:
+        last = None
+        for item in a.seq.split(","):
+            mib, k = item.split(":")
+            if mib != last:
+                plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, slab_bytes=int(float(mib) * (1 << 20)), rows_per_group=slab.rows_per_group(wmode, H, dt))
+                last = mib
+            hip.set_option("slab_window", int(k))
+            for _ in range(2):
+                slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh)
+            torch.cuda.synchronize()
+            print(f"setting {item}: R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} slabs={plan.meta['slabs']}", flush=True)
+        return
     print(f"case={a.case} dtype={a.dtype} sources={a.sources} coalesced={a.coalesced} per-edge {device_ms(base, 3, warmup=1):.3f} ms", flush=True)
     if a.ab:
         name, vals = a.ab.split("=")
@@ -74,12 +95,14 @@ def main():
             row = []
             for k in windows:
                 hip.set_option("slab_window", k)
-                ms = device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 4, warmup=1)
+                run = (lambda: slab.slab_sddmm_out(plan, m1, x.view(nodes, Fh), eo)) if sddmm else (lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh))
+                ms = device_ms(run, 4, warmup=1)
                 row.append(ms)
                 if ms < best[0]:
                     best = (ms, (blocks, mib, k))
             base()
-            err = ((out.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+            err = (((eo.float() - eref.float()).abs().max() / eref.float().abs().max()) if sddmm else
+                   ((out.float() - ref.float()).abs().max() / ref.float().abs().max())).item()
             print(f"{blocks:6d} {mib:8.1f} " + " ".join(f"{m:8.3f}" for m in row) + f"   R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} "
                   f"slabs={plan.meta['slabs']} err={err:.1e}", flush=True)
             del plan
