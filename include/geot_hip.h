@@ -262,7 +262,9 @@ size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total)
  * reduce: GEOT_REDUCE_SUM | MEAN | MAX | MIN over the messages of a row (weight modes 0 / 1; the multi-head modes sum) -
  * the aggregations PyG call sites forward (GraphSAGE mean / max on Reddit-like graphs).
  * float32 / float16 / bfloat16 storage (16-bit: fp32 accumulation, one rounding at the end, weights in the storage type),
- * rows (heads * feat * element size) of 128 / 256 / 512 / 1024 bytes.  dst is written in full. */
+ * rows (heads * feat * element size) of 128 / 256 / 512 / 1024 bytes; src_rows * row bytes <= 4 GiB (the kernel addresses a row as a
+ * 32-bit offset from the table's base; GEOT_EUNSUPPORTED beyond - such a table is no candidate for a slab sweep anyway).
+ * dst is written in full. */
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
                    int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce,
                    void *workspace, size_t workspace_bytes, void *stream);
@@ -303,7 +305,7 @@ int geot_slab_plan_edges(const geot_slab_plan_job *job, const void *scratch1, co
 /* out[e] = < mat_1[dst(e), :], mat_2[src(e), :] > in ORIGINAL edge order over the plan's edges - geot_sddmm_coo
  * (sddmm_coo_cuda, csrc/cuda/header_cuda.h:28-30) for a graph that has a plan: the backward (d/dweight) of
  * gather_weight_scatter on a dense graph.  float32 / float16 / bfloat16 (fp32 dot products, out in the storage type), rows
- * of 256 / 512 / 1024 bytes; workspace as geot_slab_spmm. */
+ * of 256 / 512 / 1024 bytes, rows_2 * row bytes <= 4 GiB (as geot_slab_spmm); workspace as geot_slab_spmm. */
 int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, int64_t feat,
                     int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 

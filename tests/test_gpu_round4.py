@@ -283,3 +283,31 @@ def test_rows_that_are_not_whole_vectors_are_padded_where_the_edges_dominate(geo
     half = geot.gather_scatter(t_si, t_di, t_x.detach().to(torch.bfloat16))          # 16-bit rows: whole vectors are 8 elements
     assert half.shape == (nodes, F) and torch.allclose(half.float(), geot.gather_scatter(t_si, t_di, t_x.detach().to(torch.bfloat16).float()), rtol=2e-2, atol=2e-2)
 
+
+
+def test_source_blocked_kernels_refuse_a_table_beyond_32_bit_row_offsets(geot):
+    """seg_slab_kernel addresses a source row as a 32-bit byte offset from the table's base (round 4: scalar base + shifted row number
+    instead of a 64-bit multiply-add per edge).  A table of more than 4 GiB is refused by the launcher - before anything is launched -
+    and never routed there by the host layer."""
+    import ctypes
+    from geot_amd import _lib, hip, slab
+    g = torch.Generator(device="cpu").manual_seed(3)
+    nodes, nnz, F = 2048, 60_000, 256
+    di = torch.sort(torch.randint(0, nodes, (nnz,), generator=g)).values.cuda()
+    si = torch.randint(0, nodes, (nnz,), generator=g).cuda()
+    x = torch.rand(nodes, F, generator=g).cuda()
+    out = torch.empty(nodes, F, device="cuda")
+    plan = slab.build_plan(si, di, nodes, nodes, F * 4, 0, 1)
+    want = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, di, x[si].double())
+    slab.slab_spmm_out(plan, None, 0, x, out, 1, F)
+    assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-5)
+    L = _lib.load()
+    ws = hip.workspace(x.device, int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), F)))
+    too_many_rows = (1 << 32) // (F * 4) + 1
+    rc = L.geot_slab_spmm(ctypes.byref(plan.struct), None, 0, x.data_ptr(), out.data_ptr(), 1, F, too_many_rows, nodes, _lib.GEOT_F32, 0,
+                          ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc != _lib.GEOT_OK and b"4 GiB" in L.geot_last_error()
+    eo = torch.empty(nnz, device="cuda")
+    rc = L.geot_slab_sddmm(ctypes.byref(plan.struct), x.data_ptr(), x.data_ptr(), eo.data_ptr(), F, nodes, too_many_rows, _lib.GEOT_F32,
+                           ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc != _lib.GEOT_OK and b"4 GiB" in L.geot_last_error()
