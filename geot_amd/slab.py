@@ -101,14 +101,23 @@ def rows_per_group(weight_mode: int, heads: int, dtype: torch.dtype) -> int:
     return int(_lib.load().geot_slab_rows_per_group_dtype(weight_mode, heads, code))
 
 
-def slab_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """out[e] = <mat_1[dst(e)], mat_2[src(e)]> in original edge order over the plan's edges (pointer-level doorway)."""
+def slab_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out: torch.Tensor, staged: bool = True) -> torch.Tensor:
+    """out[e] = <mat_1[dst(e)], mat_2[src(e)]> in original edge order over the plan's edges (pointer-level doorway).
+    staged (default): results leave the persistent kernel in plan order and a second kernel reorders them group by group through LDS
+    (geot_slab_sddmm_staged);
+    False: written straight to out[original edge id] (every result a partial write of its own: ~1.5x slower at F=128)."""
     dev = hip._require_gpu(mat_1, mat_2, out)
     L = _lib.load()
     with hip._on_device(dev):
         st = hip._stream_handle(dev)
         ws = hip.workspace(dev, int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), mat_1.shape[1])), st)
-        rc = L.geot_slab_sddmm(ctypes.byref(plan.struct), mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), mat_1.shape[1],
-                               mat_1.shape[0], mat_2.shape[0], hip._dtype_code(mat_1, "slab_sddmm"), ws.data_ptr(), ws.numel(), st)
+        if staged:
+            staging = torch.empty(out.numel(), dtype=out.dtype, device=dev)
+            rc = L.geot_slab_sddmm_staged(ctypes.byref(plan.struct), mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), staging.data_ptr(),
+                                          mat_1.shape[1], mat_1.shape[0], mat_2.shape[0], hip._dtype_code(mat_1, "slab_sddmm"),
+                                          ws.data_ptr(), ws.numel(), st)
+        else:
+            rc = L.geot_slab_sddmm(ctypes.byref(plan.struct), mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), mat_1.shape[1],
+                                   mat_1.shape[0], mat_2.shape[0], hip._dtype_code(mat_1, "slab_sddmm"), ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "geot_slab_sddmm")
     return out

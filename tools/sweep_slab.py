@@ -68,7 +68,10 @@ def main():
                 last = mib
             hip.set_option("slab_window", int(k))
             for _ in range(2):
-                slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh)
+                if sddmm:
+                    slab.slab_sddmm_out(plan, m1, x.view(nodes, Fh), eo)
+                else:
+                    slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh)
             torch.cuda.synchronize()
             print(f"setting {item}: R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} slabs={plan.meta['slabs']}", flush=True)
         return
@@ -80,8 +83,10 @@ def main():
         for rep in range(3):
             row = []
             for v in vals:
-                hip.set_option(name, v)
-                row.append(device_ms(lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh), 5, warmup=1))
+                if name != "staged":                      # ("staged=0,1": the two forms of the SDDMM's output, not a library option)
+                    hip.set_option(name, v)
+                run = (lambda: slab.slab_sddmm_out(plan, m1, x.view(nodes, Fh), eo, staged=bool(v) if name == "staged" else True)) if sddmm else (lambda: slab.slab_spmm_out(plan, w, wmode, x, out, H, Fh))
+                row.append(device_ms(run, 5, warmup=1))
             print(f"{name}: " + "  ".join(f"{v}: {m:.3f} ms" for v, m in zip(vals, row)), flush=True)
         return
     slabs = (1.0, 2.0) if a.quick else (0.5, 1.0, 1.5, 2.0, 3.0, 4.0)
