@@ -85,6 +85,7 @@ import json; d=json.load(open('$O/bench_mh.json'))
 for k,v in d['secondary'].items(): print(k, {a:b for a,b in v.items() if a in ('kernel_ms','kernel','error','kernel_ms_without_content_guard')})" ;;
     slabtests) timeout 1200 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_round4.py tests/test_gpu_guard.py -x -q -m gpu 2>&1 | tail -5 ;;
     sddmmorder) for c in sddmm128 sddmm256; do timeout 600 python3 tools/sweep_slab.py --case $c --ab staged=0,1 2>&1 | grep -v amdgpu.ids | tail -4; done ;;
+    pmcsqbench) bash tools/pmc_sq_bench.sh $O/pmc_sq_bench 2>&1 | tail -12 ;;
     pmcsddmm) bash tools/pmc_sddmm.sh $O/pmc_sddmm 2>&1 | tail -4 ;;
     pmcsq)    bash tools/pmc_slab_sq.sh $O/pmc_slab_sq 2>&1 | tail -30 ;;
     soakfinal) for seed in 101 102 103 104 105 106 107 108; do
