@@ -720,7 +720,7 @@ constexpr size_t kSyncBytes = (size_t)(8 * kProgSlots + 64) * sizeof(int); // pr
 // "slab_window": how many slabs a wave may run ahead of the slowest wave of its XCD; -2 = the rule, -1 = no synchronisation.
 // The rule (round-4 sweeps, profiles/r04/sweep_slab_*.txt, slab_window_*.txt, configs[3]'s graph), for 2-MiB slabs: 2 everywhere
 // (512-B rows without weights 3.14 vs 3.17 ms) except a per-edge weight on rows below 1 KiB, where 1 is better (fp32 F=128 4.50 vs
-// 4.75 ms, bf16 F=128 3.20 vs 3.36 ms); 1-MiB slabs (multi-head weights: the host's slab_bytes_rule): 3
+// 4.75 ms, bf16 F=128 3.20 vs 3.36 ms) - on dense graphs: from 4 uses of a source row per XCD and round; 1-MiB slabs (multi-head weights: the host's slab_bytes_rule): 3
 int g_slab_window = -2;
 
 // "slab_far": the lockstep exists so that the waves of an XCD read the SAME slab at about the same time.  A wave whose slab is far
@@ -829,7 +829,12 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.n_slabs = plan->n_slabs;
   // (slabs of <= 1 MiB - the host's choice under multi-head weights - keep step within 3 slabs)
   const bool small_slabs = ((int64_t)rowbytes << plan->slab_shift) <= ((int64_t)1 << 20);
-  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : ((weight_mode == 1 && lpr_log2 < 6) ? 1 : 2)) : g_slab_window) : -1;
+  // (uses of a source row per XCD and round: the window of 1 pays on dense graphs - Reddit scale, 12 uses: 4.50 vs 4.75 ms - and
+  // costs 3 % at 2.3 uses, profiles/r04/bench_slab_density_rule.txt: 7.60 vs 7.36 ms)
+  const int64_t rounds_ = (plan->n_groups + plan->units - 1) / (plan->units > 0 ? plan->units : 1);
+  const double uses = (double)plan->nnz / (double)(rounds_ > 0 ? rounds_ : 1) / 8.0 / (double)(src_rows > 0 ? src_rows : 1);
+  const int tight = (weight_mode == 1 && lpr_log2 < 6 && uses >= 4.0) ? 1 : 2;
+  p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : tight) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
