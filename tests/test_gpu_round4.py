@@ -311,3 +311,36 @@ def test_source_blocked_kernels_refuse_a_table_beyond_32_bit_row_offsets(geot):
     rc = L.geot_slab_sddmm(ctypes.byref(plan.struct), x.data_ptr(), x.data_ptr(), eo.data_ptr(), F, nodes, too_many_rows, _lib.GEOT_F32,
                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc != _lib.GEOT_OK and b"4 GiB" in L.geot_last_error()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_staged_sddmm_is_the_direct_sddmm_bit_for_bit_with_split_hubs(geot, dtype):
+    """geot_slab_sddmm_staged: results leave the persistent kernel in the plan's order and slab_unstage_kernel brings them into edge
+    order - through LDS where a group's edges are a contiguous range of the list, one by one where the group holds pieces of a split
+    hub.  Same dot products, only another way to their place: bit-identical to the direct form, and both equal to the per-edge kernel
+    within rounding.  The graph has split hubs (two rows with thousands of edges), ordinary rows and rows without edges."""
+    from geot_amd import hip, slab
+    g = torch.Generator(device="cpu").manual_seed(11)
+    nodes, F = 3000, 128
+    deg = torch.randint(0, 40, (nodes,), generator=g)
+    deg[7], deg[1500] = 30_000, 9_000
+    deg[100:140] = 0
+    di = torch.repeat_interleave(torch.arange(nodes), deg)
+    nnz = di.numel()
+    si = torch.randint(0, nodes, (nnz,), generator=g)
+    m1 = torch.randn(nodes, F, generator=g).to(dtype).cuda()
+    m2 = torch.randn(nodes, F, generator=g).to(dtype).cuda()
+    di, si = di.cuda(), si.cuda()
+    plan = slab.build_plan(si, di, nodes, nodes, F * m1.element_size(), 1, 1, units=64)
+    assert plan.meta["split_rows"] >= 2, plan.meta
+    direct = torch.empty(nnz, dtype=dtype, device="cuda")
+    staged = torch.full((nnz,), float("nan"), dtype=dtype, device="cuda")
+    slab.slab_sddmm_out(plan, m1, m2, direct, staged=False)
+    slab.slab_sddmm_out(plan, m1, m2, staged, staged=True)
+    assert torch.equal(direct.view(torch.int16 if dtype != torch.float32 else torch.int32), staged.view(torch.int16 if dtype != torch.float32 else torch.int32))
+    per_edge = torch.empty(nnz, dtype=dtype, device="cuda")
+    hip.sddmm_coo_out(si, di, m1, m2, per_edge)
+    want = (m1.double()[di] * m2.double()[si]).sum(1)
+    tol = 1e-4 if dtype == torch.float32 else 0.15
+    assert (staged.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    assert (per_edge.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
