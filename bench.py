@@ -262,7 +262,7 @@ def device_ms(fn, iters, warmup=2):
 
 
 SECONDARY = ("cfg1", "gws_cfg3", "gws_cfg3_local", "gws_cfg3_powerlaw_src", "gws_cfg3_blockmodel", "mh_spmm_cfg4",
-             "mh_spmm_cfg4_powerlaw_src", "mh_spmm_cfg4_coalesced", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16")
+             "mh_spmm_cfg4_powerlaw_src", "mh_spmm_cfg4_coalesced", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16", "gws_train_step_cfg4_graph")
 
 
 def profiled(entry):
@@ -567,6 +567,48 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         del si, di, truth, w, x, out, rg
         torch.cuda.empty_cache()
 
+    def train_step(name):
+        """SURVEY 8(f1), the backward path: a gather_weight_scatter TRAINING STEP through autograd on configs[3]'s graph (Reddit scale,
+        F=128, sources ascending inside every row as in a coalesced COO): forward over the source-blocked plan, d/dsrc over the plan
+        of the transposed list, d/dweight by the SDDMM over the forward's plan (results staged, then brought into edge order) - as
+        dispatched, and on the per-edge kernels (slab_mode never)."""
+        import geot_amd as geot
+        nodes, nnz, F = int(232_965 * scale), int(114_615_892 * scale), 128
+        di = powerlaw_index(nnz, nodes, 11, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(12)
+        si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+        si = (torch.sort(di * nodes + si).values % nodes).contiguous()
+        x = torch.rand(nodes, F, device=dev, generator=g, requires_grad=True)
+        w = torch.rand(nnz, device=dev, generator=g, requires_grad=True)
+        cot = torch.rand(nodes, F, device=dev, generator=g)
+
+        def step():
+            x.grad = None
+            w.grad = None
+            geot.gather_weight_scatter(si, di, w, x).backward(cot)
+        out = {"workload": f"gather_weight_scatter forward + backward (d/dsrc, d/dweight) through autograd, {nodes} nodes, {nnz} edges "
+                           f"(configs[3]'s graph, sources ascending inside every row), feat={F}, float32"}
+        old = ops.set_option("slab_mode", "auto")
+        try:
+            for mode, key in (("auto", "as_dispatched"), ("never", "per_edge_kernels")):
+                ops.set_option("slab_mode", mode)
+                ops.clear_caches()
+                for _ in range(3):           # (plans are built on the second sighting of an edge list and tried on first use)
+                    step()
+                out[key] = {"forward_ms": device_ms(lambda: geot.gather_weight_scatter(si, di, w.detach(), x.detach()), max(2, iters // 2)),
+                            "forward_backward_ms": device_ms(step, max(2, iters // 2))}
+                if mode == "auto":
+                    st = ops.stats()
+                    out["plans"] = {k: st[k] for k in ("plans", "plan_trials", "plans_rejected", "plans_declined") if k in st}
+            out["speedup_forward_backward"] = out["per_edge_kernels"]["forward_backward_ms"] / out["as_dispatched"]["forward_backward_ms"]
+        finally:
+            ops.set_option("slab_mode", old)
+            ops.clear_caches()
+        res[name] = out
+        del di, si, x, w, cot
+        torch.cuda.empty_cache()
+
     # one entry failing (out of memory on a smaller device, a comparator that does not load) must not take the others with it
     plan = [("cfg1", lambda n: cfg1(n)),
             ("gws_cfg3", lambda n: gws(n, "uniform", torch.float32)),
@@ -579,7 +621,8 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             ("mh_spmm_cfg4_powerlaw_src", lambda n: mh(n, torch.float32, "powerlaw")),
             ("mh_spmm_cfg4_coalesced", lambda n: mh(n, torch.float32, "uniform", coalesced=True)),
             ("gws_cfg3_bf16", lambda n: gws(n, "uniform", torch.bfloat16)),
-            ("mh_spmm_cfg4_bf16", lambda n: mh(n, torch.bfloat16))]
+            ("mh_spmm_cfg4_bf16", lambda n: mh(n, torch.bfloat16)),
+            ("gws_train_step_cfg4_graph", lambda n: train_step(n))]
     for name, run in plan:
         if name not in want:
             continue

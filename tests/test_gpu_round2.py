@@ -480,4 +480,6 @@ def test_bench_secondary_object_small_scale():
     assert loc["kernel_ms"] > 0 and loc["rocsparse_best_ms"] > 0 and loc["max_rel_diff_vs_rocsparse"] < 2e-5 and "+-2000" in loc["workload"]
     for name in ("gws_cfg3_bf16", "mh_spmm_cfg4_bf16"):               # additional lines: 16-bit storage, never the headline
         assert sec[name]["kernel_ms"] > 0 and "bfloat16" in sec[name]["workload"], name
+    t = sec["gws_train_step_cfg4_graph"]                              # forward + backward through autograd, both ways
+    assert "error" not in t and t["as_dispatched"]["forward_backward_ms"] > t["as_dispatched"]["forward_ms"] > 0 and t["per_edge_kernels"]["forward_backward_ms"] > 0, t
     assert r["dtype"] == "f32" and "traffic_source" in r["roofline"]
