@@ -28,7 +28,7 @@ std::shared_ptr<SlabPlanHolder> slab_build_aten(const at::Tensor &src_index, con
   auto H = std::make_shared<SlabPlanHolder>();
   const int64_t nnz = dst_index.numel();
   const int64_t lanes = rowbytes / 16;
-  const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units() * (64 / lanes);
+  const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units_for(weight_mode, rowbytes);
   const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group(weight_mode, heads);
   const auto lopt = dst_index.options();
   // row pointers of the ASCENDING dst_index by binary search (rows + 1 searches; a histogram would spend 23 ms of global
@@ -158,7 +158,7 @@ std::shared_ptr<SlabPlanHolder> slab_build_device(const at::Tensor &src_index, c
   auto H = std::make_shared<SlabPlanHolder>();
   const int64_t nnz = dst_index.numel();
   const int64_t lanes = rowbytes / 16;
-  const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units() * (64 / lanes);
+  const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units_for(weight_mode, rowbytes);
   const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group(weight_mode, heads);
   void *st = stream_of(dst_index);
   geot_slab_plan_job job;
@@ -241,11 +241,12 @@ std::shared_ptr<SlabPlanHolder> slab_build(const at::Tensor &src_index, const at
 }
 
 constexpr int64_t kSlabBytes = 2 << 20; // measured (profiles/r02/bench_slab.txt; jointly with window and workgroups per CU: profiles/r04/sweep_slab_*.txt)
-// ... and 1 MiB (with a window of 3 slabs, seg_slab.hip) under multi-head weights, since the row loop got its scalar bases (round 4,
-// profiles/r04/sweep_slab_*_v2.txt: mh fp32 7.21 vs 7.37 ms, mh bf16 5.64 vs 5.81).  Plans of one weight or none stay at 2 MiB: rows
-// of 256 / 512 bytes are within 1.5 % of their best there, and at 1 KiB the forward would gain 2 % (gws F=256 6.63 vs 6.76) where the
-// SDDMM of its backward, which runs over the same plan, loses 4 % (8.21 vs 7.90)
-int64_t slab_bytes_rule(int64_t rowbytes, int wmode) { return g_opt.slab_bytes > 0 ? g_opt.slab_bytes : (wmode >= 2 ? kSlabBytes / 2 : kSlabBytes); }
+// ... and 1 MiB (with a window of 3 slabs, seg_slab.hip) under multi-head weights on 1-KiB rows, since the row loop got its scalar
+// bases (round 4, profiles/r04/sweep_slab_*_v2.txt: mh fp32 7.21 vs 7.37 ms).  Everything else stays at 2 MiB: plans of one weight or
+// none are within 1.5 % of their best there on rows of 256 / 512 bytes, and at 1 KiB the forward would gain 2 % (gws F=256 6.63 vs
+// 6.76) where the SDDMM of its backward, which runs over the same plan, loses 4 % (8.21 vs 7.90); multi-head plans on rows of 512 / 256
+// bytes (seg_slab_mhrow_kernel): bf16 H=4 x F=64 5.24 ms at 2 MiB / window 2 against 5.41 at 1 MiB / window 3
+int64_t slab_bytes_rule(int64_t rowbytes, int wmode) { return g_opt.slab_bytes > 0 ? g_opt.slab_bytes : ((wmode >= 2 && rowbytes >= 1024) ? kSlabBytes / 2 : kSlabBytes); }
 
 // Does the graph have LOCALITY?  The source-blocked kernel pays off when the groups in flight sweep the WHOLE source table together;
 // on a graph whose sources sit near their destinations every group lives in its own few slabs, the per-edge kernels serve it out of
@@ -301,7 +302,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes, dt)) return nullptr;
   ContentKey k1, k2;
   if (!may_remember({&si, &di}) || !content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
-  const int rpg = geot_slab_rows_per_group_dtype(wmode, heads, dt);
+  const int rpg = geot_slab_rows_per_group_shape(wmode, heads, dt, rowbytes);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     sweep_expired_locked();

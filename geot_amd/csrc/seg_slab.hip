@@ -398,6 +398,240 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
+// Multi-head weights on rows of 512 / 256 bytes: ONE ROW PER WAVE-INSTRUCTION, E = row elements / 64 per lane (8 or 4 bytes a lane) -
+// the scalar path of seg_slab_kernel's 1-KiB form (group bounds, row numbers and row switches in SGPRs, 32-bit row offsets on a
+// scalar base) for the narrower rows, which the lane-group form serves with a ds_bpermute per field and per-lane row switches
+// (bf16 H=4 x F=64 at Reddit scale: 5.66 ms there).  A unit is a wave whatever the row width: the plan is built with
+// units = waves (geot_slab_units_for) and R rows of 64 x E fp32 accumulators per group.  Sum only (the multi-head modes).
+template <typename T, int E> struct SlabRaw;                       // the lane's E elements as one load
+template <> struct SlabRaw<float, 1> { typedef float type; };
+template <> struct SlabRaw<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct SlabRaw<half_t, 2> { typedef uint32_t type; };
+template <> struct SlabRaw<half_t, 4> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct SlabRaw<bf16_t, 2> { typedef uint32_t type; };
+template <> struct SlabRaw<bf16_t, 4> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <int E> struct SlabAcc { typedef float type __attribute__((ext_vector_type(E))); };
+template <> struct SlabAcc<1> { typedef float type; };
+
+template <typename T, int E> __device__ __forceinline__ void mhrow_unpack(const typename SlabRaw<T, E>::type &raw, float (&m)[E]) {
+  if constexpr (sizeof(T) == 4) {
+    if constexpr (E == 1) m[0] = raw;
+    else {
+      m[0] = raw[0];
+      m[1] = raw[1];
+    }
+  } else {
+    typedef T tE __attribute__((ext_vector_type(E)));
+    const tE x = __builtin_bit_cast(tE, raw);
+#pragma unroll
+    for (int i = 0; i < E; ++i) m[i] = (float)x[i];
+  }
+}
+template <typename T, int E> __device__ __forceinline__ typename SlabRaw<T, E>::type mhrow_pack(const float (&m)[E]) {
+  if constexpr (sizeof(T) == 4) {
+    if constexpr (E == 1) return m[0];
+    else return typename SlabRaw<T, E>::type{m[0], m[1]};
+  } else {
+    typedef T tE __attribute__((ext_vector_type(E)));
+    tE x;
+#pragma unroll
+    for (int i = 0; i < E; ++i) x[i] = (T)m[i];
+    return __builtin_bit_cast(typename SlabRaw<T, E>::type, x);
+  }
+}
+
+template <typename T, int WMODE, int E>
+__global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) {
+  static_assert(WMODE == 2 || WMODE == 3, "multi-head weights");
+  typedef typename SlabRaw<T, E>::type raw_t;
+  typedef typename SlabAcc<E>::type accv_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int R = P.rows_per_group;
+  const int hw = p.H;
+  // LDS: fp32 accumulators [4 waves][R rows][64 lanes][E], then the staged weights [4 waves][2 buffers][64 edge slots][H]
+  accv_t *accV = reinterpret_cast<accv_t *>(smem) + (size_t)wave * R * 64;
+  float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 64 * E * sizeof(float)) + (size_t)wave * 2 * 64 * hw;
+  const int wbuf_stride = 64 * hw;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t units = P.units;
+  const char *src = static_cast<const char *>(p.src);
+  const T *weight = static_cast<const T *>(p.weight);
+  T *dst = static_cast<T *>(p.dst);
+  const int h = (lane * E) / p.Fh;
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+  const int rsh = 4 + p.lpr_log2;                       // log2(row bytes)
+  const uint32_t cB = (uint32_t)lane * (uint32_t)(E * sizeof(T));
+  typedef T t4_t __attribute__((ext_vector_type(4)));
+  auto load_w4 = [&](int64_t pe) {
+    const t4_t x = *reinterpret_cast<const t4_t *>(weight + pe * 4);
+    return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+  };
+
+  // ---- loose lockstep inside an XCD (as in seg_slab_kernel) ---------------------------------------------------------
+  int my_slot = -1;
+  int *xprog = nullptr;
+  if (p.window >= 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  int published = -1, known_min = -1, timeouts = 0;
+  auto slab_sync = [&](int step) {
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return;
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      known_min = m;
+      if (m + p.window >= step || step - m > p.far) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
+    }
+  };
+  auto zero = [] {
+    accv_t z;
+    if constexpr (E == 1) z = 0.f;
+    else {
+#pragma unroll
+      for (int i = 0; i < E; ++i) z[i] = 0.f;
+    }
+    return z;
+  };
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    const bool has = pos < P.n_groups;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+    len = __builtin_amdgcn_readfirstlane(len);
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    for (int l = 0; l < R; ++l) accV[(size_t)l * 64 + lane] = zero();
+    accv_t acc = zero();
+    int cur = 255;
+
+    int my_src = 0, my_dl = 255;
+    {
+      const bool valid = lane < len;
+      my_src = valid ? P.e_src[e0 + lane] : 0;
+      if ((uint32_t)my_src >= src_rows) my_src = 0;
+      my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
+      const int64_t pe = valid ? (int64_t)P.e_perm[e0 + lane] : 0;
+      if constexpr (WMODE == 2) {
+        if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + lane * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
+        else for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
+      } else {
+        for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    int k = 0;
+    for (int off = 0; off < len; off += 64, ++k) {
+      const float *wcur = wbase + (k & 1) * wbuf_stride;
+      float *wnext = wbase + ((k + 1) & 1) * wbuf_stride;
+      const bool nvalid = off + 64 + lane < len;
+      const int64_t ne = e0 + off + 64 + lane;
+      int n_src = nvalid ? P.e_src[ne] : 0;
+      if ((uint32_t)n_src >= src_rows) n_src = 0;
+      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      const int64_t n_pe = nvalid ? (int64_t)P.e_perm[ne] : 0;
+      f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
+      int n_max = len - off;
+      n_max = n_max < 64 ? n_max : 64;
+      for (int b = 0; b < n_max; b += kU) {
+        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
+        raw_t v[kU];
+        int dls[kU];
+        float ws[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {       // (slots behind the last edge: row 0, dl = 255, weight 0 - see seg_slab_kernel)
+          const uint32_t row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
+          dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
+          ws[u] = wcur[(b + u) * hw + h];
+          v[u] = *reinterpret_cast<const raw_t *>(src + (size_t)((row << rsh) + cB));
+        }
+        if constexpr (WMODE == 2) {
+          if (b == 0 && p.H == 4 && nvalid) wn4 = load_w4(n_pe);
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (dls[u] != cur) {
+            if (cur != 255) accV[(size_t)cur * 64 + lane] = acc;
+            cur = dls[u];
+            acc = cur != 255 ? accV[(size_t)cur * 64 + lane] : zero();
+          }
+          float m[E];
+          mhrow_unpack<T, E>(v[u], m);
+          if constexpr (E == 1) acc += m[0] * ws[u];
+          else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) acc[i] += m[i] * ws[u];
+          }
+        }
+      }
+      if constexpr (WMODE == 2) {
+        if (p.H == 4) *reinterpret_cast<f4_t *>(wnext + lane * 4) = wn4;
+        else for (int q = 0; q < p.H; ++q) wnext[lane * hw + q] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+      } else {
+        for (int q = 0; q < p.H; ++q) wnext[lane * hw + q] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      my_src = n_src;
+      my_dl = n_dl;
+    }
+    if (cur != 255) accV[(size_t)cur * 64 + lane] = acc;
+    if (p.window >= 0 && my_slot >= 0) {
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
+    }
+    if (has) {
+      const int64_t v0 = P.g_vrow0[pos];
+      for (int l = 0; l < nv; ++l) {
+        const int64_t t = P.v_out[v0 + l];
+        const accv_t row = accV[(size_t)l * 64 + lane];
+        float m[E];
+        if constexpr (E == 1) m[0] = row;
+        else {
+#pragma unroll
+          for (int i = 0; i < E; ++i) m[i] = row[i];
+        }
+        if (t >= 0) {
+          if (t < p.K) *reinterpret_cast<raw_t *>(dst + t * p.F + lane * E) = mhrow_pack<T, E>(m);   // one rounding, here
+        } else {
+          *reinterpret_cast<accv_t *>(p.carry + (-t - 1) * p.F + lane * E) = row;                     // fp32
+        }
+      }
+    }
+  }
+  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+}
+
 // SDDMM over the same plan (d/dweight of gather_weight_scatter on a dense graph): out[e] = <m1[dst(e)], m2[src(e)]>.
 // The unit's <= R rows of m1 (the dst side: shared by all edges of a row) sit in LDS where the forward kernel keeps its
 // accumulators; the m2 rows are gathered slab by slab in the same loose lockstep.  The 8 dot products of a batch are
@@ -774,6 +1008,23 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype) {
 }
 int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_rows_per_group_dtype(weight_mode, heads, GEOT_F32); }
 
+// Multi-head plans over rows of 512 / 256 bytes run one row per wave-instruction (seg_slab_mhrow_kernel): a unit is a WAVE whatever
+// the row width, and a group's rows are 64 x E fp32 accumulators (E = row elements / 64).  Everything else: a unit is the
+// rowbytes / 16 lanes of a row (seg_slab_kernel).
+static bool slab_mhrow(int weight_mode, int64_t rowbytes) { return weight_mode >= 2 && weight_mode <= 3 && (rowbytes == 512 || rowbytes == 256); }
+int geot_slab_units_for(int weight_mode, int64_t rowbytes) {
+  if (slab_mhrow(weight_mode, rowbytes) || rowbytes >= 1024 || rowbytes < 16) return geot_slab_units();
+  return geot_slab_units() * (int)(1024 / rowbytes);
+}
+int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes) {
+  if (!slab_mhrow(weight_mode, rowbytes)) return geot_slab_rows_per_group_dtype(weight_mode, heads, dtype);
+  const size_t row = (size_t)(rowbytes / (dtype == GEOT_F32 ? 4 : 2)) * sizeof(float);   // a group row's accumulators
+  const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (slab_device().lds - 4 * 1024) / g_slab_blocks / 1024 * 1024;
+  int r = 32;
+  while (r > 1 && (size_t)4 * r * row + (size_t)4 * 2 * 64 * (size_t)heads * sizeof(float) > budget) --r;
+  return r;
+}
+
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total) {
   if (!plan) return 0;
   return (size_t)(plan->n_carry > 0 ? plan->n_carry : 1) * (size_t)feat_total * sizeof(float) + 256 + kSyncBytes;
@@ -806,11 +1057,16 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (src_rows < 0 || (uint64_t)src_rows * (uint64_t)rowbytes > ((uint64_t)1 << 32))
     return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: source table of at most 4 GiB (32-bit row offsets; the kernel is for tables a slab sweep can cover)");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
-  const int64_t waves = plan->units / (64 >> lpr_log2);
+  const bool mhrow = slab_mhrow(weight_mode, rowbytes);            // one row per wave-instruction: a unit is a wave
+  const int per_wave = mhrow ? 1 : (64 >> lpr_log2);
+  const int64_t waves = plan->units / per_wave;
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
-  if (plan->units % (64 >> lpr_log2) != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
-    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: the plan's unit count is not a whole number of 4-wave workgroups, at most 4 per CU of this device");
+  if (plan->units % per_wave != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
+    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: the plan's unit count is not a whole number of 4-wave workgroups, at most 4 per CU of this device "
+                                           "(geot_slab_units_for)");
   if (plan->rows_per_group < 1 || plan->rows_per_group > 32) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group 1..32");
+  const int el = (int)(F / 64);                                    // (mhrow) elements per lane
+  if (mhrow && (feat % el != 0 || F % 64 != 0)) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of row elements / 64");
   if (heads > 16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: at most 16 heads");
   const size_t need = geot_slab_workspace_bytes(plan, F);
   if (!workspace || workspace_bytes < need) return geot_internal_fail(GEOT_EWORKSPACE, "slab_spmm: workspace too small");
@@ -854,8 +1110,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   }
   if (plan->n_groups > 0) {
-    const size_t lds = slab_lds_bytes(plan->rows_per_group, weight_mode, heads, nv);
-    if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_dtype)");
+    const size_t lds = mhrow ? (size_t)4 * plan->rows_per_group * 64 * el * sizeof(float) + (size_t)4 * 2 * 64 * (size_t)heads * sizeof(float)
+                             : slab_lds_bytes(plan->rows_per_group, weight_mode, heads, nv);
+    if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_shape)");
     const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
     const bool wave_row = lpr_log2 == 6;
     int64_t cblocks = (plan->n_split + (kThreads >> lpr_log2) - 1) / (kThreads >> lpr_log2);
@@ -883,13 +1140,26 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   case 2: GEOT_SLAB_LAUNCH(T_, 2, GEOT_REDUCE_SUM); break;                                                    \
   default: GEOT_SLAB_LAUNCH(T_, 3, GEOT_REDUCE_SUM); break;                                                   \
   }
+#define GEOT_SLAB_MHROW(T_, E_)                                                                               \
+  do {                                                                                                        \
+    geot_internal_note_kernel((std::string("seg_slab_mhrow_kernel<") + slab_tname<T_>() + ", " + std::to_string(weight_mode) + ", " #E_ ">").c_str()); \
+    if (weight_mode == 2) hipLaunchKernelGGL((seg_slab_mhrow_kernel<T_, 2, E_>), grid, blk, lds, st, p);      \
+    else hipLaunchKernelGGL((seg_slab_mhrow_kernel<T_, 3, E_>), grid, blk, lds, st, p);                       \
+    if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p);    \
+  } while (0)
     const int rc = g_turn.take(st, [&]() -> int {
-      if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
+      if (mhrow) {
+        if (dtype == GEOT_F32) { if (el == 2) GEOT_SLAB_MHROW(float, 2); else GEOT_SLAB_MHROW(float, 1); }
+        else if (dtype == GEOT_F16) { if (el == 4) GEOT_SLAB_MHROW(half_t, 4); else GEOT_SLAB_MHROW(half_t, 2); }
+        else { if (el == 4) GEOT_SLAB_MHROW(bf16_t, 4); else GEOT_SLAB_MHROW(bf16_t, 2); }
+      }
+      else if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
       else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
       else { GEOT_SLAB_MODE(bf16_t) }
       const hipError_t le = hipGetLastError();
       return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
     });
+#undef GEOT_SLAB_MHROW
 #undef GEOT_SLAB_MODE
 #undef GEOT_SLAB_RED
 #undef GEOT_SLAB_LAUNCH

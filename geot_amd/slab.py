@@ -95,9 +95,13 @@ def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: i
     return out
 
 
-def rows_per_group(weight_mode: int, heads: int, dtype: torch.dtype) -> int:
-    """R of a plan for this storage type (16-bit storage keeps fp32 accumulators in LDS: half the rows per group)."""
+def rows_per_group(weight_mode: int, heads: int, dtype: torch.dtype, rowbytes: int = 0) -> int:
+    """R of a plan for this storage type (16-bit storage keeps fp32 accumulators in LDS: half the rows per group) and - given
+    `rowbytes` - for the kernel that will run it (multi-head plans over rows of 512 / 256 bytes: one row per wave-instruction, more
+    rows per group; include/geot_hip.h geot_slab_rows_per_group_shape)."""
     code = {torch.float32: _lib.GEOT_F32, torch.float16: _lib.GEOT_F16, torch.bfloat16: _lib.GEOT_BF16}[dtype]
+    if rowbytes:
+        return int(_lib.load().geot_slab_rows_per_group_shape(weight_mode, heads, code, rowbytes))
     return int(_lib.load().geot_slab_rows_per_group_dtype(weight_mode, heads, code))
 
 

@@ -254,6 +254,11 @@ int geot_slab_units(void);                                     /* waves of the p
 int geot_slab_full_chip(void);                                 /* 1: all 256 CUs / 160 KB LDS (what the density rule was measured on) */
 int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget (float32 storage) */
 int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /* ... 16-bit storage: fp32 accumulators, half the rows */
+/* What a plan's `units` and rows per group must be for the kernel that will run it.  A unit is the rowbytes / 16 lanes of a row
+ * (units = waves x 1024 / rowbytes) - except under multi-head weights (weight_mode 2 / 3) on rows of 512 / 256 bytes, which run one
+ * row per wave-instruction (8 / 4 bytes per lane): there a unit is a wave and a group holds more rows. */
+int geot_slab_units_for(int weight_mode, int64_t rowbytes);
+int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes);
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
 /* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
  * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts),

@@ -83,6 +83,8 @@ for s in $steps; do
     benchmh)  timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --only-secondary mh_spmm_cfg4,mh_spmm_cfg4_powerlaw_src,mh_spmm_cfg4_coalesced,mh_spmm_cfg4_bf16 > $O/bench_mh.json 2> $O/bench_mh.err; echo "rc=$?"; python3 -c "
 import json; d=json.load(open('$O/bench_mh.json'))
 for k,v in d['secondary'].items(): print(k, {a:b for a,b in v.items() if a in ('kernel_ms','kernel','error','kernel_ms_without_content_guard')})" ;;
+    mhrow)    timeout 1200 python3 -m pytest tests/test_gpu_slab.py -x -q -m gpu 2>&1 | tail -6
+              for spec in "mh bfloat16" "mh float16" "mh float32"; do set -- $spec; timeout 600 python3 tools/sweep_slab.py --case $1 --dtype $2 --ab slab_window=-2,-2 2>&1 | grep -v amdgpu.ids | tail -2; done ;;
     slabtests) timeout 1200 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_round4.py tests/test_gpu_guard.py -x -q -m gpu 2>&1 | tail -5 ;;
     sddmmorder) for c in sddmm128 sddmm256; do timeout 600 python3 tools/sweep_slab.py --case $c --ab staged=0,1 2>&1 | grep -v amdgpu.ids | tail -4; done ;;
     pmcsqbench) bash tools/pmc_sq_bench.sh $O/pmc_sq_bench 2>&1 | tail -12 ;;

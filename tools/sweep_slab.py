@@ -64,7 +64,7 @@ def main():
         for item in a.seq.split(","):
             mib, k = item.split(":")
             if mib != last:
-                plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, slab_bytes=int(float(mib) * (1 << 20)), rows_per_group=slab.rows_per_group(wmode, H, dt))
+                plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, slab_bytes=int(float(mib) * (1 << 20)), rows_per_group=slab.rows_per_group(wmode, H, dt, H * Fh * esz))
                 last = mib
             hip.set_option("slab_window", int(k))
             for _ in range(2):
@@ -79,7 +79,7 @@ def main():
     if a.ab:
         name, vals = a.ab.split("=")
         vals = [int(v) for v in vals.split(",")]
-        plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, rows_per_group=slab.rows_per_group(wmode, H, dt))
+        plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, rows_per_group=slab.rows_per_group(wmode, H, dt, H * Fh * esz))
         for rep in range(3):
             row = []
             for v in vals:
@@ -96,7 +96,7 @@ def main():
     for blocks in (3, 2) if not a.quick else (3,):
         hip.set_option("slab_blocks", blocks)
         for mib in slabs:
-            plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, slab_bytes=int(mib * (1 << 20)), rows_per_group=slab.rows_per_group(wmode, H, dt))
+            plan = slab.build_plan(si, di, nodes, nodes, H * Fh * esz, wmode, H, slab_bytes=int(mib * (1 << 20)), rows_per_group=slab.rows_per_group(wmode, H, dt, H * Fh * esz))
             row = []
             for k in windows:
                 hip.set_option("slab_window", k)
