@@ -344,3 +344,42 @@ def test_staged_sddmm_is_the_direct_sddmm_bit_for_bit_with_split_hubs(geot, dtyp
     tol = 1e-4 if dtype == torch.float32 else 0.15
     assert (staged.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
     assert (per_edge.double() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
+def test_multi_head_plans_on_narrow_rows_random_shapes(geot):
+    """seg_slab_mhrow_kernel (multi-head weights, rows of 512 / 256 bytes: one row per wave-instruction, a unit = a wave): random graphs
+    with split hubs, rows without edges and an out-of-range source, every (dtype, H, F per head) that makes such a row, both weight
+    layouts, plans built with the library's own units / rows per group - against float64."""
+    from geot_amd import slab
+    rng = np.random.default_rng(2024)
+    shapes = [(torch.float32, 4, 32), (torch.float32, 2, 64), (torch.float32, 2, 32), (torch.float32, 8, 8), (torch.float32, 1 + 1, 32),
+              (torch.bfloat16, 4, 64), (torch.bfloat16, 2, 128), (torch.bfloat16, 8, 32), (torch.bfloat16, 4, 32), (torch.bfloat16, 2, 64),
+              (torch.float16, 4, 64), (torch.float16, 16, 8), (torch.float16, 2, 64)]
+    for case, (dtype, H, Fh) in enumerate(shapes):
+        esz = 4 if dtype == torch.float32 else 2
+        rowbytes = H * Fh * esz
+        assert rowbytes in (256, 512), (dtype, H, Fh)
+        nodes = int(rng.integers(300, 4000))
+        deg = rng.integers(0, 60, nodes)
+        deg[rng.integers(0, nodes, 2)] = rng.integers(5_000, 40_000, 2)          # hubs that are split
+        deg[rng.integers(0, nodes, 20)] = 0                                      # rows without edges
+        di = np.repeat(np.arange(nodes), deg).astype(np.int64)
+        nnz = di.size
+        si = rng.integers(0, nodes, nnz).astype(np.int64)
+        x = torch.from_numpy(rng.random((nodes, H, Fh), dtype=np.float32) * 0.25).to(dtype)
+        w = torch.from_numpy(rng.random((nnz, H), dtype=np.float32)).to(dtype)
+        d_si, d_di, d_x, d_w = dev(si), dev(di), x.cuda(), w.cuda()
+        R = slab.rows_per_group(2, H, dtype, rowbytes)
+        plan = slab.build_plan(d_si, d_di, nodes, nodes, rowbytes, 2, H, rows_per_group=R)
+        assert plan.meta["split_rows"] >= 1 and plan.meta["units"] == slab._lib.load().geot_slab_units_for(2, rowbytes)
+        out = torch.full((nodes, H, Fh), float("nan"), dtype=dtype, device="cuda")
+        slab.slab_spmm_out(plan, d_w, 2, d_x, out, H, Fh)
+        assert "seg_slab_mhrow_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        want = torch.zeros(nodes, H, Fh, dtype=torch.float64, device="cuda")
+        want.index_add_(0, d_di, d_x.double()[d_si] * d_w.double()[:, :, None])
+        tol = 1e-5 if dtype == torch.float32 else (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+        err = (out.double() - want).abs()
+        assert bool((err <= tol * want.abs() + 1e-6).all()), (case, dtype, H, Fh, float((err / (want.abs() + 1e-6)).max()))
+        out3 = torch.empty_like(out)
+        slab.slab_spmm_out(plan, d_w.t().contiguous(), 3, d_x, out3, H, Fh)      # head-major weights: the same sums
+        assert torch.equal(out, out3), (case, dtype, H, Fh)
