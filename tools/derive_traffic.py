@@ -137,7 +137,7 @@ WORKLOADS = {
                      ("/phase A edge out", r"plan_edge_out_kernel")],
     # (rocprofv3 leaves the __bf16 instantiations mangled: DF16b)
     "gws_cfg3_bf16": [("", r"seg_tile_kernel(<" + T16 + r", 8, true, 1,|IDF16bLi8ELb1ELi1E)")],
-    "mh_spmm_cfg4_bf16": [("", r"seg_slab_kernel(<" + T16 + r", 2, false,|IDF16bLi2ELb0E)"),
+    "mh_spmm_cfg4_bf16": [("", r"seg_slab_mhrow_kernel(<" + T16 + r", 2, 4|IDF16bLi2ELi4E)"),
                           ("/per-edge [nnz,H]", r"seg_tile_kernel(<" + T16 + r", 8, true, 2,|IDF16bLi8ELb1ELi2E)")],
 }
 gather = {}
