@@ -22,6 +22,12 @@
 //   * Phase C (seg_slab_combine_kernel): the few split rows are summed from their carry slots in order.
 //
 // No global atomics, every dst row written once (dst is zero-filled first for the rows without edges).
+//
+// Kernels: seg_slab_kernel (all weight modes and reductions; rows of 1 KiB run one row per wave-instruction on scalar bases - group
+// bounds, row numbers, row switches in SGPRs -, narrower rows as lane groups of rowbytes / 16 lanes), seg_slab_mhrow_kernel (multi-head
+// weights on rows of 512 / 256 bytes: the scalar path at 8 / 4 bytes per lane, a unit = a wave), seg_slab_combine_kernel,
+// seg_slab_sddmm_kernel (d/dweight over the same plan; results staged in plan order) + slab_unstage_kernel (into edge order, a group at a
+// time through LDS).  Measurements and what bounds them: DESIGN.md section 3.1d.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
