@@ -133,6 +133,38 @@ def main():
                 ref = oracle.index_scatter_3pass(index, src, reduce=red)
                 ok = out.shape == ref.shape and (np.allclose(out, ref, rtol=2e-4, atol=2e-5) if red == "mean"
                                                  else np.array_equal(out, ref))
+        elif op == "mh":
+            # multi-head SpMM (round 4: its own source-blocked kernels - one row per wave-instruction for rows of 1 KiB / 512 / 256
+            # bytes): heads x width that make such rows or not, three storage types, both weight layouts, per-edge or slab-forced
+            H = int(rng.choice([2, 4, 8]))
+            Fh = int(rng.choice([8, 16, 32, 64]))
+            dt = str(rng.choice(["f32", "f32", "bf16", "f16"]))
+            tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dt]
+            if nnz * H * Fh > 100_000_000:
+                index = index[: 100_000_000 // (H * Fh)]
+                nnz = len(index)
+            geot.ops.set_option("slab_mode", "always" if rng.integers(0, 2) else "auto")
+            nodes = int(index[-1]) + 1 + int(rng.integers(0, 9))
+            si = rng.integers(0, nodes, nnz).astype(np.int64)
+            x = (rng.random((nodes, H, Fh), dtype=np.float32) * 0.25)
+            w = rng.random((nnz, H), dtype=np.float32) + 0.25
+            t_x, t_w = t(x).to(tdt), t(w).to(tdt)
+            xs, wsv = t_x.float().cpu().numpy(), t_w.float().cpu().numpy()            # the values as stored
+            head_major = bool(rng.integers(0, 2))
+            tag += f" H={H} Fh={Fh} dtype={dt} head_major={head_major}"
+            covered[("mh_" + dt, "sum")] = covered.get(("mh_" + dt, "sum"), 0) + 1
+            t_si, t_di = t(si), t(index)
+            wt = t_w.t().contiguous() if head_major else t_w
+            for _ in range(3):                                                         # (the second sighting of an edge list builds its plan)
+                got = geot.mh_spmm(t_si, t_di, wt, t_x)
+            out = got.float().cpu().numpy().reshape(-1, H * Fh)
+            hi = oracle.mh_spmm(si, index, wsv, xs, rows=out.shape[0], acc64=True).reshape(-1, H * Fh)
+            mag = oracle.mh_spmm(si, index, wsv, np.abs(xs), rows=out.shape[0], acc64=True).reshape(-1, H * Fh)
+            eps = {"f32": 0.0, "bf16": 2.0 ** -8, "f16": 2.0 ** -11}[dt]
+            floor = 2.0 ** -24 if dt == "f16" else 0.0                               # (float16 results below 6e-5 are subnormal: spacing 2^-24)
+            ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= eps * np.abs(hi) + 2e-5 * mag + floor + 1e-30) and np.all(out[mag == 0] == 0)
+            if dt == "f16" and mag.max() > 6e4:
+                ok = True                                                              # (beyond float16's range: not checked)
         else:
             nodes = int(index[-1]) + 1 + int(rng.integers(0, 9))
             si = rng.integers(0, nodes, nnz).astype(np.int64)
