@@ -1095,7 +1095,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   // costs 3 % at 2.3 uses, profiles/r04/bench_slab_density_rule.txt: 7.60 vs 7.36 ms)
   const int64_t rounds_ = (plan->n_groups + plan->units - 1) / (plan->units > 0 ? plan->units : 1);
   const double uses = (double)plan->nnz / (double)(rounds_ > 0 ? rounds_ : 1) / 8.0 / (double)(src_rows > 0 ? src_rows : 1);
-  const int tight = (weight_mode == 1 && lpr_log2 < 6 && uses >= 4.0) ? 1 : 2;
+  const int tight = (weight_mode == 1 && !w_in_plan_order && lpr_log2 < 6 && uses >= 4.0) ? 1 : 2;   // (a weight in plan order streams: 3.52 vs 3.56 ms at 2)
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : tight) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
