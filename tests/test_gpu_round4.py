@@ -313,26 +313,36 @@ def test_source_blocked_kernels_refuse_a_table_beyond_32_bit_row_offsets(geot):
     assert rc != _lib.GEOT_OK and b"4 GiB" in L.geot_last_error()
 
 
+@pytest.mark.parametrize("units", [64, 8])        # 8 units: groups of ~18 000 edges - longer than the unstage kernel's LDS tile
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_staged_sddmm_is_the_direct_sddmm_bit_for_bit_with_split_hubs(geot, dtype):
+def test_staged_sddmm_is_the_direct_sddmm_bit_for_bit_with_split_hubs(geot, dtype, units):
     """geot_slab_sddmm_staged: results leave the persistent kernel in the plan's order and slab_unstage_kernel brings them into edge
     order - through LDS where a group's edges are a contiguous range of the list, one by one where the group holds pieces of a split
     hub.  Same dot products, only another way to their place: bit-identical to the direct form, and both equal to the per-edge kernel
     within rounding.  The graph has split hubs (two rows with thousands of edges), ordinary rows and rows without edges."""
     from geot_amd import hip, slab
     g = torch.Generator(device="cpu").manual_seed(11)
-    nodes, F = 3000, 128
-    deg = torch.randint(0, 40, (nodes,), generator=g)
-    deg[7], deg[1500] = 30_000, 9_000
-    deg[100:140] = 0
+    F = 128
+    if units == 64:
+        nodes = 3000
+        deg = torch.randint(0, 40, (nodes,), generator=g)
+        deg[7], deg[1500] = 30_000, 9_000
+        deg[100:140] = 0
+    else:                                             # few rows of thousands of edges on ONE workgroup of units: groups longer than the tile, no split
+        nodes = 200
+        units = 4 * (1024 // (F * (4 if dtype == torch.float32 else 2)))
+        big = 2000 if dtype == torch.float32 else 8000
+        deg = torch.randint(big - 200, big + 200, (nodes,), generator=g)
     di = torch.repeat_interleave(torch.arange(nodes), deg)
     nnz = di.numel()
     si = torch.randint(0, nodes, (nnz,), generator=g)
     m1 = torch.randn(nodes, F, generator=g).to(dtype).cuda()
     m2 = torch.randn(nodes, F, generator=g).to(dtype).cuda()
     di, si = di.cuda(), si.cuda()
-    plan = slab.build_plan(si, di, nodes, nodes, F * m1.element_size(), 1, 1, units=64)
-    assert plan.meta["split_rows"] >= 2, plan.meta
+    plan = slab.build_plan(si, di, nodes, nodes, F * m1.element_size(), 1, 1, units=units)
+    assert plan.meta["split_rows"] >= (2 if nodes == 3000 else 0), plan.meta
+    if nodes == 200:
+        assert plan.meta["budget"] > (12288 if dtype == torch.float32 else 24576), plan.meta
     direct = torch.empty(nnz, dtype=dtype, device="cuda")
     staged = torch.full((nnz,), float("nan"), dtype=dtype, device="cuda")
     slab.slab_sddmm_out(plan, m1, m2, direct, staged=False)
