@@ -90,6 +90,12 @@ for k,v in d['secondary'].items(): print(k, {a:b for a,b in v.items() if a in ('
     pmcsqbench) bash tools/pmc_sq_bench.sh $O/pmc_sq_bench 2>&1 | tail -12 ;;
     pmcsddmm) bash tools/pmc_sddmm.sh $O/pmc_sddmm 2>&1 | tail -4 ;;
     pmcsq)    bash tools/pmc_slab_sq.sh $O/pmc_slab_sq 2>&1 | tail -30 ;;
+    soaklast) for seed in 131 132 133 134 135 136; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 300 --seed $seed > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-120
+              done
+              for seed in 211 212 213 214; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 200 --seed $seed --ops mh,mh,mh,gws,gs > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-120
+              done ;;
     soakmh)   for seed in 201 202 203 204; do
                 timeout 900 python3 tools/soak_fuzz.py --iters 200 --seed $seed --ops mh,mh,gws,gs,is > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -2 $O/soak_seed$seed.log | cut -c1-300
               done ;;
