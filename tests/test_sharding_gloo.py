@@ -401,6 +401,65 @@ def test_sharded_mean_max_min_prod_equal_the_unsharded_reduction(world):
                     np.testing.assert_allclose(got, full, rtol=2e-5, atol=1e-6)
 
 
+def _oracle_reduce_local_op_16(index_local, src_local, rows, reduce="sum"):
+    """16-bit storage the way the reference's CPU path treats it (csrc/cpu/index_scatter_cpu.cpp:78-86): fp32 accumulation, one
+    rounding to the storage type at the end."""
+    from oracle import api
+    out = api.index_scatter_3pass(index_local.numpy(), src_local.float().numpy(), reduce, rows=rows)
+    return torch.from_numpy(out).to(src_local.dtype)
+
+
+def _mean16_worker(rank, world, port, case, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geot_amd import sharding
+        res = {}
+        index = torch.from_numpy(case["index"])
+        for dt in (torch.float16, torch.bfloat16):
+            src = torch.from_numpy(case["src"]).to(dt)
+            ish, ssh = sharding.shard_edges(index, src, world, rank)
+            for coll in ("all_gather", "reduce_scatter"):
+                out, first_row = sharding.sharded_index_scatter(ish, ssh, local_op=_oracle_reduce_local_op_16, collective=coll, reduce="mean")
+                res[(str(dt), coll)] = (first_row, out.float().numpy().copy())
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_mean_of_16bit_rows_never_forms_a_sum_in_the_storage_type(world):
+    """the shared rows of a sharded mean used to travel as a partial SUM written in the storage type - a hub of
+    200 000 edges of values around 1 shared by the ranks is +inf in fp16 (max 65 504) and loses everything below 2^-8 of the
+    running sum in bf16, while the unsharded operator accumulates in fp32 and rounds once.  Now: mean x count in float64."""
+    from oracle import api
+    rng = np.random.default_rng(300 + world)
+    hub = np.sort(np.concatenate([rng.integers(0, 3, 500), np.full(200_000, 3), rng.integers(4, 20, 900)])).astype(np.int64)
+    case = dict(index=hub, src=(0.75 + 0.5 * rng.random((len(hub), 3), dtype=np.float32)))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mean16_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for dt, ulp in ((torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)):
+        src16 = torch.from_numpy(case["src"]).to(dt)
+        full = torch.from_numpy(api.index_scatter_3pass(case["index"], src16.float().numpy(), "mean")).to(dt).float().numpy()
+        for coll in ("all_gather", "reduce_scatter"):
+            got = np.concatenate([res[r][(str(dt), coll)][1] for r in range(world)])
+            assert got.shape == full.shape
+            assert np.isfinite(got).all(), (dt, coll)
+            # one ulp of the storage type around the unsharded result (values around 1: ulp = 2^-10 / 2^-7)
+            np.testing.assert_allclose(got, full, rtol=0, atol=1.01 * ulp)
+
+
 def test_sharded_reduce_rejects_unknown_names():
     from geot_amd import sharding
     with pytest.raises(ValueError, match="reduce argument must be either sum, prod, mean, amax or amin"):
