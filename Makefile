@@ -17,7 +17,7 @@ all: lib tools
 # one object per source under geot_amd/csrc/.obj, the stale ones compiled side by side, one link; staleness by content
 # (geot_amd/_lib.py holds the recipe: hipcc $(HIPFLAGS) -c <src> -o <obj>, then hipcc -shared <objs> -o $(LIB))
 lib: $(LIB)
-$(LIB): $(SRC) include/geot_hip.h geot_amd/csrc/internal.h
+$(LIB): $(SRC) include/geot_hip.h include/geot_hip_dev.h geot_amd/csrc/internal.h
 	python3 geot_amd/_lib.py lib
 
 tools: tools/kbench

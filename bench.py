@@ -269,7 +269,7 @@ def profiled(entry):
     """PMC-derived fabric traffic of a secondary workload's kernel, from the round's profiling session (committed under
     profiles/; tools/profile_round.sh + tools/derive_traffic.py) - a recorded measurement of the same kernel on the same
     workload, not a measurement of this run: labelled with its source."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", rnd, "gather_kernels.json")
         try:
             k = json.load(open(f))["kernels"].get(entry)
@@ -693,16 +693,28 @@ def cfg5_leg(world, rank, dev, scale, steps, warmup, cuts="equal", collective="a
         elapsed = float(t.item())
     kernel = hip.last_kernel()
     ms = device_ms(lambda: hip.gather_scatter_out(src_index, index, src, torch.empty(rows, feat, device=dev)), 3, warmup=1)
+    box = hip.profile_box(src[: 20_000_000])                  # this box's own streamed-read ceiling, now (boxes of the pool differ by ~5 %)
     uniq = int(torch.unique(src_index).numel())
     comp = index.numel() * 16 + uniq * 4 * feat + rows * 4 * feat
+    # what the per-edge gather MOVES: one row read per edge (a 57 GB table is re-read from HBM every time: 256 MiB of Infinity Cache
+    # hold 0.4 % of it; PMC: fabric traffic = 1.97 x compulsory, L2 hit 6 %, profiles/r05/cfg5_study/) + the indices + the output
+    moved = index.numel() * (16 + 4 * feat) + rows * 4 * feat
     out = {"workload": f"gather_scatter, papers100M-scale synthetic (BASELINE.json configs[4]), feat={feat}: ONE global dst-sorted list of "
                        f"{nnz_global} edges -> {rows_global} dst rows cut into {world} edge ranges ({cuts} cuts); this rank {index.numel()} edges -> "
                        f"{rows} rows; src {nodes_all} x {feat} fp32 replicated ({nodes_all * feat * 4 / 1e9:.1f} GB per GPU); 8 ranks = the full 1.6 B edges",
            "scaling": "weak", "n_gpus": world, "steps": steps, "value": nnz_global * steps / elapsed, "unit": "edges/s",
            "ms_per_step": elapsed / steps * 1e3, "boundary_exchange_ms": exchange_ms, "collective": collective if distributed else None,
-           "kernel": kernel, "kernel_ms_rank0": ms, "compulsory_bytes_rank0": comp,
+           "kernel": kernel, "kernel_ms_rank0": ms, "compulsory_bytes_rank0": comp, "distinct_source_rows_rank0": uniq,
            "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": comp / ms / 1e6 / HBM_PEAK_GBPS,
-                        "traffic": None, "traffic_source": None}}
+                        **profiled("gather_scatter_cfg5"),
+                        "moved_bytes_rank0": moved, "moved_gbps": moved / ms / 1e6,
+                        "row_gather_gbps": index.numel() * 4 * feat / ms / 1e6,
+                        "box_read_ceiling_gbps": box["read_ceiling_gbps"], "box_sclk_mhz": box["sclk_mhz"],
+                        "moved_frac_of_box_read_ceiling": moved / ms / 1e6 / box["read_ceiling_gbps"],
+                        "note": "every edge's 512-byte row comes from HBM (table 57 GB >> 256 MiB Infinity Cache): the kernel runs at the part's random-"
+                                "row rate - 4.7 TB/s of row reads from any table >= 4 GB whatever the tile shape, loads in flight, in-tile source "
+                                "order or page locality (profiles/r05/cfg5_study/exp_gather_table*.txt); compulsory bytes credit a row once, the "
+                                "graph reads it 2.2 times"}}
     del index, src_index, src
     torch.cuda.empty_cache()
     return out

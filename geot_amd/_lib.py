@@ -20,25 +20,26 @@ SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("seg_reduce_f32.hip", "seg_p
                                                      "seg_guard.hip")]
 SEG_REDUCE = os.path.join(_HERE, "csrc", "seg_reduce.hip")
 HEADER = os.path.join(_ROOT, "include", "geot_hip.h")
+DEV_HEADER = os.path.join(_ROOT, "include", "geot_hip_dev.h")     # measurement hooks + experiment switches (not the stable ABI)
 PLUGIN_PATH = os.path.join(_HERE, "_C.so")                       # the torch dispatcher plugin (csrc/torch_ops.cpp)
 PLUGIN_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("torch_ops.cpp", "host_state.cpp", "host_cache.cpp", "host_plan.cpp")]
 PLUGIN_HEADER = os.path.join(_HERE, "csrc", "host.h")
-LIB_INPUTS = SOURCES + [HEADER, os.path.join(_HERE, "csrc", "internal.h")]
+LIB_INPUTS = SOURCES + [HEADER, DEV_HEADER, os.path.join(_HERE, "csrc", "internal.h")]
 PLUGIN_INPUTS = PLUGIN_SOURCES + [PLUGIN_HEADER, HEADER]
 
 GEOT_OK = 0
 GEOT_F32, GEOT_F64, GEOT_F16, GEOT_BF16 = 0, 1, 2, 3
 GEOT_W_EDGE_MAJOR, GEOT_W_HEAD_MAJOR = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-#: every symbol include/geot_hip.h declares (tests check the library exports all of them)
+#: every symbol include/geot_hip.h and include/geot_hip_dev.h declare (tests check the library exports all of them)
 SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes", "geot_mh_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
-    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_gather_rows", "geot_index_probe",
+    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_mh_sddmm_coo", "geot_gather_rows", "geot_index_probe",
     "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_content_fingerprint", "geot_content_fingerprint_scratch_bytes", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
-    "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_units_for", "geot_slab_rows_per_group_shape", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm", "geot_slab_sddmm_staged",
+    "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_units_for", "geot_slab_rows_per_group_shape", "geot_slab_workspace_bytes", "geot_slab_spmm", "geot_slab_sddmm", "geot_slab_sddmm_staged", "geot_slab_mh_sddmm",
     "geot_slab_plan_scratch_bytes", "geot_slab_plan_rows", "geot_slab_plan_groups", "geot_slab_plan_edges",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option", "geot_last_kernel",
 ]
@@ -224,6 +225,7 @@ def load() -> ctypes.CDLL:
     L.geot_gather_weight_scatter.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_mh_spmm.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_sddmm_coo.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]
+    L.geot_mh_sddmm_coo.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]
     L.geot_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]
     L.geot_csr_workspace_bytes.restype = c_sz
     L.geot_csr_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]
@@ -243,6 +245,7 @@ def load() -> ctypes.CDLL:
     L.geot_slab_spmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_slab_sddmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_slab_sddmm_staged.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
+    L.geot_slab_mh_sddmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_profile_enable.argtypes = [c_int]
     L.geot_profile_enable.restype = None
     L.geot_profile_reset.restype = None

@@ -294,7 +294,8 @@ struct SlabEntry {
   ContentKey k1, k2;
   int64_t rows, src_rows, rowbytes, heads;
   int wmode;
-  int rpg;   // rows per group the plan was built for: the only thing the weight mode / head count changes
+  int rpg;   // rows per group the plan was built for: what the weight mode / head count changes ...
+  int64_t units; // ... and the lane-group streams it was cut for (waves for rows of >= 256 bytes): part of the lookup
   WeakStorage w1, w2; // the edge list the plan was built from (weak: the plan goes when the edge list dies)
   std::shared_ptr<SlabPlanHolder> plan;
 };

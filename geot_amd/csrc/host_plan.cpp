@@ -9,8 +9,10 @@ bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t ro
   if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024) || nnz >= ((int64_t)1 << 31) || nnz < 8000000 || out_rows < 1 ||
       src_rows >= ((int64_t)1 << 31) || !geot_slab_full_chip()) // (a partitioned / CU-masked device: the rule below was not measured there)
     return false;
-  const int64_t units = (int64_t)geot_slab_units() * (1024 / rowbytes);
-  const int64_t rpg = geot_slab_rows_per_group_dtype(1, 1, dtype); // (16-bit storage: fp32 accumulators, half the rows per group)
+  // (what the plan of this shape will be built with: a unit is a wave for every row of >= 256 bytes - geot_slab_units_for - and the
+  //  rows per group follow the kernel that runs it; 16-bit storage keeps fp32 accumulators: half the rows per group)
+  const int64_t units = (int64_t)geot_slab_units_for(1, rowbytes);
+  const int64_t rpg = geot_slab_rows_per_group_shape(1, 1, dtype, rowbytes);
   const int64_t rounds = std::max<int64_t>(1, (out_rows + rpg * units - 1) / (rpg * units));
   // uses of a source row per XCD and round; measured (profiles/r02/bench_slab_density_rule.txt, 120 M edges): 10 -> 1.50x,
   // 4.8 -> 1.34x, 2.8 -> 1.22x, 1.6 -> 1.09x, 0.8 -> 0.86x at 512-B rows; 8.8 -> 2.08x, 2.4 -> 1.62x, 1.8 -> 1.43x (Reddit2: 23 M
@@ -29,7 +31,7 @@ std::shared_ptr<SlabPlanHolder> slab_build_aten(const at::Tensor &src_index, con
   const int64_t nnz = dst_index.numel();
   const int64_t lanes = rowbytes / 16;
   const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units_for(weight_mode, rowbytes);
-  const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group(weight_mode, heads);
+  const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group_shape(weight_mode, heads, GEOT_F32, rowbytes);
   const auto lopt = dst_index.options();
   // row pointers of the ASCENDING dst_index by binary search (rows + 1 searches; a histogram would spend 23 ms of global
   // atomics on the hubs of a 115 M-edge graph - more than the rest of Phase A together)
@@ -159,7 +161,7 @@ std::shared_ptr<SlabPlanHolder> slab_build_device(const at::Tensor &src_index, c
   const int64_t nnz = dst_index.numel();
   const int64_t lanes = rowbytes / 16;
   const int64_t units = units_override > 0 ? units_override : (int64_t)geot_slab_units_for(weight_mode, rowbytes);
-  const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group(weight_mode, heads);
+  const int64_t R = rows_per_group > 0 ? rows_per_group : geot_slab_rows_per_group_shape(weight_mode, heads, GEOT_F32, rowbytes);
   void *st = stream_of(dst_index);
   geot_slab_plan_job job;
   std::memset(&job, 0, sizeof(job));
@@ -245,7 +247,7 @@ constexpr int64_t kSlabBytes = 2 << 20; // measured (profiles/r02/bench_slab.txt
 // bases (round 4, profiles/r04/sweep_slab_*_v2.txt: mh fp32 7.21 vs 7.37 ms).  Everything else stays at 2 MiB: plans of one weight or
 // none are within 1.5 % of their best there on rows of 256 / 512 bytes, and at 1 KiB the forward would gain 2 % (gws F=256 6.63 vs
 // 6.76) where the SDDMM of its backward, which runs over the same plan, loses 4 % (8.21 vs 7.90); multi-head plans on rows of 512 / 256
-// bytes (seg_slab_mhrow_kernel): bf16 H=4 x F=64 5.24 ms at 2 MiB / window 2 against 5.41 at 1 MiB / window 3
+// bytes (seg_slab_wrow_kernel): bf16 H=4 x F=64 5.24 ms at 2 MiB / window 2 against 5.41 at 1 MiB / window 3
 int64_t slab_bytes_rule(int64_t rowbytes, int wmode) { return g_opt.slab_bytes > 0 ? g_opt.slab_bytes : ((wmode >= 2 && rowbytes >= 1024) ? kSlabBytes / 2 : kSlabBytes); }
 
 // Does the graph have LOCALITY?  The source-blocked kernel pays off when the groups in flight sweep the WHOLE source table together;
@@ -303,12 +305,13 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   ContentKey k1, k2;
   if (!may_remember({&si, &di}) || !content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
   const int rpg = geot_slab_rows_per_group_shape(wmode, heads, dt, rowbytes);
+  const int64_t units = geot_slab_units_for(wmode, rowbytes);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     sweep_expired_locked();
     for (auto it = g_slab.begin(); it != g_slab.end(); ++it)
       if (it->k1 == k1 && it->k2 == k2 && it->rows == rows && it->src_rows == src.size(0) && it->rowbytes == rowbytes &&
-          it->rpg == rpg && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R)
+          it->rpg == rpg && it->units == units && !it->w1.expired() && !it->w2.expired()) { // (a plan serves every weight mode with its R and its units)
         g_slab.splice(g_slab.begin(), g_slab, it);
         g_slab.front().plan->made.before_use(src, g_slab.front().plan->keep);
         guard_check(g_slab.front().plan->fp, {&si, &di}); // (a rejected plan has released its fingerprint: the per-edge kernels read the caller's bytes)
@@ -340,7 +343,6 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
     }
   } building{k1, k2};
   if (g_opt.slab_mode != 1 && g_opt.slab_min_coverage_pct > 0 && si.is_cuda()) { // a graph with locality keeps the per-edge kernels (and pays neither Phase A nor a trial)
-    const int64_t units = (int64_t)geot_slab_units() * (1024 / std::max<int64_t>(rowbytes, 16));
     const int64_t rounds = std::max<int64_t>(1, (rows + rpg * units - 1) / (rpg * units));
     const double cover = slab_source_coverage(si, di, src.size(0), rowbytes, nnz / (rounds * units));
     std::lock_guard<std::mutex> lk(g_mu);
@@ -357,7 +359,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   const auto t0 = std::chrono::steady_clock::now();
   std::shared_ptr<SlabPlanHolder> plan;
   try {
-    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, slab_bytes_rule(rowbytes, wmode), rpg, 0);
+    plan = slab_build(si, di, rows, src.size(0), rowbytes, wmode, heads, slab_bytes_rule(rowbytes, wmode), rpg, units);
   } catch (const c10::Error &) {
     // Phase A needs ~80 bytes per edge of transient memory and keeps 9: if that does not fit, the per-edge kernels serve
     // the call (and every later one: the sighting is forgotten, a later call may try again)
@@ -371,7 +373,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   std::lock_guard<std::mutex> lk(g_mu);
   ++g_stats.plans_built;
   g_stats.plan_us += us;
-  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, rpg, weak_of(si), weak_of(di), plan});
+  g_slab.push_front(SlabEntry{k1, k2, rows, src.size(0), rowbytes, heads, wmode, rpg, units, weak_of(si), weak_of(di), plan});
   while ((int)g_slab.size() > g_opt.slab_keep) g_slab.pop_back();
   enforce_cache_budget_locked();
   return plan;

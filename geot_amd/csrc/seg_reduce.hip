@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "geot_hip.h"
+#include "geot_hip_dev.h"
 #include "internal.h"
 
 // Build: one storage type's instantiations of the tile kernel per object.  seg_reduce_{f32,f64,f16,bf16}.hip include this file
@@ -351,11 +352,14 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
     if (i == 0) keysL[0] = kp;
     const unsigned long long m = __ballot(k != kp);
     if (lane == 0) maskL[i0 >> 6] = m;
-    // descent guard (see repair_call): a key below its predecessor, BOTH inside [0, K) - keys outside that range are ignored by
-    // every kernel (the speculative `index - lo` of geot_amd/sharding.py makes leading negatives) and must not raise the alarm.
-    // Unsigned compares: the padding key -2 and the -1 in front of edge 0 are "above K".  Only a wave-uniform bit is kept here
-    // (an SGPR: the row loads in flight leave no VGPR to spare); the flag is stored once, behind the loop.
-    if constexpr (!ATOMIC) descents |= __ballot((uint64_t)k < (uint64_t)kp && (uint64_t)kp < (uint64_t)p.K);
+    // descent guard (see repair_call): a REAL edge (not the padding behind the list, not edge 0) whose key lies below its
+    // predecessor's, at least ONE of the two inside [0, K).  Keys outside that range are ignored by every kernel - the speculative
+    // `index - lo` of geot_amd/sharding.py makes leading negatives and trailing keys >= K, both ascending: no alarm; a descent
+    // between two ignored keys is harmless: no alarm - but a descent THROUGH an ignored key ([1, K+3, 1], [1, -5, 1]: row 1 would
+    // be written by two separate runs, the second overwriting the first) has one in-range side and is caught.
+    // Only a wave-uniform bit is kept here (an SGPR: the row loads in flight leave no VGPR to spare); the flag is stored once,
+    // behind the loop.
+    if constexpr (!ATOMIC) descents |= __ballot(ge > 0 && ge < p.nnz && k < kp && ((uint64_t)k < (uint64_t)p.K || (uint64_t)kp < (uint64_t)p.K));
     if constexpr (GATHER) {
       int64_t row = ge < p.nnz ? p.src_index[ge] : 0;
       if ((uint64_t)row >= (uint64_t)p.src_rows) row = 0; // out-of-range gather index: memory-safe
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
   int64_t klast = __shfl(k[0], 0, 64); // the chunk's first edge opens its first run (no run ends there)
   int nrun = 0;                        // runs of this chunk that have already ended
   if (lane == 0 && klast > kbefore + 1) gapfill(kbefore + 1, klast);
-  raise_descent(p, lane == 0 && cs > 0 && cs < nnz && (uint64_t)k[0] < (uint64_t)kbefore && (uint64_t)kbefore < (uint64_t)p.K);
+  raise_descent(p, lane == 0 && cs > 0 && cs < nnz && k[0] < kbefore && ((uint64_t)k[0] < (uint64_t)p.K || (uint64_t)kbefore < (uint64_t)p.K));
 
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -879,7 +883,8 @@ __global__ __launch_bounds__(kThreads) void seg_narrow_kernel(SegParams p) {
     if (lane == 0) kp = klast;
     const bool h = k[s] != kp;
     const unsigned long long hb = __ballot(h);
-    raise_descent(p, (uint64_t)k[s] < (uint64_t)kp && (uint64_t)kp < (uint64_t)p.K); // (both keys inside [0, K): out-of-range keys are ignored, never an alarm)
+    // (a real edge below its predecessor, one of the two keys inside [0, K) - see seg_tile_body; step 0's lane 0 was judged above)
+    raise_descent(p, cs + s * 64 + lane < nnz && (s > 0 || lane > 0) && k[s] < kp && ((uint64_t)k[s] < (uint64_t)p.K || (uint64_t)kp < (uint64_t)p.K));
     if (h && k[s] > kp + 1) gapfill(kp + 1, k[s]);
     if ((hb & 1ull) && lane == 0) {
       // the run carried in ended exactly at the step boundary: nobody in this step continues it
@@ -1131,10 +1136,10 @@ __global__ __launch_bounds__(kThreads) void seg_lane_kernel(SegParams p) {
   int64_t cur = mk[0];
   if (cur > kprev + 1) gapfill(kprev + 1, cur);
   {
-    const uint64_t uK = (uint64_t)p.K; // (both keys inside [0, K): out-of-range keys are ignored, never an alarm)
-    bool desc = e0 > 0 && (uint64_t)mk[0] < (uint64_t)kprev && (uint64_t)kprev < uK;
+    const uint64_t uK = (uint64_t)p.K; // (a real edge below its predecessor, one of the two keys inside [0, K) - see seg_tile_body)
+    bool desc = e0 > 0 && e0 < nnz && mk[0] < kprev && ((uint64_t)mk[0] < uK || (uint64_t)kprev < uK);
 #pragma unroll
-    for (int e = 1; e < E; ++e) desc = desc || ((uint64_t)mk[e] < (uint64_t)mk[e - 1] && (uint64_t)mk[e - 1] < uK);
+    for (int e = 1; e < E; ++e) desc = desc || (e0 + e < nnz && mk[e] < mk[e - 1] && ((uint64_t)mk[e] < uK || (uint64_t)mk[e - 1] < uK));
     raise_descent(p, desc);
   }
   float acc[F], head[F];
@@ -1619,13 +1624,17 @@ __global__ __launch_bounds__(kThreads) void seg_fixup_kernel(SegParams p, int64_
 // Every block owns a CONTIGUOUS chunk of edges (dst-sorted edges share their m1 row, neighbours share
 // m2 rows on graphs with locality) and chunks are handed to the XCDs in contiguous ranges (see the
 // gather modes of seg_tile_kernel): both operands then hit in the XCD's L2 instead of 8 L2s.
+// Multi-head form (H > 1; d/dweight of mh_spmm): rows are [H, F]; an "edge" of the loop is a pair (edge e, head h) = q, q = e * H + h,
+// its operands the F values of head h of rows d[e] / s[e], its result out[e * H + h] (edge-major) or out[h * nnz_e + e] (head-major).
+// `nnz` counts pairs, `stride` = H * F elements between rows.  H = 1: the plain SDDMM.
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_index,
                                                              const int64_t *dst_index,
                                                              const T *m1, const T *m2, T *out,
                                                              int64_t nnz, int64_t F,
                                                              int64_t rows1, int64_t rows2,
-                                                             int lpr_log2, int64_t chunk, int xcd_swizzle) {
+                                                             int lpr_log2, int64_t chunk, int xcd_swizzle,
+                                                             int H, int64_t stride, int head_major) {
   const int lpr = 1 << lpr_log2;
   const int ng = kThreads >> lpr_log2;
   const int g = threadIdx.x >> lpr_log2;
@@ -1641,9 +1650,16 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
   constexpr int UE = 4; // edges in flight per lane group: indices first, then all rows, then the dots
   for (int64_t eb = e0 + (int64_t)g * UE; eb < e1; eb += (int64_t)ng * UE) {
     int64_t r1[UE], r2[UE];
+    int64_t hoff[UE];       // element offset of the pair's head inside a row (0 for H = 1)
 #pragma unroll
     for (int u = 0; u < UE; ++u) {
-      const int64_t e = eb + u < e1 ? eb + u : e1 - 1;
+      const int64_t q = eb + u < e1 ? eb + u : e1 - 1;
+      int64_t e = q;
+      hoff[u] = 0;
+      if (H > 1) {
+        e = q / H;
+        hoff[u] = (q - e * H) * F;
+      }
       r1[u] = dst_index[e];
       r2[u] = src_index[e];
       if ((uint64_t)r1[u] >= (uint64_t)rows1 || (uint64_t)r2[u] >= (uint64_t)rows2) r1[u] = -1;
@@ -1655,10 +1671,10 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
     // test per group would diverge; a per-group predicate on the load is enough)
     bool same = true;
 #pragma unroll
-    for (int u = 1; u < UE; ++u) same = same && (r1[u] == r1[0]);
+    for (int u = 1; u < UE; ++u) same = same && (r1[u] == r1[0]) && (hoff[u] == hoff[0]);
     for (int64_t f = (int64_t)c * VEC; f < F; f += (int64_t)lpr * VEC) {
       A x[UE][VEC], y[UE][VEC];
-      load_vec<T, VEC, false>(m1 + (r1[0] < 0 ? 0 : r1[0]) * F + f, x[0]);
+      load_vec<T, VEC, false>(m1 + (r1[0] < 0 ? 0 : r1[0]) * stride + hoff[0] + f, x[0]);
 #pragma unroll
       for (int u = 0; u < UE; ++u) {
         const int64_t a1 = r1[u] < 0 ? 0 : r1[u], a2 = r1[u] < 0 ? 0 : r2[u];
@@ -1667,10 +1683,10 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
 #pragma unroll
             for (int i = 0; i < VEC; ++i) x[u][i] = x[0][i];
           } else {
-            load_vec<T, VEC, false>(m1 + a1 * F + f, x[u]);
+            load_vec<T, VEC, false>(m1 + a1 * stride + hoff[u] + f, x[u]);
           }
         }
-        load_vec<T, VEC, false>(m2 + a2 * F + f, y[u]);
+        load_vec<T, VEC, false>(m2 + a2 * stride + hoff[u] + f, y[u]);
       }
 #pragma unroll
       for (int u = 0; u < UE; ++u)
@@ -1681,7 +1697,15 @@ __global__ __launch_bounds__(kThreads) void sddmm_coo_kernel(const int64_t *src_
     for (int u = 0; u < UE; ++u) {
       A v = r1[u] < 0 ? A(0) : s[u];
       for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (c == 0 && eb + u < e1) out[eb + u] = (T)v;
+      if (c == 0 && eb + u < e1) {
+        const int64_t q = eb + u;
+        if (H > 1 && head_major) {
+          const int64_t e = q / H;
+          out[(q - e * H) * (nnz / H) + e] = (T)v;
+        } else {
+          out[q] = (T)v;
+        }
+      }
     }
   }
 }
@@ -2203,7 +2227,17 @@ void launch_wsum(const SegParams &p, int64_t num_tiles, int red, hipStream_t st)
 // stores (3) or the default policy (0); gathered rows - re-used across edges - the default policy only.
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC>
 void dispatch_nt(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
-  if constexpr (GATHER) launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st);
+  if constexpr (GATHER) {
+    // (experiment of round 5, geot_tune(nontemporal = 1): nt row gathers for a table whose rows are read from HBM every time -
+    //  configs[4]'s 57 GB; fp32 gather_scatter only.  Measured level: profiles/r05/cfg5_study/)
+    if constexpr (WMODE == 0 && !ATOMIC && sizeof(T) == 4 && VEC == 4) {
+      if ((nt & 1) != 0) {
+        launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 1>(p, P, st);
+        return;
+      }
+    }
+    launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st);
+  }
   else if ((nt & 3) != 0) launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 3>(p, P, st);
   else launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 0>(p, P, st);
 }
@@ -2550,12 +2584,16 @@ template <typename T> int pick_row_vec(int64_t F, const void *a, const void *b) 
   return 1;
 }
 
+// H > 1: the multi-head form - F values per head, rows of H * F values, results out[e * H + h] or (head_major) out[h * nnz + e]
 template <typename T>
 int run_sddmm(const int64_t *si, const int64_t *di, const void *m1, const void *m2, void *out,
-              int64_t nnz, int64_t F, int64_t rows1, int64_t rows2, hipStream_t st) {
-  if (nnz < 0 || F < 0) return fail(GEOT_EINVAL, "negative size");
-  if (nnz == 0) return GEOT_OK;
+              int64_t nnz, int64_t F, int64_t rows1, int64_t rows2, hipStream_t st, int64_t H = 1, int head_major = 0) {
+  if (nnz < 0 || F < 0 || H < 1) return fail(GEOT_EINVAL, "negative size");
+  if (nnz == 0 || (H > 1 && F == 0)) return GEOT_OK;
   if (!si || !di || !m1 || !m2 || !out) return fail(GEOT_EINVAL, "null pointer");
+  if (H > 64) return fail(GEOT_EUNSUPPORTED, "more than 64 heads");
+  const int64_t stride = H * F;
+  nnz *= H;                                               // the loop runs over (edge, head) pairs
   int vec = pick_row_vec<T>(F, m1, m2);
   int l = ceil_log2((F + vec - 1) / vec);
   if (l > 6) l = 6;
@@ -2574,11 +2612,11 @@ int run_sddmm(const int64_t *si, const int64_t *di, const void *m1, const void *
   T *o = static_cast<T *>(out);
   constexpr int MAXV = 16 / (int)sizeof(T);
   if (vec == MAXV)
-    hipLaunchKernelGGL((sddmm_coo_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd);
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd, (int)H, stride, head_major);
   else if (vec == 2 && MAXV >= 4)
-    hipLaunchKernelGGL((sddmm_coo_kernel<T, 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd);
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, 2>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd, (int)H, stride, head_major);
   else
-    hipLaunchKernelGGL((sddmm_coo_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd);
+    hipLaunchKernelGGL((sddmm_coo_kernel<T, 1>), dim3((unsigned)blocks), dim3(kThreads), 0, st, si, di, a, b, o, nnz, F, rows1, rows2, l, chunk, g_xcd, (int)H, stride, head_major);
   HIP_TRY(hipGetLastError());
   return GEOT_OK;
 }
@@ -2727,6 +2765,18 @@ int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const voi
   if (dtype == GEOT_F64) return run_sddmm<double>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
   if (dtype == GEOT_F16) return run_sddmm<half_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
   if (dtype == GEOT_BF16) return run_sddmm<bf16_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st);
+  return fail(GEOT_EINVAL, "bad dtype");
+}
+
+int geot_mh_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const void *mat_1, const void *mat_2, void *out, int64_t nnz,
+                      int64_t heads, int64_t feat, int64_t rows_1, int64_t rows_2, int weight_layout, int dtype, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (weight_layout != GEOT_W_EDGE_MAJOR && weight_layout != GEOT_W_HEAD_MAJOR) return fail(GEOT_EINVAL, "bad weight layout");
+  const int hm = weight_layout == GEOT_W_HEAD_MAJOR ? 1 : 0;
+  if (dtype == GEOT_F32) return run_sddmm<float>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st, heads, hm);
+  if (dtype == GEOT_F64) return run_sddmm<double>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st, heads, hm);
+  if (dtype == GEOT_F16) return run_sddmm<half_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st, heads, hm);
+  if (dtype == GEOT_BF16) return run_sddmm<bf16_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st, heads, hm);
   return fail(GEOT_EINVAL, "bad dtype");
 }
 

@@ -24,7 +24,7 @@
 // No global atomics, every dst row written once (dst is zero-filled first for the rows without edges).
 //
 // Kernels: seg_slab_kernel (all weight modes and reductions; rows of 1 KiB run one row per wave-instruction on scalar bases - group
-// bounds, row numbers, row switches in SGPRs -, narrower rows as lane groups of rowbytes / 16 lanes), seg_slab_mhrow_kernel (multi-head
+// bounds, row numbers, row switches in SGPRs -, 128-byte rows as lane groups of 8 lanes), seg_slab_wrow_kernel (every weight mode and multi-head
 // weights on rows of 512 / 256 bytes: the scalar path at 8 / 4 bytes per lane, a unit = a wave), seg_slab_combine_kernel,
 // seg_slab_sddmm_kernel (d/dweight over the same plan; results staged in plan order) + slab_unstage_kernel (into edge order, a group at a
 // time through LDS).  Measurements and what bounds them: DESIGN.md section 3.1d.
@@ -404,11 +404,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
-// Multi-head weights on rows of 512 / 256 bytes: ONE ROW PER WAVE-INSTRUCTION, E = row elements / 64 per lane (8 or 4 bytes a lane) -
-// the scalar path of seg_slab_kernel's 1-KiB form (group bounds, row numbers and row switches in SGPRs, 32-bit row offsets on a
-// scalar base) for the narrower rows, which the lane-group form serves with a ds_bpermute per field and per-lane row switches
-// (bf16 H=4 x F=64 at Reddit scale: 5.66 ms there).  A unit is a wave whatever the row width: the plan is built with
-// units = waves (geot_slab_units_for) and R rows of 64 x E fp32 accumulators per group.  Sum only (the multi-head modes).
+// Rows of 512 / 256 bytes: ONE ROW PER WAVE-INSTRUCTION, E = row elements / 64 per lane (8 or 4 bytes a lane) - the scalar path of
+// seg_slab_kernel's 1-KiB form (group bounds, row numbers and row switches in SGPRs, 32-bit row offsets on a scalar base) for the
+// narrower rows, which the lane-group form served with a ds_bpermute per field and per-lane row switches (round 4: multi-head
+// weights only - bf16 H=4 x F=64 at Reddit scale 5.66 -> 5.24 ms; round 5: every weight mode and reduction).  A unit is a wave
+// whatever the row width: the plan is built with units = waves (geot_slab_units_for) and R rows of 64 x E fp32 accumulators per
+// group.  WMODE 0 none | 1 weight[e] | 2 weight[e*H + h] | 3 weight[h*nnz + e]; p.w_in_plan_order (WMODE 1 / 2): the weight
+// array is indexed by PLAN position (a producer that emits its values in plan order - geot_slab_sddmm's staged results, a
+// static weight permuted once): no read through the edge permutation.  RED: sum | mean | max | min for WMODE 0 / 1 (multi-head: sum).
 template <typename T, int E> struct SlabRaw;                       // the lane's E elements as one load
 template <> struct SlabRaw<float, 1> { typedef float type; };
 template <> struct SlabRaw<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
@@ -446,17 +449,19 @@ template <typename T, int E> __device__ __forceinline__ typename SlabRaw<T, E>::
   }
 }
 
-template <typename T, int WMODE, int E>
-__global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) {
-  static_assert(WMODE == 2 || WMODE == 3, "multi-head weights");
+template <typename T, int WMODE, int E, int RED, int U>
+__global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
+  static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE <= 1 || RED == GEOT_REDUCE_SUM), "multi-head weights sum");
+  constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
+  constexpr bool kSel = RED == GEOT_REDUCE_MAX || RED == GEOT_REDUCE_MIN;
   typedef typename SlabRaw<T, E>::type raw_t;
   typedef typename SlabAcc<E>::type accv_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int R = P.rows_per_group;
-  const int hw = p.H;
-  // LDS: fp32 accumulators [4 waves][R rows][64 lanes][E], then the staged weights [4 waves][2 buffers][64 edge slots][H]
+  const int hw = WMODE <= 1 ? 1 : p.H;
+  // LDS: fp32 accumulators [4 waves][R rows][64 lanes][E], then the staged weights [4 waves][2 buffers][64 edge slots][hw]
   accv_t *accV = reinterpret_cast<accv_t *>(smem) + (size_t)wave * R * 64;
   float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 64 * E * sizeof(float)) + (size_t)wave * 2 * 64 * hw;
   const int wbuf_stride = 64 * hw;
@@ -465,7 +470,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) 
   const char *src = static_cast<const char *>(p.src);
   const T *weight = static_cast<const T *>(p.weight);
   T *dst = static_cast<T *>(p.dst);
-  const int h = (lane * E) / p.Fh;
+  const int h = WMODE >= 2 ? (lane * E) / p.Fh : 0;
+  const bool wpo = p.w_in_plan_order != 0;              // weights indexed by plan position
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = 4 + p.lpr_log2;                       // log2(row bytes)
   const uint32_t cB = (uint32_t)lane * (uint32_t)(E * sizeof(T));
@@ -518,12 +524,12 @@ __global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) 
       my_slot = -1;
     }
   };
-  auto zero = [] {
+  auto zero = [] {                                      // (the reduction's identity)
     accv_t z;
-    if constexpr (E == 1) z = 0.f;
+    if constexpr (E == 1) z = kIdent;
     else {
 #pragma unroll
-      for (int i = 0; i < E; ++i) z[i] = 0.f;
+      for (int i = 0; i < E; ++i) z[i] = kIdent;
     }
     return z;
   };
@@ -547,14 +553,17 @@ __global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) 
       my_src = valid ? P.e_src[e0 + lane] : 0;
       if ((uint32_t)my_src >= src_rows) my_src = 0;
       my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
-      const int64_t pe = valid ? (int64_t)P.e_perm[e0 + lane] : 0;
-      if constexpr (WMODE == 2) {
-        if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + lane * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
-        else for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
-      } else {
-        for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
+      if constexpr (WMODE != 0) {
+        const int64_t pe = valid ? (wpo ? e0 + lane : (int64_t)P.e_perm[e0 + lane]) : 0;
+        if constexpr (WMODE == 1) wbase[lane] = valid ? (float)weight[pe] : 0.f;
+        else if constexpr (WMODE == 2) {
+          if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + lane * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
+          else for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
+        } else {
+          for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     }
 
     int k = 0;
@@ -566,48 +575,57 @@ __global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) 
       int n_src = nvalid ? P.e_src[ne] : 0;
       if ((uint32_t)n_src >= src_rows) n_src = 0;
       const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
-      const int64_t n_pe = nvalid ? (int64_t)P.e_perm[ne] : 0;
+      int64_t n_pe = 0;
+      if constexpr (WMODE != 0) n_pe = nvalid ? (wpo ? ne : (int64_t)P.e_perm[ne]) : 0;
       f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
+      float wn1 = 0.f;
       int n_max = len - off;
       n_max = n_max < 64 ? n_max : 64;
-      for (int b = 0; b < n_max; b += kU) {
+      for (int b = 0; b < n_max; b += U) {
         if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
-        raw_t v[kU];
-        int dls[kU];
-        float ws[kU];
+        raw_t v[U];
+        int dls[U];
+        float ws[U];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {       // (slots behind the last edge: row 0, dl = 255, weight 0 - see seg_slab_kernel)
+        for (int u = 0; u < U; ++u) {       // (slots behind the last edge: row 0, dl = 255, weight 0 - see seg_slab_kernel)
           const uint32_t row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
           dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
-          ws[u] = wcur[(b + u) * hw + h];
+          if constexpr (WMODE != 0) ws[u] = wcur[(b + u) * hw + h];
           v[u] = *reinterpret_cast<const raw_t *>(src + (size_t)((row << rsh) + cB));
+        }
+        if constexpr (WMODE == 1) {
+          if (b == 0 && nvalid) wn1 = (float)weight[n_pe];
         }
         if constexpr (WMODE == 2) {
           if (b == 0 && p.H == 4 && nvalid) wn4 = load_w4(n_pe);
         }
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
+        for (int u = 0; u < U; ++u) {
           if (dls[u] != cur) {
             if (cur != 255) accV[(size_t)cur * 64 + lane] = acc;
             cur = dls[u];
             acc = cur != 255 ? accV[(size_t)cur * 64 + lane] : zero();
           }
-          float m[E];
-          mhrow_unpack<T, E>(v[u], m);
-          if constexpr (E == 1) acc += m[0] * ws[u];
-          else {
+          if (!kSel || dls[u] != 255) {      // (a max / min must not see the padding slots' values; their sums go to a row never written back)
+            float m[E];
+            mhrow_unpack<T, E>(v[u], m);
+            const float wu = WMODE != 0 ? ws[u] : 1.f;
+            if constexpr (E == 1) acc = slab_op<RED>(acc, WMODE != 0 ? m[0] * wu : m[0]);
+            else {
 #pragma unroll
-            for (int i = 0; i < E; ++i) acc[i] += m[i] * ws[u];
+              for (int i = 0; i < E; ++i) acc[i] = slab_op<RED>(acc[i], WMODE != 0 ? m[i] * wu : m[i]);
+            }
           }
         }
       }
-      if constexpr (WMODE == 2) {
+      if constexpr (WMODE == 1) wnext[lane] = wn1;
+      else if constexpr (WMODE == 2) {
         if (p.H == 4) *reinterpret_cast<f4_t *>(wnext + lane * 4) = wn4;
         else for (int q = 0; q < p.H; ++q) wnext[lane * hw + q] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
-      } else {
+      } else if constexpr (WMODE == 3) {
         for (int q = 0; q < p.H; ++q) wnext[lane * hw + q] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
       }
-      __builtin_amdgcn_wave_barrier();
+      if constexpr (WMODE != 0) __builtin_amdgcn_wave_barrier();
       my_src = n_src;
       my_dl = n_dl;
     }
@@ -626,6 +644,13 @@ __global__ __launch_bounds__(kThreads) void seg_slab_mhrow_kernel(SlabParams p) 
         else {
 #pragma unroll
           for (int i = 0; i < E; ++i) m[i] = row[i];
+        }
+        if constexpr (RED == GEOT_REDUCE_MEAN) {
+          if (t >= 0) {                                        // (pieces of a split row are divided after the combine)
+            const float tot = (float)P.v_total[v0 + l];
+#pragma unroll
+            for (int i = 0; i < E; ++i) m[i] = m[i] / tot;
+          }
         }
         if (t >= 0) {
           if (t < p.K) *reinterpret_cast<raw_t *>(dst + t * p.F + lane * E) = mhrow_pack<T, E>(m);   // one rounding, here
@@ -662,6 +687,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = WAVE_ROW ? 10 : 4 + p.lpr_log2;   // log2(row bytes)
   const uint32_t c16 = (uint32_t)c * 16u;
+  int lph_log2 = WAVE_ROW ? 6 : p.lpr_log2;          // lanes per head (H = 1, 2, 4, 8 on whole-wave rows; the launcher checks)
+  for (int hh = p.H; hh > 1; hh >>= 1) --lph_log2;
+  const int lph = 1 << lph_log2;
 
   int my_slot = -1;
   int *xprog = nullptr;
@@ -803,13 +831,185 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
           const float keep = b2 ? t2[1] : t2[0], give = b2 ? t2[0] : t2[1];
           s1 = keep + __shfl_xor(give, 4, 64);
         }
-        for (int o = 8; o < lpr; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        // (multi-head rows [H, Fh] - the backward of mh_spmm: a dot product per head, reduced over the lph = lpr / H lanes of a head;
+        //  the results of an edge are H neighbours: out[idx * H + h])
+        for (int o = 8; o < lph; o <<= 1) s1 += __shfl_xor(s1, o, 64);
         const int j = 4 * (c & 1) + 2 * ((c >> 1) & 1) + ((c >> 2) & 1);
         const int pe = __shfl(my_pe, b + j, lpr);          // original edge id of the batch's j-th edge
         // staged form (geot_slab_sddmm_staged): the 8 results of a batch go to 8 consecutive plan positions - one 32-byte piece;
         // slab_unstage_kernel then brings them into edge order.  Straight to out[original edge id] every result is its own
         // partial write: 3.6 GB written for 0.46 GB of results at 115 M edges, 5.5 ms instead of 3.7 (profiles/r04/pmc_sddmm.txt)
-        if (c < 8 && b + j < n_here) out[p.w_in_plan_order ? e0 + off + b + j : (int64_t)pe] = (T)s1;
+        if ((c & (lph - 1)) < 8 && b + j < n_here)
+          out[(p.w_in_plan_order ? e0 + off + b + j : (int64_t)pe) * p.H + (c >> lph_log2)] = (T)s1;
+      }
+      my_src = n_src;
+      my_dl = n_dl;
+      my_pe = n_pe;
+    }
+    if (p.window >= 0 && my_slot >= 0) {
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
+    }
+  }
+  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+}
+
+// The same SDDMM for rows of 512 / 256 bytes, ONE ROW PER WAVE-INSTRUCTION (E elements per lane; see seg_slab_wrow_kernel): the forward
+// and the SDDMM of its backward share one plan, whose units are waves.  The dot products reduce over the 64 / H lanes of a head.
+template <typename T, int E>
+__global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParams p) {
+  typedef typename SlabRaw<T, E>::type raw_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int R = P.rows_per_group;
+  raw_t *rowV = reinterpret_cast<raw_t *>(smem) + (size_t)wave * R * 64;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t units = P.units;
+  const char *m2 = static_cast<const char *>(p.src);
+  const T *m1 = static_cast<const T *>(p.weight);           // (the dst-side matrix travels in the `weight` slot)
+  T *out = static_cast<T *>(p.dst);
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+  const int rsh = 4 + p.lpr_log2;                            // log2(row bytes)
+  const uint32_t cB = (uint32_t)lane * (uint32_t)(E * sizeof(T));
+  int lph_log2 = 6;
+  for (int hh = p.H; hh > 1; hh >>= 1) --lph_log2;
+  const int lph = 1 << lph_log2;
+
+  int my_slot = -1;
+  int *xprog = nullptr;
+  if (p.window >= 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  int published = -1, known_min = -1, timeouts = 0;
+  auto slab_sync = [&](int step) {              // (as in seg_slab_kernel: every wait bounded, and bounded in aggregate)
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return;
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      known_min = m;
+      if (m + p.window >= step || step - m > p.far) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
+    }
+  };
+  auto raw_zero = [] {
+    raw_t z;
+    if constexpr (sizeof(raw_t) == 4) z = raw_t(0);
+    else z = raw_t{0, 0};
+    return z;
+  };
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    const bool has = pos < P.n_groups;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+    len = __builtin_amdgcn_readfirstlane(len);
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    const int64_t v0 = has ? P.g_vrow0[pos] : 0;
+    for (int l = 0; l < nv; ++l) {                       // the group's m1 rows (pieces of a split hub share their row)
+      const int64_t row = P.v_row[v0 + l];
+      rowV[(size_t)l * 64 + lane] = (row >= 0 && row < p.K) ? *reinterpret_cast<const raw_t *>(m1 + row * p.F + lane * E) : raw_zero();
+    }
+    int cur = 255;
+    float mrow[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) mrow[i] = 0.f;
+    int my_src = 0, my_dl = 255, my_pe = 0;
+    {
+      const bool valid = lane < len;
+      my_src = valid ? P.e_src[e0 + lane] : 0;
+      my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
+      my_pe = valid ? P.e_perm[e0 + lane] : 0;
+      if ((uint32_t)my_src >= src_rows) { my_src = 0; my_dl = 255; }   // out-of-range source: the dot is 0
+    }
+    for (int off = 0; off < len; off += 64) {
+      const bool nvalid = off + 64 + lane < len;
+      const int64_t ne = e0 + off + 64 + lane;
+      int n_src = nvalid ? P.e_src[ne] : 0;
+      int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      const int n_pe = nvalid ? P.e_perm[ne] : 0;
+      if ((uint32_t)n_src >= src_rows) { n_src = 0; n_dl = 255; }
+      const int n_here = len - off;
+      const int n_max = n_here < 64 ? n_here : 64;
+      for (int b = 0; b < n_max; b += kU) {
+        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
+        raw_t v[kU];
+        int dls[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {           // (slots behind the last edge hold row 0 and dl = 255: the dot is 0)
+          const uint32_t row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
+          dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
+          v[u] = *reinterpret_cast<const raw_t *>(m2 + (size_t)((row << rsh) + cB));
+        }
+        float pd[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (dls[u] != cur) {
+            cur = dls[u];
+            if (cur != 255) mhrow_unpack<T, E>(rowV[(size_t)cur * 64 + lane], mrow);
+            else {
+#pragma unroll
+              for (int i = 0; i < E; ++i) mrow[i] = 0.f;
+            }
+          }
+          float x[E];
+          mhrow_unpack<T, E>(v[u], x);
+          float dot = 0.f;
+#pragma unroll
+          for (int i = 0; i < E; ++i) dot += x[i] * mrow[i];
+          pd[u] = dot;
+        }
+        // 8 values x 64 lanes -> lane l with (l mod lph) < 8 holds the total of value 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1) of head l / lph
+        const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+        float q[4], t2[2], s1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float keep = b0 ? pd[i + 4] : pd[i], give = b0 ? pd[i] : pd[i + 4];
+          q[i] = keep + __shfl_xor(give, 1, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float keep = b1 ? q[i + 2] : q[i], give = b1 ? q[i] : q[i + 2];
+          t2[i] = keep + __shfl_xor(give, 2, 64);
+        }
+        {
+          const float keep = b2 ? t2[1] : t2[0], give = b2 ? t2[0] : t2[1];
+          s1 = keep + __shfl_xor(give, 4, 64);
+        }
+        for (int o = 8; o < lph; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const int j = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+        const int pe = __shfl(my_pe, b + j, 64);
+        if ((lane & (lph - 1)) < 8 && b + j < n_here)
+          out[(p.w_in_plan_order ? e0 + off + b + j : (int64_t)pe) * p.H + (lane >> lph_log2)] = (T)s1;
       }
       my_src = n_src;
       my_dl = n_dl;
@@ -970,6 +1170,8 @@ int g_slab_window = -2;
 // Such a wave does not wait.  On graphs without locality all waves sweep the table together and never get that far apart.
 int g_slab_far = 12;
 int g_slab_nt = 0;      // "slab_nt": experiment, see SlabParams::nt_plan
+int g_slab_unroll = 8;  // "slab_unroll": 8 | 16 row loads in flight per lane of the row-per-wave kernel (sums)
+int g_slab_tight = 1;   // "slab_tight": 1 = the window of 1 slab for per-call weights on dense graphs (the round-4 rule), 0 = always 2
 int g_slab_turn = 1;    // "slab_turn": 1 = the persistent grids of this process take turns on a device (see SlabTurn), 0 = launch freely
 
 int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
@@ -1014,20 +1216,22 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype) {
 }
 int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_rows_per_group_dtype(weight_mode, heads, GEOT_F32); }
 
-// Multi-head plans over rows of 512 / 256 bytes run one row per wave-instruction (seg_slab_mhrow_kernel): a unit is a WAVE whatever
-// the row width, and a group's rows are 64 x E fp32 accumulators (E = row elements / 64).  Everything else: a unit is the
-// rowbytes / 16 lanes of a row (seg_slab_kernel).
-static bool slab_mhrow(int weight_mode, int64_t rowbytes) { return weight_mode >= 2 && weight_mode <= 3 && (rowbytes == 512 || rowbytes == 256); }
+// Rows of 512 / 256 bytes run one row per wave-instruction (seg_slab_wrow_kernel, seg_slab_sddmm_wrow_kernel), rows of 1 KiB too
+// (seg_slab_kernel's WAVE_ROW form): a unit is a WAVE for every row of >= 256 bytes, whatever the weight mode, and a group's rows are
+// 64 x E fp32 accumulators (E = row elements / 64).  Only 128-byte rows (off the automatic rule) keep lane groups of 8.
+static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 int geot_slab_units_for(int weight_mode, int64_t rowbytes) {
-  if (slab_mhrow(weight_mode, rowbytes) || rowbytes >= 1024 || rowbytes < 16) return geot_slab_units();
+  (void)weight_mode;
+  if (rowbytes >= 256 || rowbytes < 16) return geot_slab_units();
   return geot_slab_units() * (int)(1024 / rowbytes);
 }
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes) {
-  if (!slab_mhrow(weight_mode, rowbytes)) return geot_slab_rows_per_group_dtype(weight_mode, heads, dtype);
+  if (!slab_wrow(rowbytes)) return geot_slab_rows_per_group_dtype(weight_mode, heads, dtype);
   const size_t row = (size_t)(rowbytes / (dtype == GEOT_F32 ? 4 : 2)) * sizeof(float);   // a group row's accumulators
   const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (slab_device().lds - 4 * 1024) / g_slab_blocks / 1024 * 1024;
+  const size_t hw = weight_mode == 0 ? 0 : ((weight_mode == 1 || weight_mode == 4) ? 1 : (size_t)heads);
   int r = 32;
-  while (r > 1 && (size_t)4 * r * row + (size_t)4 * 2 * 64 * (size_t)heads * sizeof(float) > budget) --r;
+  while (r > 1 && (size_t)4 * r * row + (size_t)4 * 2 * 64 * hw * sizeof(float) > budget) --r;
   return r;
 }
 
@@ -1040,8 +1244,10 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
                    int64_t heads, int64_t feat, int64_t src_rows, int64_t out_rows, int dtype, int reduce, void *workspace,
                    size_t workspace_bytes, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool w_in_plan_order = weight_mode == 4;   // mode 4 = mode 1 with weight[] already permuted into plan order
-  if (w_in_plan_order) weight_mode = 1;
+  // mode 4 = mode 1, mode 5 = mode 2 (edge-major [nnz, heads]) with weight[] already in the PLAN's edge order
+  const bool w_in_plan_order = weight_mode == 4 || weight_mode == 5;
+  if (weight_mode == 4) weight_mode = 1;
+  if (weight_mode == 5) weight_mode = 2;
   if (!plan || !src || !dst) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: null pointer");
   if (dtype != GEOT_F32 && dtype != GEOT_F16 && dtype != GEOT_BF16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: float32, float16 or bfloat16");
   const int tsize = dtype == GEOT_F32 ? 4 : 2, vec = 16 / tsize, nv = vec / 4;
@@ -1052,7 +1258,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (reduce == GEOT_REDUCE_MEAN && (!plan->v_total || (plan->n_split > 0 && !plan->c_total)))
     return geot_internal_fail(GEOT_EINVAL, "slab_spmm: mean needs the plan's edge counts (v_total, c_total)");
   if (weight_mode < 0 || weight_mode > 3 || (weight_mode != 0 && !weight))
-    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: weight_mode 0..4 (and a weight pointer for 1..4)");
+    return geot_internal_fail(GEOT_EINVAL, "slab_spmm: weight_mode 0..5 (and a weight pointer for 1..5)");
   const int64_t F = heads * feat;
   const int64_t rowbytes = F * tsize;
   int lpr_log2 = -1;
@@ -1063,7 +1269,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (src_rows < 0 || (uint64_t)src_rows * (uint64_t)rowbytes > ((uint64_t)1 << 32))
     return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: source table of at most 4 GiB (32-bit row offsets; the kernel is for tables a slab sweep can cover)");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
-  const bool mhrow = slab_mhrow(weight_mode, rowbytes);            // one row per wave-instruction: a unit is a wave
+  const bool mhrow = slab_wrow(rowbytes);                          // one row per wave-instruction: a unit is a wave
   const int per_wave = mhrow ? 1 : (64 >> lpr_log2);
   const int64_t waves = plan->units / per_wave;
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
@@ -1072,7 +1278,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
                                            "(geot_slab_units_for)");
   if (plan->rows_per_group < 1 || plan->rows_per_group > 32) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group 1..32");
   const int el = (int)(F / 64);                                    // (mhrow) elements per lane
-  if (mhrow && (feat % el != 0 || F % 64 != 0)) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of row elements / 64");
+  if (mhrow && weight_mode >= 2 && (feat % el != 0 || F % 64 != 0)) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of row elements / 64");
   if (heads > 16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: at most 16 heads");
   const size_t need = geot_slab_workspace_bytes(plan, F);
   if (!workspace || workspace_bytes < need) return geot_internal_fail(GEOT_EWORKSPACE, "slab_spmm: workspace too small");
@@ -1095,7 +1301,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   // costs 3 % at 2.3 uses, profiles/r04/bench_slab_density_rule.txt: 7.60 vs 7.36 ms)
   const int64_t rounds_ = (plan->n_groups + plan->units - 1) / (plan->units > 0 ? plan->units : 1);
   const double uses = (double)plan->nnz / (double)(rounds_ > 0 ? rounds_ : 1) / 8.0 / (double)(src_rows > 0 ? src_rows : 1);
-  const int tight = (weight_mode == 1 && !w_in_plan_order && lpr_log2 < 6 && uses >= 4.0) ? 1 : 2;   // (a weight in plan order streams: 3.52 vs 3.56 ms at 2)
+  const int tight = (weight_mode == 1 && !w_in_plan_order && lpr_log2 < 6 && uses >= 4.0 && g_slab_tight) ? 1 : 2;   // (a weight in plan order streams: 3.52 vs 3.56 ms at 2)
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : tight) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
@@ -1116,7 +1322,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   }
   if (plan->n_groups > 0) {
-    const size_t lds = mhrow ? (size_t)4 * plan->rows_per_group * 64 * el * sizeof(float) + (size_t)4 * 2 * 64 * (size_t)heads * sizeof(float)
+    const size_t hw_lds = weight_mode == 0 ? 0 : (weight_mode == 1 ? 1 : (size_t)heads);
+    const size_t lds = mhrow ? (size_t)4 * plan->rows_per_group * 64 * el * sizeof(float) + (size_t)4 * 2 * 64 * hw_lds * sizeof(float)
                              : slab_lds_bytes(plan->rows_per_group, weight_mode, heads, nv);
     if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_shape)");
     const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
@@ -1146,18 +1353,37 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   case 2: GEOT_SLAB_LAUNCH(T_, 2, GEOT_REDUCE_SUM); break;                                                    \
   default: GEOT_SLAB_LAUNCH(T_, 3, GEOT_REDUCE_SUM); break;                                                   \
   }
-#define GEOT_SLAB_MHROW(T_, E_)                                                                               \
+#define GEOT_SLAB_WROW_U(T_, W, E_, RED_, U_)                                                                 \
   do {                                                                                                        \
-    geot_internal_note_kernel((std::string("seg_slab_mhrow_kernel<") + slab_tname<T_>() + ", " + std::to_string(weight_mode) + ", " #E_ ">").c_str()); \
-    if (weight_mode == 2) hipLaunchKernelGGL((seg_slab_mhrow_kernel<T_, 2, E_>), grid, blk, lds, st, p);      \
-    else hipLaunchKernelGGL((seg_slab_mhrow_kernel<T_, 3, E_>), grid, blk, lds, st, p);                       \
-    if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p);    \
+    geot_internal_note_kernel((std::string("seg_slab_wrow_kernel<") + slab_tname<T_>() + ", " #W ", " #E_ ", " + std::to_string((int)RED_) + ", " #U_ ">").c_str()); \
+    hipLaunchKernelGGL((seg_slab_wrow_kernel<T_, W, E_, RED_, U_>), grid, blk, lds, st, p);                  \
+    if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, RED_>), cgrid, blk, 0, st, p);               \
   } while (0)
+  // (16 loads in flight per lane: an experiment switch, "slab_unroll"; instantiated for the sums only)
+#define GEOT_SLAB_WROW(T_, W, E_, RED_)                                                                       \
+  do {                                                                                                        \
+    if (RED_ == GEOT_REDUCE_SUM && g_slab_unroll == 16) GEOT_SLAB_WROW_U(T_, W, E_, GEOT_REDUCE_SUM, 16);     \
+    else GEOT_SLAB_WROW_U(T_, W, E_, RED_, 8);                                                                \
+  } while (0)
+#define GEOT_SLAB_WROW_RED(T_, W, E_)                                                                         \
+  switch (reduce) {                                                                                           \
+  case GEOT_REDUCE_MEAN: GEOT_SLAB_WROW(T_, W, E_, GEOT_REDUCE_MEAN); break;                                  \
+  case GEOT_REDUCE_MAX: GEOT_SLAB_WROW(T_, W, E_, GEOT_REDUCE_MAX); break;                                    \
+  case GEOT_REDUCE_MIN: GEOT_SLAB_WROW(T_, W, E_, GEOT_REDUCE_MIN); break;                                    \
+  default: GEOT_SLAB_WROW(T_, W, E_, GEOT_REDUCE_SUM); break;                                                 \
+  }
+#define GEOT_SLAB_WROW_MODE(T_, E_)                                                                           \
+  switch (weight_mode) {                                                                                      \
+  case 0: GEOT_SLAB_WROW_RED(T_, 0, E_) break;                                                                \
+  case 1: GEOT_SLAB_WROW_RED(T_, 1, E_) break;                                                                \
+  case 2: GEOT_SLAB_WROW(T_, 2, E_, GEOT_REDUCE_SUM); break;                                                  \
+  default: GEOT_SLAB_WROW(T_, 3, E_, GEOT_REDUCE_SUM); break;                                                 \
+  }
     const int rc = g_turn.take(st, [&]() -> int {
       if (mhrow) {
-        if (dtype == GEOT_F32) { if (el == 2) GEOT_SLAB_MHROW(float, 2); else GEOT_SLAB_MHROW(float, 1); }
-        else if (dtype == GEOT_F16) { if (el == 4) GEOT_SLAB_MHROW(half_t, 4); else GEOT_SLAB_MHROW(half_t, 2); }
-        else { if (el == 4) GEOT_SLAB_MHROW(bf16_t, 4); else GEOT_SLAB_MHROW(bf16_t, 2); }
+        if (dtype == GEOT_F32) { if (el == 2) { GEOT_SLAB_WROW_MODE(float, 2) } else { GEOT_SLAB_WROW_MODE(float, 1) } }
+        else if (dtype == GEOT_F16) { if (el == 4) { GEOT_SLAB_WROW_MODE(half_t, 4) } else { GEOT_SLAB_WROW_MODE(half_t, 2) } }
+        else { if (el == 4) { GEOT_SLAB_WROW_MODE(bf16_t, 4) } else { GEOT_SLAB_WROW_MODE(bf16_t, 2) } }
       }
       else if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
       else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
@@ -1165,7 +1391,10 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
       const hipError_t le = hipGetLastError();
       return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
     });
-#undef GEOT_SLAB_MHROW
+#undef GEOT_SLAB_WROW_MODE
+#undef GEOT_SLAB_WROW_RED
+#undef GEOT_SLAB_WROW
+#undef GEOT_SLAB_WROW_U
 #undef GEOT_SLAB_MODE
 #undef GEOT_SLAB_RED
 #undef GEOT_SLAB_LAUNCH
@@ -1174,31 +1403,45 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   return GEOT_OK;
 }
 
-static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging,
-                           int64_t feat, int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+// staging != NULL: the persistent kernel writes its results in the plan's edge order into `staging`; `unstage`: a second kernel brings
+// them into original edge order in `out` (otherwise plan order IS the result and `out` is not touched)
+static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t heads,
+                           int64_t feat, int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream,
+                           bool unstage = true) {
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!plan || !mat_1 || !mat_2 || !out) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: null pointer");
+  if (!plan || !mat_1 || !mat_2 || (!out && (unstage || !staging))) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: null pointer");
   if (dtype != GEOT_F32 && dtype != GEOT_F16 && dtype != GEOT_BF16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: float32, float16 or bfloat16");
   if (!plan->v_row) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan has no v_row table");
-  const int64_t rowbytes = feat * (dtype == GEOT_F32 ? 4 : 2);
+  if (heads < 1 || feat < 1) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: bad sizes");
+  const int tsize = dtype == GEOT_F32 ? 4 : 2;
+  const int64_t F = heads * feat;
+  const int64_t rowbytes = F * tsize;
   int lpr_log2 = -1;
   for (int l = 4; l <= 6; ++l)
     if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
   if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: rows of 256, 512 or 1024 bytes only");
+  // a dot product per head is reduced over the 64 / heads lanes of the head: heads 1, 2, 4 or 8, at least 8 lanes each
+  if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 1, 2, 4 or 8 heads");
   if ((((uintptr_t)mat_1) | ((uintptr_t)mat_2) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 16-byte aligned operands");
   if (rows_2 < 0 || (uint64_t)rows_2 * (uint64_t)rowbytes > ((uint64_t)1 << 32))
     return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: mat_2 of at most 4 GiB (32-bit row offsets)");
-  const int64_t waves = plan->units / (64 >> lpr_log2);
+  const int64_t waves = plan->units;                       // rows of >= 256 bytes: a unit is a wave (geot_slab_units_for)
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
-  if (plan->units % (64 >> lpr_log2) != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
+  if (waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
     return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan's unit count is not a whole number of 4-wave workgroups, at most 4 per CU of this device");
+  if (plan->rows_per_group < 1 || plan->rows_per_group > 32) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: rows_per_group 1..32");
   if (!workspace || workspace_bytes < 256 + kSyncBytes) return geot_internal_fail(GEOT_EWORKSPACE, "slab_sddmm: workspace too small");
+  const size_t lds = (size_t)4 * plan->rows_per_group * (size_t)rowbytes;       // the group's mat_1 rows, storage type
+  if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_shape)");
+  const bool staged = staging != nullptr;
+  const int64_t ebytes = heads * tsize;                    // one edge's results
+  if (staged && unstage && ebytes != 2 && ebytes != 4 && ebytes != 8 && ebytes != 16)
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm_staged: heads x element size of 2, 4, 8 or 16 bytes");
   if (plan->n_groups == 0) return GEOT_OK;
   SlabParams p;
   p.plan = *plan;
   p.weight = mat_1;
   p.src = mat_2;
-  const bool staged = staging != nullptr;
   p.dst = staged ? staging : out;
   p.carry = nullptr;
   p.far = g_slab_far;
@@ -1206,8 +1449,8 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   p.w_in_plan_order = staged ? 1 : 0;
   p.src_rows = rows_2;
   p.K = rows_1;
-  p.F = feat;
-  p.H = 1;
+  p.F = F;
+  p.H = (int)heads;
   p.Fh = (int)feat;
   p.rowbytes = (uint32_t)rowbytes;
   p.lpr_log2 = lpr_log2;
@@ -1222,43 +1465,58 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
     e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   }
-  const size_t lds = (size_t)4 * plan->rows_per_group * 1024;
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
-#define GEOT_SLAB_SDDMM(T_)                                                                                  \
+  const int el = (int)(F / 64);                            // (rows of 512 / 256 bytes) elements per lane
+#define GEOT_SLAB_SDDMM(T_, E2_, E1_)                                                                        \
   do {                                                                                                        \
     if (lpr_log2 == 6) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, true>), grid, blk, lds, st, p);          \
-    else hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, false>), grid, blk, lds, st, p);                       \
+    else if (el == E2_) hipLaunchKernelGGL((seg_slab_sddmm_wrow_kernel<T_, E2_>), grid, blk, lds, st, p);     \
+    else hipLaunchKernelGGL((seg_slab_sddmm_wrow_kernel<T_, E1_>), grid, blk, lds, st, p);                    \
   } while (0)
   const int rc = g_turn.take(st, [&]() -> int {
-    if (dtype == GEOT_F32) GEOT_SLAB_SDDMM(float);
-    else if (dtype == GEOT_F16) GEOT_SLAB_SDDMM(half_t);
-    else GEOT_SLAB_SDDMM(bf16_t);
+    if (dtype == GEOT_F32) GEOT_SLAB_SDDMM(float, 2, 1);
+    else if (dtype == GEOT_F16) GEOT_SLAB_SDDMM(half_t, 4, 2);
+    else GEOT_SLAB_SDDMM(bf16_t, 4, 2);
     const hipError_t le = hipGetLastError();
     return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
   });
 #undef GEOT_SLAB_SDDMM
-  if (rc != GEOT_OK || !staged) return rc;
+  if (rc != GEOT_OK || !staged || !unstage) return rc;
   int64_t ublocks = plan->n_groups < (int64_t)slab_device().cus * 8 ? plan->n_groups : (int64_t)slab_device().cus * 8;
   constexpr int kTileBytes = 48 * 1024;                    // (a group of configs[3]'s plans: ~6 000 results)
-  if (dtype == GEOT_F32)
-    hipLaunchKernelGGL((slab_unstage_kernel<float>), dim3((unsigned)ublocks), dim3(kThreads), kTileBytes, st, plan->g_begin, plan->e_perm,
-                       static_cast<const float *>(staging), static_cast<float *>(out), plan->n_groups, kTileBytes / 4);
-  else
-    hipLaunchKernelGGL((slab_unstage_kernel<uint16_t>), dim3((unsigned)ublocks), dim3(kThreads), kTileBytes, st, plan->g_begin, plan->e_perm,
-                       static_cast<const uint16_t *>(staging), static_cast<uint16_t *>(out), plan->n_groups, kTileBytes / 2);
+#define GEOT_UNSTAGE(ET_)                                                                                     \
+  hipLaunchKernelGGL((slab_unstage_kernel<ET_>), dim3((unsigned)ublocks), dim3(kThreads), kTileBytes, st, plan->g_begin, plan->e_perm, \
+                     static_cast<const ET_ *>(staging), static_cast<ET_ *>(out), plan->n_groups, kTileBytes / (int)sizeof(ET_))
+  if (ebytes == 2) GEOT_UNSTAGE(uint16_t);
+  else if (ebytes == 4) GEOT_UNSTAGE(float);
+  else if (ebytes == 8) GEOT_UNSTAGE(uint64_t);
+  else GEOT_UNSTAGE(f4_t);
+#undef GEOT_UNSTAGE
   const hipError_t ue = hipGetLastError();
   return ue == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(ue));
 }
 
 int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, int64_t feat, int64_t rows_1,
                     int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
-  return slab_sddmm_impl(plan, mat_1, mat_2, out, nullptr, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream);
+  return slab_sddmm_impl(plan, mat_1, mat_2, out, nullptr, 1, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream);
 }
 
 int geot_slab_sddmm_staged(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t feat,
                            int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
   if (!staging) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm_staged: null staging buffer");
-  return slab_sddmm_impl(plan, mat_1, mat_2, out, staging, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream);
+  return slab_sddmm_impl(plan, mat_1, mat_2, out, staging, 1, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream);
+}
+
+// Multi-head form (d/dweight of geot_mh_spmm over the plan of its forward): out(e, h) = <mat_1[dst(e), h, :], mat_2[src(e), h, :]>,
+// out[e * heads + h] (edge-major, the layout the source-blocked forward reads).  out == NULL: the results stay in `staging`, in the
+// PLAN's edge order - what geot_slab_spmm's weight_mode 5 reads back without a permutation (attention: SDDMM -> per-row softmax in
+// plan order -> SpMM).  heads 1 / 2 / 4 / 8, heads x element size <= 16 bytes.
+int geot_slab_mh_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t heads, int64_t feat,
+                       int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!staging && !out) return geot_internal_fail(GEOT_EINVAL, "slab_mh_sddmm: null output");
+  if (!out)     // plan order is the result: the persistent kernel writes it, no second step
+    return slab_sddmm_impl(plan, mat_1, mat_2, nullptr, staging, heads, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream, false);
+  return slab_sddmm_impl(plan, mat_1, mat_2, out, staging, heads, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream);
 }
 
 void geot_internal_slab_option(const char *name, int value) {
@@ -1266,6 +1524,8 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_turn") g_slab_turn = value != 0;
   if (name && std::string(name) == "slab_far" && value >= 0) g_slab_far = value;
   if (name && std::string(name) == "slab_nt") g_slab_nt = value != 0;
+  if (name && std::string(name) == "slab_unroll" && (value == 8 || value == 16)) g_slab_unroll = value;
+  if (name && std::string(name) == "slab_tight") g_slab_tight = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 

@@ -122,11 +122,14 @@ at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, 
     else {
       hipStream_t st = static_cast<hipStream_t>(stream_of(on));
       constexpr int kEv = 2 * kTrialReps + 1;
-      hipEvent_t ev[kEv] = {};
-      for (hipEvent_t &e : ev) TORCH_CHECK(hipEventCreate(&e) == hipSuccess, "hipEventCreate failed");
-      auto destroy = [&]() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); };
+      struct Events {                                               // (RAII: a failure part-way through creates no leak, every exit destroys)
+        hipEvent_t e[kEv] = {};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+      } evs;
+      hipEvent_t *ev = evs.e;
+      for (int i = 0; i < kEv; ++i) TORCH_CHECK(hipEventCreate(&ev[i]) == hipSuccess, "hipEventCreate failed");
       at::Tensor o2 = at::empty_like(o);
-      try {
+      {
         bool plan_ok = run_plan(o);                                 // untimed: warms both paths
         run_edges(o2);
         TORCH_CHECK(hipEventRecord(ev[0], st) == hipSuccess, "hipEventRecord failed");
@@ -137,7 +140,6 @@ at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, 
           TORCH_CHECK(hipEventRecord(ev[2 * r + 2], st) == hipSuccess, "hipEventRecord failed");
         }
         if (!plan_ok) {                                             // (released under our feet: cannot happen while we hold trial_mu, but stay safe)
-          destroy();
           run_edges(o);
           return o;
         }
@@ -150,7 +152,6 @@ at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, 
           t_plan = std::min(t_plan, a);
           t_edges = std::min(t_edges, b);
         }
-        destroy();
         plan->trial_ms[kind][0] = t_plan;
         plan->trial_ms[kind][1] = t_edges;
         const bool keep_plan = t_plan <= t_edges;
@@ -176,9 +177,6 @@ at::Tensor plan_or_edges(const std::shared_ptr<SlabPlanHolder> &plan, int kind, 
           }
         }
         return keep_plan ? o : o2;
-      } catch (...) {
-        destroy();
-        throw;
       }
     }
   }
@@ -575,6 +573,27 @@ at::Tensor sddmm_coo_op(const at::Tensor &si_in, const at::Tensor &di_in, const 
   return out;
 }
 
+// d/dweight of mh_spmm: out(e, h) = <mat_1[dst_index[e], h, :], mat_2[src_index[e], h, :]>, laid out like the weight it is the
+// gradient of - [nnz, H] or (head_major) [H, nnz].  The reference's mh_spmm has no backward (geot/mh_spmm.py:4-12); the pattern is
+// sddmm_coo_impl of the single-head op (geot/gather_weight_scatter.py:8-12,46-50).
+at::Tensor mh_sddmm_op(const at::Tensor &si_in, const at::Tensor &di_in, const at::Tensor &m1_in, const at::Tensor &m2_in, bool head_major) {
+  TORCH_CHECK(si_in.dim() == 1 && di_in.dim() == 1 && si_in.size(0) == di_in.size(0), "src_index and dst_index must be 1 dimensional");
+  TORCH_CHECK(m1_in.dim() == 3 && m2_in.dim() == 3 && m1_in.size(1) == m2_in.size(1) && m1_in.size(2) == m2_in.size(2),
+              "mat_1 and mat_2 must be 3 dimensional with the same heads and feature dimensions");
+  require_gpu("mh_sddmm", {&si_in, &di_in, &m1_in, &m2_in});
+  TORCH_CHECK(m1_in.scalar_type() == m2_in.scalar_type(), "expected mat_2 of dtype ", toString(m1_in.scalar_type()), " but found ",
+              toString(m2_in.scalar_type()));
+  GEOT_DEVICE_GUARD(m1_in);
+  at::Tensor si = as_int64(si_in), di = as_int64(di_in);
+  at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
+  const int64_t nnz = di.size(0), heads = m1.size(1), feat = m1.size(2);
+  at::Tensor out = head_major ? at::empty({heads, nnz}, m1.options()) : at::empty({nnz, heads}, m1.options());
+  if (nnz == 0 || heads == 0) return out;
+  GEOT_CALL(geot_mh_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), out.data_ptr(), nnz, heads, feat, m1.size(0), m2.size(0),
+                              head_major ? GEOT_W_HEAD_MAJOR : GEOT_W_EDGE_MAJOR, dtype_code(m1, "mh_sddmm"), stream_of(m1)));
+  return out;
+}
+
 
 // csrc/csr_gws.cpp:24-35: any integer dtype for indptr / indices; indptr.size(0) output rows (the last one always zero)
 at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in, const at::Tensor &weight_in, const at::Tensor &src_in) {
@@ -673,6 +692,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("gather_weight_scatter_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");
   m.def("mh_spmm_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");
   m.def("gather_rows(Tensor index, Tensor src) -> Tensor");
+  m.def("mh_sddmm(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2, bool head_major) -> Tensor");
   m.def("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)");
   m.def("transposed_weight(Tensor src_index, Tensor dst_index, Tensor weight) -> Tensor");
   m.def("transpose_edges_weighted(Tensor src_index, Tensor dst_index, Tensor weight) -> (Tensor, Tensor, Tensor, Tensor)");
@@ -699,6 +719,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.impl("gather_weight_scatter_rows", GUARDED(gather_weight_scatter_rows_op));               \
   m.impl("mh_spmm_rows", GUARDED(mh_spmm_rows_op));                                           \
   m.impl("gather_rows", GUARDED(gather_rows_op));                                             \
+  m.impl("mh_sddmm", GUARDED(mh_sddmm_op));                                                   \
   m.impl("transpose_edges", GUARDED(transpose_edges_op));                                     \
   m.impl("transposed_weight", GUARDED(transposed_weight_op));                               \
   m.impl("transpose_edges_weighted", GUARDED(transpose_edges_weighted_op))
@@ -722,6 +743,7 @@ TORCH_LIBRARY_IMPL(geot, CPU, m) {
   m.impl("gather_weight_scatter_rows", gather_weight_scatter_rows_op);
   m.impl("mh_spmm_rows", mh_spmm_rows_op);
   m.impl("gather_rows", gather_rows_cpu_op); // (the backward of the CPU index_scatter)
+  m.impl("mh_sddmm", mh_sddmm_op);
   m.impl("transpose_edges", transpose_edges_op);
   m.impl("transposed_weight", transposed_weight_op);
   m.impl("transpose_edges_weighted", transpose_edges_weighted_op);

@@ -223,6 +223,20 @@ def sddmm_coo_out(src_index, dst_index, mat_1, mat_2, out) -> torch.Tensor:
     return out
 
 
+def mh_sddmm_coo_out(src_index, dst_index, mat_1, mat_2, out, head_major: bool) -> torch.Tensor:
+    """out(e, h) = <mat_1[dst_index[e], h], mat_2[src_index[e], h]>; mat_* [rows, H, F]; out [nnz, H] or (head_major) [H, nnz]."""
+    dev = _require_gpu(src_index, dst_index, mat_1, mat_2, out)
+    L = _lib.load()
+    dt = _dtype_code(mat_1, "mh_sddmm_coo")
+    with _on_device(dev):
+        rc = L.geot_mh_sddmm_coo(_index_ptr(src_index, "src_index"), _index_ptr(dst_index, "dst_index"),
+                                 mat_1.data_ptr(), mat_2.data_ptr(), out.data_ptr(), dst_index.numel(), mat_1.shape[1], mat_1.shape[2],
+                                 mat_1.shape[0], mat_2.shape[0], _lib.GEOT_W_HEAD_MAJOR if head_major else _lib.GEOT_W_EDGE_MAJOR, dt,
+                                 _stream_handle(dev))
+    _lib.check(rc, "geot_mh_sddmm_coo")
+    return out
+
+
 def gather_rows_out(index, src, out) -> torch.Tensor:
     dev = _require_gpu(index, src, out)
     L = _lib.load()

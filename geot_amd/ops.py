@@ -233,6 +233,12 @@ def _(src_index, dst_index, weight, src, rows):
     return src.new_empty([rows, src.shape[1], src.shape[2]])
 
 
+@torch.library.register_fake("geot::mh_sddmm")
+def _(src_index, dst_index, mat_1, mat_2, head_major):
+    nnz, heads = dst_index.shape[0], mat_1.shape[1]
+    return mat_1.new_empty([heads, nnz] if head_major else [nnz, heads])
+
+
 @torch.library.register_fake("geot::gather_rows")
 def _(index, src):
     return src.new_empty([index.shape[0], *src.shape[1:]])
@@ -323,6 +329,82 @@ torch.library.register_autograd("geot::gather_weight_scatter_rows", lambda ctx, 
                                 setup_context=_gws_setup_context)
 
 
+def _gr_setup(ctx, inputs, output):
+    src_index, dst_index, weight, src, reduce = inputs
+    ctx.reduce = _aggr_kind(reduce)
+    ctx.has_weight = weight is not None
+    ctx.save_for_backward(src_index, dst_index, src, *((weight,) if weight is not None else ()))
+
+
+def _gr_backward(ctx, grad):
+    """Backward of ``geot::gather_reduce`` (PyG's aggr= on the gather ops; the reference's GPU kernels ignore ``reduce`` and its
+    wrappers differentiate the sum only, geot/gather_scatter.py:21-39, gather_weight_scatter.py:31-51).
+
+    mean: out[d] = (1 / deg d) * sum_e w_e src[s_e]  ->  the SUM backward on grad / deg - d/dsrc over the cached transposed edge
+    list, d/dweight by the SDDMM - with deg = edges per destination row (rows without edges keep gradient 0).
+    max / min / prod: no gradient here - refused loudly (as index_scatter does for its non-sum reductions) rather than a silent
+    zero from autograd's fallback."""
+    if ctx.reduce != "mean":
+        raise NotImplementedError(f"gather_scatter / gather_weight_scatter: backward is implemented for reduce='sum' and 'mean' only (got '{ctx.reduce}')")
+    src_index, dst_index, src, *rest = ctx.saved_tensors
+    weight = rest[0] if rest else None
+    rows = grad.shape[0]
+    ones = torch.ones((dst_index.shape[0], 1), dtype=torch.float32, device=grad.device)
+    deg = torch.ops.geot.index_scatter(0, dst_index, ones, "sum", True)          # [index[-1] + 1, 1] - the forward's row rule
+    if deg.shape[0] != rows:                                                          # (cannot differ; stay safe)
+        deg = torch.nn.functional.pad(deg, (0, 0, 0, rows - deg.shape[0])) if deg.shape[0] < rows else deg[:rows]
+    g = (grad / deg.clamp_(min=1.0).to(grad.dtype)).contiguous()
+    need_w = ctx.has_weight and ctx.needs_input_grad[2]
+    need_src = ctx.needs_input_grad[3]
+    src_grad = weight_grad = None
+    if need_src:
+        if weight is None:
+            _, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+            src_grad = torch.ops.geot.gather_scatter_rows(src_index_bwd, dst_index_bwd, g, src.shape[0])
+        else:
+            _, dst_index_bwd, src_index_bwd, weight_bwd = torch.ops.geot.transpose_edges_weighted(src_index, dst_index, weight.detach())
+            src_grad = torch.ops.geot.gather_weight_scatter_rows(src_index_bwd, dst_index_bwd, weight_bwd, g, src.shape[0])
+    if need_w:
+        weight_grad = torch.ops.geot.sddmm_coo_impl(src_index, dst_index, g, src.detach())
+    return None, None, weight_grad, src_grad, None
+
+
+torch.library.register_autograd("geot::gather_reduce", _gr_backward, setup_context=_gr_setup)
+
+
+def _mh_setup(ctx, inputs, output):
+    src_index, dst_index, weight, src = inputs[:4]
+    ctx.save_for_backward(src_index, dst_index, weight, src)
+
+
+def _mh_backward(ctx, grad):
+    """Backward of ``geot::mh_spmm`` - the reference ships none (geot/mh_spmm.py:4-12), so a GAT layer rewritten onto it
+    (geot/match_replace/fused_mh_spmm.py:4-50) is inference-only there.  Same pattern as gather_weight_scatter
+    (geot/gather_weight_scatter.py:31-51), per head:
+
+    d/dsrc[s, h, :]  = sum over the edges leaving s of w[e, h] * grad[d_e, h, :]  = mh_spmm over the transposed edge list with the
+                       weights in its order (rows permuted by one row gather);
+    d/dweight[e, h]  = <grad[d_e, h, :], src[s_e, h, :]>  = the multi-head SDDMM, in the weight's own layout and edge order."""
+    src_index, dst_index, weight, src = ctx.saved_tensors
+    grad = grad.contiguous()
+    nnz = src_index.shape[0]
+    head_major = not (weight.dim() == 2 and weight.shape[0] == nnz and weight.shape[1] == src.shape[1])   # (layout pick of mh_spmm_base.h:38-49)
+    need_w, need_src = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+    src_grad = weight_grad = None
+    if need_src:
+        perm, dst_index_bwd, src_index_bwd = _sorted_by_source(src_index, dst_index)
+        w_em = weight.detach().t().contiguous() if head_major else weight.detach().contiguous()
+        w_bwd = torch.ops.geot.gather_rows(perm, w_em)
+        src_grad = torch.ops.geot.mh_spmm_rows(src_index_bwd, dst_index_bwd, w_bwd, grad, src.shape[0])
+    if need_w:
+        weight_grad = torch.ops.geot.mh_sddmm(src_index, dst_index, grad, src.detach(), head_major)
+    return None, None, weight_grad, src_grad, None
+
+
+torch.library.register_autograd("geot::mh_spmm", _mh_backward, setup_context=_mh_setup)
+torch.library.register_autograd("geot::mh_spmm_rows", _mh_backward, setup_context=_mh_setup)
+
+
 def _is_setup(ctx, inputs, output):
     dim, index, src, reduce, _sorted = inputs
     ctx.save_for_backward(index)
@@ -377,7 +459,8 @@ def gather_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.
 
     The trailing ``reduce`` is what the reference's own callers pass (models/conv/spmm.py:5-8 forwards the
     layer's ``aggr``; test/test_gather_scatter.py:25): 'sum' / 'add' run the differentiable op of the
-    reference; 'mean' / 'min' / 'max' / 'prod' aggregate the messages of every row (forward only).
+    reference; 'mean' / 'min' / 'max' / 'prod' aggregate the messages of every row ('mean' is differentiable too; the
+    others refuse a backward pass loudly).
     """
     if _aggr_kind(reduce) == "sum":
         return torch.ops.geot.gather_scatter(src_index, dst_index, src)

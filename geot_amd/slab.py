@@ -125,3 +125,24 @@ def slab_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out
                                    mat_1.shape[0], mat_2.shape[0], hip._dtype_code(mat_1, "slab_sddmm"), ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "geot_slab_sddmm")
     return out
+
+
+def slab_mh_sddmm_out(plan: SlabPlan, mat_1: torch.Tensor, mat_2: torch.Tensor, out: Optional[torch.Tensor],
+                      staging: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[e, h] = <mat_1[dst(e), h], mat_2[src(e), h]> over the plan's edges, mat_* [rows, H, F] (geot_slab_mh_sddmm).
+    out given: [nnz, H] in ORIGINAL edge order (through `staging` and the unstage kernel).  out None: the results stay in plan
+    order - returned as the [nnz, H] staging tensor, what slab_spmm_out reads back under weight_mode 5 (H = 1: mode 4)."""
+    dev = hip._require_gpu(mat_1, mat_2)
+    L = _lib.load()
+    H, F = mat_1.shape[1], mat_1.shape[2]
+    nnz = int(plan.struct.nnz)
+    if staging is None:
+        staging = torch.empty((nnz, H), dtype=mat_1.dtype, device=dev)
+    with hip._on_device(dev):
+        st = hip._stream_handle(dev)
+        ws = hip.workspace(dev, int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), H * F)), st)
+        rc = L.geot_slab_mh_sddmm(ctypes.byref(plan.struct), mat_1.data_ptr(), mat_2.data_ptr(), None if out is None else out.data_ptr(),
+                                  staging.data_ptr(), H, F, mat_1.shape[0], mat_2.shape[0], hip._dtype_code(mat_1, "slab_mh_sddmm"),
+                                  ws.data_ptr(), ws.numel(), st)
+    _lib.check(rc, "geot_slab_mh_sddmm")
+    return staging if out is None else out

@@ -51,7 +51,11 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 1
+/* 2 (round 5): geot_slab_plan carries slab_shift / n_slabs; a plan's `units` are WAVES for every row of >= 256 bytes
+ * (geot_slab_units_for / geot_slab_rows_per_group_shape), split hubs are interleaved, weights may arrive in plan order for the
+ * multi-head mode too (weight_mode 5), geot_slab_mh_sddmm / geot_mh_sddmm_coo; the measurement hooks and experiment switches moved
+ * to geot_hip_dev.h. */
+#define GEOT_ABI_VERSION 2
 
 enum {
   GEOT_OK = 0,
@@ -129,6 +133,13 @@ int geot_mh_spmm(const int64_t *src_index, const int64_t *dst_index, const void 
 int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const void *mat_1,
                    const void *mat_2, void *out, int64_t nnz, int64_t feat, int64_t rows_1,
                    int64_t rows_2, int dtype, void *stream);
+
+/* Multi-head SDDMM: out(e, h) = < mat_1[dst_index[e], h, :], mat_2[src_index[e], h, :] >, mat_* [rows, heads, feat];
+ * out laid out like geot_mh_spmm's weight: out[e*heads + h] (GEOT_W_EDGE_MAJOR) or out[h*nnz + e] (GEOT_W_HEAD_MAJOR).
+ * d/dweight of geot_mh_spmm (mat_1 = the output's gradient, mat_2 = src).  The reference has no counterpart: its mh_spmm has
+ * no backward (geot/mh_spmm.py:4-12); the pattern is sddmm_coo_cuda for the single-head op (geot/gather_weight_scatter.py:8-12,46-50). */
+int geot_mh_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const void *mat_1, const void *mat_2, void *out, int64_t nnz,
+                      int64_t heads, int64_t feat, int64_t rows_1, int64_t rows_2, int weight_layout, int dtype, void *stream);
 
 /* dst[e, :] = src[index[e], :] */
 int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
@@ -219,7 +230,8 @@ int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *
  * when a graph is dense enough for its source rows to be re-used out of an XCD's L2: Reddit scale runs ~2x
  * faster than the per-edge gather.  The edge list is pre-arranged ONCE (Phase A: geot_slab_plan_rows / _groups / _edges
  * below, driven by the host layer and kept per edge list): all arrays below are DEVICE memory in processing order.
- *   units            lane-group streams of the persistent grid = geot_slab_units() * (64 / lanes per row)
+ *   units            streams of the persistent grid: its WAVES (geot_slab_units()) for rows of >= 256 bytes - one row per wave-
+ *                    instruction -, waves x 8 lane groups for 128-byte rows (geot_slab_units_for)
  *   groups           <= rows_per_group consecutive (virtual) dst rows with about equal edge counts, ordered by
  *                    size (descending); group at position p is run by unit (p % units) in round (p / units)
  *   e_src/e_dl/e_perm  per edge, grouped by position and sorted by (source slab, row in group): source row,
@@ -254,16 +266,18 @@ int geot_slab_units(void);                                     /* waves of the p
 int geot_slab_full_chip(void);                                 /* 1: all 256 CUs / 160 KB LDS (what the density rule was measured on) */
 int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget (float32 storage) */
 int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /* ... 16-bit storage: fp32 accumulators, half the rows */
-/* What a plan's `units` and rows per group must be for the kernel that will run it.  A unit is the rowbytes / 16 lanes of a row
- * (units = waves x 1024 / rowbytes) - except under multi-head weights (weight_mode 2 / 3) on rows of 512 / 256 bytes, which run one
- * row per wave-instruction (8 / 4 bytes per lane): there a unit is a wave and a group holds more rows. */
+/* What a plan's `units` and rows per group must be for the kernel that will run it.  Rows of 256 / 512 / 1024 bytes run one row per
+ * wave-instruction (4 / 8 / 16 bytes per lane): a unit is a WAVE whatever the weight mode, and a group holds as many rows as the LDS
+ * budget allows for that row width, storage type and number of staged weights (ABI 2; ABI 1 cut rows below 1 KiB into lane groups
+ * unless the weights were multi-head).  Rows of 128 bytes (never routed automatically): 8 lane groups per wave. */
 int geot_slab_units_for(int weight_mode, int64_t rowbytes);
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes);
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
 /* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
  * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts),
  * 4 = 1 with weight[] already permuted into the plan's edge order (weight[i] belongs to e_perm[i]: a static weight,
- * e.g. a normalised adjacency, permuted once by the caller).
+ * e.g. a normalised adjacency, permuted once by the caller), 5 = 2 likewise (weight[i*heads + h] belongs to e_perm[i]: attention
+ * coefficients that were COMPUTED in plan order - geot_slab_mh_sddmm with out = NULL - never pass through the edge permutation).
  * reduce: GEOT_REDUCE_SUM | MEAN | MAX | MIN over the messages of a row (weight modes 0 / 1; the multi-head modes sum) -
  * the aggregations PyG call sites forward (GraphSAGE mean / max on Reddit-like graphs).
  * float32 / float16 / bfloat16 storage (16-bit: fp32 accumulation, one rounding at the end, weights in the storage type),
@@ -321,14 +335,14 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
 int geot_slab_sddmm_staged(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t feat,
                            int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
- * With profiling on, every segment-reduction call records hipEvents around its kernels on
- * the call's stream; geot_profile_read waits for them and returns the accumulated device
- * time per kernel class since the last reset. */
-void geot_profile_enable(int on);
-void geot_profile_reset(void);
-/* main = tile kernel, fixup = carry/gap kernel, aux = memsets; *_calls = launches counted */
-int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls);
+/* Multi-head SDDMM over the plan (d/dweight of geot_mh_spmm on a dense graph; the scores of an attention layer):
+ * out(e, h) = < mat_1[dst(e), h, :], mat_2[src(e), h, :] >, mat_* [rows, heads, feat], heads 1 / 2 / 4 / 8, rows of 256 / 512 / 1024
+ * bytes.  `staging`: plan->nnz x heads elements of scratch.  out != NULL: results in ORIGINAL edge order, out[e*heads + h] (heads x
+ * element size of 2 / 4 / 8 / 16 bytes).  out == NULL: the results STAY in `staging`, in the plan's edge order - what geot_slab_spmm
+ * reads back under weight_mode 5 (heads = 1: weight_mode 4) with no permutation in between.  The reference has no counterpart
+ * (geot/mh_spmm.py:4-12: no backward; its attention layers compute scores with torch ops, models/conv/gatconv.py). */
+int geot_slab_mh_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t heads, int64_t feat,
+                       int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* THE DESCENT CONTRACT of every sorted entry point (geot_index_scatter(sorted = 1), geot_index_scatter_reduce, geot_gather_*,
  * geot_mh_spmm, geot_csr_gws): the kernels verify "dst_index ascending" while they stage the keys (keys outside
@@ -339,39 +353,6 @@ int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t
  * raised: word[0] = repaired, word[1] = NaN-filled.  A caller that set no alarm word hears nothing - it must not pass
  * sorted = 1 on faith for reductions other than sum (probe first: geot_index_probe).  The reference tolerates a wrong
  * `sorted` promise for sum only (its kernels ignore `reduce` on the GPU): this is a documented difference. */
-
-/* Name of the dominant kernel the calling thread's LAST operator call launched, spelled as rocprofv3 prints it
- * (e.g. "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"): bench.py labels its roofline with what the launcher
- * picked instead of a literal.  Valid until the thread's next call; "" before the first. */
-const char *geot_last_kernel(void);
-
-/* What this box can do right now (bench.py reports it next to the roofline: devices of the pool differ by a few
- * per cent): best-of-`iters` bandwidth of a pure non-temporal 16-B-per-lane read of `buf` (device memory, `bytes`
- * long), and the shader clock a busy wave sees (MHz; s_memtime ticks per 100 MHz s_memrealtime tick).
- * Synchronous; allocates a few bytes; not capturable. */
-int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps, double *sclk_mhz, void *stream);
-
-/* Tuning knobs for experiments: edges per lane-group sub-chunk (0 = auto), forced vector
- * width in elements (0 = auto), non-temporal policy (-1 = auto; 0 = default cache policy, anything else = nt row loads AND nt
- * dst stores on streamed rows - gathered rows always use the default policy; the half-and-half forms of round 1 are no longer
- * instantiated), lanes per row log2 (-1 = auto). */
-void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
-/* named switches: "handoff" = 1 | 0: the tile kernel of a sorted geot_index_scatter* call finishes the runs that straddle
- * tiles itself (write-through carry rows + per-tile flags; the second launch then only tidies up) | classic second pass;
- * "unroll" = 0 | 8 | 16 row loads in flight per lane (fp32 index_scatter, 0 = rule);
- * "narrow" = 1 | 0 lane-per-edge kernel for fp32 rows of <= 7 elements; "xcd" = 1 | 0 XCD-contiguous tile
- * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
- * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
- * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
- * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free);
- * "slab_far" = n: a slowest wave more than n steps behind is not waited for (12); "slab_turn" = 1 | 0: the persistent
- * source-blocked grids of this process take turns per device (a launch waits on its stream for the event of the previous one;
- * skipped on a capturing stream); "slab_nt" = 0 | 1: experiment, non-temporal loads of the plan's streams;
- * "handoff_tries" = polls of a predecessor's flag before a run is left to the second launch (0: sample once);
- * "lds_floor" = -1 | bytes: dynamic LDS a tile-kernel launch asks for at least - the cap on workgroups per CU
- * (-1: the rule; 33000 -> 4, 41000 -> 3, 54000 -> 2 per CU); "gather_grid" = tiles a gathered fp32 call is cut into
- * at least (4096; 0 off); "sddmm_shift" = -1 | n: lanes per row of the per-edge SDDMM = natural >> n (-1: the rule) */
-void geot_set_option(const char *name, int value);
 
 #ifdef __cplusplus
 }

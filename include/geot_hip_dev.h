@@ -1,0 +1,63 @@
+/*
+ * geot_hip_dev.h -- measurement hooks and experiment switches of libgeot_hip.so.
+ *
+ * NOT part of the stable ABI of include/geot_hip.h: nothing a caller of the operators needs, and the option NAMES and
+ * their values change from build to build (they exist so that bench.py, tools/ and the tests can time kernels, label a
+ * roofline with the kernel the launcher picked, and force code paths).  A maintainer binding the reference to the
+ * library binds geot_hip.h only and checks geot_abi_version() against GEOT_ABI_VERSION.
+ */
+#ifndef GEOT_HIP_DEV_H
+#define GEOT_HIP_DEV_H
+
+#include "geot_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- measurement hooks (used by bench.py / tools; not needed by a caller) ---------------
+ * With profiling on, every segment-reduction call records hipEvents around its kernels on
+ * the call's stream; geot_profile_read waits for them and returns the accumulated device
+ * time per kernel class since the last reset. */
+void geot_profile_enable(int on);
+void geot_profile_reset(void);
+/* main = tile kernel, fixup = carry/gap kernel, aux = memsets; *_calls = launches counted */
+int geot_profile_read(double *main_ms, double *fixup_ms, double *aux_ms, int64_t *calls);
+
+/* Name of the dominant kernel the calling thread's LAST operator call launched, spelled as rocprofv3 prints it
+ * (e.g. "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"): bench.py labels its roofline with what the launcher
+ * picked instead of a literal.  Valid until the thread's next call; "" before the first. */
+const char *geot_last_kernel(void);
+
+/* What this box can do right now (bench.py reports it next to the roofline: devices of the pool differ by a few
+ * per cent): best-of-`iters` bandwidth of a pure non-temporal 16-B-per-lane read of `buf` (device memory, `bytes`
+ * long), and the shader clock a busy wave sees (MHz; s_memtime ticks per 100 MHz s_memrealtime tick).
+ * Synchronous; allocates a few bytes; not capturable. */
+int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps, double *sclk_mhz, void *stream);
+
+/* Tuning knobs for experiments: edges per lane-group sub-chunk (0 = auto), forced vector
+ * width in elements (0 = auto), non-temporal policy (-1 = auto; 0 = default cache policy, anything else = nt row loads AND nt
+ * dst stores on streamed rows - gathered rows always use the default policy; the half-and-half forms of round 1 are no longer
+ * instantiated), lanes per row log2 (-1 = auto). */
+void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
+/* named switches: "handoff" = 1 | 0: the tile kernel of a sorted geot_index_scatter* call finishes the runs that straddle
+ * tiles itself (write-through carry rows + per-tile flags; the second launch then only tidies up) | classic second pass;
+ * "unroll" = 0 | 8 | 16 row loads in flight per lane (fp32 index_scatter, 0 = rule);
+ * "narrow" = 1 | 0 lane-per-edge kernel for fp32 rows of <= 7 elements; "xcd" = 1 | 0 XCD-contiguous tile
+ * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
+ * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
+ * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
+ * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free);
+ * "slab_far" = n: a slowest wave more than n steps behind is not waited for (12); "slab_turn" = 1 | 0: the persistent
+ * source-blocked grids of this process take turns per device (a launch waits on its stream for the event of the previous one;
+ * skipped on a capturing stream); "slab_nt" = 0 | 1: experiment, non-temporal loads of the plan's streams;
+ * "handoff_tries" = polls of a predecessor's flag before a run is left to the second launch (0: sample once);
+ * "lds_floor" = -1 | bytes: dynamic LDS a tile-kernel launch asks for at least - the cap on workgroups per CU
+ * (-1: the rule; 33000 -> 4, 41000 -> 3, 54000 -> 2 per CU); "gather_grid" = tiles a gathered fp32 call is cut into
+ * at least (4096; 0 off); "sddmm_shift" = -1 | n: lanes per row of the per-edge SDDMM = natural >> n (-1: the rule) */
+void geot_set_option(const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOT_HIP_DEV_H */

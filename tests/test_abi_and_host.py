@@ -16,7 +16,8 @@ from geot_amd import _lib, ops
 
 
 def declared_functions():
-    text = open(os.path.join(ROOT, "include", "geot_hip.h")).read()
+    import glob
+    text = "".join(open(h).read() for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(geot_[a-z_0-9]+)\s*\(", text)))
 
@@ -30,6 +31,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names            # the Python loader binds the same list
     assert L.geot_abi_version() == _lib.ABI_VERSION
     assert b"gfx950" in ctypes.cast(ctypes.CDLL(_lib.LIB_PATH).geot_build_info, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_stable_header_has_no_experiment_switches():
+    """a maintainer binding per INTEGRATION.md binds geot_hip.h; the tuning knobs and measurement hooks live
+    in geot_hip_dev.h, and the ABI version moved with the plan contract."""
+    stable = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "geot_hip.h")).read(), flags=re.S)
+    for name in ("geot_tune", "geot_set_option", "geot_profile_enable", "geot_last_kernel"):
+        assert name not in stable, name
+    dev = open(os.path.join(ROOT, "include", "geot_hip_dev.h")).read()
+    assert "geot_tune" in dev and "geot_set_option" in dev and "NOT part of the stable ABI" in dev
+    assert "#define GEOT_ABI_VERSION 2" in open(os.path.join(ROOT, "include", "geot_hip.h")).read() and _lib.ABI_VERSION == 2
 
 
 def test_library_is_gfx950_code_object():

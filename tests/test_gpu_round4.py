@@ -357,7 +357,7 @@ def test_staged_sddmm_is_the_direct_sddmm_bit_for_bit_with_split_hubs(geot, dtyp
 
 
 def test_multi_head_plans_on_narrow_rows_random_shapes(geot):
-    """seg_slab_mhrow_kernel (multi-head weights, rows of 512 / 256 bytes: one row per wave-instruction, a unit = a wave): random graphs
+    """seg_slab_wrow_kernel (round 4: seg_slab_mhrow_kernel; multi-head weights, rows of 512 / 256 bytes: one row per wave-instruction, a unit = a wave): random graphs
     with split hubs, rows without edges and an out-of-range source, every (dtype, H, F per head) that makes such a row, both weight
     layouts, plans built with the library's own units / rows per group - against float64."""
     from geot_amd import slab
@@ -384,7 +384,7 @@ def test_multi_head_plans_on_narrow_rows_random_shapes(geot):
         assert plan.meta["split_rows"] >= 1 and plan.meta["units"] == slab._lib.load().geot_slab_units_for(2, rowbytes)
         out = torch.full((nodes, H, Fh), float("nan"), dtype=dtype, device="cuda")
         slab.slab_spmm_out(plan, d_w, 2, d_x, out, H, Fh)
-        assert "seg_slab_mhrow_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        assert "seg_slab_wrow_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
         want = torch.zeros(nodes, H, Fh, dtype=torch.float64, device="cuda")
         want.index_add_(0, d_di, d_x.double()[d_si] * d_w.double()[:, :, None])
         tol = 1e-5 if dtype == torch.float32 else (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""The source-blocked kernels at BASELINE.json configs[3]'s graph (Reddit scale stand-in: 232 965 nodes, 114.6 M power-law edges,
+uniform-random sources), one line per (operator, storage type, row width, weight form): milliseconds per launch through the
+pointer-level doorway (geot_amd/slab.py), plans built with the library's own units and rows per group.  Round 5: every row of
+256 / 512 bytes runs one row per wave-instruction (seg_slab_wrow_kernel), weights may arrive in plan order (modes 4 / 5), the
+multi-head SDDMM runs over the plan (`profiles/r05/slab_cases_*.txt`).
+
+    python tools/bench_slab_cases.py [--scale 1.0] [--only mh,gws,...] [--options slab_unroll=16,slab_tight=0]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import device_ms, powerlaw_index  # noqa: E402
+from geot_amd import hip, slab  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--options", default="", help="comma-separated name=value library options set for the whole run")
+    ap.add_argument("--iters", type=int, default=4)
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    for item in filter(None, a.options.split(",")):
+        k, v = item.split("=")
+        hip.set_option(k, int(v))
+    only = set(filter(None, a.only.split(",")))
+    nodes, nnz = int(232_965 * a.scale), int(114_615_892 * a.scale)
+    print(f"# {hip.build_info()}  nodes={nodes} nnz={nnz} options={a.options or '-'}", flush=True)
+    di = powerlaw_index(nnz, nodes, 11, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(12)
+    si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+    plans = {}
+
+    def plan_for(rowbytes, wmode, H, dtype):
+        R = slab.rows_per_group(wmode, H, dtype, rowbytes)
+        key = (rowbytes, R)
+        if key not in plans:
+            plans.clear()                                  # (one plan at a time: 1 GB each)
+            plans[key] = slab.build_plan(si, di, nodes, nodes, rowbytes, wmode, H, rows_per_group=R)
+        return plans[key]
+
+    def line(name, fn, extra=""):
+        ms = device_ms(fn, a.iters, warmup=2)
+        print(f"{name:64s} {ms:8.3f} ms   {hip.last_kernel()} {extra}", flush=True)
+        return ms
+
+    for dtype, tname in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        esz = 4 if dtype == torch.float32 else 2
+        # ---- multi-head SpMM, H = 4 x F = 64 (configs[3])
+        if not only or "mh" in only:
+            H, Fh = 4, 64
+            x = torch.rand(nodes, H, Fh, device=dev, generator=g).to(dtype)
+            w = torch.rand(nnz, H, device=dev, generator=g).to(dtype)
+            out = torch.empty(nodes, H, Fh, device=dev, dtype=dtype)
+            plan = plan_for(H * Fh * esz, 2, H, dtype)
+            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh),
+                 f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']}")
+            wp = w[plan.tensors["e_perm"].long()].contiguous()
+            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights in PLAN order (mode 5)", lambda: slab.slab_spmm_out(plan, wp, 5, x, out, H, Fh))
+            del wp
+            if not only or "sddmm" in only:
+                q = torch.rand(nodes, H, Fh, device=dev, generator=g).to(dtype)
+                s_edge = torch.empty(nnz, H, device=dev, dtype=dtype)
+                staging = torch.empty(nnz, H, device=dev, dtype=dtype)
+                line(f"mh_sddmm H=4 F=64 {tname}, results in edge order (staged + unstage)", lambda: slab.slab_mh_sddmm_out(plan, q, x, s_edge, staging))
+                line(f"mh_sddmm H=4 F=64 {tname}, results left in plan order", lambda: slab.slab_mh_sddmm_out(plan, q, x, None, staging))
+                line(f"mh_sddmm H=4 F=64 {tname}, per-edge kernel", lambda: hip.mh_sddmm_coo_out(si, di, q, x, s_edge, False))
+                del q, s_edge, staging
+            del x, w, out
+        # ---- single weight / no weight, F = 128 and F = 64
+        for F in (128, 64):
+            if only and "gws" not in only:
+                break
+            if F * esz < 256:
+                continue
+            x = torch.rand(nodes, F, device=dev, generator=g).to(dtype)
+            w = torch.rand(nnz, device=dev, generator=g).to(dtype)
+            out = torch.empty(nodes, F, device=dev, dtype=dtype)
+            plan = plan_for(F * esz, 1, 1, dtype)
+            line(f"gws F={F} {tname} rows {F * esz} B, weight[e] in edge order", lambda: slab.slab_spmm_out(plan, w, 1, x, out, 1, F),
+                 f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']}")
+            wp = w[plan.tensors["e_perm"].long()].contiguous()
+            line(f"gws F={F} {tname} rows {F * esz} B, weight in PLAN order (mode 4)", lambda: slab.slab_spmm_out(plan, wp, 4, x, out, 1, F))
+            line(f"gs  F={F} {tname} rows {F * esz} B, no weight", lambda: slab.slab_spmm_out(plan, None, 0, x, out, 1, F))
+            line(f"gs  F={F} {tname} rows {F * esz} B, mean", lambda: slab.slab_spmm_out(plan, None, 0, x, out, 1, F, reduce="mean"))
+            if not only or "sddmm" in only:
+                m1 = torch.rand(nodes, F, device=dev, generator=g).to(dtype)
+                o = torch.empty(nnz, device=dev, dtype=dtype)
+                line(f"sddmm F={F} {tname}, staged", lambda: slab.slab_sddmm_out(plan, m1, x, o, staged=True))
+                del m1, o
+            del x, w, wp, out
+    print("# done")
+
+
+if __name__ == "__main__":
+    main()

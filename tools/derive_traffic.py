@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_round")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 COPY_BYTES = 2_684_354_560            # tools/kbench copy: 160 Mi float4 elements
@@ -136,8 +136,9 @@ WORKLOADS = {
                      ("/per-edge [H,nnz]", r"seg_tile_kernel<float, 4, true, 3,"), ("/phase A edge keys", r"plan_edge_keys_kernel"),
                      ("/phase A edge out", r"plan_edge_out_kernel")],
     # (rocprofv3 leaves the __bf16 instantiations mangled: DF16b)
+    "gather_scatter_cfg5": [("", r"seg_tile_kernel<float, 4, true, 0,")],
     "gws_cfg3_bf16": [("", r"seg_tile_kernel(<" + T16 + r", 8, true, 1,|IDF16bLi8ELb1ELi1E)")],
-    "mh_spmm_cfg4_bf16": [("", r"seg_slab_mhrow_kernel(<" + T16 + r", 2, 4|IDF16bLi2ELi4E)"),
+    "mh_spmm_cfg4_bf16": [("", r"seg_slab_wrow_kernel(<" + T16 + r", 2, 4|IDF16bLi2ELi4E)"),
                           ("/per-edge [nnz,H]", r"seg_tile_kernel(<" + T16 + r", 8, true, 2,|IDF16bLi8ELb1ELi2E)")],
 }
 gather = {}
@@ -171,7 +172,7 @@ for w, wanted in WORKLOADS.items():
             g["l2_hit_rate"] = hit / (hit + miss)
         if atom is not None:
             g["TCC_EA0_ATOMIC_sum"] = atom
-        comp = sec.get("compulsory_bytes")
+        comp = sec.get("compulsory_bytes") or sec.get("compulsory_bytes_rank0")
         if comp and not suffix.startswith("/phase A"):
             g["compulsory_bytes"] = comp
             g["frac_of_8TBps_on_compulsory_bytes"] = comp / (g["average_ms"] * 1e-3) / 8e12

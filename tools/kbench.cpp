@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "geot_hip.h"
+#include "geot_hip_dev.h"
 
 #define CK(x)                                                                                   \
   do {                                                                                          \

@@ -19,11 +19,13 @@ for c in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
       > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err"
 done
 # ---- the secondary workloads, one at a time
-for w in gws_cfg3 gws_cfg3_local gws_cfg3_powerlaw_src gws_cfg3_blockmodel_asis gws_cfg3_blockmodel_renum mh_spmm_cfg4 mh_spmm_cfg4_powerlaw_src gws_cfg3_bf16 mh_spmm_cfg4_bf16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $w \
+# (gather_scatter_cfg5 = BASELINE.json configs[4]'s one-GPU shard: bench.py selects it with `--only-secondary cfg5`)
+for w in ${WORKLOADS:-gws_cfg3 gws_cfg3_local gws_cfg3_powerlaw_src gws_cfg3_blockmodel_asis gws_cfg3_blockmodel_renum mh_spmm_cfg4 mh_spmm_cfg4_powerlaw_src gws_cfg3_bf16 mh_spmm_cfg4_bf16 gather_scatter_cfg5}; do
+  sel=$w; [ $w = gather_scatter_cfg5 ] && sel=cfg5
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
       > "$OUT/kt_$w.json" 2> "$OUT/kt_$w.err"
   for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; do
-    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${c}__$w" -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $w \
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${c}__$w" -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
         > "$OUT/pmc_${c}__$w.json" 2> "$OUT/pmc_${c}__$w.err"
   done
 done
