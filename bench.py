@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["cfg2", "cfg5"], default="cfg2")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink cfg5 / the secondary workloads (tests)")
+    ap.add_argument("--src-sharding", choices=["replicated", "node"], default="replicated",
+                    help="cfg5 at N > 1: source features replicated on every rank (56.9 GB each) or sharded by contiguous node ranges, the rows a "
+                         "rank's edge range references fetched per step with one all_to_all_single (SURVEY 8e, second option)")
     ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the 10 M-edge problem split over the ranks)")
     ap.add_argument("--cuts", choices=["equal", "aligned"], default="equal",
                     help="N > 1: equal = neighbouring shards share their boundary key (one small all_gather of partial rows per "
@@ -262,7 +265,8 @@ def device_ms(fn, iters, warmup=2):
 
 
 SECONDARY = ("cfg1", "gws_cfg3", "gws_cfg3_local", "gws_cfg3_powerlaw_src", "gws_cfg3_blockmodel", "mh_spmm_cfg4",
-             "mh_spmm_cfg4_powerlaw_src", "mh_spmm_cfg4_coalesced", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16", "gws_train_step_cfg4_graph")
+             "mh_spmm_cfg4_powerlaw_src", "mh_spmm_cfg4_coalesced", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16", "gws_train_step_cfg4_graph",
+             "mh_train_step_cfg4_graph")
 
 
 def profiled(entry):
@@ -388,6 +392,11 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         guard_was = ops.set_option("content_guard", 0)
         ms_unguarded = device_ms(lambda: geot.mh_spmm(si, di, w, x), iters, warmup=1)
         ops.set_option("content_guard", guard_was)
+        # ... and through the opt-in static-graph handle (owns its index clones and its plan: no fingerprint, no lookup)
+        handle = geot.Graph(si, di, num_src=nodes, num_dst=nodes)
+        ms_handle = device_ms(lambda: handle.mh_spmm(w, x), iters, warmup=4)
+        handle_stats = dict(handle.stats)
+        del handle
         hip.mh_spmm_out(si, di, w, x, out, False)
         torch.cuda.synchronize()
         diff = float(((geot.mh_spmm(si, di, w, x).float() - out.float()).abs().max() / out.float().abs().max()).item())
@@ -400,6 +409,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             "kernel_ms": ms,
             "content_guard": "on: every call re-reads both index arrays and compares their fingerprint with the plan's (kernel_ms includes it)",
             "kernel_ms_without_content_guard": ms_unguarded,
+            "kernel_ms_with_graph_handle": ms_handle, "graph_handle": handle_stats,
             "kernel": kernel + (" (+ memset, combine)" if slab_used else ""),     # what the operator launched (geot_last_kernel)
             "plan_trial_ms": {"plan": st1["trial_plan_us"] / 1e3, "per_edge": st1["trial_edges_us"] / 1e3} if st1["plan_trials"] > st0["plan_trials"] else None,
             "source_blocked_path": slab_used,
@@ -602,6 +612,94 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                     st = ops.stats()
                     out["plans"] = {k: st[k] for k in ("plans", "plan_trials", "plans_rejected", "plans_declined") if k in st}
             out["speedup_forward_backward"] = out["per_edge_kernels"]["forward_backward_ms"] / out["as_dispatched"]["forward_backward_ms"]
+            # the same step with the content guard off, and through the opt-in static-graph handle (geot_amd.Graph: owns its clones of
+            # the index arrays and its plans - no fingerprint, no cache lookup)
+            ops.set_option("slab_mode", "auto")
+            guard_was = ops.set_option("content_guard", 0)
+            for _ in range(3):
+                step()
+            out["without_content_guard"] = {"forward_backward_ms": device_ms(step, max(2, iters // 2))}
+            ops.set_option("content_guard", guard_was)
+            ops.clear_caches()
+            handle = geot.Graph(si, di, num_src=nodes, num_dst=nodes)
+
+            def hstep():
+                x.grad = None
+                w.grad = None
+                handle.gather_weight_scatter(w, x).backward(cot)
+            for _ in range(3):
+                hstep()
+            out["with_graph_handle"] = {"forward_ms": device_ms(lambda: handle.gather_weight_scatter(w.detach(), x.detach()), max(2, iters // 2)),
+                                        "forward_backward_ms": device_ms(hstep, max(2, iters // 2)), "handle": dict(handle.stats)}
+            del handle
+        finally:
+            ops.set_option("slab_mode", old)
+            ops.clear_caches()
+        res[name] = out
+        del di, si, x, w, cot
+        torch.cuda.empty_cache()
+
+    def mh_train_step(name):
+        """SURVEY 8(f1) for the multi-head operator: a GAT-style step on configs[3]'s graph - mh_spmm forward,
+        d/dsrc over the transposed list, d/dweight by the multi-head SDDMM - through autograd: as dispatched (plans found by the host
+        layer), on the per-edge kernels, and through the static-graph handle; plus the attention form that keeps the coefficients in the
+        plan's edge order from the score SDDMM to the SpMM."""
+        import geot_amd as geot
+        nodes, nnz, H, F = int(232_965 * scale), int(114_615_892 * scale), 4, 64
+        di = powerlaw_index(nnz, nodes, 11, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(12)
+        si = torch.randint(0, nodes, (nnz,), device=dev, generator=g)
+        x = torch.rand(nodes, H, F, device=dev, generator=g, requires_grad=True)
+        w = torch.rand(nnz, H, device=dev, generator=g, requires_grad=True)
+        cot = torch.rand(nodes, H, F, device=dev, generator=g)
+
+        def step():
+            x.grad = None
+            w.grad = None
+            geot.mh_spmm(si, di, w, x).backward(cot)
+        out = {"workload": f"mh_spmm forward + backward (d/dsrc, d/dweight) through autograd, {nodes} nodes, {nnz} edges (configs[3]'s graph, "
+                           f"uniform-random sources), heads={H} feat={F}, float32"}
+        old = ops.set_option("slab_mode", "auto")
+        try:
+            for mode, key in (("auto", "as_dispatched"), ("never", "per_edge_kernels")):
+                ops.set_option("slab_mode", mode)
+                ops.clear_caches()
+                for _ in range(3):
+                    step()
+                out[key] = {"forward_ms": device_ms(lambda: geot.mh_spmm(si, di, w.detach(), x.detach()), max(2, iters // 2)),
+                            "forward_backward_ms": device_ms(step, max(2, iters // 2))}
+            out["speedup_forward_backward"] = out["per_edge_kernels"]["forward_backward_ms"] / out["as_dispatched"]["forward_backward_ms"]
+            ops.set_option("slab_mode", "auto")
+            ops.clear_caches()
+            handle = geot.Graph(si, di, num_src=nodes, num_dst=nodes)
+
+            def hstep():
+                x.grad = None
+                w.grad = None
+                handle.mh_spmm(w, x).backward(cot)
+            for _ in range(3):
+                hstep()
+            out["with_graph_handle"] = {"forward_ms": device_ms(lambda: handle.mh_spmm(w.detach(), x.detach()), max(2, iters // 2)),
+                                        "forward_backward_ms": device_ms(hstep, max(2, iters // 2))}
+            # attention: scores by the SDDMM, exp, the SpMM - per-edge tensors in edge order (operators) and in plan order (handle)
+            q = torch.rand(nodes, H, F, device=dev, generator=g) / 8
+            k = torch.rand(nodes, H, F, device=dev, generator=g) / 8
+
+            def att_ops():
+                s = torch.ops.geot.mh_sddmm(si, di, q, k, False)
+                return geot.mh_spmm(si, di, torch.exp(s), x.detach())
+
+            def att_handle():
+                s = handle.mh_sddmm(q, k, plan_order=True)
+                return handle.mh_spmm(s.with_values(torch.exp(s.values)), x.detach())
+            for _ in range(3):
+                att_ops()
+                att_handle()
+            out["attention_forward_ms"] = {"operators_edge_order": device_ms(att_ops, max(2, iters // 2)),
+                                           "graph_handle_plan_order": device_ms(att_handle, max(2, iters // 2))}
+            out["handle"] = dict(handle.stats)
+            del handle, q, k
         finally:
             ops.set_option("slab_mode", old)
             ops.clear_caches()
@@ -622,7 +720,8 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             ("mh_spmm_cfg4_coalesced", lambda n: mh(n, torch.float32, "uniform", coalesced=True)),
             ("gws_cfg3_bf16", lambda n: gws(n, "uniform", torch.bfloat16)),
             ("mh_spmm_cfg4_bf16", lambda n: mh(n, torch.bfloat16)),
-            ("gws_train_step_cfg4_graph", lambda n: train_step(n))]
+            ("gws_train_step_cfg4_graph", lambda n: train_step(n)),
+            ("mh_train_step_cfg4_graph", lambda n: mh_train_step(n))]
     for name, run in plan:
         if name not in want:
             continue
@@ -785,13 +884,24 @@ def main():
         index, src_index, first_key, rows, nnz_global, cut_edges = global_list_shard(
             rows_global, nnz_target, nodes_all, world, rank, args.cuts, seed=13, device=dev)
         nnz = index.numel()
+        node_sharded = distributed and args.src_sharding == "node"
         gen = torch.Generator(device=dev)
         gen.manual_seed(15)                                                # src is REPLICATED: same seed on every rank
-        src = torch.rand(nodes_all, feat, device=dev, generator=gen)
+        if node_sharded:                                                   # ... or this rank's contiguous range of nodes only (its own seed)
+            node_offsets = [nodes_all * r // world for r in range(world + 1)]
+            gen.manual_seed(15 + rank)
+            src = torch.rand(node_offsets[rank + 1] - node_offsets[rank], feat, device=dev, generator=gen)
+            halo = sharding.HaloPlan.build(src_index, node_offsets)       # (a collective; once per edge list)
+        else:
+            src = torch.rand(nodes_all, feat, device=dev, generator=gen)
         uniq = int(torch.unique(src_index).numel())
         alg = nnz * 16 + uniq * 4 * feat + rows * 4 * feat                 # compulsory bytes
         key_offset = first_key
-        if distributed:
+        if node_sharded:
+            def step(collective=args.collective):
+                return sharding.sharded_gather_scatter_node(src_index, index, src, node_offsets, key_offset=key_offset, timing=timing,
+                                                            collective=collective, halo=halo)[0]
+        elif distributed:
             def step(collective=args.collective):
                 return sharding.sharded_gather_scatter(src_index, index, src, key_offset=key_offset, timing=timing, collective=collective)[0]
         else:
@@ -799,9 +909,11 @@ def main():
                 return geot.gather_scatter(src_index, index, src)
         workload = (f"gather_scatter, papers100M-scale synthetic, feat={feat}: one global dst-sorted list of {nnz_global} edges -> "
                     f"{rows_global} dst rows cut into {world} edge ranges ({args.cuts} cuts), rank 0 holds {nnz} edges / {rows} rows; "
-                    f"src {nodes_all} x {feat} fp32 replicated (BASELINE.json configs[4]; 8 ranks weak = the full 1.6 B edges)")
+                    f"src {nodes_all} x {feat} fp32 " + (f"sharded by node ({src.shape[0]} rows on this rank; halo plan: {halo.mode}, {halo.rows_fetched} rows = "
+                                                       f"{halo.bytes_fetched(4 * feat) / 1e9:.2f} GB fetched per step)" if node_sharded else "replicated") +
+                    " (BASELINE.json configs[4]; 8 ranks weak = the full 1.6 B edges)")
         step_desc = "geot.gather_scatter(src_index, dst_index, src)" + (" via sharding.sharded_gather_scatter" if distributed else "")
-        metric = "aggregated edges/sec, gather_scatter feat=128, edge-sharded, src replicated"
+        metric = "aggregated edges/sec, gather_scatter feat=128, edge-sharded, src " + ("sharded by node" if node_sharded else "replicated")
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -894,6 +1006,14 @@ def main():
             res["ranks_seen"] = dist.get_world_size()      # what the process group reports (after init_process_group)
             res["cuts"] = args.cuts
             res["dist_backend"] = backend
+            if args.workload == "cfg5":
+                res["src_sharding"] = args.src_sharding
+                if args.src_sharding == "node":
+                    fe = timing.get("fetch_events")
+                    res["source_rows_fetch"] = {"mode": halo.mode, "rows_fetched_per_step_rank0": halo.rows_fetched, "table_rows_rank0": halo.table_rows,
+                                                "bytes_fetched_per_step_rank0": halo.bytes_fetched(4 * feat),
+                                                "fetch_ms_rank0": (sum(a.elapsed_time(b) for a, b in fe) / len(fe)) if fe else None,
+                                                "src_rows_on_this_rank": int(src.shape[0]), "src_rows_total": nodes_all}
         if not distributed and args.workload == "cfg2" and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(index, src)

@@ -28,10 +28,13 @@ from .ops import (  # noqa: E402
     sddmm_coo_impl,
 )
 
+from .graph import Graph, PlanOrdered  # noqa: E402
+
 __version__ = "0.1.0"
 
 __all__ = [
     "index_scatter", "gather_scatter", "gather_weight_scatter", "mh_spmm", "mh_spmm_transposed",
     "csr_gws", "coo_to_csr", "csr_gws_impl",
     "gather_scatter_impl", "gather_weight_scatter_impl", "sddmm_coo_impl", "get_reduction_enum", "hip",
+    "Graph", "PlanOrdered",
 ]

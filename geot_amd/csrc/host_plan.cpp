@@ -385,7 +385,8 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
 bool run_slab(SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat, int red) {
   const std::vector<at::Tensor> pinned = H.pinned(); // this launch's own references: a release() meanwhile cannot free under the kernel
   if (pinned.empty()) return false;
-  const at::Tensor ws = workspace(src, geot_slab_workspace_bytes(&H.plan, heads * feat));
+  // (room for the call's weights in plan order: edge-order weights are staged inside the kernel instead of read through the permutation)
+  const at::Tensor ws = workspace(src, geot_slab_workspace_bytes_staged(&H.plan, heads * feat, wmode, heads, dtype_code(src, "slab")));
   GEOT_CALL(geot_slab_spmm(&H.plan, weight, wmode, src.data_ptr(), out.data_ptr(), heads, feat, src.size(0), out.size(0), dtype_code(src, "slab"),
                            red, ws.data_ptr(), ws.numel(), stream_of(src)));
   H.launched_on(src, pinned);

@@ -62,7 +62,7 @@ struct SlabParams {
   int window;           // a wave may be at most `window` slabs ahead of the slowest wave of its XCD; < 0: no sync
   int far;              // ... but a slowest wave MORE than `far` steps behind is not waited for: nothing it reads can still be shared
   int nt_plan;          // experiment: non-temporal loads of the plan's edge fields and of the weights (read once per launch)
-  int w_in_plan_order;  // WMODE 1: weight[] is indexed by plan position (a static weight permuted once), not by edge id
+  int w_in_plan_order;  // WMODE 1 / 2: weight[] is indexed by plan position (a static weight permuted once, scores computed in plan order), not by edge id
 };
 constexpr int kProgSlots = 512;
 constexpr int kProgIdle = 0x7f7f7f7f;
@@ -127,6 +127,85 @@ template <int RED> __device__ __forceinline__ void slab_acc(f4_t &acc, const f4_
   }
 }
 
+// A unit's edges are read in the PLAN's order, their weights live in the caller's EDGE order: weight[e_perm[i]].  Read that way inside
+// the row loop, every 4-byte weight drags a 64-byte line through the fabric each time the sweep comes back to its neighbourhood
+// (a group's edges are a contiguous range of edge ids, its ~10 k weights a 40 KB block touched over the whole life of the group:
+// ~15 GB of lines for 1.8 GB of weights at configs[3], and 1.1 ms of a 4.5 ms gws call at F = 128).  Given room in the workspace
+// (geot_slab_workspace_bytes_staged) the call brings the weights into plan order FIRST - this kernel: e_perm streamed, the weights
+// gathered while their group's block is hot in L2 (consecutive plan positions belong to one group), written out coalesced - and the
+// row loop streams them and never reads e_perm.  Inside the persistent kernel (every unit its own group's weights at the start of
+// its round) the same idea LOST: 4 edges per pass +0.3-1.0 ms, 16 per pass cost the row loop its registers (profiles/r05/
+// slab_cases__lane_groups__staging_*_in_kernel.txt).
+template <typename V>
+__global__ __launch_bounds__(kThreads) void slab_stage_weights_kernel(const int32_t *__restrict__ e_perm, const V *__restrict__ weight,
+                                                                      V *__restrict__ wst, int64_t nnz) {
+  constexpr int kS = 8;
+  const int64_t per_block = (int64_t)kThreads * kS;
+  for (int64_t base = (int64_t)blockIdx.x * per_block; base < nnz; base += (int64_t)gridDim.x * per_block) {
+    int pe[kS];
+#pragma unroll
+    for (int k = 0; k < kS; ++k) {
+      const int64_t i = base + (int64_t)k * kThreads + threadIdx.x;
+      pe[k] = i < nnz ? __builtin_nontemporal_load(e_perm + i) : -1;
+    }
+    V v[kS];
+#pragma unroll
+    for (int k = 0; k < kS; ++k)
+      if (pe[k] >= 0) v[k] = weight[pe[k]];
+#pragma unroll
+    for (int k = 0; k < kS; ++k)
+      if (pe[k] >= 0) __builtin_nontemporal_store(v[k], wst + base + (int64_t)k * kThreads + threadIdx.x);
+  }
+}
+
+// The same pre-pass a group at a time through LDS (the mirror image of slab_unstage_kernel): a group's edges are a CONTIGUOUS range
+// of the dst-sorted list unless it holds a piece of a split hub, so its weights are one contiguous block - read coalesced into LDS,
+// picked out of it in plan order, written coalesced.  No 64-byte L2 request per 4-byte weight.  Groups whose ids span more than the
+// tile (hub pieces: interleaved over the whole row) gather directly.
+template <typename V>
+__global__ __launch_bounds__(kThreads) void slab_stage_weights_lds_kernel(const int64_t *__restrict__ g_begin, const int32_t *__restrict__ e_perm,
+                                                                          const V *__restrict__ weight, V *__restrict__ wst, int64_t n_groups,
+                                                                          int tile_elems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  V *tile = reinterpret_cast<V *>(smem);
+  __shared__ int s_min, s_max;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t e0 = g_begin[g];
+    const int len = (int)(g_begin[g + 1] - e0);
+    if (threadIdx.x == 0) {
+      s_min = 0x7fffffff;
+      s_max = -1;
+    }
+    __syncthreads();
+    int mn = 0x7fffffff, mx = -1;
+    for (int i = threadIdx.x; i < len; i += kThreads) {
+      const int e = e_perm[e0 + i];
+      mn = e < mn ? e : mn;
+      mx = e > mx ? e : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && len > 0) {
+      atomicMin(&s_min, mn);
+      atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    const int base = s_min, span = s_max - s_min + 1;
+    if (len > 0 && span <= tile_elems) {
+      for (int i = threadIdx.x; i < span; i += kThreads) tile[i] = __builtin_nontemporal_load(weight + base + i);
+      __syncthreads();
+      for (int i = threadIdx.x; i < len; i += kThreads) __builtin_nontemporal_store(tile[e_perm[e0 + i] - base], wst + e0 + i);
+    } else {
+      for (int i = threadIdx.x; i < len; i += kThreads) wst[e0 + i] = weight[e_perm[e0 + i]];
+    }
+    __syncthreads();
+  }
+}
+
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // WAVE_ROW: rows of 1 KiB - the whole wave is one unit, edge fields are read with v_readlane (scalar row bases)
 //
@@ -159,6 +238,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   const int64_t units = P.units;
   const char *src = static_cast<const char *>(p.src);
   const T *weight = static_cast<const T *>(p.weight);
+  const bool wpo = p.w_in_plan_order != 0;               // weights indexed by plan position (given so, or staged by the pre-pass)
   T *dst = static_cast<T *>(p.dst);
   const int h = WMODE >= 2 ? (c * VEC) / p.Fh : 0;
   typedef T t4_t __attribute__((ext_vector_type(4)));
@@ -268,8 +348,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       if ((uint32_t)my_src >= src_rows) my_src = 0;   // (checked once per edge, here, not in the row loop)
       my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
       if constexpr (WMODE != 0) {
-        const int64_t pe = valid ? (int64_t)P.e_perm[e0 + c] : 0;
-        if constexpr (WMODE == 1) wbase[c] = valid ? (float)weight[p.w_in_plan_order ? e0 + c : pe] : 0.f;
+        const int64_t pe = valid ? (wpo ? e0 + c : (int64_t)P.e_perm[e0 + c]) : 0;
+        if constexpr (WMODE == 1) wbase[c] = valid ? (float)weight[pe] : 0.f;
         if constexpr (WMODE == 2) {
           if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + c * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
           else for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
@@ -291,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       if ((uint32_t)n_src >= src_rows) n_src = 0;
       const int n_dl = nvalid ? (int)(ntp ? __builtin_nontemporal_load(P.e_dl + ne) : P.e_dl[ne]) : 255;
       int64_t n_pe = 0;
-      if constexpr (WMODE != 0) n_pe = nvalid ? (int64_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne]) : 0;
+      if constexpr (WMODE != 0) n_pe = nvalid ? (wpo ? ne : (int64_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne])) : 0;
       f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
       float wn1 = 0.f;
 
@@ -326,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         }
         if constexpr (WMODE != 0) {
           if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
-            if constexpr (WMODE == 1) wn1 = nvalid ? (float)weight[p.w_in_plan_order ? ne : n_pe] : 0.f;
+            if constexpr (WMODE == 1) wn1 = nvalid ? (float)weight[n_pe] : 0.f;
             if constexpr (WMODE == 2) {
               if (p.H == 4) { if (nvalid) wn4 = load_w4(n_pe); }
             }
@@ -471,7 +551,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
   const T *weight = static_cast<const T *>(p.weight);
   T *dst = static_cast<T *>(p.dst);
   const int h = WMODE >= 2 ? (lane * E) / p.Fh : 0;
-  const bool wpo = p.w_in_plan_order != 0;              // weights indexed by plan position
+  const bool wpo = p.w_in_plan_order != 0;              // weights indexed by plan position (given so, or staged by the pre-pass)
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = 4 + p.lpr_log2;                       // log2(row bytes)
   const uint32_t cB = (uint32_t)lane * (uint32_t)(E * sizeof(T));
@@ -1172,6 +1252,8 @@ int g_slab_far = 12;
 int g_slab_nt = 0;      // "slab_nt": experiment, see SlabParams::nt_plan
 int g_slab_unroll = 8;  // "slab_unroll": 8 | 16 row loads in flight per lane of the row-per-wave kernel (sums)
 int g_slab_tight = 1;   // "slab_tight": 1 = the window of 1 slab for per-call weights on dense graphs (the round-4 rule), 0 = always 2
+int g_slab_stage_lds = 1; // "slab_stage_lds": 1 = the pre-pass goes a group at a time through LDS (one weight per edge), 0 = gathers straight from global memory
+int g_slab_stage = 1;   // "slab_stage": 1 = edge-order weights are staged into plan order inside the kernel when the workspace has room, 0 = read through e_perm
 int g_slab_turn = 1;    // "slab_turn": 1 = the persistent grids of this process take turns on a device (see SlabTurn), 0 = launch freely
 
 int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
@@ -1216,17 +1298,25 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype) {
 }
 int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_rows_per_group_dtype(weight_mode, heads, GEOT_F32); }
 
-// Rows of 512 / 256 bytes run one row per wave-instruction (seg_slab_wrow_kernel, seg_slab_sddmm_wrow_kernel), rows of 1 KiB too
-// (seg_slab_kernel's WAVE_ROW form): a unit is a WAVE for every row of >= 256 bytes, whatever the weight mode, and a group's rows are
-// 64 x E fp32 accumulators (E = row elements / 64).  Only 128-byte rows (off the automatic rule) keep lane groups of 8.
+// WHICH FORM RUNS A PLAN is decided by the plan's `units`.  Rows of 1 KiB: a unit is a wave (seg_slab_kernel's WAVE_ROW form).  Rows
+// of 512 / 256 bytes have two forms: lane groups of rowbytes / 16 lanes (units = waves x 1024 / rowbytes; seg_slab_kernel: 16 bytes
+// per lane, 2 / 4 rows per wave-instruction) and one row per wave-instruction (units = waves; seg_slab_wrow_kernel: 8 / 4 bytes per
+// lane, scalar row bases and row switches).  Measured at configs[3]'s graph (profiles/r05/slab_cases__row_per_wave_for_every_weight_
+// mode__*.txt against round 4's lane groups): the row-per-wave form wins under MULTI-HEAD weights (bf16 H=4 x F=64 5.66 -> 5.24 ms:
+// per-edge field shuffles and per-lane head selects go away) and LOSES everywhere else - gs F=128 fp32 4.15 vs 3.14 ms, gws 4.94 vs
+// 4.50, the SDDMM 6.86 vs 4.52: half the bytes per load instruction, and a weightless lane-group kernel already reads at the L2's
+// 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
+int g_slab_wrow_all = 0;
+static bool slab_wants_wrow(int weight_mode, int64_t rowbytes) {
+  return slab_wrow(rowbytes) && (g_slab_wrow_all || weight_mode == 2 || weight_mode == 3 || weight_mode == 5);
+}
 int geot_slab_units_for(int weight_mode, int64_t rowbytes) {
-  (void)weight_mode;
-  if (rowbytes >= 256 || rowbytes < 16) return geot_slab_units();
+  if (slab_wants_wrow(weight_mode, rowbytes) || rowbytes >= 1024 || rowbytes < 16) return geot_slab_units();
   return geot_slab_units() * (int)(1024 / rowbytes);
 }
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes) {
-  if (!slab_wrow(rowbytes)) return geot_slab_rows_per_group_dtype(weight_mode, heads, dtype);
+  if (!slab_wants_wrow(weight_mode, rowbytes)) return geot_slab_rows_per_group_dtype(weight_mode, heads, dtype);
   const size_t row = (size_t)(rowbytes / (dtype == GEOT_F32 ? 4 : 2)) * sizeof(float);   // a group row's accumulators
   const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (slab_device().lds - 4 * 1024) / g_slab_blocks / 1024 * 1024;
   const size_t hw = weight_mode == 0 ? 0 : ((weight_mode == 1 || weight_mode == 4) ? 1 : (size_t)heads);
@@ -1235,9 +1325,18 @@ int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, in
   return r;
 }
 
+// Scratch of geot_slab_spmm: control words, progress words, carry rows - and, optionally, room for the weights in plan order
+// (geot_slab_workspace_bytes_staged: nnz x heads elements more): given that room, a call with EDGE-order weights (modes 1 / 2)
+// stages them inside the kernel (stage_weights) instead of reading them through the permutation.
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total) {
   if (!plan) return 0;
-  return (size_t)(plan->n_carry > 0 ? plan->n_carry : 1) * (size_t)feat_total * sizeof(float) + 256 + kSyncBytes;
+  return ((size_t)(plan->n_carry > 0 ? plan->n_carry : 1) * (size_t)feat_total * sizeof(float) + 256 + kSyncBytes + 255) & ~(size_t)255;
+}
+size_t geot_slab_workspace_bytes_staged(const geot_slab_plan *plan, int64_t feat_total, int weight_mode, int64_t heads, int dtype) {
+  if (!plan) return 0;
+  const size_t base = geot_slab_workspace_bytes(plan, feat_total);
+  if (weight_mode != 1 && !(weight_mode == 2 && g_slab_stage == 2)) return base;   // (multi-head weights: staged on request only, see geot_slab_spmm)
+  return base + (size_t)plan->nnz * (size_t)(weight_mode == 1 ? 1 : heads) * (dtype == GEOT_F32 ? 4 : 2);
 }
 
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
@@ -1246,6 +1345,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   hipStream_t st = static_cast<hipStream_t>(stream);
   // mode 4 = mode 1, mode 5 = mode 2 (edge-major [nnz, heads]) with weight[] already in the PLAN's edge order
   const bool w_in_plan_order = weight_mode == 4 || weight_mode == 5;
+  const int mode_given = weight_mode;
   if (weight_mode == 4) weight_mode = 1;
   if (weight_mode == 5) weight_mode = 2;
   if (!plan || !src || !dst) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: null pointer");
@@ -1269,7 +1369,14 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (src_rows < 0 || (uint64_t)src_rows * (uint64_t)rowbytes > ((uint64_t)1 << 32))
     return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: source table of at most 4 GiB (32-bit row offsets; the kernel is for tables a slab sweep can cover)");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
-  const bool mhrow = slab_wrow(rowbytes);                          // one row per wave-instruction: a unit is a wave
+  // rows of 512 / 256 bytes: the plan's units say which form it was cut for - lane groups (waves x 1024 / rowbytes) or one row per
+  // wave-instruction (waves); a plan with another unit count (tests, callers with their own grids) follows geot_slab_units_for's rule
+  bool mhrow = false;
+  if (slab_wrow(rowbytes)) {
+    if (plan->units == (int64_t)geot_slab_units() * (64 >> lpr_log2)) mhrow = false;
+    else if (plan->units == (int64_t)geot_slab_units()) mhrow = true;
+    else mhrow = slab_wants_wrow(mode_given, rowbytes);
+  }
   const int per_wave = mhrow ? 1 : (64 >> lpr_log2);
   const int64_t waves = plan->units / per_wave;
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
@@ -1301,11 +1408,22 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   // costs 3 % at 2.3 uses, profiles/r04/bench_slab_density_rule.txt: 7.60 vs 7.36 ms)
   const int64_t rounds_ = (plan->n_groups + plan->units - 1) / (plan->units > 0 ? plan->units : 1);
   const double uses = (double)plan->nnz / (double)(rounds_ > 0 ? rounds_ : 1) / 8.0 / (double)(src_rows > 0 ? src_rows : 1);
-  const int tight = (weight_mode == 1 && !w_in_plan_order && lpr_log2 < 6 && uses >= 4.0 && g_slab_tight) ? 1 : 2;   // (a weight in plan order streams: 3.52 vs 3.56 ms at 2)
+  const bool staged_w = g_slab_stage && weight_mode == 1 && workspace_bytes >= geot_slab_workspace_bytes_staged(plan, F, weight_mode, heads, dtype);
+  const int tight = (weight_mode == 1 && !w_in_plan_order && !staged_w && lpr_log2 < 6 && uses >= 4.0 && g_slab_tight) ? 1 : 2;   // (a weight in plan order streams: 3.52 vs 3.56 ms at 2)
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : tight) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
+  // room behind the carry rows for the weights in plan order -> the kernel stages them itself (geot_slab_workspace_bytes_staged)
+  void *wstage = nullptr;
+  const int64_t wbytes = (weight_mode == 1 ? 1 : heads) * tsize;               // one edge's weights
+  // (measured at configs[3]'s graph, profiles/r05/slab_cases__lane_groups__weights_staged_by_a_prepass.txt: one weight per edge - gws
+  //  F=128 fp32 4.50 -> 3.98 ms, F=64 3.40 -> 2.74, bf16 F=128 3.19 -> 2.79; four heads of weights: the pre-pass moves 4 GB and costs more
+  //  than the permuted reads - fp32 7.18 -> 7.51, bf16 5.24 -> 5.61: multi-head weights are staged only on request, "slab_stage" = 2)
+  if (!w_in_plan_order && (weight_mode == 1 || (weight_mode == 2 && g_slab_stage == 2)) && g_slab_stage && plan->n_groups > 0 &&
+      (wbytes == 2 || wbytes == 4 || wbytes == 8 || wbytes == 16) && (((uintptr_t)weight) & (wbytes - 1)) == 0 &&
+      workspace_bytes >= geot_slab_workspace_bytes_staged(plan, F, weight_mode, heads, dtype))
+    wstage = static_cast<char *>(workspace) + need;
   p.src_rows = src_rows;
   p.K = out_rows;
   p.F = F;
@@ -1320,6 +1438,24 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   if (p.window >= 0) {
     e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);                              // every word = kProgIdle
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
+  }
+  if (wstage) {   // the weights into plan order first; the row loop then streams them (p.w_in_plan_order)
+    const int64_t per_block = (int64_t)kThreads * 8;
+    int64_t sblocks = (plan->nnz + per_block - 1) / per_block;
+    if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
+    const dim3 sgrid((unsigned)(sblocks > 0 ? sblocks : 1)), sblk(kThreads);
+    constexpr int kStageTile = 60 * 1024;
+    int64_t gblocks = plan->n_groups < (int64_t)slab_device().cus * 8 ? plan->n_groups : (int64_t)slab_device().cus * 8;
+    const dim3 ggrid((unsigned)(gblocks > 0 ? gblocks : 1));
+    if (g_slab_stage_lds && wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_lds_kernel<uint32_t>), ggrid, sblk, kStageTile, st, plan->g_begin, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->n_groups, kStageTile / 4);
+    else if (g_slab_stage_lds && wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_lds_kernel<uint16_t>), ggrid, sblk, kStageTile, st, plan->g_begin, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->n_groups, kStageTile / 2);
+    else
+    if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
+    else if (wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->nnz);
+    else if (wbytes == 8) hipLaunchKernelGGL((slab_stage_weights_kernel<uint64_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(wstage), plan->nnz);
+    else hipLaunchKernelGGL((slab_stage_weights_kernel<f4_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const f4_t *>(weight), static_cast<f4_t *>(wstage), plan->nnz);
+    p.weight = wstage;
+    p.w_in_plan_order = 1;
   }
   if (plan->n_groups > 0) {
     const size_t hw_lds = weight_mode == 0 ? 0 : (weight_mode == 1 ? 1 : (size_t)heads);
@@ -1425,13 +1561,24 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   if ((((uintptr_t)mat_1) | ((uintptr_t)mat_2) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 16-byte aligned operands");
   if (rows_2 < 0 || (uint64_t)rows_2 * (uint64_t)rowbytes > ((uint64_t)1 << 32))
     return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: mat_2 of at most 4 GiB (32-bit row offsets)");
-  const int64_t waves = plan->units;                       // rows of >= 256 bytes: a unit is a wave (geot_slab_units_for)
+  // the form follows the plan's units, as in geot_slab_spmm: lane groups (the plan of a single-weight forward) or one row per
+  // wave-instruction (a multi-head plan; "slab_wrow_all"); the multi-head SDDMM needs whole-wave rows
+  bool wrow = false;
+  if (slab_wrow(rowbytes)) {
+    if (plan->units == (int64_t)geot_slab_units() * (64 >> lpr_log2)) wrow = false;
+    else if (plan->units == (int64_t)geot_slab_units()) wrow = true;
+    else wrow = slab_wants_wrow(heads > 1 ? 2 : 1, rowbytes);
+  }
+  if (heads > 1 && lpr_log2 < 6 && !wrow)
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_mh_sddmm: needs a plan cut into waves (geot_slab_units_for with weight_mode 2)");
+  const int per_wave = (wrow || lpr_log2 == 6) ? 1 : (64 >> lpr_log2);
+  const int64_t waves = plan->units / per_wave;
   const int64_t cu_waves = (int64_t)4 * slab_device().cus;
-  if (waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
+  if (plan->units % per_wave != 0 || waves % 4 != 0 || waves < 4 || waves > cu_waves * 4)
     return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: the plan's unit count is not a whole number of 4-wave workgroups, at most 4 per CU of this device");
   if (plan->rows_per_group < 1 || plan->rows_per_group > 32) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: rows_per_group 1..32");
   if (!workspace || workspace_bytes < 256 + kSyncBytes) return geot_internal_fail(GEOT_EWORKSPACE, "slab_sddmm: workspace too small");
-  const size_t lds = (size_t)4 * plan->rows_per_group * (size_t)rowbytes;       // the group's mat_1 rows, storage type
+  const size_t lds = (size_t)4 * plan->rows_per_group * (size_t)(wrow ? rowbytes : 1024);   // the group's mat_1 rows, storage type (per wave: R rows x its units)
   if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_sddmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_shape)");
   const bool staged = staging != nullptr;
   const int64_t ebytes = heads * tsize;                    // one edge's results
@@ -1470,6 +1617,7 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
 #define GEOT_SLAB_SDDMM(T_, E2_, E1_)                                                                        \
   do {                                                                                                        \
     if (lpr_log2 == 6) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, true>), grid, blk, lds, st, p);          \
+    else if (!wrow) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, false>), grid, blk, lds, st, p);            \
     else if (el == E2_) hipLaunchKernelGGL((seg_slab_sddmm_wrow_kernel<T_, E2_>), grid, blk, lds, st, p);     \
     else hipLaunchKernelGGL((seg_slab_sddmm_wrow_kernel<T_, E1_>), grid, blk, lds, st, p);                    \
   } while (0)
@@ -1526,6 +1674,9 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_nt") g_slab_nt = value != 0;
   if (name && std::string(name) == "slab_unroll" && (value == 8 || value == 16)) g_slab_unroll = value;
   if (name && std::string(name) == "slab_tight") g_slab_tight = value != 0;
+  if (name && std::string(name) == "slab_stage" && value >= 0 && value <= 2) g_slab_stage = value;
+  if (name && std::string(name) == "slab_wrow_all") g_slab_wrow_all = value != 0;
+  if (name && std::string(name) == "slab_stage_lds") g_slab_stage_lds = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 

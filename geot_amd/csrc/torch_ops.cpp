@@ -587,10 +587,38 @@ at::Tensor mh_sddmm_op(const at::Tensor &si_in, const at::Tensor &di_in, const a
   at::Tensor si = as_int64(si_in), di = as_int64(di_in);
   at::Tensor m1 = m1_in.contiguous(), m2 = m2_in.contiguous();
   const int64_t nnz = di.size(0), heads = m1.size(1), feat = m1.size(2);
+  if (nnz == 0 || heads == 0) return head_major ? at::empty({heads, nnz}, m1.options()) : at::empty({nnz, heads}, m1.options());
+  const int dt = dtype_code(m1, "mh_sddmm");
+  auto per_edge = [&](at::Tensor &o, bool hm) {
+    GEOT_CALL(geot_mh_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), o.data_ptr(), nnz, heads, feat, m1.size(0), m2.size(0),
+                                hm ? GEOT_W_HEAD_MAJOR : GEOT_W_EDGE_MAJOR, dt, stream_of(m1)));
+  };
+  // a dense graph that has (or now earns) the source-blocked plan of its forward mh_spmm: the SDDMM over that plan, the gathered
+  // rows re-used out of L2 (results edge-major; a head-major caller gets them transposed)
+  const int64_t rowbytes = heads * feat * m1.element_size(), ebytes = heads * m1.element_size();
+  if (m1.scalar_type() != at::kDouble && (heads == 1 || heads == 2 || heads == 4 || heads == 8) && ebytes <= 16 &&
+      (rowbytes == 256 || rowbytes == 512 || rowbytes == 1024) && (feat * m1.element_size()) % 16 == 0 && m1.size(0) < ((int64_t)1 << 31) &&
+      (g_opt.slab_mode == 1 || (g_opt.slab_mode == 0 && slab_worthwhile(nnz, m1.size(0), m2.size(0), rowbytes, dt))) &&
+      (tl_capturing || index_facts(di).ascending)) {
+    if (auto plan = slab_plan_for(si, di, m1.size(0), m2, 2, heads)) {
+      at::Tensor out = at::empty({nnz, heads}, m1.options());
+      auto run_plan = [&](at::Tensor &o) -> bool {
+        const std::vector<at::Tensor> pinned = plan->pinned();
+        if (pinned.empty()) return false;
+        const at::Tensor ws = workspace(m1, geot_slab_workspace_bytes(&plan->plan, heads * feat));
+        const at::Tensor staging = at::empty_like(o);
+        GEOT_CALL(geot_slab_mh_sddmm(&plan->plan, m1.data_ptr(), m2.data_ptr(), o.data_ptr(), staging.data_ptr(), heads, feat, m1.size(0), m2.size(0), dt,
+                                     ws.data_ptr(), ws.numel(), stream_of(m1)));
+        plan->launched_on(m1, pinned);
+        return true;
+      };
+      auto run_edges = [&](at::Tensor &o) { per_edge(o, false); };
+      out = plan_or_edges(plan, 1, out, m1, run_plan, run_edges);
+      return head_major ? out.t().contiguous() : out;
+    }
+  }
   at::Tensor out = head_major ? at::empty({heads, nnz}, m1.options()) : at::empty({nnz, heads}, m1.options());
-  if (nnz == 0 || heads == 0) return out;
-  GEOT_CALL(geot_mh_sddmm_coo(index_ptr(si), index_ptr(di), m1.data_ptr(), m2.data_ptr(), out.data_ptr(), nnz, heads, feat, m1.size(0), m2.size(0),
-                              head_major ? GEOT_W_HEAD_MAJOR : GEOT_W_EDGE_MAJOR, dtype_code(m1, "mh_sddmm"), stream_of(m1)));
+  per_edge(out, head_major);
   return out;
 }
 

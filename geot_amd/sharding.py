@@ -385,6 +385,127 @@ def sharded_gather_scatter(src_index_shard: torch.Tensor, dst_index_shard: torch
                            collective, reduce)
 
 
+# ---- node-sharded source features (second option) -----------------------------------------------------------
+# Replicating `src` costs 56.9 GB per GPU at configs[4] and caps the graph at what one GPU holds.  With the nodes partitioned into
+# contiguous ranges - rank r holds src[node_offsets[r] : node_offsets[r + 1]] - a rank's edge range references a set of source rows
+# that is FIXED per edge list: found once (`HaloPlan`), fetched per call with ONE all_to_all_single (every rank sends each other rank
+# the rows it asked for), and the local kernel runs over the compact table of exactly those rows (src_index renumbered once).  When
+# the halo is most of the table anyway (> `all_gather_above` of it: uniform-random sources at small world sizes) one all_gather of
+# the shards is cheaper and needs no renumbering of the features - the plan then says so.  The reference has no counterpart
+# (single-GPU; csrc/gather_scatter.cpp:25-34 reads the whole table).
+class HaloPlan:
+    """What rank `rank` must fetch to run its edge range, for one (edge list, node partition).  Built collectively (`build`)."""
+
+    def __init__(self):
+        self.mode = "halo"            # "halo": all_to_all_single of the rows asked for | "all_gather": every shard, padded to the largest
+        self.compact_index = None     # int64 [nnz]: src_index renumbered into the table the local kernel gathers from
+        self.table_rows = 0
+        self.send_rows = None         # int64: MY local rows the ranks asked for, grouped by asking rank (mine included)
+        self.send_splits = self.recv_splits = None
+        self.pad_rows = 0             # (all_gather) rows per rank in the gathered table
+        self.rows_fetched = 0         # rows this rank receives from OTHER ranks per call
+        self.rows_table_total = 0
+
+    @staticmethod
+    def build(src_index_shard: torch.Tensor, node_offsets: List[int], group=None, all_gather_above: float = 0.5) -> "HaloPlan":
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if len(node_offsets) != world + 1 or any(node_offsets[i] > node_offsets[i + 1] for i in range(world)):
+            raise ValueError("node_offsets: world + 1 ascending row offsets")
+        dev = src_index_shard.device
+        host = dev.type == "cuda" and dist.get_backend(group) == "gloo"     # (test ranks sharing one GPU: stage through the host)
+        offs = torch.tensor(node_offsets, dtype=torch.int64, device=dev)
+        n_total = int(node_offsets[-1])
+        plan = HaloPlan()
+        plan.rows_table_total = n_total
+        needed = torch.unique(src_index_shard)                                # ascending global ids = owner-major (owners are contiguous ranges)
+        if needed.numel() and (int(needed[0]) < 0 or int(needed[-1]) >= n_total):
+            raise ValueError("src_index outside the node partition")
+        # every rank takes the same decision: the LARGEST halo decides (one collective either way)
+        frac = torch.tensor([needed.numel() / max(n_total, 1)], dtype=torch.float64, device="cpu" if host or dev.type == "cpu" else dev)
+        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=group)
+        if float(frac.item()) > all_gather_above:
+            plan.mode = "all_gather"
+            plan.pad_rows = max(node_offsets[r + 1] - node_offsets[r] for r in range(world))
+            owner = torch.bucketize(src_index_shard, offs[1:], right=True)
+            plan.compact_index = (owner * plan.pad_rows + (src_index_shard - offs[owner])).contiguous()
+            plan.table_rows = world * plan.pad_rows
+            plan.rows_fetched = n_total - (node_offsets[rank + 1] - node_offsets[rank])
+            return plan
+        plan.compact_index = torch.searchsorted(needed, src_index_shard).contiguous()
+        plan.table_rows = int(needed.numel())
+        bounds = torch.searchsorted(needed, offs)                               # needed[bounds[o] : bounds[o + 1]] live on rank o
+        want = (bounds[1:] - bounds[:-1])
+        plan.recv_splits = [int(v) for v in want.tolist()]
+        asked = torch.empty(world, dtype=torch.int64, device="cpu" if host else dev)
+        dist.all_to_all_single(asked, want.cpu() if host else want, group=group)  # how many rows each rank asks ME for
+        plan.send_splits = [int(v) for v in asked.tolist()]
+        ids = torch.empty(sum(plan.send_splits), dtype=torch.int64, device="cpu" if host else dev)
+        dist.all_to_all_single(ids, needed.cpu() if host else needed, plan.send_splits, plan.recv_splits, group=group)
+        plan.send_rows = (ids.to(dev) - node_offsets[rank]).contiguous()
+        plan.rows_fetched = plan.table_rows - plan.recv_splits[rank]
+        return plan
+
+    def fetch(self, src_shard: torch.Tensor, group=None) -> torch.Tensor:
+        """The table the local kernel gathers from, [table_rows, *feat]: one collective."""
+        dev = src_shard.device
+        host = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+        feat = tuple(src_shard.shape[1:])
+        if self.mode == "all_gather":
+            mine = src_shard
+            if mine.shape[0] < self.pad_rows:
+                mine = torch.cat([mine, mine.new_zeros((self.pad_rows - mine.shape[0],) + feat)])
+            send = mine.contiguous().cpu() if host else mine.contiguous()
+            table = torch.empty((self.table_rows,) + feat, dtype=src_shard.dtype, device=send.device)
+            dist.all_gather_into_tensor(table, send, group=group)
+            return table.to(dev) if host else table
+        send = src_shard.index_select(0, self.send_rows)
+        send = send.cpu() if host else send
+        table = torch.empty((self.table_rows,) + feat, dtype=src_shard.dtype, device=send.device)
+        dist.all_to_all_single(table, send, self.recv_splits, self.send_splits, group=group)
+        return table.to(dev) if host else table
+
+    def bytes_fetched(self, row_bytes: int) -> int:
+        return int(self.rows_fetched) * int(row_bytes)
+
+
+_halo_seen: dict = {}
+
+
+def sharded_gather_scatter_node(src_index_shard: torch.Tensor, dst_index_shard: torch.Tensor, src_shard: torch.Tensor,
+                                node_offsets: List[int], weight_shard: Optional[torch.Tensor] = None,
+                                group: Optional[dist.ProcessGroup] = None, local_op: Optional[Callable] = None,
+                                exchange: bool = True, key_offset: Optional[int] = None, timing: Optional[dict] = None,
+                                collective: str = "all_gather", reduce: str = "sum", halo: Optional[HaloPlan] = None,
+                                all_gather_above: float = 0.5) -> Tuple[torch.Tensor, int]:
+    """:func:`sharded_gather_scatter` with NODE-SHARDED source features: ``src_shard`` = this rank's rows
+    ``src[node_offsets[rank] : node_offsets[rank + 1]]`` (``src_index_shard`` keeps GLOBAL node ids).  Same rows as the replicated
+    form (the local kernel sees the same values in the same edge order: bit-equal).  ``halo``: a plan built earlier with
+    ``HaloPlan.build`` (a collective); otherwise built on the first call with this edge list and remembered per index identity.
+    ``timing`` receives "halo_plan" (the plan: mode, rows fetched) and, on the GPU, event pairs around the fetch ("fetch_events")."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if halo is None:
+        ident = _ident(src_index_shard, world, rank, tuple(node_offsets))
+        halo = _halo_seen.get(ident) if ident is not None else None
+        if halo is None:
+            halo = HaloPlan.build(src_index_shard, node_offsets, group, all_gather_above)
+            if ident is not None:
+                _halo_seen[ident] = halo
+                if len(_halo_seen) > 16:
+                    _halo_seen.pop(next(iter(_halo_seen)))
+    ev = None
+    if timing is not None and src_shard.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    table = halo.fetch(src_shard, group)
+    if ev is not None:
+        ev[1].record()
+        timing.setdefault("fetch_events", []).append(ev)
+    if timing is not None:
+        timing["halo_plan"] = halo
+    return sharded_gather_scatter(halo.compact_index, dst_index_shard, table, weight_shard, group, local_op, exchange, key_offset, timing,
+                                  collective, reduce)
+
+
 def shard_edges(index: torch.Tensor, src: torch.Tensor, world: int, rank: int, aligned: bool = False):
     """Slice a replicated (index, src) pair for ``rank`` (helper for tests and examples)."""
     cuts = segment_aligned_cuts(index, world) if aligned else equal_edge_cuts(index.numel(), world)

@@ -74,7 +74,7 @@ def build_plan(src_index: torch.Tensor, dst_index: torch.Tensor, out_rows: int, 
 
 
 def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: int, src: torch.Tensor, out: torch.Tensor,
-                  heads: int, feat: int, reduce: str = "sum") -> torch.Tensor:
+                  heads: int, feat: int, reduce: str = "sum", stage_weights: bool = True) -> torch.Tensor:
     """out[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges (pointer-level doorway);
     reduce: 'sum' | 'mean' | 'max' | 'min' (weight modes 0 / 1)."""
     tensors = [src, out] + ([weight] if weight is not None else [])
@@ -86,8 +86,12 @@ def slab_spmm_out(plan: SlabPlan, weight: Optional[torch.Tensor], weight_mode: i
     L = _lib.load()
     with hip._on_device(dev):
         st = hip._stream_handle(dev)
-        nbytes = int(L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), heads * feat))
+        # (with room for the weights in plan order: edge-order weights are then staged inside the kernel, `stage_weights=False`: read through e_perm)
+        nbytes = int(L.geot_slab_workspace_bytes_staged(ctypes.byref(plan.struct), heads * feat, weight_mode, heads, hip._dtype_code(src, "slab_spmm"))
+                     if stage_weights else L.geot_slab_workspace_bytes(ctypes.byref(plan.struct), heads * feat))
         ws = hip.workspace(dev, nbytes, st)
+        if not stage_weights:
+            ws = ws[:nbytes]
         rc = L.geot_slab_spmm(ctypes.byref(plan.struct), None if weight is None else weight.data_ptr(), weight_mode,
                               src.data_ptr(), out.data_ptr(), heads, feat, src.shape[0], out.shape[0], hip._dtype_code(src, "slab_spmm"),
                               hip._REDUCE_CODES[reduce], ws.data_ptr(), ws.numel(), st)

@@ -51,10 +51,10 @@
 extern "C" {
 #endif
 
-/* 2 (round 5): geot_slab_plan carries slab_shift / n_slabs; a plan's `units` are WAVES for every row of >= 256 bytes
- * (geot_slab_units_for / geot_slab_rows_per_group_shape), split hubs are interleaved, weights may arrive in plan order for the
- * multi-head mode too (weight_mode 5), geot_slab_mh_sddmm / geot_mh_sddmm_coo; the measurement hooks and experiment switches moved
- * to geot_hip_dev.h. */
+/* 2 (round 5): geot_slab_plan carries slab_shift / n_slabs and its `units` select the kernel form (geot_slab_units_for /
+ * geot_slab_rows_per_group_shape), split hubs are interleaved, weights may arrive in plan order for the multi-head mode too
+ * (weight_mode 5) or are staged into it by the kernel (geot_slab_workspace_bytes_staged), geot_slab_mh_sddmm / geot_mh_sddmm_coo;
+ * the measurement hooks and experiment switches moved to geot_hip_dev.h. */
 #define GEOT_ABI_VERSION 2
 
 enum {
@@ -230,8 +230,8 @@ int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *
  * when a graph is dense enough for its source rows to be re-used out of an XCD's L2: Reddit scale runs ~2x
  * faster than the per-edge gather.  The edge list is pre-arranged ONCE (Phase A: geot_slab_plan_rows / _groups / _edges
  * below, driven by the host layer and kept per edge list): all arrays below are DEVICE memory in processing order.
- *   units            streams of the persistent grid: its WAVES (geot_slab_units()) for rows of >= 256 bytes - one row per wave-
- *                    instruction -, waves x 8 lane groups for 128-byte rows (geot_slab_units_for)
+ *   units            streams of the persistent grid (geot_slab_units_for): its waves (geot_slab_units()) where a row is a whole
+ *                    wave-instruction, waves x 1024 / rowbytes lane groups otherwise
  *   groups           <= rows_per_group consecutive (virtual) dst rows with about equal edge counts, ordered by
  *                    size (descending); group at position p is run by unit (p % units) in round (p / units)
  *   e_src/e_dl/e_perm  per edge, grouped by position and sorted by (source slab, row in group): source row,
@@ -266,13 +266,19 @@ int geot_slab_units(void);                                     /* waves of the p
 int geot_slab_full_chip(void);                                 /* 1: all 256 CUs / 160 KB LDS (what the density rule was measured on) */
 int geot_slab_rows_per_group(int weight_mode, int64_t heads);  /* R that fits the LDS budget (float32 storage) */
 int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /* ... 16-bit storage: fp32 accumulators, half the rows */
-/* What a plan's `units` and rows per group must be for the kernel that will run it.  Rows of 256 / 512 / 1024 bytes run one row per
- * wave-instruction (4 / 8 / 16 bytes per lane): a unit is a WAVE whatever the weight mode, and a group holds as many rows as the LDS
- * budget allows for that row width, storage type and number of staged weights (ABI 2; ABI 1 cut rows below 1 KiB into lane groups
- * unless the weights were multi-head).  Rows of 128 bytes (never routed automatically): 8 lane groups per wave. */
+/* What a plan's `units` and rows per group must be for the kernel that will run it.  A unit is the rowbytes / 16 lanes of a row
+ * (units = waves x 1024 / rowbytes) - except under multi-head weights (weight_mode 2 / 3 / 5) on rows of 512 / 256 bytes, which run
+ * one row per wave-instruction (8 / 4 bytes per lane): there a unit is a wave and a group holds more rows.  geot_slab_spmm /
+ * geot_slab_sddmm read the form off the plan's `units` (a plan cut into waves runs row-per-wave under any weight mode; measured
+ * slower than lane groups except under multi-head weights: profiles/r05/slab_cases__row_per_wave_*). */
 int geot_slab_units_for(int weight_mode, int64_t rowbytes);
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes);
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
+/* ... plus room for the call's weights in plan order (nnz x heads elements; weight modes 1 / 2 only, otherwise the same number).
+ * Given that much, geot_slab_spmm stages EDGE-order weights into plan order inside the kernel - every unit its own group's, at the
+ * start of its round - instead of reading each one through the edge permutation in the row loop (gws F=128 fp32 at Reddit scale:
+ * 4.50 -> see profiles/r05/slab_cases_*; the permuted reads cost ~15 GB of 64-byte lines for 1.8 GB of weights under 4 heads). */
+size_t geot_slab_workspace_bytes_staged(const geot_slab_plan *plan, int64_t feat_total, int weight_mode, int64_t heads, int dtype);
 /* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
  * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts),
  * 4 = 1 with weight[] already permuted into the plan's edge order (weight[i] belongs to e_perm[i]: a static weight,

@@ -191,3 +191,114 @@ def test_bench_cfg5_world8_strong():
     assert r["ranks_seen"] == WORLD and r["scaling"] == "strong" and r["value"] > 1e8
     # the full (scaled) configuration, cut into 8: ~2 M edges per rank at --scale 0.01
     assert abs(r["config"]["nnz_per_gpu"] * WORLD - int(1_615_685_872 * 0.01)) < 0.02 * 1_615_685_872 * 0.01
+
+
+# ---- the RCCL branch of the protocol at world > 1 (one GPU: the transport is shimmed, the code path is the real one) ------------------
+def _shim_rccl():
+    """Make torch.distributed look like an RCCL group to geot_amd.sharding while the bytes travel over gloo: `get_backend` says
+    "nccl", and the collectives sharding.py uses accept DEVICE tensors (staged through the host here; RCCL moves them over xGMI).
+    With this, `_sharded_reduce`'s device branch - key all_gather on a side stream, pinned copy, event, collectives queued on the
+    stream - runs with world > 1 on one GPU (it had only ever run at world 1)."""
+    import torch.distributed as dist
+    real = {n: getattr(dist, n) for n in ("all_gather_into_tensor", "reduce_scatter_tensor", "all_reduce", "all_to_all_single")}
+
+    def staged(name, out_pos, in_pos):
+        def call(*args, **kw):
+            args = list(args)
+            devs = [a for a in args if torch.is_tensor(a) and a.is_cuda]
+            if not devs:
+                return real[name](*args, **kw)
+            torch.cuda.current_stream().synchronize()            # (gloo reads host memory: the producer kernels must be done)
+            outs = {}
+            for i, a in enumerate(args):
+                if torch.is_tensor(a) and a.is_cuda:
+                    outs[i] = a
+                    args[i] = a.cpu()
+            r = real[name](*args, **kw)
+            for i in out_pos:
+                if i in outs:
+                    outs[i].copy_(args[i])
+            return r
+        return call
+    dist.all_gather_into_tensor = staged("all_gather_into_tensor", (0,), (1,))
+    dist.reduce_scatter_tensor = staged("reduce_scatter_tensor", (0,), (1,))
+    dist.all_reduce = staged("all_reduce", (0,), (0,))
+    dist.all_to_all_single = staged("all_to_all_single", (0,), (1,))
+    dist.get_backend = lambda group=None: "nccl"
+
+
+def _rccl_rank(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import geot_amd
+        from geot_amd import sharding
+        _shim_rccl()
+        res = {}
+        si, di, w, x = (torch.from_numpy(a).cuda() for a in _global_list(True))
+        cuts = sharding.equal_edge_cuts(di.numel(), world)
+        e0, e1 = cuts[rank], cuts[rank + 1]
+        si_s, di_s, w_s = si[e0:e1].clone(), di[e0:e1].clone(), w[e0:e1].clone()
+        full = geot_amd.gather_weight_scatter(si, di, w, x)
+        for coll in ("all_gather", "reduce_scatter"):
+            timing = {}
+            for it in range(3):                                   # (the second call launches on the remembered keys, underneath the key exchange)
+                out, first = sharding.sharded_gather_scatter(si_s, di_s, x, weight_shard=w_s, collective=coll, timing=timing)
+            res[coll] = (first, out.shape[0], bool(torch.equal(out, full[first:first + out.shape[0]])),
+                         len(timing.get("key_events", [])), len(timing.get("exchange_events", [])), "key_wall_ms" in timing)
+        # node-sharded sources on the HIP kernels: the halo by all_to_all_single and the all_gather form, against the replicated rows
+        nodes = x.shape[0]
+        offs = [nodes * r // world for r in range(world + 1)]
+        rep, first = sharding.sharded_gather_scatter(si_s, di_s, x, weight_shard=w_s)
+        for name, above in (("halo", 2.0), ("all_gather", 0.0)):
+            timing = {}
+            out, f2 = sharding.sharded_gather_scatter_node(si_s, di_s, x[offs[rank]:offs[rank + 1]].contiguous(), offs, weight_shard=w_s,
+                                                           all_gather_above=above, timing=timing,
+                                                           halo=sharding.HaloPlan.build(si_s, offs, None, above))
+            res["node_" + name] = (f2, out.shape[0], bool(f2 == first and torch.equal(out, rep)), timing["halo_plan"].mode,
+                                   len(timing.get("fetch_events", [])))
+        q.put((rank, res, full.shape[0]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_of_the_protocol_runs_at_world_4_on_one_gpu():
+    import torch.multiprocessing as mp
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    K = got[0][2]
+    for coll in ("all_gather", "reduce_scatter"):
+        row = 0
+        for rank, res, _ in got:
+            first, n, ok, key_events, exchange_events, via_host = res[coll]
+            assert ok and first == row, (coll, rank)
+            assert key_events == 3 and exchange_events == 3 and not via_host, (coll, rank, key_events, exchange_events, via_host)   # the DEVICE branch ran
+            row += n
+        assert row == K
+    for name in ("node_halo", "node_all_gather"):
+        for rank, res, _ in got:
+            f2, n, ok, mode, fetches = res[name]
+            assert ok and mode == name[5:] and fetches == 1, (name, rank, mode)
+
+
+def test_bench_cfg5_world8_node_sharded_sources():
+    """`bench.py --workload cfg5 --src-sharding node`: every rank holds 1/8 of the source rows and fetches what its edge range references
+    per step; the line reports the plan's mode and the bytes exchanged.  Uniform-random sources reference (almost) every row: the plan
+    takes the all_gather form; the timed step includes the fetch."""
+    r = _bench(["--src-sharding", "node"])
+    assert r["ranks_seen"] == WORLD and r["src_sharding"] == "node" and r["value"] > 1e7
+    f = r["source_rows_fetch"]
+    assert f["mode"] in ("halo", "all_gather") and f["bytes_fetched_per_step_rank0"] > 0 and f["fetch_ms_rank0"] > 0
+    assert f["src_rows_on_this_rank"] * WORLD <= f["src_rows_total"] + WORLD
+    assert "sharded by node" in r["metric"] and "sharded by node" in r["config"]["workload"]

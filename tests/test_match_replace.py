@@ -122,3 +122,59 @@ def test_rewritten_model_is_trainable():
         at = int(err.argmax())
         atol = 1e-5 * float(b.abs().max())
         assert torch.allclose(a, b, rtol=1e-3, atol=atol), (name, float(err.max()), float(b.flatten()[at]), at, int((err > atol + 1e-3 * b.abs()).sum()))
+
+
+class GATLayer(torch.nn.Module):
+    """A GAT layer written with aten ops, scores and softmax included: what geot/match_replace/fused_mh_spmm.py:4-50 of the reference
+    rewrites onto mh_spmm - where the layer then stops training, because the reference's mh_spmm has no backward
+    (geot/mh_spmm.py:4-12)."""
+
+    def __init__(self, fin, heads, fout):
+        super().__init__()
+        self.heads, self.fout = heads, fout
+        self.lin = torch.nn.Linear(fin, heads * fout, bias=False)
+        self.att_src = torch.nn.Parameter(torch.randn(heads, fout) * 0.3)
+        self.att_dst = torch.nn.Parameter(torch.randn(heads, fout) * 0.3)
+
+    def forward(self, x, edge_index):
+        row, col = edge_index[0], edge_index[1]
+        h = self.lin(x).view(-1, self.heads, self.fout)
+        a_src, a_dst = (h * self.att_src).sum(-1), (h * self.att_dst).sum(-1)                 # [N, H]
+        e = torch.exp(torch.nn.functional.leaky_relu(a_src.index_select(0, col) + a_dst.index_select(0, row), 0.2))
+        denom = torch.zeros_like(a_dst).index_add(0, row, e)
+        alpha = e / denom.index_select(0, row)                                                  # [nnz, H]
+        msg = alpha.unsqueeze(-1) * h.index_select(0, col)
+        return torch.zeros_like(h).index_add(0, row, msg)                                        # -> mh_spmm
+
+
+@pytest.mark.gpu
+def test_rewritten_gat_layer_takes_an_optimiser_step():
+    """`mh_spmm` differentiates (d/dsrc over the transposed list, d/dweight by the multi-head SDDMM), so a GAT
+    layer rewritten by `pattern_transform` trains: one SGD step of the rewritten program moves the parameters exactly as the eager
+    model's step does."""
+    from geot_amd.match_replace import pattern_transform
+    torch._dynamo.reset()
+    torch.manual_seed(3)
+    n, nnz, fin, heads, fout = 1200, 40_000, 24, 4, 16
+    x, ei, _ = _inputs(n=n, nnz=nnz, f=fin, device="cuda", seed=11)
+    eager = GATLayer(fin, heads, fout).cuda()
+    twin = GATLayer(fin, heads, fout).cuda()
+    twin.load_state_dict(eager.state_dict())
+    ep = pattern_transform(twin, (x, ei))
+    assert torch.ops.geot.mh_spmm_rows.default in _targets(ep)
+    fused = ep.module()
+    target = torch.rand(n, heads, fout, device="cuda")
+    steps = {}
+    for name, mod in (("eager", eager), ("fused", fused)):
+        opt = torch.optim.SGD(mod.parameters(), lr=0.05)
+        before = [p.detach().clone() for p in mod.parameters()]
+        loss = (mod(x, ei) - target).square().mean()
+        opt.zero_grad()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mod.parameters()), name
+        opt.step()
+        steps[name] = (float(loss), sorted(((n_, (p.detach() - b)) for (n_, p), b in zip(mod.named_parameters(), before)), key=lambda t: t[0]))
+    assert abs(steps["eager"][0] - steps["fused"][0]) <= 1e-5 * abs(steps["eager"][0])
+    for (na, da), (nb, db) in zip(steps["eager"][1], steps["fused"][1]):
+        assert da.shape == db.shape and float(da.abs().max()) > 0, na                      # the step moved the parameter ...
+        assert torch.allclose(da, db, rtol=2e-3, atol=2e-5 * float(da.abs().max()) + 1e-9), (na, nb, float((da - db).abs().max()))   # ... the same way

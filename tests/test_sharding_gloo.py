@@ -242,6 +242,85 @@ def test_sharded_gather_weight_scatter_replicated_src():
     np.testing.assert_allclose(got, full, rtol=1e-5, atol=1e-6)
 
 
+def _node_worker(rank, world, port, case, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geot_amd import sharding
+        from oracle import api
+
+        def local_op(si, di, w, x, rows, reduce="sum"):
+            if reduce != "sum":
+                raise NotImplementedError
+            return torch.from_numpy(api.gather_weight_scatter(si.numpy(), di.numpy(), None if w is None else w.numpy(),
+                                                              x.numpy(), rows=rows))
+        t = torch.from_numpy
+        cuts = sharding.equal_edge_cuts(len(case["dst"]), world)
+        sl = slice(cuts[rank], cuts[rank + 1])
+        offs = case["node_offsets"]
+        x_mine = t(case["x"][offs[rank]:offs[rank + 1]])
+        res = {}
+        rep, first = sharding.sharded_gather_scatter(t(case["si"][sl]), t(case["dst"][sl]), t(case["x"]), weight_shard=t(case["w"][sl]),
+                                                     local_op=local_op)
+        res["replicated"] = (first, rep.numpy().copy())
+        for name, above in (("halo", 2.0), ("all_gather", 0.0), ("rule", 0.5)):
+            timing = {}
+            out, first = sharding.sharded_gather_scatter_node(t(case["si"][sl]), t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]),
+                                                              local_op=local_op, all_gather_above=above, timing=timing,
+                                                              halo=sharding.HaloPlan.build(t(case["si"][sl]), offs, None, above))
+            plan = timing["halo_plan"]
+            res[name] = (first, out.numpy().copy(), plan.mode, plan.rows_fetched, plan.table_rows)
+        # the remembered plan (no `halo=`): built on the first call, found on the second
+        a, _ = sharding.sharded_gather_scatter_node(t(case["si"][sl]), t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
+        b, _ = sharding.sharded_gather_scatter_node(t(case["si"][sl]), t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
+        assert torch.equal(a, b) and torch.equal(a, rep)
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_node_sharded_sources_give_the_replicated_rows_bit_for_bit(world):
+    """SURVEY.md section 8(e), second option: every rank owns a contiguous range of source rows and fetches the rows its edge range
+    references with one all_to_all_single ("halo") - or all shards with one all_gather when the halo is most of the table.  The local
+    kernel sees the same values in the same edge order: the rows equal the replicated form bit for bit.  Uneven node ranges (one rank
+    owns no node at world 8), sources with locality (small halos) and without."""
+    rng = np.random.default_rng(60 + world)
+    nodes, nnz, F = 400, 9000, 6
+    dst = powerlaw_index(nnz, nodes, 4)
+    near = np.clip(dst + rng.integers(-25, 26, nnz), 0, nodes - 1)                # sources near their destination: small halos
+    si = np.where(rng.random(nnz) < 0.8, near, rng.integers(0, nodes, nnz)).astype(np.int64)
+    cuts = sorted(rng.choice(np.arange(1, nodes), size=world - 1, replace=False).tolist())
+    if world == 8:
+        cuts[3] = cuts[2]                                                          # a rank that owns no node
+    case = dict(dst=dst, si=si, w=rng.random(nnz, dtype=np.float32), x=rng.random((nodes, F), dtype=np.float32),
+                node_offsets=[0] + cuts + [nodes])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_node_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        first, rep = res[r]["replicated"]
+        for name in ("halo", "all_gather", "rule"):
+            f2, out, mode, fetched, table_rows = res[r][name]
+            assert f2 == first and np.array_equal(out, rep), (r, name)
+            if name != "rule":
+                assert mode == name
+        own = case["node_offsets"][r + 1] - case["node_offsets"][r]
+        assert res[r]["all_gather"][3] == nodes - own                                  # every other rank's rows
+        assert res[r]["halo"][3] < nodes - own or world == 2                           # the halo: only what the edge range references
+        assert res[r]["halo"][4] <= nodes
+
+
 def _repeat_worker(rank, world, port, case, q):
     import sys
     sys.path.insert(0, ROOT)

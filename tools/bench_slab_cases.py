@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """The source-blocked kernels at BASELINE.json configs[3]'s graph (Reddit scale stand-in: 232 965 nodes, 114.6 M power-law edges,
 uniform-random sources), one line per (operator, storage type, row width, weight form): milliseconds per launch through the
-pointer-level doorway (geot_amd/slab.py), plans built with the library's own units and rows per group.  Round 5: every row of
-256 / 512 bytes runs one row per wave-instruction (seg_slab_wrow_kernel), weights may arrive in plan order (modes 4 / 5), the
-multi-head SDDMM runs over the plan (`profiles/r05/slab_cases_*.txt`).
+pointer-level doorway (geot_amd/slab.py), plans built with the library's own units and rows per group.  Round 5: weights may arrive
+in plan order (modes 4 / 5), one weight per edge in edge order is staged into plan order by a pre-pass when the workspace has room
+("as the ABI serves them"; `stage_weights=False` = read through the permutation in the row loop), the multi-head SDDMM runs over the
+plan; `--options slab_wrow_all=1`: every plan of 512 / 256-byte rows cut into waves (`profiles/r05/slab_cases_*.txt`).
 
     python tools/bench_slab_cases.py [--scale 1.0] [--only mh,gws,...] [--options slab_unroll=16,slab_tight=0]
 """
@@ -61,8 +62,9 @@ def main():
             w = torch.rand(nnz, H, device=dev, generator=g).to(dtype)
             out = torch.empty(nodes, H, Fh, device=dev, dtype=dtype)
             plan = plan_for(H * Fh * esz, 2, H, dtype)
-            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh),
-                 f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']}")
+            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, as the ABI serves them", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh),
+                 f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} units={plan.meta['units']}")
+            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, through e_perm", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh, stage_weights=False))
             wp = w[plan.tensors["e_perm"].long()].contiguous()
             line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights in PLAN order (mode 5)", lambda: slab.slab_spmm_out(plan, wp, 5, x, out, H, Fh))
             del wp
@@ -85,8 +87,9 @@ def main():
             w = torch.rand(nnz, device=dev, generator=g).to(dtype)
             out = torch.empty(nodes, F, device=dev, dtype=dtype)
             plan = plan_for(F * esz, 1, 1, dtype)
-            line(f"gws F={F} {tname} rows {F * esz} B, weight[e] in edge order", lambda: slab.slab_spmm_out(plan, w, 1, x, out, 1, F),
-                 f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']}")
+            line(f"gws F={F} {tname} rows {F * esz} B, weight[e] in edge order, as the ABI serves them", lambda: slab.slab_spmm_out(plan, w, 1, x, out, 1, F),
+                 f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} units={plan.meta['units']}")
+            line(f"gws F={F} {tname} rows {F * esz} B, weight[e] in edge order, through e_perm", lambda: slab.slab_spmm_out(plan, w, 1, x, out, 1, F, stage_weights=False))
             wp = w[plan.tensors["e_perm"].long()].contiguous()
             line(f"gws F={F} {tname} rows {F * esz} B, weight in PLAN order (mode 4)", lambda: slab.slab_spmm_out(plan, wp, 4, x, out, 1, F))
             line(f"gs  F={F} {tname} rows {F * esz} B, no weight", lambda: slab.slab_spmm_out(plan, None, 0, x, out, 1, F))
