@@ -107,16 +107,10 @@ struct SegParams {
   unsigned long long epoch;
   int handoff;              // 1: the tile kernel finishes the straddling runs itself, the second launch only tidies up
   int ho_tries;             // polls of a predecessor's flag before a run is left to the second launch
-  int single;               // 1 (hand-off mode only): NO second launch - the call's tag is completed on the device (ctrl[kCtrlLaunch]), large
-                            // gaps are filled by their tile, the last tile to finish tidies up and does the rare repairs (finish_launch)
 };
 
 // control words at the head of the workspace (zero between calls)
-enum { kCtrlGaps = 0, kCtrlTicket = 1, kCtrlDescent = 2, kCtrlZeroed = 3, kCtrlGo = 4, kCtrlChunk = 5, kCtrlDone = 6, kCtrlDeferred = 7,
-       kCtrlLaunch = 8 /* single-launch calls completed on this workspace: the one word that is NOT zero between calls */,
-       kCtrlTick0 = 16 /* .. 31: first-level end-of-tile tickets of a single-launch call (tile mod 16) */ };
-constexpr int kTickN = 16; // (one counter for all 19 532 tiles of the graded call serialises at the memory side: ~60 ns per same-address atomic = 1.1 ms)
-constexpr int kGapSlots = 16; // large gaps a tile of a single-launch call lists in LDS and fills with all its threads
+enum { kCtrlGaps = 0, kCtrlTicket = 1, kCtrlDescent = 2, kCtrlZeroed = 3, kCtrlGo = 4, kCtrlChunk = 5, kCtrlDone = 6, kCtrlDeferred = 7 };
 
 // wave-uniform: some lane saw its key below its predecessor's -> the index is NOT ascending, whatever the caller or the
 // host layer's remembered facts said.  One plain store; the fix-up kernel (next launch) reads it.
@@ -199,15 +193,8 @@ __device__ __forceinline__ void store_vec(T *p, const typename AccOf<T>::type (&
 #pragma unroll
     for (int i = 0; i < VEC; ++i) x[i] = (T)v[i];
   }
-  if constexpr (NT) {
-#ifdef GEOT_NT_SC1   // experiment (tools/_ab): streamed dst rows written THROUGH (sc1 nt) - no dirty line of dst is left in any XCD's L2
-    if constexpr (sizeof(V) == 16) {
-      asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-      return;
-    }
-#endif
-    __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
-  } else *reinterpret_cast<V *>(p) = x;
+  if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<V *>(p));
+  else *reinterpret_cast<V *>(p) = x;
 }
 
 // Reductions of the reference's CPU path (csrc/cpu/index_scatter_cpu.cpp:124-134; init / update /
@@ -239,7 +226,6 @@ struct SmemLayout {
   size_t off_p;    // T     [2*ng][FB]
   size_t off_w;    // T     [te*hw]  : edge weights, edge-major
   size_t off_cnt;  // int   [2*ng]   : edge counts of the partials (mean)
-  size_t off_gap;  // int64 [2*kGapSlots + 1] : large gaps of this tile (first row, rows), then their count (single-launch calls)
   size_t bytes;
 };
 
@@ -258,86 +244,8 @@ __host__ __device__ inline SmemLayout smem_layout(int lpr_log2, int cg, int vec,
   L.off_w = o;    o += (size_t)tsize * L.te * hw;
   o = (o + 7) & ~(size_t)7;
   L.off_cnt = o;  o += sizeof(int) * (size_t)(2 * ng);
-  o = (o + 7) & ~(size_t)7;
-  L.off_gap = o;  o += sizeof(int64_t) * (size_t)(2 * kGapSlots + 1);
   L.bytes = (o + 15) & ~(size_t)15;
   return L;
-}
-
-// Single-launch calls (SegParams::single): what the second launch used to do, done by wave 0 of the LAST tile to finish.  Every tile
-// has drained its stores and taken a ticket before this runs, and everything read here was stored write-through (sc1) or is read with
-// agent-scope atomics.  Common case: two flag words are zero -> reset the ticket, count the launch (the next call's tag), done.
-// Rare: runs a tile gave up waiting for (`deferred`) are redone exactly as seg_fixup_kernel redoes them - the tile in which a
-// straddling run ends walks back, float64 meeting, one rounding: the same bits - and a descent is repaired the reference's way
-// (zero-fill + one float atomic per element; other reductions / 16-bit storage: NaN-fill), serially: one wave instead of the chip,
-// ~50 ms per million edges at F = 64 - once per index, the alarm word then makes the host layer probe again.
-template <typename T, int RED>
-__device__ __forceinline__ void finish_launch(const SegParams &p, int64_t num_tiles) {
-  using A = typename AccOf<T>::type;
-  constexpr bool MEAN = RED == RED_MEAN;
-  const int lane = threadIdx.x & 63;
-  const int lpr = 1 << p.lpr_log2, R = 64 >> p.lpr_log2, gq = lane >> p.lpr_log2, c = lane & (lpr - 1);
-  const int64_t F = p.F, K = p.K;
-  T *dst = static_cast<T *>(p.dst);
-  const unsigned long long desc = __hip_atomic_load(&p.ctrl[kCtrlDescent], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long deferred = __hip_atomic_load(&p.ctrl[kCtrlDeferred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long ngl = atomicAdd(&p.ctrl[kCtrlGaps], 0ull);   // (counted with atomics by the tiles: read the same way)
-  if (ngl != 0ull && desc == 0ull) {   // large gaps beyond a tile's LDS list: rare twice over
-    const int64_t ngap = (int64_t)ngl < p.gap_cap ? (int64_t)ngl : p.gap_cap;
-    for (int64_t gi = 0; gi < ngap; ++gi) {
-      const int64_t lo = __hip_atomic_load(&p.gap_list[2 * gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int64_t total = __hip_atomic_load(&p.gap_list[2 * gi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * F;
-      for (int64_t i = lane; i < total; i += 64) dst[lo * F + i] = T(0);
-    }
-  }
-  if (desc != 0ull) {
-    constexpr bool kCanRepair = RED == RED_SUM && std::is_same<T, float>::value;
-    const T fill = kCanRepair ? T(0) : (T)NAN;
-    for (int64_t i = lane; i < K * F; i += 64) dst[i] = fill;
-    if constexpr (kCanRepair) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __threadfence(); // the zeros must be in memory before the (memory-side) atomics
-      const T *src = static_cast<const T *>(p.src);
-      for (int64_t e = 0; e < p.nnz; ++e) {
-        const int64_t k = p.dst_index[e];
-        if ((uint64_t)k >= (uint64_t)K) continue;
-        for (int64_t f = lane; f < F; f += 64) atomicAdd(dst + k * F + f, src[e * F + f]);
-      }
-    }
-    if (lane == 0 && p.alarm) __hip_atomic_store(p.alarm + (kCanRepair ? 0 : 1), (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  } else if (deferred != 0ull) {
-    if constexpr (std::is_same<A, float>::value) {
-      const float *carry = static_cast<const float *>(p.carry);
-      auto cload = [&](int64_t row, int64_t f) { return (double)__hip_atomic_load(carry + row * F + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-      for (int64_t t = 1 + gq; t < num_tiles; t += R) {
-        const int64_t m = __hip_atomic_load(&p.meta[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!((m & 1) && !(m & 2))) continue;               // the tile in which a run that came in from the left ENDS
-        const int64_t kend = m >> 2;
-        for (int64_t f = c; f < F; f += lpr) {
-          double acc = cload(t * 2, f);
-          int64_t cnt = 0;
-          if constexpr (MEAN) cnt = __hip_atomic_load(&p.ccnt[t * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int64_t jt = t - 1; jt >= 0; --jt) {
-            const bool single = (__hip_atomic_load(&p.meta[jt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
-            acc = red_op<double, RED>(cload(jt * 2 + (single ? 0 : 1), f), acc);
-            if constexpr (MEAN) cnt += __hip_atomic_load(&p.ccnt[jt * 2 + (single ? 0 : 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!single) break;                              // the tile in which the run starts
-          }
-          if constexpr (MEAN) acc *= 1.0 / (double)cnt;
-          if ((uint64_t)kend < (uint64_t)K) dst[kend * F + f] = (T)(A)acc;
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) {
-    __threadfence();
-    __hip_atomic_store(&p.ctrl[kCtrlDescent], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&p.ctrl[kCtrlDeferred], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&p.ctrl[kCtrlTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ngl != 0ull) atomicExch(&p.ctrl[kCtrlGaps], 0ull);
-    atomicAdd(&p.ctrl[kCtrlLaunch], 1ull);
-  }
 }
 
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
@@ -369,7 +277,6 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
   A *pL = reinterpret_cast<A *>(smem + L.off_p);
   A *wL = reinterpret_cast<A *>(smem + L.off_w);
   int *cntL = reinterpret_cast<int *>(smem + L.off_cnt);
-  int64_t *gapL = reinterpret_cast<int64_t *>(smem + L.off_gap);      // [2 * kGapSlots] gaps, [2 * kGapSlots] their count
   constexpr bool MEAN = RED == RED_MEAN;
   // the instantiations that can finish their straddling runs in-kernel ("hand-off", at the end of the kernel): streamed
   // rows, fp32 accumulators, whole 16-byte pieces per lane, no per-run counts
@@ -378,9 +285,6 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   publish_word(p);
-  if constexpr (kHandoff) {
-    if (p.single && tid == 0) gapL[2 * kGapSlots] = 0;   // (this tile's list of large gaps, see gapfill)
-  }
   // Gather modes: blocks are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so give
   // every XCD a CONTIGUOUS range of tiles - neighbouring dst rows of a graph with locality gather
   // overlapping src rows, which then hit in that XCD's L2.  Pure placement: any mapping is correct.
@@ -474,7 +378,7 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
     }
   }
   if (tid == 0) keysL[te + 1] = ts + te < p.nnz ? p.dst_index[ts + te] : kNoKey;
-  if (descents != 0ull && lane == 0) __hip_atomic_store(&p.ctrl[kCtrlDescent], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (write-through: a single-launch call's last tile reads it)
+  if (descents != 0ull && lane == 0) p.ctrl[kCtrlDescent] = 1ull;
   __syncthreads();
 
   if constexpr (!ATOMIC) {
@@ -509,22 +413,10 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
         for (int64_t r = lo; r < hi; ++r) put(dstf + r * F, z);
       }
     } else if (c == 0 && blockIdx.y == 0) {
-      // single-launch calls have no second launch to fill a large gap with the whole chip: it is listed in LDS and filled by all
-      // threads of this tile after the walk; a tile with more large gaps than slots lists the rest globally, for the call's last
-      // tile to fill (finish_launch)
-      int lslot = kGapSlots;
-      if constexpr (kHandoff) {
-        if (p.single) lslot = (int)atomicAdd(reinterpret_cast<unsigned long long *>(gapL + 2 * kGapSlots), 1ull);
-      }
-      if (lslot < kGapSlots) {
-        gapL[2 * lslot] = lo;
-        gapL[2 * lslot + 1] = cnt;
-      } else {
-        const unsigned long long slot = atomicAdd(&p.ctrl[0], 1ull);
-        if ((int64_t)slot < p.gap_cap) {   // (written through: a single-launch call's last tile reads the list while the kernel runs)
-          __hip_atomic_store(&p.gap_list[2 * slot], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&p.gap_list[2 * slot + 1], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+      const unsigned long long slot = atomicAdd(&p.ctrl[0], 1ull);
+      if ((int64_t)slot < p.gap_cap) {
+        p.gap_list[2 * slot] = lo;
+        p.gap_list[2 * slot + 1] = cnt;
       }
     }
   };
@@ -630,19 +522,6 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
 
   // ---- merge the tile's LDS partials in edge order ---------------------------------------------
   __syncthreads();
-  if constexpr (kHandoff) {
-    if (p.single) {   // this tile's large gaps: whole rows of zeros, every thread a 16-byte piece per step (F is a whole number of pieces here)
-      const int ngap = (int)(gapL[2 * kGapSlots] < kGapSlots ? gapL[2 * kGapSlots] : kGapSlots);
-      for (int gi = 0; gi < ngap; ++gi) {
-        T *base = dst + gapL[2 * gi] * F;
-        const int64_t total = gapL[2 * gi + 1] * F;
-        A z[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) z[i] = A(0);
-        for (int64_t i = (int64_t)tid * VEC; i < total; i += (int64_t)kThreads * VEC) store_vec<T, VEC, NTS>(base + i, z);
-      }
-    }
-  }
   const int64_t kprev_tile = keysL[0];
   const int64_t knext_tile = keysL[n + 1];
   const int ne = 2 * ng;
@@ -768,14 +647,7 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
     if (p.handoff) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      // the call's tag of the hand-off flags.  Single-launch calls complete it on the device - the launches this workspace has
-      // finished (counted up by the last tile of every such call, after every tile has taken its end-of-tile ticket, i.e. after
-      // every tile has read the word here): a replayed hipGraph re-uses the host's half, and nobody lowers the flags between replays.
-      // (Read only now, into scalar registers: nothing of it is alive across the row walk.)
-      unsigned long long epoch = p.epoch;
-      if (p.single)
-        epoch += (unsigned long long)((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&p.ctrl[kCtrlLaunch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFFFFu);
-      if (tid == 0) __hip_atomic_store(&p.flags[tile], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(&p.flags[tile], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (g == 0 && ho_pending) {
         const float *carry = static_cast<const float *>(p.carry);
         // (one feature block in this mode: the lane's element offset is recomputed here rather than kept alive across the walk)
@@ -800,11 +672,11 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
           const int64_t mine = j - cc;
           bool ready = false;
           if (mine >= 0) {
-            ready = __hip_atomic_load(&p.flags[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+            ready = __hip_atomic_load(&p.flags[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch;
             if (cc == 0) {
               for (int tries = 0; !ready && tries < p.ho_tries; ++tries) {
                 __builtin_amdgcn_s_sleep(1);
-                ready = __hip_atomic_load(&p.flags[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                ready = __hip_atomic_load(&p.flags[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.epoch;
               }
             }
           }
@@ -860,27 +732,8 @@ __device__ __forceinline__ void seg_tile_body(const SegParams &p) {
           for (int q = 0; q < VEC; ++q) ho_head[q] = (A)hacc[q];
           if (active && (uint64_t)ho_key < (uint64_t)K) store_vec<T, VEC, NTS>(dstf + ho_key * F, ho_head);
         } else if (c == 0) {
-          __hip_atomic_store(&p.ctrl[kCtrlDeferred], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          p.ctrl[kCtrlDeferred] = 1ull;
         }
-      }
-      if (p.single && tid < 64) {   // (wave 0: it holds lane group 0, the only one that stored anything behind the barrier above)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int last = 0;
-        // (no fence: an agent-scope release writes the XCD's whole L2 back - measured 4x on the graded call.  What the last tile
-        //  reads of this tile was stored write-through and has been drained, s_waitcnt above and before the flag store.)
-        // Two levels of tickets: tile t counts on word t mod 16, the tile that completes a word resets it and counts on the common
-        // one - 16 + 16 same-address atomics in a row instead of one per tile (19 532 of them: 1.1 ms at the memory side's ~60 ns each).
-        if (tid == 0) {
-          const unsigned long long nt = gridDim.x;
-          const int j = (int)(tile % kTickN);
-          const unsigned long long mine = (nt - (unsigned long long)j + kTickN - 1) / kTickN;      // tiles that count on word j
-          if (atomicAdd(&p.ctrl[kCtrlTick0 + j], 1ull) == mine - 1ull) {
-            atomicExch(&p.ctrl[kCtrlTick0 + j], 0ull);
-            const unsigned long long words = nt < (unsigned long long)kTickN ? nt : (unsigned long long)kTickN;
-            last = atomicAdd(&p.ctrl[kCtrlTicket], 1ull) == words - 1ull;
-          }
-        }
-        if (__builtin_amdgcn_readfirstlane(last)) finish_launch<T, RED>(p, (int64_t)gridDim.x);
       }
     }
   }
@@ -2019,7 +1872,6 @@ GEOT_SHARED(std::atomic<int>, g_hub, {-1})         // window sums for hub chains
 GEOT_SHARED(std::atomic<int>, g_handoff_tries, {20000}) // "handoff_tries": polls before a tile leaves a run to the second launch (0: tests of that path).  ~0.5 us a
                                           // poll: ~10 ms - the predecessor is an EARLIER workgroup (dispatched in order: running or done), its whole life is
                                           // microseconds; the 400 000 of round 3 let a stalled workgroup spin for 0.2 s
-GEOT_SHARED(std::atomic<int>, g_single, {1})       // "single_launch": 1 = hand-off calls run WITHOUT the second launch (the last tile to finish tidies up), 0 = always two launches
 GEOT_SHARED(std::atomic<int>, g_handoff, {1})      // in-kernel hand-off of the tile carries ("handoff" option): 1 = where the kernels support it, 0 = classic second pass
 GEOT_SHARED(std::atomic<int>, g_ragged, {1})       // "ragged": 1 = rows that are not whole 16-byte vectors keep full-width lanes (seg_tile_rag_kernel), 0 = the 8- / 4-byte-per-lane kernels
 GEOT_SHARED(std::atomic<int>, g_narrow, {1})       // fp32 rows of <= kNarrowMaxF values: 1 = lane-sequential kernel, 2 = lane-per-edge scan kernel, 0 = lane groups
@@ -2492,15 +2344,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   p.handoff = (g_handoff && ho_pays && sorted && mode == 0 && !narrow_path && acc_f32 && P.vec % 4 == 0 && !P.ragged && P.nfb == 1 && nnz > 0) ? 1 : 0;
   p.ho_tries = g_handoff_tries;
   p.flags = reinterpret_cast<unsigned long long *>(wsc + P.flag_off);
-  // Single-launch form of the hand-off (round 5): the second launch of such a call did nothing but lower the flags - needed only
-  // because a replayed hipGraph re-uses its tag.  The tag is now completed on the device (ctrl[kCtrlLaunch], counted up by the last
-  // tile of every single-launch call: host half << 24 | launches this workspace has finished), large gaps are filled by their own
-  // tile, and the last tile to finish takes the rare repairs (finish_launch).  4.6 us + a kernel boundary less per call:
-  // ~1.5 % of the graded step, a quarter of a launch-bound call.
-  p.single = (p.handoff && g_single) ? 1 : 0;
-  const unsigned long long call_no = ++g_epoch;
-  p.epoch = p.single ? (0x6E07000000000000ull + ((call_no & 0xFFFFFFull) << 24))     // [16-bit mark | 24-bit call | 24-bit launches of the workspace]
-                     : (0x6E07A5C300000000ull + (call_no & 0xFFFFFFFFull));           // (a tag no stale word of the workspace will equal)
+  p.epoch = 0x6E07A5C300000000ull + (++g_epoch & 0xFFFFFFFFull); // (a tag no stale word of the workspace will equal)
   // a pending geot_publish_word is consumed by the first kernel of this call if that kernel is one of the three that
   // publish (tile / lane / narrow kernel; not the LDS-bin kernel of the unsorted atomic path)
   const bool lds_bin = !sorted && (size_t)K * (size_t)F * sizeof(T) <= 48 * 1024 && g_tune.lpr_log2 != 7;
@@ -2514,7 +2358,7 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // tile kernel and the fix-up.  Everything else keeps two launches.  "hub" option: 1 forces, 0 forbids.
   const bool use_wsum = sorted && P.num_tiles > 64 &&
                         (g_hub == 1 || (g_hub < 0 && P.num_tiles >= 256 && nnz / 4096 >= K));
-  if (use_wsum) p.handoff = p.single = 0; // (long chains of tiles under one key: the window sums and the classic second pass are the fast way)
+  if (use_wsum) p.handoff = 0; // (long chains of tiles under one key: the window sums and the classic second pass are the fast way)
   p.wsum = use_wsum ? wsc + P.wsum_off : nullptr;
   p.wcnt = use_wsum ? reinterpret_cast<int64_t *>(wsc + P.wcnt_off) : nullptr;
   p.wflag = use_wsum ? reinterpret_cast<int *>(wsc + P.wflag_off) : nullptr;
@@ -2672,11 +2516,9 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     int64_t blocks = (P.num_tiles + tiles_per_block - 1) / tiles_per_block;
     if (blocks < 1) blocks = 1;
     if (use_wsum) launch_wsum<T>(p, P.num_tiles, red, st);
-    if (!p.single) {               // (single-launch calls: the tile kernel's last tile has done what this launch would do)
-      launch_fixup<T>(p, blocks, P.num_tiles, red, st);
-      HIP_TRY(hipGetLastError());
-      rec.has_fix = true;
-    }
+    launch_fixup<T>(p, blocks, P.num_tiles, red, st);
+    HIP_TRY(hipGetLastError());
+    rec.has_fix = true;
   }
   if (prof) {
     HIP_TRY(hipEventRecord(rec.e3, st));
@@ -3041,7 +2883,7 @@ static void prof_drain_locked() {
     hipEventElapsedTime(&f, r.e2, r.e3);
     g_prof.aux_ms += a;
     g_prof.main_ms += m;
-    if (r.has_fix) g_prof.fix_ms += f;   // (a single-launch call has no second launch: the two events bracket nothing)
+    g_prof.fix_ms += f;
     g_prof.calls += 1;
     g_prof.pool.push_back(r.e0);
     g_prof.pool.push_back(r.e1);
@@ -3113,7 +2955,6 @@ void geot_set_option(const char *name, int value) {
   if (name && std::string(name) == "lds_floor") g_lds_floor = value;
   if (name && std::string(name) == "narrow") g_narrow = value;
   if (name && std::string(name) == "handoff") g_handoff = value;
-  if (name && std::string(name) == "single_launch") g_single = value != 0;
   if (name && std::string(name) == "ragged") g_ragged = value != 0;
   if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
   if (name && std::string(name) == "hub") g_hub = value;

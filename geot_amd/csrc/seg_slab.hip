@@ -158,53 +158,9 @@ __global__ __launch_bounds__(kThreads) void slab_stage_weights_kernel(const int3
   }
 }
 
-// The same pre-pass a group at a time through LDS (the mirror image of slab_unstage_kernel): a group's edges are a CONTIGUOUS range
-// of the dst-sorted list unless it holds a piece of a split hub, so its weights are one contiguous block - read coalesced into LDS,
-// picked out of it in plan order, written coalesced.  No 64-byte L2 request per 4-byte weight.  Groups whose ids span more than the
-// tile (hub pieces: interleaved over the whole row) gather directly.
-template <typename V>
-__global__ __launch_bounds__(kThreads) void slab_stage_weights_lds_kernel(const int64_t *__restrict__ g_begin, const int32_t *__restrict__ e_perm,
-                                                                          const V *__restrict__ weight, V *__restrict__ wst, int64_t n_groups,
-                                                                          int tile_elems) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  V *tile = reinterpret_cast<V *>(smem);
-  __shared__ int s_min, s_max;
-  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t e0 = g_begin[g];
-    const int len = (int)(g_begin[g + 1] - e0);
-    if (threadIdx.x == 0) {
-      s_min = 0x7fffffff;
-      s_max = -1;
-    }
-    __syncthreads();
-    int mn = 0x7fffffff, mx = -1;
-    for (int i = threadIdx.x; i < len; i += kThreads) {
-      const int e = e_perm[e0 + i];
-      mn = e < mn ? e : mn;
-      mx = e > mx ? e : mx;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
-      mn = a < mn ? a : mn;
-      mx = b > mx ? b : mx;
-    }
-    if ((threadIdx.x & 63) == 0 && len > 0) {
-      atomicMin(&s_min, mn);
-      atomicMax(&s_max, mx);
-    }
-    __syncthreads();
-    const int base = s_min, span = s_max - s_min + 1;
-    if (len > 0 && span <= tile_elems) {
-      for (int i = threadIdx.x; i < span; i += kThreads) tile[i] = __builtin_nontemporal_load(weight + base + i);
-      __syncthreads();
-      for (int i = threadIdx.x; i < len; i += kThreads) __builtin_nontemporal_store(tile[e_perm[e0 + i] - base], wst + e0 + i);
-    } else {
-      for (int i = threadIdx.x; i < len; i += kThreads) wst[e0 + i] = weight[e_perm[e0 + i]];
-    }
-    __syncthreads();
-  }
-}
+// (A form of this pre-pass that takes a group's weight block through LDS - coalesced in, picked in plan order, coalesced out, the
+// mirror image of slab_unstage_kernel - measured SLOWER than this plain gather: gws F=128 fp32 4.52 vs 4.00 ms per call,
+// profiles/r05/slab_cases__weight_prepass_through_lds.txt; three barriers per group cost more than the L2 requests they save.)
 
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // WAVE_ROW: rows of 1 KiB - the whole wave is one unit, edge fields are read with v_readlane (scalar row bases)
@@ -1252,7 +1208,6 @@ int g_slab_far = 12;
 int g_slab_nt = 0;      // "slab_nt": experiment, see SlabParams::nt_plan
 int g_slab_unroll = 8;  // "slab_unroll": 8 | 16 row loads in flight per lane of the row-per-wave kernel (sums)
 int g_slab_tight = 1;   // "slab_tight": 1 = the window of 1 slab for per-call weights on dense graphs (the round-4 rule), 0 = always 2
-int g_slab_stage_lds = 1; // "slab_stage_lds": 1 = the pre-pass goes a group at a time through LDS (one weight per edge), 0 = gathers straight from global memory
 int g_slab_stage = 1;   // "slab_stage": 1 = edge-order weights are staged into plan order inside the kernel when the workspace has room, 0 = read through e_perm
 int g_slab_turn = 1;    // "slab_turn": 1 = the persistent grids of this process take turns on a device (see SlabTurn), 0 = launch freely
 
@@ -1444,12 +1399,6 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     int64_t sblocks = (plan->nnz + per_block - 1) / per_block;
     if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
     const dim3 sgrid((unsigned)(sblocks > 0 ? sblocks : 1)), sblk(kThreads);
-    constexpr int kStageTile = 60 * 1024;
-    int64_t gblocks = plan->n_groups < (int64_t)slab_device().cus * 8 ? plan->n_groups : (int64_t)slab_device().cus * 8;
-    const dim3 ggrid((unsigned)(gblocks > 0 ? gblocks : 1));
-    if (g_slab_stage_lds && wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_lds_kernel<uint32_t>), ggrid, sblk, kStageTile, st, plan->g_begin, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->n_groups, kStageTile / 4);
-    else if (g_slab_stage_lds && wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_lds_kernel<uint16_t>), ggrid, sblk, kStageTile, st, plan->g_begin, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->n_groups, kStageTile / 2);
-    else
     if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
     else if (wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->nnz);
     else if (wbytes == 8) hipLaunchKernelGGL((slab_stage_weights_kernel<uint64_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(wstage), plan->nnz);
@@ -1676,7 +1625,6 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_tight") g_slab_tight = value != 0;
   if (name && std::string(name) == "slab_stage" && value >= 0 && value <= 2) g_slab_stage = value;
   if (name && std::string(name) == "slab_wrow_all") g_slab_wrow_all = value != 0;
-  if (name && std::string(name) == "slab_stage_lds") g_slab_stage_lds = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 

@@ -276,92 +276,19 @@ def test_plan_order_attention_pipeline(geot, dtype, H, Fh):
     assert float((out_plan.double() - ref).abs().max()) <= otol * float(ref.abs().max())
 
 
-# ---- the hand-off without a second launch (single_launch) ---------------------------------------------------------------------------
-def _gappy_index(rng, nnz, K):
-    """Ascending keys with large gaps of every kind: a leading gap, dozens of gaps of 17 .. 5000 empty rows (more than a tile's 16 LDS
-    slots inside one tile's key range), a hub over many tiles, and a last key far below K (rows behind it come out 0)."""
-    keys = np.sort(rng.choice(np.arange(3000, K - 200_000), size=nnz // 40, replace=False))
-    keys = keys[(keys % 9000) > 5100]                                             # wipes 5100-row stripes: large gaps
-    sparse = np.arange(20_000, 20_000 + 40 * 30, 30)                             # 40 keys 30 apart: > 16 large gaps in one tile
-    index = np.concatenate([rng.choice(keys, size=nnz - 40_000 - sparse.size), np.full(40_000, keys[len(keys) // 2]), sparse])
-    return np.sort(index).astype(np.int64)
-
-
-@pytest.mark.parametrize("dtype,F,red", [(torch.float32, 64, "sum"), (torch.float32, 128, "mean"), (torch.bfloat16, 64, "sum"),
-                                          (torch.float32, 64, "max")])
-def test_single_launch_gives_the_two_launch_bits(geot, dtype, F, red):
-    """Round 5: a hand-off call runs WITHOUT the second launch - tag completed on the device, large gaps filled by their tile (LDS list;
-    the overflow by the call's last tile), rows behind the last key zeroed, tidy-up by the last tile to finish.  Same bits as the
-    two-launch form, new data every call, control words left zero (the launch counter aside)."""
-    from geot_amd import hip
-    rng = np.random.default_rng(41)
-    nnz, K = 1_500_000, 900_000
-    index = _gappy_index(rng, nnz, K)
-    t_index = dev(index)
-    outs = {}
-    for it in range(3):
-        src = (torch.rand(nnz, F, device="cuda") * (it + 1)).to(dtype)
-        for single in (1, 0, 1):
-            hip.set_option("single_launch", single)
-            try:
-                out = torch.full((K, F), 5.0, device="cuda", dtype=dtype)
-                hip.profile_enable(True)
-                hip.profile_reset()
-                hip.index_scatter_out(t_index, src, out, sorted=True, reduce=red)
-                prof = hip.profile_read()
-                hip.profile_enable(False)
-            finally:
-                hip.set_option("single_launch", 1)
-            assert (prof["fixup_ms"] == 0.0) == (single == 1), (single, prof)     # the second launch is gone / there
-            key = (it, single)
-            if key in outs:
-                assert torch.equal(outs[key].view(torch.int16 if dtype != torch.float32 else torch.int32),
-                                   out.view(torch.int16 if dtype != torch.float32 else torch.int32))
-            outs[key] = out
-        a, b = outs[(it, 1)], outs[(it, 0)]
-        assert torch.equal(a.view(torch.int16 if dtype != torch.float32 else torch.int32), b.view(torch.int16 if dtype != torch.float32 else torch.int32)), it
-        if red == "sum":
-            cnt = torch.bincount(t_index, minlength=K)
-            want = torch.segment_reduce(src.double(), "sum", lengths=cnt, axis=0, unsafe=True)
-            tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
-            assert float((a.double() - want).abs().max()) <= tol * float(want.abs().max())
-            assert float(a[cnt == 0].abs().max()) == 0.0                           # every gap and the tail are exact zeros
-
-
-def test_single_launch_deferred_runs_and_graph_replays(geot):
-    """`handoff_tries` = 0 leaves every straddling run to the call's LAST TILE (finish_launch): same bits as the normal mode.  And a
-    captured single-launch call replays with new data - its tag's device half counts the workspace's launches - interleaved with
-    eager calls of another shape on the same workspace."""
-    from geot_amd import hip
-    rng = np.random.default_rng(43)
-    nnz, K, F = 2_000_000, 40_000, 64
-    index = powerlaw_index(nnz, K, 5)
-    index[: nnz // 3] = index[nnz // 3]
-    index = np.sort(index)
-    index[-1] = K - 1
-    t_index = dev(index)
-    src = torch.rand(nnz, F, device="cuda")
-    normal = hip.index_scatter_out(t_index, src, torch.empty(K, F, device="cuda"), sorted=True)
-    hip.set_option("handoff_tries", 0)
-    try:
-        deferred = hip.index_scatter_out(t_index, src, torch.empty(K, F, device="cuda"), sorted=True)
-    finally:
-        hip.set_option("handoff_tries", 20000)
-    assert torch.equal(normal.view(torch.int32), deferred.view(torch.int32))
-    other_i = dev(np.sort(rng.integers(0, 5000, 700_000)).astype(np.int64))
-    other_s = torch.rand(700_000, 64, device="cuda")
-    geot.index_scatter(0, src, t_index, "sum", True)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        out = geot.index_scatter(0, src, t_index, "sum", True)
-    cnt = torch.bincount(t_index, minlength=K)
-    for it in range(8):
-        src.copy_(torch.rand_like(src) * (it + 1))
-        g.replay()
-        g.replay()                                                                    # (two replays back to back: same host tag, next device count)
-        want = torch.segment_reduce(src.double(), "sum", lengths=cnt, axis=0, unsafe=True)
-        assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-5), it
-        o2 = geot.index_scatter(0, other_s, other_i, "sum", True)
-        w2 = torch.zeros(int(other_i[-1]) + 1, 64, device="cuda", dtype=torch.float64).index_add_(0, other_i, other_s.double())
-        assert torch.allclose(o2.double(), w2, rtol=1e-5, atol=1e-5), it
+def test_hang_hunt_quick(tmp_path):
+    """tools/hang_hunt.py stays in the suite's orbit: ten fresh-process runs of round 3's three-thread
+    scenario (three workers on one dense graph, persistent source-blocked grids in flight) under the watchdog, five with the
+    library's turn-taking and five without - every run finishes, none is killed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    for turn in (1, 0):
+        out = tmp_path / f"turn{turn}"
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hang_hunt.py"), "--scenario", "threads", "--runs", "5", "--slab-turn", str(turn),
+                            "--T", "60", "--iters", "10", "--out", str(out)], capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        summary = json.load(open(out / f"threads_turn{turn}_guard1_always_summary.json"))
+        assert summary["hung"] is None and summary.get("failed") is None and len(summary["runs"]) == 5, summary
+        assert all(r["rc"] == 0 and not r["hung"] for r in summary["runs"]), summary["runs"]

@@ -179,6 +179,18 @@ for w, wanted in WORKLOADS.items():
             if "fabric_bytes_per_launch" in g:
                 g["traffic_over_compulsory"] = g["fabric_bytes_per_launch"] / comp
         gather[w + suffix] = g
+# configs[0] (launch-bound): the tile kernel's own duration from the kernel trace of `bench.py --only-secondary cfg1`
+kt1 = kernel_times(os.path.join(src, "kt_cfg1", "bench_kernel_stats.csv"))
+if kt1:
+    shutil.copy(os.path.join(src, "kt_cfg1", "bench_kernel_stats.csv"), os.path.join(dst, "kernel_stats__cfg1.csv"))
+    try:
+        kname = json.load(open(os.path.join(src, "kt_cfg1.json")))["secondary"]["cfg1"]["kernel"]      # what the launcher picked (geot_last_kernel)
+    except Exception:
+        kname = "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 8>"
+    tile = next((v for k, v in kt1.items() if kname in k), None)
+    fix = next((v for k, v in kt1.items() if "seg_fixup_kernel<float" in k), None)
+    if tile:
+        gather["cfg1"] = {"kernel": kname, **tile, "second_launch_us": fix["average_ms"] * 1e3 if fix else None}
 if "gws_cfg3_blockmodel_asis" in gather:                # bench.py's entry `gws_cfg3_blockmodel` quotes the as-shipped kernel
     gather["gws_cfg3_blockmodel"] = dict(gather["gws_cfg3_blockmodel_asis"])
 json.dump({"method": "one rocprofv3 pass set per workload (tools/profile_round.sh: bench.py --only-secondary <workload>): --kernel-trace "

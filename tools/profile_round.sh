@@ -29,6 +29,9 @@ for w in ${WORKLOADS:-gws_cfg3 gws_cfg3_local gws_cfg3_powerlaw_src gws_cfg3_blo
         > "$OUT/pmc_${c}__$w.json" 2> "$OUT/pmc_${c}__$w.err"
   done
 done
+# configs[0] is launch-bound: its kernel's own duration can only come from a trace (HIP events bracket the launch gap too)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfg1" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary cfg1 \
+    > "$OUT/kt_cfg1.json" 2> "$OUT/kt_cfg1.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/cal_$c" -o cal -- ./tools/kbench copy > "$OUT/cal_$c.txt" 2> "$OUT/cal_$c.err"
 done
