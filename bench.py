@@ -955,6 +955,7 @@ def main():
         return sum(a.elapsed_time(b) for a, b in events) / len(events) if events else None
 
     exchange_ms = mean_ms(timing.get("exchange_events"))
+    fetch_ms = mean_ms(timing.get("fetch_events"))     # (--src-sharding node: the per-step fetch of the source rows)
     key_ms = mean_ms(timing.get("key_events"))
     if key_ms is None and timing.get("key_wall_ms"):
         key_ms = sum(timing["key_wall_ms"]) / len(timing["key_wall_ms"])
@@ -1029,10 +1030,9 @@ def main():
             if args.workload == "cfg5":
                 res["src_sharding"] = args.src_sharding
                 if args.src_sharding == "node":
-                    fe = timing.get("fetch_events")
                     res["source_rows_fetch"] = {"mode": halo.mode, "rows_fetched_per_step_rank0": halo.rows_fetched, "table_rows_rank0": halo.table_rows,
                                                 "bytes_fetched_per_step_rank0": halo.bytes_fetched(4 * feat),
-                                                "fetch_ms_rank0": (sum(a.elapsed_time(b) for a, b in fe) / len(fe)) if fe else None,
+                                                "fetch_ms_rank0": fetch_ms,
                                                 "src_rows_on_this_rank": int(src.shape[0]), "src_rows_total": nodes_all}
         if not distributed and args.workload == "cfg2" and not args.no_cpu_baseline:
             try:

@@ -39,7 +39,7 @@ SYMBOLS = [
     "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_mh_sddmm_coo", "geot_gather_rows", "geot_index_probe",
     "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_content_fingerprint", "geot_content_fingerprint_scratch_bytes", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
-    "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_units_for", "geot_slab_rows_per_group_shape", "geot_slab_workspace_bytes", "geot_slab_workspace_bytes_staged", "geot_slab_spmm", "geot_slab_sddmm", "geot_slab_sddmm_staged", "geot_slab_mh_sddmm",
+    "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_units_for", "geot_slab_rows_per_group_shape", "geot_slab_workspace_bytes", "geot_slab_workspace_bytes_staged", "geot_slab_spmm", "geot_slab_sddmm", "geot_slab_sddmm_staged", "geot_slab_mh_sddmm", "geot_slab_to_plan_order",
     "geot_slab_plan_scratch_bytes", "geot_slab_plan_rows", "geot_slab_plan_groups", "geot_slab_plan_edges",
     "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option", "geot_last_kernel",
 ]
@@ -247,6 +247,7 @@ def load() -> ctypes.CDLL:
     L.geot_slab_spmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_slab_sddmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_slab_sddmm_staged.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
+    L.geot_slab_to_plan_order.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_i64, c_int, c_vp]
     L.geot_slab_mh_sddmm.argtypes = [ctypes.POINTER(SlabPlan), c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_sz, c_vp]
     L.geot_profile_enable.argtypes = [c_int]
     L.geot_profile_enable.restype = None

@@ -1490,6 +1490,28 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 
 // staging != NULL: the persistent kernel writes its results in the plan's edge order into `staging`; `unstage`: a second kernel brings
 // them into original edge order in `out` (otherwise plan order IS the result and `out` is not touched)
+// out[i, :] = weight[e_perm[i], :] - per-edge values (heads per edge) from the caller's edge order into the plan's: what weight modes 4 / 5
+// read.  heads x element size of 2 / 4 / 8 / 16 bytes (GEOT_EUNSUPPORTED otherwise: the caller permutes by other means).
+int geot_slab_to_plan_order(const geot_slab_plan *plan, const void *weight, void *out, int64_t heads, int dtype, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!plan || !weight || !out || heads < 1) return geot_internal_fail(GEOT_EINVAL, "slab_to_plan_order: bad arguments");
+  if (dtype != GEOT_F32 && dtype != GEOT_F16 && dtype != GEOT_BF16) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_to_plan_order: float32, float16 or bfloat16");
+  const int64_t wbytes = heads * (dtype == GEOT_F32 ? 4 : 2);
+  if ((wbytes != 2 && wbytes != 4 && wbytes != 8 && wbytes != 16) || ((((uintptr_t)weight) | ((uintptr_t)out)) & (uintptr_t)(wbytes - 1)))
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_to_plan_order: heads x element size of 2, 4, 8 or 16 bytes, aligned");
+  if (plan->nnz == 0) return GEOT_OK;
+  const int64_t per_block = (int64_t)kThreads * 8;
+  int64_t sblocks = (plan->nnz + per_block - 1) / per_block;
+  if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
+  const dim3 sgrid((unsigned)sblocks), sblk(kThreads);
+  if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(out), plan->nnz);
+  else if (wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(out), plan->nnz);
+  else if (wbytes == 8) hipLaunchKernelGGL((slab_stage_weights_kernel<uint64_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(out), plan->nnz);
+  else hipLaunchKernelGGL((slab_stage_weights_kernel<f4_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const f4_t *>(weight), static_cast<f4_t *>(out), plan->nnz);
+  const hipError_t le = hipGetLastError();
+  return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
+}
+
 static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t heads,
                            int64_t feat, int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream,
                            bool unstage = true) {

@@ -341,6 +341,10 @@ int geot_slab_sddmm(const geot_slab_plan *plan, const void *mat_1, const void *m
 int geot_slab_sddmm_staged(const geot_slab_plan *plan, const void *mat_1, const void *mat_2, void *out, void *staging, int64_t feat,
                            int64_t rows_1, int64_t rows_2, int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* out[i, :] = weight[e_perm[i], :]: per-edge values (heads per edge) from the caller's edge order into the plan's - what weight modes
+ * 4 / 5 read (a static weight permuted once).  heads x element size of 2 / 4 / 8 / 16 bytes; GEOT_EUNSUPPORTED otherwise. */
+int geot_slab_to_plan_order(const geot_slab_plan *plan, const void *weight, void *out, int64_t heads, int dtype, void *stream);
+
 /* Multi-head SDDMM over the plan (d/dweight of geot_mh_spmm on a dense graph; the scores of an attention layer):
  * out(e, h) = < mat_1[dst(e), h, :], mat_2[src(e), h, :] >, mat_* [rows, heads, feat], heads 1 / 2 / 4 / 8, rows of 256 / 512 / 1024
  * bytes.  `staging`: plan->nnz x heads elements of scratch.  out != NULL: results in ORIGINAL edge order, out[e*heads + h] (heads x

@@ -167,6 +167,17 @@ def test_a_new_edge_list_in_the_same_tensors_forward_and_plan(geot, oracle, ops)
     si4 = rng.integers(0, K, nnz).astype(np.int64)
     behind_the_version_counter(t_si, si4)
     close(geot.mh_spmm(t_si, t_di, t_wh, t_x3).reshape(K, -1), oracle.mh_spmm(si4, di2, wh, x3, rows=K, acc64=True).reshape(K, -1), "mh_spmm")
+    # the static MULTI-HEAD weight in plan order (round 5: weight mode 5 - kept like the single weight is): the third call reads the
+    # plan-order copy; new values behind the version counter must still win
+    for _ in range(3):
+        got = geot.mh_spmm(t_si, t_di, t_wh, t_x3)
+    close(got.reshape(K, -1), oracle.mh_spmm(si4, di2, wh, x3, rows=K, acc64=True).reshape(K, -1), "mh_spmm, static weight in plan order")
+    wh2 = rng.random((nnz, H), dtype=np.float32)
+    stale1 = ops.stats()["stale_products"]
+    behind_the_version_counter(t_wh, wh2)
+    close(geot.mh_spmm(t_si, t_di, t_wh, t_x3).reshape(K, -1), oracle.mh_spmm(si4, di2, wh2, x3, rows=K, acc64=True).reshape(K, -1),
+          "mh_spmm, new weight values behind the version counter")
+    assert ops.stats()["stale_products"] == stale1 + 1
 
 
 def test_a_new_edge_list_in_the_same_tensors_backward(geot, oracle, ops):
