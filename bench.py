@@ -613,12 +613,19 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         w = torch.rand(nnz, device=dev, generator=g, requires_grad=True)
         cot = torch.rand(nodes, F, device=dev, generator=g)
 
+        def touch():
+            # the weights CHANGE every step, as under an optimiser (an in-place update bumps the version counter): nothing derived from
+            # their values - a transposed or plan-order copy - survives from one step to the next, for the operators or the handle
+            with torch.no_grad():
+                w.mul_(1.0)
+
         def step():
             x.grad = None
             w.grad = None
+            touch()
             geot.gather_weight_scatter(si, di, w, x).backward(cot)
         out = {"workload": f"gather_weight_scatter forward + backward (d/dsrc, d/dweight) through autograd, {nodes} nodes, {nnz} edges "
-                           f"(configs[3]'s graph, sources ascending inside every row), feat={F}, float32"}
+                           f"(configs[3]'s graph, sources ascending inside every row), feat={F}, float32; the weight is updated in place before every step"}
         old = ops.set_option("slab_mode", "auto")
         try:
             for mode, key in (("auto", "as_dispatched"), ("never", "per_edge_kernels")):
@@ -646,6 +653,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             def hstep():
                 x.grad = None
                 w.grad = None
+                touch()
                 handle.gather_weight_scatter(w, x).backward(cot)
             for _ in range(3):
                 hstep()
@@ -674,12 +682,17 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         w = torch.rand(nnz, H, device=dev, generator=g, requires_grad=True)
         cot = torch.rand(nodes, H, F, device=dev, generator=g)
 
+        def touch():                                   # (the weights change every step, as under an optimiser)
+            with torch.no_grad():
+                w.mul_(1.0)
+
         def step():
             x.grad = None
             w.grad = None
+            touch()
             geot.mh_spmm(si, di, w, x).backward(cot)
         out = {"workload": f"mh_spmm forward + backward (d/dsrc, d/dweight) through autograd, {nodes} nodes, {nnz} edges (configs[3]'s graph, "
-                           f"uniform-random sources), heads={H} feat={F}, float32"}
+                           f"uniform-random sources), heads={H} feat={F}, float32; the weight is updated in place before every step"}
         old = ops.set_option("slab_mode", "auto")
         try:
             for mode, key in (("auto", "as_dispatched"), ("never", "per_edge_kernels")):
@@ -697,6 +710,7 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             def hstep():
                 x.grad = None
                 w.grad = None
+                touch()
                 handle.mh_spmm(w, x).backward(cot)
             for _ in range(3):
                 hstep()

@@ -2228,8 +2228,8 @@ void launch_wsum(const SegParams &p, int64_t num_tiles, int red, hipStream_t st)
 template <typename T, int VEC, bool GATHER, int WMODE, bool ATOMIC>
 void dispatch_nt(const SegParams &p, const Plan &P, hipStream_t st, int nt) {
   if constexpr (GATHER) {
-    // (experiment of round 5, geot_tune(nontemporal = 1): nt row gathers for a table whose rows are read from HBM every time -
-    //  configs[4]'s 57 GB; fp32 gather_scatter only.  Measured level: profiles/r05/cfg5_study/)
+    // (round 5: nt row gathers for a table whose rows are read from HBM every time - configs[4]'s 57 GB: +2.5 %; fp32 gather_scatter
+    //  only; run_segment_op selects it for tables beyond 4 GiB, geot_tune(nontemporal = 0 | 1) forces either)
     if constexpr (WMODE == 0 && !ATOMIC && sizeof(T) == 4 && VEC == 4) {
       if ((nt & 1) != 0) {
         launch_tile<T, VEC, GATHER, WMODE, ATOMIC, 1>(p, P, st);
@@ -2368,6 +2368,11 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
   // gathered rows are re-used across edges -> default cache policy there.
   const int tune_nt = g_tune.nt;
   int nt = tune_nt >= 0 ? tune_nt : (mode == 0 ? 3 : 0);
+  // ... except gathers from a table that no cache can hold (> 4 GiB: 16 x the Infinity Cache): every row comes from HBM whatever the
+  // policy, and non-temporal gathers keep the rows from pushing the indices and the output out - configs[4]'s shard (57 GB table):
+  // 4.81 -> 4.93 TB/s of row reads (profiles/r05/cfg5_study/exp_gather_table__session2_quick_with_nt_gathers.txt).  fp32 gather_scatter
+  // only (the one instantiation, see dispatch_nt); smaller tables keep the default policy (re-used rows: measured in round 1).
+  if (tune_nt < 0 && mode == 1 && (uint64_t)src_rows * (uint64_t)p.rowbytes > ((uint64_t)4 << 30)) nt = 1;
 
   Prof::Rec rec{};
   const bool prof = g_prof.on;
