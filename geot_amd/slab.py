@@ -40,6 +40,16 @@ class SlabPlan:
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors.values())
 
+    def with_e_perm(self, e_perm: torch.Tensor) -> "SlabPlan":
+        """The same plan reading its per-edge weights through ANOTHER index (int32 [nnz]: plan position -> position in the weight array):
+        every other array is shared.  geot_amd.Graph uses it to hand the backward's kernels weights that live in the forward's order."""
+        if e_perm.dtype != torch.int32 or e_perm.numel() != self.tensors["e_perm"].numel() or not e_perm.is_contiguous():
+            raise ValueError("with_e_perm: a contiguous int32 tensor with one entry per edge")
+        scalars = {name: getattr(self.struct, name) for name in _SCALARS + ("slab_shift", "n_slabs")}
+        twin = SlabPlan({**self.tensors, "e_perm": e_perm}, scalars, dict(self.meta))
+        twin.base = getattr(self, "base", self)
+        return twin
+
 
 def worthwhile(nnz: int, out_rows: int, src_rows: int, rowbytes: int) -> bool:
     """Is the graph dense enough for L2 re-use?  Per round the chip holds R x units output rows; each XCD then reads

@@ -133,6 +133,40 @@ def main():
                 ref = oracle.index_scatter_3pass(index, src, reduce=red)
                 ok = out.shape == ref.shape and (np.allclose(out, ref, rtol=2e-4, atol=2e-5) if red == "mean"
                                                  else np.array_equal(out, ref))
+        elif op == "mh_bwd":
+            # round 5: mh_spmm's backward - d/dsrc over the transposed list (its own plan when slab-forced), d/dweight by the multi-head
+            # SDDMM (per edge or over the forward's plan) - against plain-torch float64 autograd of the reference test's formula
+            H = int(rng.choice([2, 4, 8]))
+            Fh = int(rng.choice([16, 32, 64]))
+            if nnz > 1_000_000:
+                index = index[:1_000_000]
+                nnz = len(index)
+            geot.ops.set_option("slab_mode", "always" if rng.integers(0, 2) else "auto")
+            nodes = int(index[-1]) + 1 + int(rng.integers(0, 9))
+            si = rng.integers(0, nodes, nnz).astype(np.int64)
+            head_major = bool(rng.integers(0, 2))
+            tag += f" H={H} Fh={Fh} head_major={head_major} nodes={nodes}"
+            covered[("mh_bwd", "sum")] = covered.get(("mh_bwd", "sum"), 0) + 1
+            t_si, t_di = t(si), t(index)
+            t_x = t(rng.random((nodes, H, Fh), dtype=np.float32)).requires_grad_()
+            w_em = t(rng.random((nnz, H), dtype=np.float32) + 0.25)
+            t_w = (w_em.t().contiguous() if head_major else w_em.clone()).requires_grad_()
+            rows = int(index[-1]) + 1
+            up = t(rng.random((rows, H, Fh), dtype=np.float32))
+            ok = True
+            for _ in range(2):                                                         # (the second sighting builds the plans)
+                y = geot.mh_spmm(t_si, t_di, t_w, t_x)
+                gx, gw = torch.autograd.grad(y, [t_x, t_w], up)
+            xr, wr = t_x.detach().double().requires_grad_(), w_em.double().requires_grad_()
+            ref = torch.zeros(rows, H, Fh, device="cuda", dtype=torch.float64).index_add_(0, t_di, xr[t_si] * wr[:, :, None])
+            rgx, rgw = torch.autograd.grad(ref, [xr, wr], up.double())
+            if head_major:
+                rgw = rgw.t()
+            for name, a_, b_ in (("y", y, ref), ("d/dsrc", gx, rgx), ("d/dweight", gw, rgw)):
+                if a_.shape != b_.shape or float((a_.double() - b_).abs().max()) > 3e-5 * float(b_.abs().max()) + 1e-30:
+                    ok = False
+                    tag += f" FAILED:{name}"
+            out = hi = mag = None
         elif op == "mh":
             # multi-head SpMM (round 4: its own source-blocked kernels - one row per wave-instruction for rows of 1 KiB / 512 / 256
             # bytes): heads x width that make such rows or not, three storage types, both weight layouts, per-edge or slab-forced
