@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--options", default="", help="comma-separated name=value library options set for the whole run")
     ap.add_argument("--iters", type=int, default=4)
+    ap.add_argument("--slab-mib", type=float, default=0.0, help="slab size of the plans (0 = the host layer's rule)")
+    ap.add_argument("--dtypes", default="fp32,bf16")
     a = ap.parse_args()
     dev = torch.device("cuda")
     for item in filter(None, a.options.split(",")):
@@ -33,7 +35,7 @@ def main():
         hip.set_option(k, int(v))
     only = set(filter(None, a.only.split(",")))
     nodes, nnz = int(232_965 * a.scale), int(114_615_892 * a.scale)
-    print(f"# {hip.build_info()}  nodes={nodes} nnz={nnz} options={a.options or '-'}", flush=True)
+    print(f"# {hip.build_info()}  nodes={nodes} nnz={nnz} options={a.options or '-'} slab_mib={a.slab_mib or 'rule'}", flush=True)
     di = powerlaw_index(nnz, nodes, 11, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(12)
@@ -45,7 +47,7 @@ def main():
         key = (rowbytes, R)
         if key not in plans:
             plans.clear()                                  # (one plan at a time: 1 GB each)
-            plans[key] = slab.build_plan(si, di, nodes, nodes, rowbytes, wmode, H, rows_per_group=R)
+            plans[key] = slab.build_plan(si, di, nodes, nodes, rowbytes, wmode, H, rows_per_group=R, slab_bytes=int(a.slab_mib * (1 << 20)))
         return plans[key]
 
     def line(name, fn, extra=""):
@@ -54,6 +56,8 @@ def main():
         return ms
 
     for dtype, tname in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        if tname not in a.dtypes.split(","):
+            continue
         esz = 4 if dtype == torch.float32 else 2
         # ---- multi-head SpMM, H = 4 x F = 64 (configs[3])
         if not only or "mh" in only:
