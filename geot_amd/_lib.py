@@ -36,7 +36,7 @@ ABI_VERSION = 2
 SYMBOLS = [
     "geot_abi_version", "geot_last_error", "geot_build_info", "geot_workspace_bytes", "geot_mh_workspace_bytes",
     "geot_workspace_init", "geot_index_scatter", "geot_index_scatter_reduce", "geot_gather_reduce", "geot_gather_scatter",
-    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_mh_sddmm_coo", "geot_gather_rows", "geot_index_probe",
+    "geot_gather_weight_scatter", "geot_mh_spmm", "geot_sddmm_coo", "geot_mh_sddmm_coo", "geot_gather_select_backward", "geot_gather_rows", "geot_index_probe",
     "geot_publish_word", "geot_publish_pending", "geot_set_alarm_word", "geot_content_fingerprint", "geot_content_fingerprint_scratch_bytes", "geot_index_probe_range", "geot_sort_supported", "geot_sort_workspace_bytes", "geot_sort_index",
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_units_for", "geot_slab_rows_per_group_shape", "geot_slab_workspace_bytes", "geot_slab_workspace_bytes_staged", "geot_slab_spmm", "geot_slab_sddmm", "geot_slab_sddmm_staged", "geot_slab_mh_sddmm", "geot_slab_to_plan_order",
@@ -226,6 +226,7 @@ def load() -> ctypes.CDLL:
     L.geot_mh_spmm.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_sz, c_vp]
     L.geot_sddmm_coo.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp]
     L.geot_mh_sddmm_coo.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp]
+    L.geot_gather_select_backward.argtypes = [c_vp] * 9 + [c_i64, c_i64, c_i64, c_i64, c_int, c_vp]
     L.geot_gather_rows.argtypes = [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]
     L.geot_csr_workspace_bytes.restype = c_sz
     L.geot_csr_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]

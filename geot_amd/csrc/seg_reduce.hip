@@ -1772,6 +1772,52 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const int64_t *in
 // CSR row pointers -> per-edge row ids (dst_index) so that csr_gws can run on the tile kernel.
 // One lane group of 16 per row, rows round-robin over groups; a hub row is filled by its group in
 // 16-edge steps (the pass moves 8 B per edge: ~3 % of a gws call at F=128).
+// Backward of the max / min aggregation of the gather ops (PyG's aggr='max' on gather_scatter / gather_weight_scatter): the gradient of
+// out[d, f] = max_e m(e, f), m(e, f) = w_e * x[s_e, f], goes to the messages that ATTAIN the extremum, divided evenly among ties
+// (torch.scatter_reduce's rule).  Two passes over the dst-sorted list, a lane group per edge, three row gathers each (x[s_e], out[d_e],
+// grad[d_e]; consecutive edges share d):
+//   PASS 0  ties[d, f] += 1 for every attaining message                                  (float atomics: one per selected element)
+//   PASS 1  grad_src[s_e, f] += w_e * grad[d_e, f] / ties[d_e, f]   for attaining messages (float atomics: ~K x F of them in all)
+//           grad_weight[e]    = sum_f x[s_e, f] * grad[d_e, f] / ties[d_e, f] over them   (plain store)
+// A message attains when it equals out[d, f] IN THE STORAGE TYPE - exactly how the forward produced it (one multiply, the same
+// rounding).  NaN never compares equal: a row whose extremum is NaN passes no gradient.  The sums into grad_src are atomic adds: their
+// order is not fixed (a source with several selected edges of one column), unlike every forward kernel here.  fp32 / fp64.
+template <typename T, int PASS>
+__global__ __launch_bounds__(kThreads) void select_backward_kernel(const int64_t *__restrict__ src_index, const int64_t *__restrict__ dst_index,
+                                                                   const T *__restrict__ weight, const T *__restrict__ x, const T *__restrict__ out,
+                                                                   const T *__restrict__ grad, T *__restrict__ ties, T *__restrict__ grad_src,
+                                                                   T *__restrict__ grad_weight, int64_t nnz, int64_t F, int64_t src_rows, int64_t K,
+                                                                   int lpr_log2) {
+  const int lpr = 1 << lpr_log2, ng = kThreads >> lpr_log2;
+  const int g = threadIdx.x >> lpr_log2, c = threadIdx.x & (lpr - 1);
+  for (int64_t e = (int64_t)blockIdx.x * ng + g; e < nnz; e += (int64_t)gridDim.x * ng) {
+    const int64_t s = src_index[e], d = dst_index[e];
+    const bool ok = (uint64_t)s < (uint64_t)src_rows && (uint64_t)d < (uint64_t)K;
+    const T w = weight ? weight[e] : T(1);
+    T dot = T(0);
+    if (ok) {
+      for (int64_t f = c; f < F; f += lpr) {
+        const T xv = x[s * F + f];
+        const T m = weight ? xv * w : xv;
+        if (m == out[d * F + f]) {
+          if constexpr (PASS == 0) atomicAdd(ties + d * F + f, T(1));
+          else {
+            const T gshare = grad[d * F + f] / ties[d * F + f];
+            atomicAdd(grad_src + s * F + f, w * gshare);
+            dot += xv * gshare;
+          }
+        }
+      }
+    }
+    if constexpr (PASS == 1) {
+      if (grad_weight) {
+        for (int o = lpr >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (c == 0) grad_weight[e] = dot;
+      }
+    }
+  }
+}
+
 template <typename PTR>
 __global__ __launch_bounds__(kThreads) void csr_expand_kernel(const PTR *__restrict__ indptr,
                                                               int64_t nrow, int64_t nnz,
@@ -2651,6 +2697,29 @@ int run_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nn
   return GEOT_OK;
 }
 
+template <typename T>
+int run_select_backward(const int64_t *si, const int64_t *di, const void *w, const void *x, const void *out, const void *grad, void *ties,
+                               void *gsrc, void *gw, int64_t nnz, int64_t F, int64_t src_rows, int64_t K, hipStream_t st) {
+  if (nnz < 0 || F < 0 || src_rows < 0 || K < 0) return fail(GEOT_EINVAL, "negative size");
+  if (!gsrc || !ties || (nnz > 0 && (!si || !di || !x || !out || !grad))) return fail(GEOT_EINVAL, "null pointer");
+  HIP_TRY(hipMemsetAsync(gsrc, 0, (size_t)src_rows * (size_t)F * sizeof(T), st));
+  HIP_TRY(hipMemsetAsync(ties, 0, (size_t)K * (size_t)F * sizeof(T), st));
+  if (nnz == 0 || F == 0) return GEOT_OK;
+  int l = ceil_log2(F);
+  if (l > 6) l = 6;
+  if (l < 2) l = 2;
+  const int ng = kThreads >> l;
+  int64_t blocks = (nnz + ng - 1) / ng;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  const dim3 grid((unsigned)blocks), blk(kThreads);
+  hipLaunchKernelGGL((select_backward_kernel<T, 0>), grid, blk, 0, st, si, di, static_cast<const T *>(w), static_cast<const T *>(x), static_cast<const T *>(out),
+                     static_cast<const T *>(grad), static_cast<T *>(ties), static_cast<T *>(gsrc), static_cast<T *>(gw), nnz, F, src_rows, K, l);
+  hipLaunchKernelGGL((select_backward_kernel<T, 1>), grid, blk, 0, st, si, di, static_cast<const T *>(w), static_cast<const T *>(x), static_cast<const T *>(out),
+                     static_cast<const T *>(grad), static_cast<T *>(ties), static_cast<T *>(gsrc), static_cast<T *>(gw), nnz, F, src_rows, K, l);
+  HIP_TRY(hipGetLastError());
+  return GEOT_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -2783,6 +2852,15 @@ int geot_mh_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const 
   if (dtype == GEOT_F16) return run_sddmm<half_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st, heads, hm);
   if (dtype == GEOT_BF16) return run_sddmm<bf16_t>(src_index, dst_index, mat_1, mat_2, out, nnz, feat, rows_1, rows_2, st, heads, hm);
   return fail(GEOT_EINVAL, "bad dtype");
+}
+
+int geot_gather_select_backward(const int64_t *src_index, const int64_t *dst_index, const void *weight, const void *src, const void *out,
+                                const void *grad, void *ties, void *grad_src, void *grad_weight, int64_t nnz, int64_t feat, int64_t src_rows,
+                                int64_t out_rows, int dtype, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == GEOT_F32) return run_select_backward<float>(src_index, dst_index, weight, src, out, grad, ties, grad_src, grad_weight, nnz, feat, src_rows, out_rows, st);
+  if (dtype == GEOT_F64) return run_select_backward<double>(src_index, dst_index, weight, src, out, grad, ties, grad_src, grad_weight, nnz, feat, src_rows, out_rows, st);
+  return fail(GEOT_EUNSUPPORTED, "gather_select_backward: float32 / float64 (float atomics)");
 }
 
 int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,

@@ -669,6 +669,33 @@ at::Tensor mh_sddmm_op(const at::Tensor &si_in, const at::Tensor &di_in, const a
 }
 
 
+// Backward of the max / min aggregation of the gather ops: (grad_src, grad_weight) - the gradient of out[d, f] goes to the messages that
+// attain it, divided evenly among ties (torch.scatter_reduce's rule).  No counterpart in the reference (its wrappers differentiate the
+// sum only, geot/gather_scatter.py:21-39).
+std::tuple<at::Tensor, at::Tensor> gather_select_backward_op(const at::Tensor &si_in, const at::Tensor &di_in, const c10::optional<at::Tensor> &weight,
+                                                             const at::Tensor &src, const at::Tensor &out, const at::Tensor &grad) {
+  check_gather(si_in, di_in, src, 2);
+  const bool has_w = weight.has_value() && weight->defined();
+  TORCH_CHECK(out.dim() == 2 && grad.dim() == 2 && out.sizes() == grad.sizes() && out.size(1) == src.size(1), "out and grad must be [rows, feat] of the forward result");
+  require_gpu("gather_select_backward", {&si_in, &di_in, &src, &out, &grad, has_w ? &*weight : nullptr});
+  TORCH_CHECK(src.scalar_type() == at::kFloat || src.scalar_type() == at::kDouble,
+              "gather_scatter / gather_weight_scatter: the backward of reduce='max' / 'min' needs float32 or float64 (float atomics), got ", toString(src.scalar_type()));
+  TORCH_CHECK(out.scalar_type() == src.scalar_type() && grad.scalar_type() == src.scalar_type() && (!has_w || weight->scalar_type() == src.scalar_type()),
+              "gather_select_backward: one dtype for src, out, grad and weight");
+  GEOT_DEVICE_GUARD(src);
+  at::Tensor si = as_int64(si_in), di = as_int64(di_in);
+  at::Tensor x = src.contiguous(), o = out.contiguous(), g = grad.contiguous();
+  at::Tensor w = has_w ? weight->contiguous() : at::Tensor();
+  const int64_t nnz = di.numel(), feat = x.size(1);
+  at::Tensor gsrc = at::empty_like(x), ties = at::empty_like(o);
+  at::Tensor gw = has_w ? at::empty({nnz}, x.options()) : at::empty({0}, x.options());
+  GEOT_CALL(geot_gather_select_backward(index_ptr(si), index_ptr(di), has_w ? w.data_ptr() : nullptr, x.data_ptr(), o.data_ptr(), g.data_ptr(), ties.data_ptr(),
+                                        gsrc.data_ptr(), has_w ? gw.data_ptr() : nullptr, nnz, feat, x.size(0), o.size(0), dtype_code(x, "gather_select_backward"),
+                                        stream_of(x)));
+  return std::make_tuple(gsrc, gw);
+}
+
+
 // csrc/csr_gws.cpp:24-35: any integer dtype for indptr / indices; indptr.size(0) output rows (the last one always zero)
 at::Tensor csr_gws_op(const at::Tensor &indptr_in, const at::Tensor &indices_in, const at::Tensor &weight_in, const at::Tensor &src_in) {
   TORCH_CHECK(indptr_in.dim() == 1 && indices_in.dim() == 1, "indptr and indices must be 1 dimensional");
@@ -767,6 +794,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.def("mh_spmm_rows(Tensor src_index, Tensor dst_index, Tensor weight, Tensor src, SymInt rows) -> Tensor");
   m.def("gather_rows(Tensor index, Tensor src) -> Tensor");
   m.def("mh_sddmm(Tensor src_index, Tensor dst_index, Tensor mat_1, Tensor mat_2, bool head_major) -> Tensor");
+  m.def("gather_select_backward(Tensor src_index, Tensor dst_index, Tensor? weight, Tensor src, Tensor out, Tensor grad) -> (Tensor, Tensor)");
   m.def("transpose_edges(Tensor src_index, Tensor dst_index) -> (Tensor, Tensor, Tensor)");
   m.def("transposed_weight(Tensor src_index, Tensor dst_index, Tensor weight) -> Tensor");
   m.def("transpose_edges_weighted(Tensor src_index, Tensor dst_index, Tensor weight) -> (Tensor, Tensor, Tensor, Tensor)");
@@ -794,6 +822,7 @@ TORCH_LIBRARY_FRAGMENT(geot, m) {
   m.impl("mh_spmm_rows", GUARDED(mh_spmm_rows_op));                                           \
   m.impl("gather_rows", GUARDED(gather_rows_op));                                             \
   m.impl("mh_sddmm", GUARDED(mh_sddmm_op));                                                   \
+  m.impl("gather_select_backward", GUARDED(gather_select_backward_op));                       \
   m.impl("transpose_edges", GUARDED(transpose_edges_op));                                     \
   m.impl("transposed_weight", GUARDED(transposed_weight_op));                               \
   m.impl("transpose_edges_weighted", GUARDED(transpose_edges_weighted_op))
@@ -818,6 +847,7 @@ TORCH_LIBRARY_IMPL(geot, CPU, m) {
   m.impl("mh_spmm_rows", mh_spmm_rows_op);
   m.impl("gather_rows", gather_rows_cpu_op); // (the backward of the CPU index_scatter)
   m.impl("mh_sddmm", mh_sddmm_op);
+  m.impl("gather_select_backward", gather_select_backward_op);
   m.impl("transpose_edges", transpose_edges_op);
   m.impl("transposed_weight", transposed_weight_op);
   m.impl("transpose_edges_weighted", transpose_edges_weighted_op);

@@ -239,6 +239,11 @@ def _(src_index, dst_index, mat_1, mat_2, head_major):
     return mat_1.new_empty([heads, nnz] if head_major else [nnz, heads])
 
 
+@torch.library.register_fake("geot::gather_select_backward")
+def _(src_index, dst_index, weight, src, out, grad):
+    return src.new_empty(src.shape), src.new_empty([dst_index.shape[0] if weight is not None else 0])
+
+
 @torch.library.register_fake("geot::gather_rows")
 def _(index, src):
     return src.new_empty([index.shape[0], *src.shape[1:]])
@@ -333,7 +338,7 @@ def _gr_setup(ctx, inputs, output):
     src_index, dst_index, weight, src, reduce = inputs
     ctx.reduce = _aggr_kind(reduce)
     ctx.has_weight = weight is not None
-    ctx.save_for_backward(src_index, dst_index, src, *((weight,) if weight is not None else ()))
+    ctx.save_for_backward(src_index, dst_index, src, *((weight,) if weight is not None else ()), *((output,) if ctx.reduce in ("max", "min") else ()))
 
 
 def _gr_backward(ctx, grad):
@@ -342,10 +347,19 @@ def _gr_backward(ctx, grad):
 
     mean: out[d] = (1 / deg d) * sum_e w_e src[s_e]  ->  the SUM backward on grad / deg - d/dsrc over the cached transposed edge
     list, d/dweight by the SDDMM - with deg = edges per destination row (rows without edges keep gradient 0).
-    max / min / prod: no gradient here - refused loudly (as index_scatter does for its non-sum reductions) rather than a silent
-    zero from autograd's fallback."""
-    if ctx.reduce != "mean":
-        raise NotImplementedError(f"gather_scatter / gather_weight_scatter: backward is implemented for reduce='sum' and 'mean' only (got '{ctx.reduce}')")
+    max / min: the gradient of out[d, f] goes to the messages that attain it, divided evenly among ties (torch.scatter_reduce's rule;
+    ``geot::gather_select_backward``: float32 / float64, sums into d/dsrc by float atomics).
+    prod: no gradient here - refused loudly (as index_scatter does for its non-sum reductions) rather than a silent zero from
+    autograd's fallback."""
+    if ctx.reduce not in ("mean", "max", "min"):
+        raise NotImplementedError(f"gather_scatter / gather_weight_scatter: backward is implemented for reduce='sum', 'mean', 'max' and 'min' only (got '{ctx.reduce}')")
+    if ctx.reduce in ("max", "min"):
+        src_index, dst_index, src, *rest = ctx.saved_tensors
+        out = rest[-1]
+        weight = rest[0] if ctx.has_weight else None
+        gsrc, gw = torch.ops.geot.gather_select_backward(src_index, dst_index, None if weight is None else weight.detach(), src.detach(), out.detach(),
+                                                         grad.contiguous())
+        return None, None, (gw if ctx.has_weight and ctx.needs_input_grad[2] else None), (gsrc if ctx.needs_input_grad[3] else None), None
     src_index, dst_index, src, *rest = ctx.saved_tensors
     weight = rest[0] if rest else None
     rows = grad.shape[0]
@@ -459,8 +473,8 @@ def gather_scatter(src_index: torch.Tensor, dst_index: torch.Tensor, src: torch.
 
     The trailing ``reduce`` is what the reference's own callers pass (models/conv/spmm.py:5-8 forwards the
     layer's ``aggr``; test/test_gather_scatter.py:25): 'sum' / 'add' run the differentiable op of the
-    reference; 'mean' / 'min' / 'max' / 'prod' aggregate the messages of every row ('mean' is differentiable too; the
-    others refuse a backward pass loudly).
+    reference; 'mean' / 'min' / 'max' / 'prod' aggregate the messages of every row ('mean', 'max' and 'min' are differentiable
+    too; 'prod' refuses a backward pass loudly).
     """
     if _aggr_kind(reduce) == "sum":
         return torch.ops.geot.gather_scatter(src_index, dst_index, src)

@@ -141,6 +141,15 @@ int geot_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const voi
 int geot_mh_sddmm_coo(const int64_t *src_index, const int64_t *dst_index, const void *mat_1, const void *mat_2, void *out, int64_t nnz,
                       int64_t heads, int64_t feat, int64_t rows_1, int64_t rows_2, int weight_layout, int dtype, void *stream);
 
+/* Backward of the max / min aggregation of the gather ops (geot_gather_reduce with GEOT_REDUCE_MAX / MIN): the gradient of
+ * out[d, f] goes to the messages (weight[e] *) src[src_index[e], f] that ATTAIN out[d, f], divided evenly among ties
+ * (torch.scatter_reduce's rule).  grad_src [src_rows, feat] is written in full; grad_weight [nnz] may be NULL; `ties` is
+ * out_rows x feat elements of scratch.  The sums into grad_src are float atomics (order not fixed).  float32 / float64.
+ * No counterpart in the reference (its GPU kernels ignore `reduce`, its wrappers differentiate the sum only). */
+int geot_gather_select_backward(const int64_t *src_index, const int64_t *dst_index, const void *weight, const void *src, const void *out,
+                                const void *grad, void *ties, void *grad_src, void *grad_weight, int64_t nnz, int64_t feat, int64_t src_rows,
+                                int64_t out_rows, int dtype, void *stream);
+
 /* dst[e, :] = src[index[e], :] */
 int geot_gather_rows(const int64_t *index, const void *src, void *dst, int64_t nnz,
                      int64_t feat, int64_t src_rows, int dtype, void *stream);

@@ -100,16 +100,46 @@ def test_mean_aggregation_is_differentiable(geot, weighted, dtype):
     assert float(grads[0][-2:].abs().max()) == 0.0          # source nodes without out-edges: gradient rows exist and are zero
 
 
-@pytest.mark.parametrize("reduce", ["max", "min", "prod"])
-def test_selection_aggregations_refuse_a_backward_pass(geot, reduce):
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("reduce", ["max", "min"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_max_min_aggregation_gradients_follow_torch_scatter_reduce(geot, reduce, weighted, dtype):
+    """The gradient of a max / min aggregation goes to the messages that attain it, evenly among ties - torch.scatter_reduce's rule.
+    Data with MANY exact ties (features quantised to a few values, some weights equal) against plain-torch autograd of
+    scatter_reduce(amax / amin, include_self=False) over the materialised messages."""
+    rng = np.random.default_rng(21)
+    nodes, nnz, F = 300, 9000, 24
+    si, di = _graph(rng, nodes, nnz)
+    x = (torch.randint(0, 4, (nodes, F), device="cuda").to(dtype) / 2 - 0.5).requires_grad_()
+    w = (torch.randint(1, 3, (nnz,), device="cuda").to(dtype) / 2).requires_grad_() if weighted else None
+    out = geot.gather_weight_scatter(si, di, w, x, reduce) if weighted else geot.gather_scatter(si, di, x, reduce)
+    up = torch.rand_like(out)
+    grads = torch.autograd.grad(out, [x] + ([w] if weighted else []), up)
+    xr = x.detach().double().requires_grad_()
+    wr = w.detach().double().requires_grad_() if weighted else None
+    msg = xr[si] * (wr[:, None] if weighted else 1.0)
+    ref = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).scatter_reduce(0, di[:, None].expand(-1, F), msg, "amax" if reduce == "max" else "amin",
+                                                                                  include_self=False)
+    assert torch.equal(out.double(), ref)                      # selections: exact
+    refg = torch.autograd.grad(ref, [xr] + ([wr] if weighted else []), up.double())
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    for g, r in zip(grads, refg):
+        assert g.shape == r.shape and g.dtype == dtype
+        assert torch.allclose(g.double(), r, rtol=tol * 10, atol=tol * 10 * float(r.abs().max()))
+
+
+def test_prod_aggregation_refuses_a_backward_pass(geot):
     """... and what has no gradient here says so (like index_scatter's non-sum reductions, ops._is_backward) instead of autograd's
-    silent fallback."""
+    silent fallback; 16-bit storage has no float atomic for the max / min backward and says so too."""
     rng = np.random.default_rng(18)
     si, di = _graph(rng, 50, 700)
     x = torch.rand(50, 8, device="cuda", requires_grad=True)
-    out = geot.gather_scatter(si, di, x, reduce)
-    with pytest.raises(NotImplementedError, match="backward is implemented for reduce='sum' and 'mean' only"):
+    out = geot.gather_scatter(si, di, x, "prod")
+    with pytest.raises(NotImplementedError, match="backward is implemented for reduce='sum', 'mean', 'max' and 'min' only"):
         out.sum().backward()
+    xh = torch.rand(50, 8, device="cuda").bfloat16().requires_grad_()
+    with pytest.raises(RuntimeError, match="needs float32 or float64"):
+        geot.gather_scatter(si, di, xh, "max").float().sum().backward()
 
 
 def _mh_dense(si, di, w_em, x, rows):

@@ -41,6 +41,10 @@ def cases(g):
         "gather_scatter_impl": (G.gather_scatter_impl.default, (g["si"], g["di"], g["x"])),
         "gather_weight_scatter_impl": (G.gather_weight_scatter_impl.default, (g["si"], g["di"], g["w"], g["x"])),
         "gather_reduce": (G.gather_reduce.default, (g["si"], g["di"], g["w"], g["x"], "max")),
+        "gather_reduce_mean_grad": (G.gather_reduce.default, (g["si"], g["di"], rg(g["w"]), rg(g["x"]), "mean")),
+        "gather_reduce_max_grad": (G.gather_reduce.default, (g["si"], g["di"], rg(g["w"]), rg(g["x"]), "max")),
+        "mh_spmm_grad": (G.mh_spmm.default, (g["si"], g["di"], rg(g["wh"]), rg(g["xh"]), "sum")),
+        "mh_sddmm": (G.mh_sddmm.default, (g["si"], g["di"], g["xh"], g["xh"], False)),
         "gather_scatter_rows": (G.gather_scatter_rows.default, (g["si"], g["di"], rg(g["x"]), g["n"])),
         "gather_weight_scatter_rows": (G.gather_weight_scatter_rows.default, (g["si"], g["di"], rg(g["w"]), rg(g["x"]), g["n"])),
         "mh_spmm": (G.mh_spmm.default, (g["si"], g["di"], g["wh"], g["xh"], "sum")),
@@ -57,12 +61,12 @@ def cases(g):
 
 
 NAMES = ["index_scatter", "index_scatter_grad", "index_scatter_mean", "gather_scatter", "gather_weight_scatter", "gather_scatter_impl",
-         "gather_weight_scatter_impl", "gather_reduce", "gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm", "mh_spmm_rows",
+         "gather_weight_scatter_impl", "gather_reduce", "gather_reduce_mean_grad", "gather_reduce_max_grad", "mh_spmm_grad", "mh_sddmm", "gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm", "mh_spmm_rows",
          "sddmm_coo_impl", "csr_gws", "csr_gws_impl", "gather_rows", "transpose_edges", "transposed_weight", "transpose_edges_weighted",
          "coo_to_csr"]
 
 
-STATIC_SHAPE = {"gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm_rows", "sddmm_coo_impl", "gather_rows", "transpose_edges",
+STATIC_SHAPE = {"mh_sddmm", "gather_scatter_rows", "gather_weight_scatter_rows", "mh_spmm_rows", "sddmm_coo_impl", "gather_rows", "transpose_edges",
                 "transposed_weight", "transpose_edges_weighted", "csr_gws_impl"}
 
 
