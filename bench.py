@@ -408,6 +408,11 @@ def secondary(dev, scale=1.0, iters=5, only=None):
         # ... and through the opt-in static-graph handle (owns its index clones and its plan: no fingerprint, no lookup)
         handle = geot.Graph(si, di, num_src=nodes, num_dst=nodes)
         ms_handle = device_ms(lambda: handle.mh_spmm(w, x), iters, warmup=4)
+        # ... with the (static) coefficients handed over in plan order once - what the dispatched operator's cache does behind the
+        # guard, here the caller's explicit choice
+        w_plan = handle.plan_order(w, x)
+        ms_handle_static = device_ms(lambda: handle.mh_spmm(w_plan, x), iters, warmup=2)
+        del w_plan
         handle_stats = dict(handle.stats)
         del handle
         hip.mh_spmm_out(si, di, w, x, out, False)
@@ -422,7 +427,12 @@ def secondary(dev, scale=1.0, iters=5, only=None):
             "kernel_ms": ms,
             "content_guard": "on: every call re-reads both index arrays and compares their fingerprint with the plan's (kernel_ms includes it)",
             "kernel_ms_without_content_guard": ms_unguarded,
-            "kernel_ms_with_graph_handle": ms_handle, "graph_handle": handle_stats,
+            "kernel_ms_with_graph_handle": ms_handle_static, "kernel_ms_with_graph_handle_edge_order_weights": ms_handle,
+            "graph_handle": "geot_amd.Graph: owns index clones and plans, no fingerprint, no cache lookup.  kernel_ms_with_graph_handle: coefficients handed over in "
+                            "plan order once (Graph.plan_order) - like-for-like with kernel_ms_without_content_guard, whose host-layer cache keeps a static "
+                            "weight tensor in plan order; ..._edge_order_weights: a fresh [nnz, H] tensor in edge order every call, read through the plan's edge "
+                            "permutation in the row loop",
+            "graph_handle_stats": handle_stats,
             "kernel": kernel + (" (+ memset, combine)" if slab_used else ""),     # what the operator launched (geot_last_kernel)
             "plan_trial_ms": {"plan": st1["trial_plan_us"] / 1e3, "per_edge": st1["trial_edges_us"] / 1e3} if st1["plan_trials"] > st0["plan_trials"] else None,
             "source_blocked_path": slab_used,

@@ -299,7 +299,7 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   // rows of 256 / 512 / 1024 bytes; 128-byte rows run too but were measured slower than the per-edge kernels (DESIGN.md
   // section 3.1d): only when the path is forced
   if ((rowbytes != 256 && rowbytes != 512 && rowbytes != 1024 && !(rowbytes == 128 && g_opt.slab_mode == 1)) || nnz == 0 ||
-      nnz >= ((int64_t)1 << 31) || src.size(0) * rowbytes > ((int64_t)1 << 32))   // (32-bit row offsets in the kernel: a table of at most 4 GiB)
+      nnz >= ((int64_t)1 << 31) || src.size(0) * rowbytes >= ((int64_t)1 << 32))   // (32-bit row offsets in the kernel: a table below 4 GiB)
     return nullptr;
   if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes, dt)) return nullptr;
   ContentKey k1, k2;

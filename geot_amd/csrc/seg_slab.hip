@@ -34,6 +34,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 #include "geot_hip.h"
 #include "internal.h"
@@ -63,6 +64,8 @@ struct SlabParams {
   int far;              // ... but a slowest wave MORE than `far` steps behind is not waited for: nothing it reads can still be shared
   int nt_plan;          // experiment: non-temporal loads of the plan's edge fields and of the weights (read once per launch)
   int w_in_plan_order;  // WMODE 1 / 2: weight[] is indexed by plan position (a static weight permuted once, scores computed in plan order), not by edge id
+  int probe;            // timing experiment ("slab_probe"): the gathered table's buffer descriptor has ZERO records - every row read of the
+                        // wave-row forms is dropped by the range check (returns 0, no memory traffic), the instruction stream stays
 };
 constexpr int kProgSlots = 512;
 constexpr int kProgIdle = 0x7f7f7f7f;
@@ -162,6 +165,19 @@ __global__ __launch_bounds__(kThreads) void slab_stage_weights_kernel(const int3
 // mirror image of slab_unstage_kernel - measured SLOWER than this plain gather: gws F=128 fp32 4.52 vs 4.00 ms per call,
 // profiles/r05/slab_cases__weight_prepass_through_lds.txt; three barriers per group cost more than the L2 requests they save.)
 
+// A gathered row read of the wave-row forms: buffer_load with the table as the buffer (base + size in four SGPRs, made once per wave
+// from kernel arguments), the lane's byte offset inside the row in voffset (loop-invariant) and the ROW's byte offset - wave-uniform,
+// out of v_readlane - in soffset: no vector instruction per edge for the address (global_load wanted a 64-bit add per edge).  The
+// table is below 4 GiB (geot_slab_spmm / geot_slab_sddmm refuse more): offsets and the record count fit 32 bits.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_table_rsrc(const void *table, int64_t rows, int row_shift, int probe = 0) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(table), 0, probe ? 0 : (int)(uint32_t)((uint64_t)rows << row_shift), 0x00020000);
+}
+template <typename RAW> __device__ __forceinline__ RAW slab_row_load(__amdgpu_buffer_rsrc_t table, uint32_t lane_bytes, uint32_t row_bytes_off) {
+  if constexpr (sizeof(RAW) == 4) return __builtin_bit_cast(RAW, __builtin_amdgcn_raw_buffer_load_b32(table, lane_bytes, row_bytes_off, 0));
+  else if constexpr (sizeof(RAW) == 8) return __builtin_bit_cast(RAW, __builtin_amdgcn_raw_buffer_load_b64(table, lane_bytes, row_bytes_off, 0));
+  else return __builtin_bit_cast(RAW, __builtin_amdgcn_raw_buffer_load_b128(table, lane_bytes, row_bytes_off, 0));
+}
+
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // WAVE_ROW: rows of 1 KiB - the whole wave is one unit, edge fields are read with v_readlane (scalar row bases)
 //
@@ -185,7 +201,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   const int R = P.rows_per_group;
   const int hw = WMODE == 0 ? 0 : (WMODE == 1 ? 1 : p.H);
   // LDS: fp32 accumulators [4 waves][G units][R rows][lpr lanes][NV] float4 = 4 * R * NV KiB, then the staged
-  // weights [4 waves][2 buffers][64 edge slots][hw] (fp32)
+  // weights [4 waves][2 buffers][G units][hw][lpr edge slots] (fp32; head-major inside a unit's block: the row loop reads edge
+  // b+u's weight at (a per-lane base: block + head) + b + u)
   float *accS = reinterpret_cast<float *>(smem) + ((size_t)(wave * G + sub) * R) * 4 * NV * lpr;
   float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 1024 * NV) + (size_t)wave * 2 * 64 * (hw > 0 ? hw : 1) +
                  (size_t)sub * lpr * (hw > 0 ? hw : 1);
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = WAVE_ROW ? 10 : 4 + p.lpr_log2;   // log2(row bytes)
   const uint32_t c16 = (uint32_t)c * 16u;
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
 
   // ---- loose lockstep inside an XCD -------------------------------------------------------------------------------
   // The natural lockstep (same start, same work) drifts like a random walk: with ~6000 edges per group the waves of an
@@ -307,18 +325,21 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         const int64_t pe = valid ? (wpo ? e0 + c : (int64_t)P.e_perm[e0 + c]) : 0;
         if constexpr (WMODE == 1) wbase[c] = valid ? (float)weight[pe] : 0.f;
         if constexpr (WMODE == 2) {
-          if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + c * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
-          else for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
+          if (p.H == 4) {
+            const f4_t w4 = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wbase[q * lpr + c] = w4[q];
+          } else for (int q = 0; q < p.H; ++q) wbase[q * lpr + c] = valid ? (float)weight[pe * p.H + q] : 0.f;
         }
         if constexpr (WMODE == 3)
-          for (int q = 0; q < p.H; ++q) wbase[c * hw + q] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
+          for (int q = 0; q < p.H; ++q) wbase[q * lpr + c] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
         __builtin_amdgcn_wave_barrier();
       }
     }
 
     int k = 0;
     for (int off = 0; off < maxlen; off += lpr, ++k) {
-      const float *wcur = wbase + (k & 1) * wbuf_stride;
+      const float *wcur = wbase + (k & 1) * wbuf_stride + h * lpr;       // this lane's head
       float *wnext = wbase + ((k + 1) & 1) * wbuf_stride;
       // next chunk's fields: in flight underneath this chunk's rows
       const bool nvalid = off + lpr + c < len;
@@ -328,8 +349,12 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       const int n_dl = nvalid ? (int)(ntp ? __builtin_nontemporal_load(P.e_dl + ne) : P.e_dl[ne]) : 255;
       int64_t n_pe = 0;
       if constexpr (WMODE != 0) n_pe = nvalid ? (wpo ? ne : (int64_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne])) : 0;
-      f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
-      float wn1 = 0.f;
+      // (the next chunk's weights are held AS LOADED until they are staged at the end of the chunk: converting a 16-bit weight here
+      // would put a full wait - behind the batch of row loads just issued - into the first batch of every chunk)
+      t4_t wn4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wn4[q] = (T)0.f;
+      T wn1 = (T)0.f;
 
       const int n_here = len - off;                  // edges of this unit in the chunk (<= 0: none)
       int n_max = maxlen - off;
@@ -357,20 +382,21 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
             row = (uint32_t)__shfl(my_src, b + u, lpr);
             dls[u] = __shfl(my_dl, b + u, lpr);
           }
-          if constexpr (WMODE != 0) ws[u] = wcur[(b + u) * hw + h];
-          v[u] = *reinterpret_cast<const f4_t *>(src + (size_t)((row << rsh) + c16));
+          if constexpr (WMODE != 0) ws[u] = wcur[b + u];
+          if constexpr (WAVE_ROW) v[u] = slab_row_load<f4_t>(table, c16, row << rsh);
+          else v[u] = *reinterpret_cast<const f4_t *>(src + (size_t)((row << rsh) + c16));
         }
         if constexpr (WMODE != 0) {
           if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
-            if constexpr (WMODE == 1) wn1 = nvalid ? (float)weight[n_pe] : 0.f;
+            if constexpr (WMODE == 1) { if (nvalid) wn1 = weight[n_pe]; }
             if constexpr (WMODE == 2) {
-              if (p.H == 4) { if (nvalid) wn4 = load_w4(n_pe); }
+              if (p.H == 4) { if (nvalid) wn4 = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + n_pe * 4)) : *reinterpret_cast<const t4_t *>(weight + n_pe * 4); }
             }
           }
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          if (dls[u] != cur) {                       // the open row goes back to LDS, the new one comes out of it
+          if (__builtin_expect(dls[u] != cur, 0)) {  // the open row goes back to LDS, the new one comes out of it (rare: laid out of line)
             if (cur != 255) {
 #pragma unroll
               for (int q = 0; q < NV; ++q) accV[((size_t)cur * lpr + c) * NV + q] = acc[q];
@@ -394,13 +420,15 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       }
       // stage the next chunk
       if constexpr (WMODE != 0) {
-        if constexpr (WMODE == 1) wnext[c] = wn1;
+        if constexpr (WMODE == 1) wnext[c] = (float)wn1;
         if constexpr (WMODE == 2) {
-          if (p.H == 4) *reinterpret_cast<f4_t *>(wnext + c * 4) = wn4;
-          else for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+          if (p.H == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wnext[q * lpr + c] = (float)wn4[q];
+          } else for (int q = 0; q < p.H; ++q) wnext[q * lpr + c] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
         }
         if constexpr (WMODE == 3)
-          for (int q = 0; q < p.H; ++q) wnext[c * hw + q] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+          for (int q = 0; q < p.H; ++q) wnext[q * lpr + c] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
         __builtin_amdgcn_wave_barrier();
       }
       my_src = n_src;
@@ -497,7 +525,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int R = P.rows_per_group;
   const int hw = WMODE <= 1 ? 1 : p.H;
-  // LDS: fp32 accumulators [4 waves][R rows][64 lanes][E], then the staged weights [4 waves][2 buffers][64 edge slots][hw]
+  // LDS: fp32 accumulators [4 waves][R rows][64 lanes][E], then the staged weights [4 waves][2 buffers][hw][64 edge slots] -
+  // HEAD-major inside a buffer: the row loop's read of edge b+u's weight is (a per-lane base: buffer + head) + a scalar batch offset
+  // + an immediate, no address arithmetic per edge
   accv_t *accV = reinterpret_cast<accv_t *>(smem) + (size_t)wave * R * 64;
   float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 64 * E * sizeof(float)) + (size_t)wave * 2 * 64 * hw;
   const int wbuf_stride = 64 * hw;
@@ -507,10 +537,11 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
   const T *weight = static_cast<const T *>(p.weight);
   T *dst = static_cast<T *>(p.dst);
   const int h = WMODE >= 2 ? (lane * E) / p.Fh : 0;
-  const bool wpo = p.w_in_plan_order != 0;              // weights indexed by plan position (given so, or staged by the pre-pass)
+  const bool wpo_rt = p.w_in_plan_order != 0;           // weights indexed by plan position (given so, or staged by the pre-pass)
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = 4 + p.lpr_log2;                       // log2(row bytes)
   const uint32_t cB = (uint32_t)lane * (uint32_t)(E * sizeof(T));
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
   typedef T t4_t __attribute__((ext_vector_type(4)));
   auto load_w4 = [&](int64_t pe) {
     const t4_t x = *reinterpret_cast<const t4_t *>(weight + pe * 4);
@@ -583,61 +614,98 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
     accv_t acc = zero();
     int cur = 255;
 
+    // An edge's two fields travel as ONE word, (source row << 8) | row in group (rows are >= 256 B in a table below 4 GiB: < 2^24
+    // rows; a group has at most 32 rows, 255 = padding): one v_readlane per edge instead of two, the split is scalar arithmetic
     int my_src = 0, my_dl = 255;
+    uint32_t my_edge = 255;
     {
       const bool valid = lane < len;
       my_src = valid ? P.e_src[e0 + lane] : 0;
       if ((uint32_t)my_src >= src_rows) my_src = 0;
       my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
+      my_edge = ((uint32_t)my_src << 8) | (uint32_t)my_dl;
       if constexpr (WMODE != 0) {
-        const int64_t pe = valid ? (wpo ? e0 + lane : (int64_t)P.e_perm[e0 + lane]) : 0;
+        const int64_t pe = valid ? (wpo_rt ? e0 + lane : (int64_t)P.e_perm[e0 + lane]) : 0;
         if constexpr (WMODE == 1) wbase[lane] = valid ? (float)weight[pe] : 0.f;
         else if constexpr (WMODE == 2) {
-          if (p.H == 4) *reinterpret_cast<f4_t *>(wbase + lane * 4) = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
-          else for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[pe * p.H + q] : 0.f;
+          if (p.H == 4) {
+            const f4_t w4 = valid ? load_w4(pe) : f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wbase[q * 64 + lane] = w4[q];
+          } else for (int q = 0; q < p.H; ++q) wbase[q * 64 + lane] = valid ? (float)weight[pe * p.H + q] : 0.f;
         } else {
-          for (int q = 0; q < p.H; ++q) wbase[lane * hw + q] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
+          for (int q = 0; q < p.H; ++q) wbase[q * 64 + lane] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
       }
     }
 
+    // (the chunk loop exists twice, for weights in plan order and through e_perm: with the choice made at run time inside one body the
+    // compiler guards e_perm's in-flight entry with vmcnt(0) waits on BOTH paths)
+    auto chunks = [&](auto wpo_c) __attribute__((always_inline)) {
+    constexpr bool wpo = decltype(wpo_c)::value;
     int k = 0;
     for (int off = 0; off < len; off += 64, ++k) {
-      const float *wcur = wbase + (k & 1) * wbuf_stride;
+      const float *wcur = wbase + (k & 1) * wbuf_stride + h * 64;          // this lane's head
       float *wnext = wbase + ((k + 1) & 1) * wbuf_stride;
+      // The next chunk's fields are loaded BEHIND the first batch's row gathers (below), not here: vector-memory operations retire in
+      // issue order, so a stream read issued ahead of the gathers (an HBM miss, several times a gather's L2 hit) is waited for by the
+      // very first row of the chunk - one full miss per 64 edges on every wave's critical path.
+      // They are loaded by EVERY lane, unconditionally (lanes behind the group's end re-read its last edge and drop the value when the
+      // chunk is handed over): a predicated load is a branch to the compiler, and behind a branch it waits for vmcnt(0).
       const bool nvalid = off + 64 + lane < len;
-      const int64_t ne = e0 + off + 64 + lane;
-      int n_src = nvalid ? P.e_src[ne] : 0;
-      if ((uint32_t)n_src >= src_rows) n_src = 0;
-      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
-      int64_t n_pe = 0;
-      if constexpr (WMODE != 0) n_pe = nvalid ? (wpo ? ne : (int64_t)P.e_perm[ne]) : 0;
-      f4_t wn4 = {0.f, 0.f, 0.f, 0.f};
-      float wn1 = 0.f;
+      const int64_t ne = e0 + (nvalid ? off + 64 + lane : len - 1);
+      int n_src = 0, n_dl = 255;
+      uint32_t n_pe32 = 0;                               // (e_perm's entry stays as loaded until the weight read uses it)
+      // (the next chunk's weights are held AS LOADED until they are staged at the end of the chunk: converting a 16-bit weight here
+      // would put a full wait - behind the batch of row loads just issued - into the first batch of every chunk)
+      t4_t wn4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wn4[q] = (T)0.f;
+      T wn1 = (T)0.f;
       int n_max = len - off;
       n_max = n_max < 64 ? n_max : 64;
-      for (int b = 0; b < n_max; b += U) {
-        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
+      // (the first batch is its own copy of the body: there the next chunk's field loads are unconditional, and the compiler counts
+      // them - a conditional load inside one shared body made every batch's last row wait for vmcnt(0))
+      auto batch = [&](const int b, auto first_c) __attribute__((always_inline)) {
+        constexpr bool kFirst = decltype(first_c)::value;
+        if (p.window >= 0) slab_sync(r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, b) >> (8 + p.slab_shift)));
+        if constexpr (WMODE == 1 || WMODE == 2) {
+          // the next chunk's weights, in edge order: their place comes out of e_perm (loaded behind the first batch) - read it at the
+          // TOP of the second batch, where everything outstanding is a batch old, not behind that batch's gathers
+          if (!kFirst && !wpo && b == U) {
+            uint32_t pe = n_pe32;
+            asm volatile("" : "+v"(pe));      // (keeps the address arithmetic - and with it the wait for e_perm's entry - HERE, not at its load)
+            if constexpr (WMODE == 1) wn1 = weight[pe];
+            else if (p.H == 4) wn4 = *reinterpret_cast<const t4_t *>(weight + (size_t)pe * 4);
+          }
+        }
         raw_t v[U];
         int dls[U];
         float ws[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {       // (slots behind the last edge: row 0, dl = 255, weight 0 - see seg_slab_kernel)
-          const uint32_t row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
-          dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
-          if constexpr (WMODE != 0) ws[u] = wcur[(b + u) * hw + h];
-          v[u] = *reinterpret_cast<const raw_t *>(src + (size_t)((row << rsh) + cB));
+          const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane(my_edge, b + u);
+          dls[u] = (int)(edge & 255u);
+          if constexpr (WMODE != 0) ws[u] = wcur[b + u];
+          v[u] = slab_row_load<raw_t>(table, cB, (edge & ~255u) << (rsh - 8));
         }
-        if constexpr (WMODE == 1) {
-          if (b == 0 && nvalid) wn1 = (float)weight[n_pe];
+        if constexpr (kFirst) {
+          n_src = P.e_src[ne];
+          n_dl = (int)P.e_dl[ne];
+          if constexpr (WMODE != 0) {
+            if (!wpo) n_pe32 = (uint32_t)P.e_perm[ne];
+          }
         }
-        if constexpr (WMODE == 2) {
-          if (b == 0 && p.H == 4 && nvalid) wn4 = load_w4(n_pe);
+        if (kFirst && wpo) {                // the next chunk's weights, in plan order: with the fields
+          if constexpr (WMODE == 1) wn1 = weight[ne];
+          if constexpr (WMODE == 2) {
+            if (p.H == 4) wn4 = *reinterpret_cast<const t4_t *>(weight + ne * 4);
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (dls[u] != cur) {
+          if (__builtin_expect(dls[u] != cur, 0)) {      // (rare: the switch is laid out of line, the common path falls through)
             if (cur != 255) accV[(size_t)cur * 64 + lane] = acc;
             cur = dls[u];
             acc = cur != 255 ? accV[(size_t)cur * 64 + lane] : zero();
@@ -653,18 +721,30 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
             }
           }
         }
-      }
-      if constexpr (WMODE == 1) wnext[lane] = wn1;
+      };
+      batch(0, std::true_type{});
+      for (int b = U; b < n_max; b += U) batch(b, std::false_type{});
+      if constexpr (WMODE == 1) wnext[lane] = nvalid ? (float)wn1 : 0.f;
       else if constexpr (WMODE == 2) {
-        if (p.H == 4) *reinterpret_cast<f4_t *>(wnext + lane * 4) = wn4;
-        else for (int q = 0; q < p.H; ++q) wnext[lane * hw + q] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+        if (p.H == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wnext[q * 64 + lane] = nvalid ? (float)wn4[q] : 0.f;
+        } else {
+          const int64_t n_pe = wpo ? ne : (int64_t)n_pe32;
+          for (int q = 0; q < p.H; ++q) wnext[q * 64 + lane] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+        }
       } else if constexpr (WMODE == 3) {
-        for (int q = 0; q < p.H; ++q) wnext[lane * hw + q] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+        const int64_t n_pe = wpo ? ne : (int64_t)n_pe32;
+        for (int q = 0; q < p.H; ++q) wnext[q * 64 + lane] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
       }
       if constexpr (WMODE != 0) __builtin_amdgcn_wave_barrier();
-      my_src = n_src;
-      my_dl = n_dl;
+      my_src = (nvalid && (uint32_t)n_src < src_rows) ? n_src : 0;
+      my_dl = nvalid ? n_dl : 255;
+      my_edge = ((uint32_t)my_src << 8) | (uint32_t)my_dl;
     }
+    };
+    if (WMODE == 0 || wpo_rt) chunks(std::true_type{});
+    else chunks(std::false_type{});
     if (cur != 255) accV[(size_t)cur * 64 + lane] = acc;
     if (p.window >= 0 && my_slot >= 0) {
       published = (r + 1) * p.n_slabs;
@@ -699,6 +779,243 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
   if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
+// Rows of 512 bytes under multi-head weights, TWO ROWS PER WAVE-INSTRUCTION (an EXPERIMENT, option "slab_pair"; off by default): the
+// plan of seg_slab_wrow_kernel (a unit = a wave, R rows per group, group bounds / row switches in SGPRs) read at 16 bytes a lane -
+// lanes 0..31 gather the row of edge 2j, lanes 32..63 the row of edge 2j+1 OF THE SAME UNIT.  The idea: fp32 rows of 512 B run at
+// 3.14 ms with 16 bytes a lane (lane groups) and 4.15 ms with 8 (one row per instruction), so halve the gather instructions of the
+// 16-bit multi-head plans too, without the lane groups' per-lane row switches and uneven units.  The result (bf16 H=4 x F=64 at
+// Reddit scale, weights in plan order): 4.63 ms against seg_slab_wrow_kernel's 4.50 - SLOWER, and the counters say why
+// (profiles/r05/pmc_slab_probe/): 12.2 vector instructions per edge against 10.4 (eight unpacks and four packed FMAs per pair stay,
+// the per-half row offsets cost a ds_bpermute + shift-or per pair, the row switches are tested twice), LDS instructions 1.9 per edge
+// against 0.6, and neither kernel waits for its row gathers in the first place (with the gathers DROPPED, "slab_probe", both keep
+// 97-98 % of their time).  Kept for rows where the balance differs; tests/test_gpu_round5.py runs it against the float64 sums.
+// Each half keeps ITS open row's partial sum in registers; a half's row switch (a
+// scalar test per edge, as before) ADDS its partial sum into the row's LDS accumulators - read-add-write by that half's lanes only,
+// the halves one after the other (LDS operations of a wave execute in order), so two halves holding pieces of the same row never
+// collide - and starts the new row from zero: the same LDS traffic as one row per instruction (which wrote the old row and read the
+// new one).  A row's sum is (sum over its even-position edges) + (sum over its odd-position edges), in plan order inside each: fixed
+// by the plan, not by timing.  WMODE 2 weight[e*H + h] | 3 weight[h*nnz + e]; p.w_in_plan_order as in seg_slab_wrow_kernel.
+template <typename T, int WMODE>
+__global__ __launch_bounds__(kThreads) void seg_slab_wpair_kernel(SlabParams p) {
+  static_assert(WMODE == 2 || WMODE == 3, "multi-head weights");
+  constexpr int VEC = SlabVec<T>::VEC, NV = SlabVec<T>::NV;
+  constexpr int kI = 8;                                  // gather instructions in flight per lane = 16 edges a batch
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, c = lane & 31;
+  const int R = P.rows_per_group;
+  const int hw = p.H;
+  // LDS: fp32 accumulators [4 waves][R rows][32 lanes][NV] float4 (= seg_slab_wrow_kernel's bytes), then the staged weights
+  // [4 waves][2 buffers][hw][64 edge slots]
+  f4_t *accV = reinterpret_cast<f4_t *>(smem) + (size_t)wave * R * 32 * NV;
+  float *wbase = reinterpret_cast<float *>(smem + (size_t)4 * R * 32 * NV * sizeof(f4_t)) + (size_t)wave * 2 * 64 * hw;
+  const int wbuf_stride = 64 * hw;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t units = P.units;
+  const T *weight = static_cast<const T *>(p.weight);
+  T *dst = static_cast<T *>(p.dst);
+  const int h = (c * VEC) / p.Fh;
+  const bool wpo = p.w_in_plan_order != 0;
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+  constexpr int rsh = 9;                                 // log2(row bytes)
+  const uint32_t c16 = (uint32_t)c * 16u;
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
+  typedef T t4_t __attribute__((ext_vector_type(4)));
+
+  // ---- loose lockstep inside an XCD (as in seg_slab_kernel) ---------------------------------------------------------
+  int my_slot = -1;
+  int *xprog = nullptr;
+  if (p.window >= 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  int published = -1, known_min = -1, timeouts = 0;
+  auto slab_sync = [&](int step) {
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return;
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      known_min = m;
+      if (m + p.window >= step || step - m > p.far) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
+    }
+  };
+  const f4_t z4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    const bool has = pos < P.n_groups;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+    len = __builtin_amdgcn_readfirstlane(len);
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    for (int l = half; l < R; l += 2)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) accV[((size_t)l * 32 + c) * NV + q] = z4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a row zeroed by one half is added into by the other)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f4_t acc[NV];                                         // this half's open row: lanes 0..31 the even-position edges', 32..63 the odd ones'
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = z4;
+    int cur0 = 255, cur1 = 255;                           // the halves' open rows (wave-uniform)
+    auto hand_in = [&](int which, int row) {              // half `which` adds its partial sum into LDS row `row` and starts from zero
+      if (half == which) {
+        if (row != 255) {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) accV[((size_t)row * 32 + c) * NV + q] += acc[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) acc[q] = z4;
+      }
+      // The other half's lanes may add into the SAME LDS words next (both halves often hold pieces of one row): to the compiler those
+      // are other threads, and without this it is free to read for both halves first and write twice (seen: a hub lost 18 % of its
+      // pieces in the 16-bit instantiations).  The hardware runs a wave's LDS operations in order; the compiler must not reorder them.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    int my_src = 0, my_dl = 255;
+    {
+      const bool valid = lane < len;
+      my_src = valid ? P.e_src[e0 + lane] : 0;
+      if ((uint32_t)my_src >= src_rows) my_src = 0;
+      my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
+      const int64_t pe = valid ? (wpo ? e0 + lane : (int64_t)P.e_perm[e0 + lane]) : 0;
+      if constexpr (WMODE == 2) {
+        if (p.H == 4) {
+          t4_t w4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w4[q] = (T)0.f;
+          if (valid) w4 = *reinterpret_cast<const t4_t *>(weight + pe * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wbase[q * 64 + lane] = (float)w4[q];
+        } else for (int q = 0; q < p.H; ++q) wbase[q * 64 + lane] = valid ? (float)weight[pe * p.H + q] : 0.f;
+      } else {
+        for (int q = 0; q < p.H; ++q) wbase[q * 64 + lane] = valid ? (float)weight[(int64_t)q * P.nnz + pe] : 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    int k = 0;
+    for (int off = 0; off < len; off += 64, ++k) {
+      const float *wcur = wbase + (k & 1) * wbuf_stride + h * 64 + half;    // this lane's head, this half's edge of a pair
+      float *wnext = wbase + ((k + 1) & 1) * wbuf_stride;
+      const bool nvalid = off + 64 + lane < len;
+      const int64_t ne = e0 + off + 64 + lane;
+      int n_src = nvalid ? P.e_src[ne] : 0;
+      if ((uint32_t)n_src >= src_rows) n_src = 0;
+      const int n_dl = nvalid ? (int)P.e_dl[ne] : 255;
+      const int64_t n_pe = nvalid ? (wpo ? ne : (int64_t)P.e_perm[ne]) : 0;
+      t4_t wn4;                                           // (held as loaded until staged: see seg_slab_kernel)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wn4[q] = (T)0.f;
+      int n_max = len - off;
+      n_max = n_max < 64 ? n_max : 64;
+      for (int b = 0; b < n_max; b += 2 * kI) {
+        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
+        f4_t v[kI];
+        int dl0[kI], dl1[kI];
+        float ws[kI];
+        const int pick = (b + half) << 2;
+#pragma unroll
+        for (int u = 0; u < kI; ++u) {      // (slots behind the last edge: row 0, dl = 255, weight 0 - see seg_slab_kernel)
+          // this half's source row: lane (b + 2u + half)'s field through the LDS crossbar (one ds_bpermute, the pair offset in its
+          // immediate) - two v_readlane + a select + moves cost five vector instructions per pair
+          const uint32_t row = (uint32_t)__builtin_amdgcn_ds_bpermute(pick + 8 * u, my_src);
+          dl0[u] = __builtin_amdgcn_readlane(my_dl, b + 2 * u);
+          dl1[u] = __builtin_amdgcn_readlane(my_dl, b + 2 * u + 1);
+          ws[u] = wcur[b + 2 * u];
+          v[u] = slab_row_load<f4_t>(table, (row << rsh) + c16, 0);
+        }
+        if constexpr (WMODE == 2) {
+          if (b == 0 && p.H == 4 && nvalid) wn4 = *reinterpret_cast<const t4_t *>(weight + n_pe * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < kI; ++u) {
+          if (__builtin_expect(dl0[u] != cur0, 0)) {
+            hand_in(0, cur0);
+            cur0 = dl0[u];
+          }
+          if (__builtin_expect(dl1[u] != cur1, 0)) {
+            hand_in(1, cur1);
+            cur1 = dl1[u];
+          }
+          f4_t m[NV];
+          slab_unpack<T>(v[u], m);
+#pragma unroll
+          for (int q = 0; q < NV; ++q) acc[q] += m[q] * ws[u];
+        }
+      }
+      if constexpr (WMODE == 2) {
+        if (p.H == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wnext[q * 64 + lane] = (float)wn4[q];
+        } else for (int q = 0; q < p.H; ++q) wnext[q * 64 + lane] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+      } else {
+        for (int q = 0; q < p.H; ++q) wnext[q * 64 + lane] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      my_src = n_src;
+      my_dl = n_dl;
+    }
+    hand_in(0, cur0);
+    hand_in(1, cur1);
+    if (p.window >= 0 && my_slot >= 0) {
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
+    }
+    if (has) {                                            // the group's rows, two at a time (a half each)
+      const int64_t v0 = P.g_vrow0[pos];
+      for (int l0 = 0; l0 < nv; l0 += 2) {
+        const int l = l0 + half;
+        if (l < nv) {
+          const int64_t t = P.v_out[v0 + l];
+          f4_t row[NV];
+#pragma unroll
+          for (int q = 0; q < NV; ++q) row[q] = accV[((size_t)l * 32 + c) * NV + q];
+          if (t >= 0) {
+            if (t < p.K) *reinterpret_cast<f4_t *>(dst + t * p.F + c * VEC) = slab_pack<T>(row);      // one rounding, here
+          } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) *reinterpret_cast<f4_t *>(p.carry + (-t - 1) * p.F + c * VEC + 4 * q) = row[q];   // fp32
+          }
+        }
+      }
+    }
+  }
+  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+}
+
 // SDDMM over the same plan (d/dweight of gather_weight_scatter on a dense graph): out[e] = <m1[dst(e)], m2[src(e)]>.
 // The unit's <= R rows of m1 (the dst side: shared by all edges of a row) sit in LDS where the forward kernel keeps its
 // accumulators; the m2 rows are gathered slab by slab in the same loose lockstep.  The 8 dot products of a batch are
@@ -723,6 +1040,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = WAVE_ROW ? 10 : 4 + p.lpr_log2;   // log2(row bytes)
   const uint32_t c16 = (uint32_t)c * 16u;
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
   int lph_log2 = WAVE_ROW ? 6 : p.lpr_log2;          // lanes per head (H = 1, 2, 4, 8 on whole-wave rows; the launcher checks)
   for (int hh = p.H; hh > 1; hh >>= 1) --lph_log2;
   const int lph = 1 << lph_log2;
@@ -834,12 +1152,13 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
             row = (uint32_t)__shfl(my_src, b + u, lpr);
             dls[u] = __shfl(my_dl, b + u, lpr);
           }
-          v[u] = *reinterpret_cast<const f4_t *>(m2 + (size_t)((row << rsh) + c16));
+          if constexpr (WAVE_ROW) v[u] = slab_row_load<f4_t>(table, c16, row << rsh);
+          else v[u] = *reinterpret_cast<const f4_t *>(m2 + (size_t)((row << rsh) + c16));
         }
         float pd[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          if (dls[u] != cur) {
+          if (__builtin_expect(dls[u] != cur, 0)) {
             cur = dls[u];
             slab_unpack<T>(cur != 255 ? rowV[(size_t)cur * lpr + c] : f4_t{0.f, 0.f, 0.f, 0.f}, mrow);
           }
@@ -908,6 +1227,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const int rsh = 4 + p.lpr_log2;                            // log2(row bytes)
   const uint32_t cB = (uint32_t)lane * (uint32_t)(E * sizeof(T));
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
   int lph_log2 = 6;
   for (int hh = p.H; hh > 1; hh >>= 1) --lph_log2;
   const int lph = 1 << lph_log2;
@@ -1004,12 +1324,12 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
         for (int u = 0; u < kU; ++u) {           // (slots behind the last edge hold row 0 and dl = 255: the dot is 0)
           const uint32_t row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
           dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
-          v[u] = *reinterpret_cast<const raw_t *>(m2 + (size_t)((row << rsh) + cB));
+          v[u] = slab_row_load<raw_t>(table, cB, row << rsh);
         }
         float pd[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          if (dls[u] != cur) {
+          if (__builtin_expect(dls[u] != cur, 0)) {
             cur = dls[u];
             if (cur != 255) mhrow_unpack<T, E>(rowV[(size_t)cur * 64 + lane], mrow);
             else {
@@ -1263,6 +1583,9 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 int g_slab_wrow_all = 0;
+int g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
+int g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured
+                        // SLOWER than seg_slab_wrow_kernel (bf16 H=4 x F=64, weights in plan order: 4.63 vs 4.50 ms), so off: see the kernel's header
 static bool slab_wants_wrow(int weight_mode, int64_t rowbytes) {
   return slab_wrow(rowbytes) && (g_slab_wrow_all || weight_mode == 2 || weight_mode == 3 || weight_mode == 5);
 }
@@ -1321,8 +1644,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (rowbytes == ((int64_t)16 << l)) lpr_log2 = l;
   if (lpr_log2 < 0) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: rows of 128, 256, 512 or 1024 bytes only");
   if (feat % vec != 0 && weight_mode >= 2) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: feat per head must be a multiple of 16 bytes");
-  if (src_rows < 0 || (uint64_t)src_rows * (uint64_t)rowbytes > ((uint64_t)1 << 32))
-    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: source table of at most 4 GiB (32-bit row offsets; the kernel is for tables a slab sweep can cover)");
+  if (src_rows < 0 || (uint64_t)src_rows * (uint64_t)rowbytes >= ((uint64_t)1 << 32))
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: source table below 4 GiB (32-bit row offsets; the kernel is for tables a slab sweep can cover)");
   if ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_spmm: 16-byte aligned operands");
   // rows of 512 / 256 bytes: the plan's units say which form it was cut for - lane groups (waves x 1024 / rowbytes) or one row per
   // wave-instruction (waves); a plan with another unit count (tests, callers with their own grids) follows geot_slab_units_for's rule
@@ -1368,6 +1691,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? (small_slabs ? 3 : tight) : g_slab_window) : -1;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
+  p.probe = g_slab_probe;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
   // room behind the carry rows for the weights in plan order -> the kernel stages them itself (geot_slab_workspace_bytes_staged)
   void *wstage = nullptr;
@@ -1464,8 +1788,19 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   case 2: GEOT_SLAB_WROW(T_, 2, E_, GEOT_REDUCE_SUM); break;                                                  \
   default: GEOT_SLAB_WROW(T_, 3, E_, GEOT_REDUCE_SUM); break;                                                 \
   }
+#define GEOT_SLAB_WPAIR(T_)                                                                                   \
+  do {                                                                                                        \
+    geot_internal_note_kernel((std::string("seg_slab_wpair_kernel<") + slab_tname<T_>() + (weight_mode == 2 ? ", 2>" : ", 3>")).c_str()); \
+    if (weight_mode == 2) hipLaunchKernelGGL((seg_slab_wpair_kernel<T_, 2>), grid, blk, lds, st, p);          \
+    else hipLaunchKernelGGL((seg_slab_wpair_kernel<T_, 3>), grid, blk, lds, st, p);                           \
+    if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p);    \
+  } while (0)
     const int rc = g_turn.take(st, [&]() -> int {
-      if (mhrow) {
+      if (mhrow && g_slab_pair && weight_mode >= 2 && rowbytes == 512 && feat % vec == 0) {
+        if (dtype == GEOT_F32) { GEOT_SLAB_WPAIR(float); }
+        else if (dtype == GEOT_F16) { GEOT_SLAB_WPAIR(half_t); }
+        else { GEOT_SLAB_WPAIR(bf16_t); }
+      } else if (mhrow) {
         if (dtype == GEOT_F32) { if (el == 2) { GEOT_SLAB_WROW_MODE(float, 2) } else { GEOT_SLAB_WROW_MODE(float, 1) } }
         else if (dtype == GEOT_F16) { if (el == 4) { GEOT_SLAB_WROW_MODE(half_t, 4) } else { GEOT_SLAB_WROW_MODE(half_t, 2) } }
         else { if (el == 4) { GEOT_SLAB_WROW_MODE(bf16_t, 4) } else { GEOT_SLAB_WROW_MODE(bf16_t, 2) } }
@@ -1476,6 +1811,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
       const hipError_t le = hipGetLastError();
       return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
     });
+#undef GEOT_SLAB_WPAIR
 #undef GEOT_SLAB_WROW_MODE
 #undef GEOT_SLAB_WROW_RED
 #undef GEOT_SLAB_WROW
@@ -1530,8 +1866,8 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   // a dot product per head is reduced over the 64 / heads lanes of the head: heads 1, 2, 4 or 8, at least 8 lanes each
   if (heads != 1 && heads != 2 && heads != 4 && heads != 8) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 1, 2, 4 or 8 heads");
   if ((((uintptr_t)mat_1) | ((uintptr_t)mat_2) | ((uintptr_t)workspace)) & 15) return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: 16-byte aligned operands");
-  if (rows_2 < 0 || (uint64_t)rows_2 * (uint64_t)rowbytes > ((uint64_t)1 << 32))
-    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: mat_2 of at most 4 GiB (32-bit row offsets)");
+  if (rows_2 < 0 || (uint64_t)rows_2 * (uint64_t)rowbytes >= ((uint64_t)1 << 32))
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: mat_2 below 4 GiB (32-bit row offsets)");
   // the form follows the plan's units, as in geot_slab_spmm: lane groups (the plan of a single-weight forward) or one row per
   // wave-instruction (a multi-head plan; "slab_wrow_all"); the multi-head SDDMM needs whole-wave rows
   bool wrow = false;
@@ -1564,6 +1900,7 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   p.carry = nullptr;
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
+  p.probe = g_slab_probe;
   p.w_in_plan_order = staged ? 1 : 0;
   p.src_rows = rows_2;
   p.K = rows_1;
@@ -1647,6 +1984,8 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_tight") g_slab_tight = value != 0;
   if (name && std::string(name) == "slab_stage" && value >= 0 && value <= 2) g_slab_stage = value;
   if (name && std::string(name) == "slab_wrow_all") g_slab_wrow_all = value != 0;
+  if (name && std::string(name) == "slab_pair") g_slab_pair = value != 0;
+  if (name && std::string(name) == "slab_probe") g_slab_probe = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 

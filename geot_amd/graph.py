@@ -126,7 +126,7 @@ class Graph:
         if self.slab_mode == "never" or dtype not in _SLAB_DTYPES or rowbytes not in (256, 512, 1024) or self.nnz >= 2 ** 31:
             return None
         si, di, rows = self._edges(which)
-        if table_rows * rowbytes > 2 ** 32:
+        if table_rows * rowbytes >= 2 ** 32:
             return None
         R = slab.rows_per_group(wmode, heads, dtype, rowbytes)
         units = int(slab._lib.load().geot_slab_units_for(wmode, rowbytes))
@@ -340,9 +340,23 @@ class Graph:
             return PlanOrdered(self, holder[0], values)
         return values
 
-    def plan_order(self, values: torch.Tensor, like: PlanOrdered) -> PlanOrdered:
-        """Edge-order values -> the order of ``like``'s plan (one gather)."""
-        return PlanOrdered(self, like.plan, _EdgeToPlan.apply(self, like.plan, values))
+    def plan_order(self, values: torch.Tensor, like: Union[PlanOrdered, torch.Tensor]):
+        """Edge-order values -> plan order (one gather).  ``like``: a PlanOrdered (its plan), or the feature table a following
+        ``gather_weight_scatter`` / ``mh_spmm`` will read ([N, F] / [N, H, F]) - the plan those calls use for rows of that shape and
+        type.  The way to hand over coefficients that do not change between calls (a normalised adjacency, frozen attention): permute
+        once, pass the PlanOrdered every call - the row loop then reads them as a stream.  Returns ``values`` unchanged when the graph
+        has no plan for that shape (not dense enough, or a row width the source-blocked kernels do not serve)."""
+        if isinstance(like, PlanOrdered):
+            plan = like.plan
+        else:
+            mh = like.dim() == 3
+            H, F = (like.shape[1], like.shape[2]) if mh else (1, like.shape[1])
+            plan = self._plan("fwd", H * F * like.element_size(), 2 if mh else 1, H, like.dtype, _rows(like))
+            if mh and (F * like.element_size()) % 16 != 0:
+                plan = None
+            if plan is None:
+                return values
+        return PlanOrdered(self, plan, _EdgeToPlan.apply(self, plan, values))
 
 
 def _kind(reduce: str) -> str:

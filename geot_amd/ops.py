@@ -365,8 +365,7 @@ def _gr_backward(ctx, grad):
     rows = grad.shape[0]
     ones = torch.ones((dst_index.shape[0], 1), dtype=torch.float32, device=grad.device)
     deg = torch.ops.geot.index_scatter(0, dst_index, ones, "sum", True)          # [index[-1] + 1, 1] - the forward's row rule
-    if deg.shape[0] != rows:                                                          # (cannot differ; stay safe)
-        deg = torch.nn.functional.pad(deg, (0, 0, 0, rows - deg.shape[0])) if deg.shape[0] < rows else deg[:rows]
+    torch._check(deg.shape[0] == rows, lambda: "gather_reduce backward: the gradient's rows differ from the forward's (dst_index[-1] + 1)")
     g = (grad / deg.clamp_(min=1.0).to(grad.dtype)).contiguous()
     need_w = ctx.has_weight and ctx.needs_input_grad[2]
     need_src = ctx.needs_input_grad[3]

@@ -81,6 +81,12 @@ def test_handle_gives_the_operators_results_forward_and_backward(geot, mode):
     for a, b in ((yh, refh), (gxh, rgxh), (gwh, rgwh)):
         assert a.shape == b.shape
         assert float((a.double() - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    # static coefficients: permuted once for the table the calls will read, the same numbers as the edge-order call
+    wp = g.plan_order(wh.detach(), xh.detach())
+    assert isinstance(wp, geot.PlanOrdered) == (mode == "always")
+    assert torch.equal(g.mh_spmm(wp, xh.detach()), yh.detach())
+    w1p = g.plan_order(w.detach(), x.detach())
+    assert torch.equal(g.gather_weight_scatter(w1p, x.detach()), y.detach())
     # sddmm with its own backward
     m1 = torch.rand(nodes, F, device="cuda", requires_grad=True)
     s = g.sddmm(m1, x)

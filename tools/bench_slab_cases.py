@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--slab-mib", type=float, default=0.0, help="slab size of the plans (0 = the host layer's rule)")
     ap.add_argument("--dtypes", default="fp32,bf16")
+    ap.add_argument("--rows-per-group", type=int, default=0, help="R of every plan (0 = the library's rule): fewer rows = more rounds")
+    ap.add_argument("--mh-lane-groups", action="store_true", help="multi-head plans over 512 / 256-byte rows cut into lane groups (16 bytes a lane) "
+                                                                  "instead of waves")
     a = ap.parse_args()
     dev = torch.device("cuda")
     for item in filter(None, a.options.split(",")):
@@ -44,10 +47,15 @@ def main():
 
     def plan_for(rowbytes, wmode, H, dtype):
         R = slab.rows_per_group(wmode, H, dtype, rowbytes)
-        key = (rowbytes, R)
+        units = 0
+        if a.mh_lane_groups and wmode == 2 and rowbytes in (256, 512):
+            R = slab.rows_per_group(wmode, H, dtype)
+            units = int(slab._lib.load().geot_slab_units_for(0, rowbytes))
+        R = a.rows_per_group or R
+        key = (rowbytes, R, units)
         if key not in plans:
             plans.clear()                                  # (one plan at a time: 1 GB each)
-            plans[key] = slab.build_plan(si, di, nodes, nodes, rowbytes, wmode, H, rows_per_group=R, slab_bytes=int(a.slab_mib * (1 << 20)))
+            plans[key] = slab.build_plan(si, di, nodes, nodes, rowbytes, wmode, H, rows_per_group=R, units=units, slab_bytes=int(a.slab_mib * (1 << 20)))
         return plans[key]
 
     def line(name, fn, extra=""):
