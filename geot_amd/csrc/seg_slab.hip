@@ -1986,7 +1986,7 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_wrow_all") g_slab_wrow_all = value != 0;
   if (name && std::string(name) == "slab_pair") g_slab_pair = value != 0;
   if (name && std::string(name) == "slab_probe") g_slab_probe = value != 0;
-  if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
+  if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 6) g_slab_blocks = value;
 }
 
 } // extern "C"
