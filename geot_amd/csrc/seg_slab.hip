@@ -161,6 +161,44 @@ __global__ __launch_bounds__(kThreads) void slab_stage_weights_kernel(const int3
   }
 }
 
+// The same for 2- and 4-byte weights, four consecutive plan positions per lane: e_perm arrives as one 16-byte load, the four gathered
+// weights leave as one 8- / 16-byte store - a third of the instructions per element (the pass is issue-bound like the row loops:
+// 0.59 ms for 1.4 GB at Reddit scale before).  e_perm and wst 16- / (4 x sizeof V)-byte aligned (the launcher checks wst).
+template <typename V>
+__global__ __launch_bounds__(kThreads) void slab_stage_weights_x4_kernel(const int32_t *__restrict__ e_perm, const V *__restrict__ weight,
+                                                                         V *__restrict__ wst, int64_t nnz) {
+  typedef int i4_t __attribute__((ext_vector_type(4)));
+  typedef V v4_t __attribute__((ext_vector_type(4)));
+  constexpr int kS = 2;
+  const int64_t quads = nnz >> 2;
+  const int64_t per_block = (int64_t)kThreads * kS;
+  for (int64_t base = (int64_t)blockIdx.x * per_block; base < quads; base += (int64_t)gridDim.x * per_block) {
+    i4_t pe[kS];
+    bool ok[kS];
+#pragma unroll
+    for (int k = 0; k < kS; ++k) {
+      const int64_t q = base + (int64_t)k * kThreads + threadIdx.x;
+      ok[k] = q < quads;
+      pe[k] = ok[k] ? __builtin_nontemporal_load(reinterpret_cast<const i4_t *>(e_perm) + q) : i4_t{0, 0, 0, 0};
+    }
+    v4_t v[kS];
+#pragma unroll
+    for (int k = 0; k < kS; ++k) {
+      v[k][0] = weight[pe[k][0]];          // (lanes past the end re-read element 0: no branch around the loads)
+      v[k][1] = weight[pe[k][1]];
+      v[k][2] = weight[pe[k][2]];
+      v[k][3] = weight[pe[k][3]];
+    }
+#pragma unroll
+    for (int k = 0; k < kS; ++k)
+      if (ok[k]) __builtin_nontemporal_store(v[k], reinterpret_cast<v4_t *>(wst) + base + (int64_t)k * kThreads + threadIdx.x);
+  }
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < (nnz & 3)) {
+    const int64_t i = (quads << 2) + threadIdx.x;
+    wst[i] = weight[e_perm[i]];
+  }
+}
+
 // (A form of this pre-pass that takes a group's weight block through LDS - coalesced in, picked in plan order, coalesced out, the
 // mirror image of slab_unstage_kernel - measured SLOWER than this plain gather: gws F=128 fp32 4.52 vs 4.00 ms per call,
 // profiles/r05/slab_cases__weight_prepass_through_lds.txt; three barriers per group cost more than the L2 requests they save.)
@@ -1723,7 +1761,10 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     int64_t sblocks = (plan->nnz + per_block - 1) / per_block;
     if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
     const dim3 sgrid((unsigned)(sblocks > 0 ? sblocks : 1)), sblk(kThreads);
-    if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
+    const bool x4 = (((uintptr_t)wstage | (uintptr_t)plan->e_perm) & 15) == 0 && plan->nnz >= 4;
+    if (wbytes == 2 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
+    else if (wbytes == 4 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->nnz);
+    else if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
     else if (wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->nnz);
     else if (wbytes == 8) hipLaunchKernelGGL((slab_stage_weights_kernel<uint64_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(wstage), plan->nnz);
     else hipLaunchKernelGGL((slab_stage_weights_kernel<f4_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const f4_t *>(weight), static_cast<f4_t *>(wstage), plan->nnz);
@@ -1840,7 +1881,10 @@ int geot_slab_to_plan_order(const geot_slab_plan *plan, const void *weight, void
   int64_t sblocks = (plan->nnz + per_block - 1) / per_block;
   if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
   const dim3 sgrid((unsigned)sblocks), sblk(kThreads);
-  if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(out), plan->nnz);
+  const bool x4 = (((uintptr_t)out | (uintptr_t)plan->e_perm) & 15) == 0 && plan->nnz >= 4;
+  if (wbytes == 2 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(out), plan->nnz);
+  else if (wbytes == 4 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(out), plan->nnz);
+  else if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(out), plan->nnz);
   else if (wbytes == 4) hipLaunchKernelGGL((slab_stage_weights_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(out), plan->nnz);
   else if (wbytes == 8) hipLaunchKernelGGL((slab_stage_weights_kernel<uint64_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(out), plan->nnz);
   else hipLaunchKernelGGL((slab_stage_weights_kernel<f4_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const f4_t *>(weight), static_cast<f4_t *>(out), plan->nnz);
