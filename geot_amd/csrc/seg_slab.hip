@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   const int64_t units = P.units;
   const char *src = static_cast<const char *>(p.src);
   const T *weight = static_cast<const T *>(p.weight);
-  const bool wpo = p.w_in_plan_order != 0;               // weights indexed by plan position (given so, or staged by the pre-pass)
+  const bool wpo_rt = p.w_in_plan_order != 0;            // weights indexed by plan position (given so, or staged by the pre-pass)
   T *dst = static_cast<T *>(p.dst);
   const int h = WMODE >= 2 ? (c * VEC) / p.Fh : 0;
   typedef T t4_t __attribute__((ext_vector_type(4)));
@@ -353,14 +353,18 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
     int cur = 255;                                   // no open row
 
     // fields of the first chunk, its weights into buffer 0
+    // (whole-wave rows: an edge's two fields travel as ONE word, (source row << 8) | row in group - 1-KiB rows in a table below
+    // 4 GiB are < 2^22 rows, a group has at most 32, 255 = padding: one v_readlane per edge, the split is scalar arithmetic)
     int my_src = 0, my_dl = 255;
+    uint32_t my_edge = 255;
     {
       const bool valid = c < len;
       my_src = valid ? P.e_src[e0 + c] : 0;
       if ((uint32_t)my_src >= src_rows) my_src = 0;   // (checked once per edge, here, not in the row loop)
       my_dl = valid ? (int)P.e_dl[e0 + c] : 255;
+      my_edge = ((uint32_t)my_src << 8) | (uint32_t)my_dl;
       if constexpr (WMODE != 0) {
-        const int64_t pe = valid ? (wpo ? e0 + c : (int64_t)P.e_perm[e0 + c]) : 0;
+        const int64_t pe = valid ? (wpo_rt ? e0 + c : (int64_t)P.e_perm[e0 + c]) : 0;
         if constexpr (WMODE == 1) wbase[c] = valid ? (float)weight[pe] : 0.f;
         if constexpr (WMODE == 2) {
           if (p.H == 4) {
@@ -375,18 +379,22 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       }
     }
 
+    // (the chunk loop exists twice, for weights in plan order and through e_perm - see seg_slab_wrow_kernel: with the choice made at
+    // run time inside one body the compiler guards e_perm's in-flight entry with vmcnt(0) waits on both paths)
+    auto chunks = [&](auto wpo_c) __attribute__((always_inline)) {
+    constexpr bool wpo = decltype(wpo_c)::value;
     int k = 0;
     for (int off = 0; off < maxlen; off += lpr, ++k) {
       const float *wcur = wbase + (k & 1) * wbuf_stride + h * lpr;       // this lane's head
       float *wnext = wbase + ((k + 1) & 1) * wbuf_stride;
-      // next chunk's fields: in flight underneath this chunk's rows
+      // Whole-wave rows (a chunk = 64 edges): the next chunk's fields are loaded BEHIND the first batch's row gathers (below), not
+      // here: vector-memory operations retire in issue order, so a stream read issued ahead of the gathers (an HBM miss, several times
+      // a gather's L2 hit) is waited for by the chunk's first row.  Every lane loads, unconditionally (lanes behind their unit's end re-read its last edge and drop the value
+      // when the chunk is handed over): a predicated load is a branch, and behind a branch the compiler waits for vmcnt(0).
       const bool nvalid = off + lpr + c < len;
-      const int64_t ne = e0 + off + lpr + c;
-      int n_src = nvalid ? (ntp ? __builtin_nontemporal_load(P.e_src + ne) : P.e_src[ne]) : 0;
-      if ((uint32_t)n_src >= src_rows) n_src = 0;
-      const int n_dl = nvalid ? (int)(ntp ? __builtin_nontemporal_load(P.e_dl + ne) : P.e_dl[ne]) : 255;
-      int64_t n_pe = 0;
-      if constexpr (WMODE != 0) n_pe = nvalid ? (wpo ? ne : (int64_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne])) : 0;
+      const int64_t ne = WAVE_ROW ? e0 + (nvalid ? off + lpr + c : (len > 0 ? len - 1 : 0)) : e0 + off + lpr + c;
+      int n_src = 0, n_dl = 255;
+      uint32_t n_pe32 = 0;                            // (e_perm's entry stays as loaded until the weight read uses it)
       // (the next chunk's weights are held AS LOADED until they are staged at the end of the chunk: converting a 16-bit weight here
       // would put a full wait - behind the batch of row loads just issued - into the first batch of every chunk)
       t4_t wn4;
@@ -397,9 +405,35 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       const int n_here = len - off;                  // edges of this unit in the chunk (<= 0: none)
       int n_max = maxlen - off;
       n_max = n_max < lpr ? n_max : lpr;
-      for (int b = 0; b < n_max; b += kU) {
+      auto next_fields = [&]() __attribute__((always_inline)) {
+        if (WAVE_ROW || nvalid) {                    // (lane groups: predicated - their chunks are short, the clamp's arithmetic shows)
+          n_src = ntp ? __builtin_nontemporal_load(P.e_src + ne) : P.e_src[ne];
+          n_dl = (int)(ntp ? __builtin_nontemporal_load(P.e_dl + ne) : P.e_dl[ne]);
+          if constexpr (WMODE != 0) {
+            if (!wpo) n_pe32 = (uint32_t)(ntp ? __builtin_nontemporal_load(P.e_perm + ne) : P.e_perm[ne]);
+            else {                                   // ... and its weights, when they sit in plan order
+              if constexpr (WMODE == 1) wn1 = weight[ne];
+              if constexpr (WMODE == 2) {
+                if (p.H == 4) wn4 = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + ne * 4)) : *reinterpret_cast<const t4_t *>(weight + ne * 4);
+              }
+            }
+          }
+        }
+      };
+      auto batch = [&](const int b, auto first_c) __attribute__((always_inline)) {     // (the first batch is its own copy of the body)
+        constexpr bool kFirst = decltype(first_c)::value;
+        if constexpr (WMODE == 1 || WMODE == 2) {
+          // the next chunk's weights, in edge order: their place comes out of e_perm (loaded behind the first batch) - read at the TOP
+          // of the second batch, where everything outstanding is a batch old, not behind that batch's gathers
+          if (!kFirst && !wpo && b == kU) {
+            uint32_t pe = n_pe32;
+            asm volatile("" : "+v"(pe));      // (keeps the address arithmetic - and the wait for e_perm's entry - HERE, not at its load)
+            if constexpr (WMODE == 1) wn1 = weight[pe];
+            else if (p.H == 4) wn4 = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + (size_t)pe * 4)) : *reinterpret_cast<const t4_t *>(weight + (size_t)pe * 4);
+          }
+        }
         if (p.window >= 0) {                         // which slab does this batch start in (the wave's first unit decides)
-          const int first_row = __builtin_amdgcn_readlane(my_src, b);
+          const int first_row = WAVE_ROW ? (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, b) >> 8) : __builtin_amdgcn_readlane(my_src, b);
           const int has_edge = __builtin_amdgcn_readfirstlane(n_here) > b;
           if (has_edge) slab_sync(r * p.n_slabs + (first_row >> p.slab_shift));
         }
@@ -412,26 +446,19 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         // checks): scalar base + 32-bit lane offset, no 64-bit multiply per edge.
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          uint32_t row;
           if constexpr (WAVE_ROW) {
-            row = (uint32_t)__builtin_amdgcn_readlane(my_src, b + u);
-            dls[u] = __builtin_amdgcn_readlane(my_dl, b + u);
+            const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane(my_edge, b + u);
+            dls[u] = (int)(edge & 255u);
+            if constexpr (WMODE != 0) ws[u] = wcur[b + u];
+            v[u] = slab_row_load<f4_t>(table, c16, (edge & ~255u) << 2);       // (row << 10)
           } else {
-            row = (uint32_t)__shfl(my_src, b + u, lpr);
+            const uint32_t row = (uint32_t)__shfl(my_src, b + u, lpr);
             dls[u] = __shfl(my_dl, b + u, lpr);
-          }
-          if constexpr (WMODE != 0) ws[u] = wcur[b + u];
-          if constexpr (WAVE_ROW) v[u] = slab_row_load<f4_t>(table, c16, row << rsh);
-          else v[u] = *reinterpret_cast<const f4_t *>(src + (size_t)((row << rsh) + c16));
-        }
-        if constexpr (WMODE != 0) {
-          if (b == 0) {                              // the next chunk's edge ids have landed behind batch 0's rows
-            if constexpr (WMODE == 1) { if (nvalid) wn1 = weight[n_pe]; }
-            if constexpr (WMODE == 2) {
-              if (p.H == 4) { if (nvalid) wn4 = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + n_pe * 4)) : *reinterpret_cast<const t4_t *>(weight + n_pe * 4); }
-            }
+            if constexpr (WMODE != 0) ws[u] = wcur[b + u];
+            v[u] = *reinterpret_cast<const f4_t *>(src + (size_t)((row << rsh) + c16));
           }
         }
+        if constexpr (kFirst && WAVE_ROW) next_fields();     // behind this batch's gathers
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           if (__builtin_expect(dls[u] != cur, 0)) {  // the open row goes back to LDS, the new one comes out of it (rare: laid out of line)
@@ -455,23 +482,44 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
             }
           }
         }
+      };
+      // (lane groups: a chunk is lpr = 32 / 16 / 8 edges - two to four batches -, so the fields go first: behind the first batch they
+      // would have half the chunk to arrive; measured 1 % slower on the weightless plans)
+      if constexpr (!WAVE_ROW) next_fields();
+      batch(0, std::true_type{});
+      for (int b = kU; b < n_max; b += kU) batch(b, std::false_type{});
+      if constexpr (WMODE == 1 || WMODE == 2) {
+        // (a chunk of ONE batch - 128-byte rows, lpr = 8 - has no second batch to fetch the edge-order weights in: here, then)
+        if (!wpo && n_max <= kU && nvalid) {
+          if constexpr (WMODE == 1) wn1 = weight[n_pe32];
+          else if (p.H == 4) wn4 = *reinterpret_cast<const t4_t *>(weight + (size_t)n_pe32 * 4);
+        }
       }
       // stage the next chunk
       if constexpr (WMODE != 0) {
-        if constexpr (WMODE == 1) wnext[c] = (float)wn1;
+        if constexpr (WMODE == 1) wnext[c] = nvalid ? (float)wn1 : 0.f;
         if constexpr (WMODE == 2) {
           if (p.H == 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wnext[q * lpr + c] = (float)wn4[q];
-          } else for (int q = 0; q < p.H; ++q) wnext[q * lpr + c] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+            for (int q = 0; q < 4; ++q) wnext[q * lpr + c] = nvalid ? (float)wn4[q] : 0.f;
+          } else {
+            const int64_t n_pe = wpo ? ne : (int64_t)n_pe32;
+            for (int q = 0; q < p.H; ++q) wnext[q * lpr + c] = nvalid ? (float)weight[n_pe * p.H + q] : 0.f;
+          }
         }
-        if constexpr (WMODE == 3)
+        if constexpr (WMODE == 3) {
+          const int64_t n_pe = wpo ? ne : (int64_t)n_pe32;
           for (int q = 0; q < p.H; ++q) wnext[q * lpr + c] = nvalid ? (float)weight[(int64_t)q * P.nnz + n_pe] : 0.f;
+        }
         __builtin_amdgcn_wave_barrier();
       }
-      my_src = n_src;
-      my_dl = n_dl;
+      my_src = (nvalid && (uint32_t)n_src < src_rows) ? n_src : 0;
+      my_dl = nvalid ? n_dl : 255;
+      my_edge = ((uint32_t)my_src << 8) | (uint32_t)my_dl;
     }
+    };
+    if (WMODE == 0 || wpo_rt) chunks(std::true_type{});
+    else chunks(std::false_type{});
     if (cur != 255) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) accV[((size_t)cur * lpr + c) * NV + q] = acc[q];

@@ -266,6 +266,36 @@ def test_row_per_wave_kernels_every_weight_mode_and_reduction(geot, oracle, dtyp
             check(out, want.cpu().numpy().astype(np.float64), (red, weighted))
 
 
+@pytest.mark.parametrize("dtype,H,Fh", [(torch.float32, 1, 32), (torch.bfloat16, 1, 64), (torch.float32, 4, 8), (torch.float16, 2, 32),
+                                         (torch.float32, 1, 64), (torch.float32, 4, 64)])
+def test_weights_in_every_order_on_every_chunk_length(geot, dtype, H, Fh):
+    """The three ways a weight reaches the row loop - through e_perm inside it, staged by the pre-pass, given in plan order - on plans
+    whose chunks are ONE batch long (rows of 128 bytes: 8 edges a chunk, where the edge-order weights of the next chunk cannot be
+    fetched 'a batch later'), two (256 bytes) and eight (whole-wave rows): equal bits, and the float64 sums."""
+    from geot_amd import slab
+    rng = np.random.default_rng(7 * H + Fh)
+    nodes, nnz = 2000, 250_000
+    si, di = _dense_graph(rng, nodes, nnz)
+    esz = 4 if dtype == torch.float32 else 2
+    rowbytes = H * Fh * esz
+    mh = H > 1
+    x = torch.from_numpy(rng.random((nodes, H, Fh), dtype=np.float32)).to(dtype).cuda()
+    w = torch.from_numpy(rng.random((nnz, H) if mh else (nnz,), dtype=np.float32)).to(dtype).cuda()
+    d_si, d_di = dev(si), dev(di)
+    wm = 2 if mh else 1
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, rowbytes, wm, H, rows_per_group=slab.rows_per_group(wm, H, dtype, rowbytes))
+    outs = []
+    for weight, mode, kw in ((w, wm, dict(stage_weights=False)), (w, wm, {}), (w[plan.tensors["e_perm"].long()].contiguous(), wm + 3, {})):
+        o = torch.full((nodes, H, Fh), float("nan"), device="cuda", dtype=dtype)
+        slab.slab_spmm_out(plan, weight, mode, x if mh else x.view(nodes, Fh), o if mh else o.view(nodes, Fh), H, Fh, **kw)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), geot.hip.last_kernel()
+    wd = w.double() if mh else w.double()[:, None]
+    ref = torch.zeros(nodes, H, Fh, device="cuda", dtype=torch.float64).index_add_(0, d_di, x.double()[d_si] * wd[:, :, None])
+    tol = 1e-5 if dtype == torch.float32 else (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6)
+    assert float((outs[0].double() - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dtype,H,Fh", [(torch.bfloat16, 4, 64), (torch.float32, 4, 32), (torch.float16, 8, 32), (torch.float32, 2, 64)])
 def test_two_rows_per_instruction_kernel_gives_the_sums(geot, dtype, H, Fh):
     """seg_slab_wpair_kernel (option slab_pair; off by default - measured slower, kept as an experiment): multi-head plans over 512-byte
