@@ -1465,6 +1465,179 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
   if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
 }
 
+// The multi-head SDDMM of 16-bit plans on the MATRIX cores (round 5): out[e, h] = <m1[dst(e), h, :], m2[src(e), h, :]> is a
+// contraction over FEATURES, and that is the K dimension of an MFMA with both operands in the layout memory already has them in:
+// v_mfma_f32_16x16x32_{bf16,f16} takes A[16 edges][32 features] with lane l holding 8 consecutive features (16 bytes) of edge l & 15
+// - a 16-byte piece of a gathered m2 row - and B[32 features][16 rows] with lane l holding 8 consecutive features of row l & 15 - a
+// piece of one of the group's <= 16 m1 rows, which stay in registers for the whole group.  One instruction forms all 16 x 16
+// (edge, row) products of a 32-feature slice; the one wanted per edge, D[m][dl(m)], is picked out through a small LDS exchange, the
+// other 15 are the price.  It is worth it because these kernels are bound by vector-instruction issue, not by their gathers (§3.1d
+// of DESIGN.md: with the gathers dropped they keep 97 % of their time): the row-per-wave kernel spends ~20 wave-instructions per edge
+// on unpacking two 16-bit rows and multiplying them, this one ~3 (8 loads, 8 MFMAs and the exchange per 16 edges), and the MFMAs
+// themselves are 0.4 ms of work at Reddit scale.  Nothing is contaminated by the unused products: a result element is the sum over
+// its OWN row's and edge's features only.  Plans cut into waves, R <= 16 rows per group, rows of 32 x NCH elements (512 / 256 bytes),
+// CPH slices per head (H = NCH / CPH heads), results in the plan's edge order (staged); fp32 accumulation as everywhere, the sum order
+// inside a head is the hardware's (32 features per step, CPH steps).
+template <typename T, int NCH, int CPH>
+__global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParams p) {
+  static_assert(sizeof(T) == 2 && (NCH == 8 || NCH == 4) && NCH % CPH == 0, "16-bit rows of 512 / 256 bytes");
+  constexpr int H = NCH / CPH;
+  constexpr int rsh = NCH == 8 ? 9 : 8;                  // log2(row bytes)
+  typedef T t8_t __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, kb = lane >> 4;               // operand maps: A[row n][k = 8 kb + j], B[k = 8 kb + j][col n]; D[row 4 kb + j][col n]
+  f4_t *xch = reinterpret_cast<f4_t *>(smem) + (size_t)wave * (H * 64);     // the exchange: [H][4 row blocks][16 cols] x 4 rows
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t units = P.units;
+  const T *m1 = static_cast<const T *>(p.weight);        // (the dst-side matrix travels in the `weight` slot)
+  T *out = static_cast<T *>(p.dst);
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
+  t8_t zero8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) zero8[i] = (T)0.f;
+
+  int my_slot = -1;
+  int *xprog = nullptr;
+  if (p.window >= 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  int published = -1, known_min = -1, timeouts = 0;
+  auto slab_sync = [&](int step) {              // (as in seg_slab_kernel: every wait bounded, and bounded in aggregate)
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return;
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      known_min = m;
+      if (m + p.window >= step || step - m > p.far) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
+    }
+  };
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    const bool has = pos < P.n_groups;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+    len = __builtin_amdgcn_readfirstlane(len);
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    const int64_t v0 = has ? P.g_vrow0[pos] : 0;
+    // the group's m1 rows as B fragments, in registers for the whole group (pieces of a split hub share their row)
+    t8_t bfrag[NCH];
+    {
+      const int64_t row = n < nv ? P.v_row[v0 + n] : -1;
+      const bool ok = row >= 0 && row < p.K;
+      const T *rp = m1 + (ok ? row : 0) * p.F + 8 * kb;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) bfrag[c] = ok ? *reinterpret_cast<const t8_t *>(rp + 32 * c) : zero8;
+    }
+    int my_src = 0, my_dl = 255;
+    {
+      const bool valid = lane < len;
+      my_src = valid ? P.e_src[e0 + lane] : 0;
+      my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
+      if ((uint32_t)my_src >= src_rows) { my_src = 0; my_dl = 255; }   // out-of-range source: the dot is 0
+    }
+    for (int off = 0; off < len; off += 64) {
+      const bool nvalid = off + 64 + lane < len;
+      const int64_t ne = e0 + (nvalid ? off + 64 + lane : len - 1);    // (every lane loads: see seg_slab_wrow_kernel)
+      int n_src = 0, n_dl = 255;
+      const int n_here = len - off;
+      const int n_max = n_here < 64 ? n_here : 64;
+      for (int t = 0; t < 4 && 16 * t < n_max; ++t) {
+        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, 16 * t) >> p.slab_shift));
+        // lane (n, kb): edge m = 16 t + n of the chunk - its source row and row in group through the LDS crossbar
+        const int pick = (16 * t + n) << 2;
+        const uint32_t srow = (uint32_t)__builtin_amdgcn_ds_bpermute(pick, my_src);
+        const int dlm = __builtin_amdgcn_ds_bpermute(pick, my_dl);
+        const uint32_t voff = (srow << rsh) + 16u * (uint32_t)kb;
+        t8_t afrag[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) afrag[c] = __builtin_bit_cast(t8_t, slab_row_load<f4_t>(table, voff + 64u * c, 0));
+        if (t == 0) {                            // the next chunk's fields, behind this tile's gathers
+          n_src = P.e_src[ne];
+          n_dl = (int)P.e_dl[ne];
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          f4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < CPH; ++cc) {
+            if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
+            else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
+          }
+          xch[(h * 4 + kb) * 16 + n] = d;        // D[row 4 kb + j][col n], j = 0..3
+        }
+        // (the exchange crosses lanes: to the compiler these are other threads' words - keep the order, see seg_slab_wpair_kernel)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) {                         // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
+          const int e = off + 16 * t + lane;
+          if (e < len) {
+            const float *xf = reinterpret_cast<const float *>(xch);
+            T res[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+              const float v = dlm != 255 ? xf[(((h * 4 + (lane >> 2)) * 16 + dlm) << 2) + (lane & 3)] : 0.f;
+              res[h] = (T)v;
+            }
+            T *op = out + (e0 + e) * H;
+            if constexpr (H == 1) op[0] = res[0];
+            else {
+              typedef T tH_t __attribute__((ext_vector_type(H)));
+              tH_t pk;
+#pragma unroll
+              for (int h = 0; h < H; ++h) pk[h] = res[h];
+              *reinterpret_cast<tH_t *>(op) = pk;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      my_src = (nvalid && (uint32_t)n_src < src_rows) ? n_src : 0;
+      my_dl = (nvalid && (uint32_t)n_src < src_rows) ? n_dl : 255;
+    }
+    if (p.window >= 0 && my_slot >= 0) {
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
+    }
+  }
+  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+}
+
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row).  The pieces meet in FLOAT64 and are
 // rounded once: a hub of 300 k edges is thousands of pieces, and with interleaved pieces (Phase A) they can all be nearly EQUAL
 // (two distinct source rows: every piece samples both in proportion) - adding thousands of equal fp32 values to a growing fp32
@@ -1669,6 +1842,7 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 int g_slab_wrow_all = 0;
+int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over a plan on the matrix cores (seg_slab_sddmm_mfma_kernel); 0 = the row-per-wave kernel
 int g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
 int g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured
                         // SLOWER than seg_slab_wrow_kernel (bf16 H=4 x F=64, weights in plan order: 4.63 vs 4.50 ms), so off: see the kernel's header
@@ -2014,6 +2188,33 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   }
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
   const int el = (int)(F / 64);                            // (rows of 512 / 256 bytes) elements per lane
+  // 16-bit multi-head plans, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's rows fit one
+  // 16-column operand and a head is a whole number of 32-feature slices
+  const int nch = (int)(F / 32);
+  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && (rowbytes == 512 || rowbytes == 256) && plan->rows_per_group <= 16 && heads <= nch &&
+      nch % heads == 0 && (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
+    const size_t xlds = (size_t)4 * (size_t)heads * 64 * sizeof(f4_t);
+    const int cph = nch / (int)heads;
+    const int rc = g_turn.take(st, [&]() -> int {
+#define GEOT_SLAB_MFMA(T_)                                                                                     \
+      do {                                                                                                     \
+        geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(nch) + ", " + std::to_string(cph) + ">").c_str()); \
+        if (nch == 8 && cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 8>), grid, blk, xlds, st, p);      \
+        else if (nch == 8 && cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 4>), grid, blk, xlds, st, p); \
+        else if (nch == 8 && cph == 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 2>), grid, blk, xlds, st, p); \
+        else if (nch == 8 && cph == 1) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 1>), grid, blk, xlds, st, p); \
+        else if (nch == 4 && cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4, 4>), grid, blk, xlds, st, p); \
+        else if (nch == 4 && cph == 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4, 2>), grid, blk, xlds, st, p); \
+        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4, 1>), grid, blk, xlds, st, p);                            \
+      } while (0)
+      if (dtype == GEOT_F16) GEOT_SLAB_MFMA(half_t);
+      else GEOT_SLAB_MFMA(bf16_t);
+#undef GEOT_SLAB_MFMA
+      const hipError_t le = hipGetLastError();
+      return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
+    });
+    if (rc != GEOT_OK || !unstage) return rc;
+  } else {
 #define GEOT_SLAB_SDDMM(T_, E2_, E1_)                                                                        \
   do {                                                                                                        \
     if (lpr_log2 == 6) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, true>), grid, blk, lds, st, p);          \
@@ -2030,6 +2231,7 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   });
 #undef GEOT_SLAB_SDDMM
   if (rc != GEOT_OK || !staged || !unstage) return rc;
+  }
   int64_t ublocks = plan->n_groups < (int64_t)slab_device().cus * 8 ? plan->n_groups : (int64_t)slab_device().cus * 8;
   constexpr int kTileBytes = 48 * 1024;                    // (a group of configs[3]'s plans: ~6 000 results)
 #define GEOT_UNSTAGE(ET_)                                                                                     \
@@ -2078,6 +2280,7 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_wrow_all") g_slab_wrow_all = value != 0;
   if (name && std::string(name) == "slab_pair") g_slab_pair = value != 0;
   if (name && std::string(name) == "slab_probe") g_slab_probe = value != 0;
+  if (name && std::string(name) == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
   if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 6) g_slab_blocks = value;
 }
 
