@@ -1475,7 +1475,14 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 // of DESIGN.md: with the gathers dropped they keep 97 % of their time): the row-per-wave kernel spends ~20 wave-instructions per edge
 // on unpacking two 16-bit rows and multiplying them, this one ~3 (8 loads, 8 MFMAs and the exchange per 16 edges), and the MFMAs
 // themselves are 0.4 ms of work at Reddit scale.  Nothing is contaminated by the unused products: a result element is the sum over
-// its OWN row's and edge's features only.  Plans cut into waves, R <= 16 rows per group, rows of 32 x NCH elements (512 / 256 bytes),
+// its OWN row's and edge's features only.
+// MEASURED (an experiment, option "slab_sddmm_mfma", off by default): exact on integer data for every shape and both types
+// (tests/test_gpu_round5.py), and SLOWER than the row-per-wave kernel at Reddit scale - bf16 H=4 x F=64, results in plan order: 7.33 vs
+// 5.84 ms - although with the gathers dropped ("slab_probe") it needs 3.73 ms against 5.65: the operand map makes every gather
+// instruction fetch 16 rows x 64 bytes (four lanes per edge), i.e. two 64-byte requests per 128-byte line and 8 requests per edge where
+// the row-per-wave kernel makes 4 whole-line ones, and THIS form does wait for its gathers (profiles/r05/
+// slab_cases__mh_sddmm_matrix_cores_ab.txt).  What would make it win: rows brought in whole (8 bytes a lane, one edge per
+// instruction) and turned into operand fragments through LDS, and the four tiles of a chunk pipelined - not built this round.  Plans cut into waves, R <= 16 rows per group, rows of 32 x NCH elements (512 / 256 bytes),
 // CPH slices per head (H = NCH / CPH heads), results in the plan's edge order (staged); fp32 accumulation as everywhere, the sum order
 // inside a head is the hardware's (32 features per step, CPH steps).
 template <typename T, int NCH, int CPH>
@@ -1842,7 +1849,8 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 int g_slab_wrow_all = 0;
-int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over a plan on the matrix cores (seg_slab_sddmm_mfma_kernel); 0 = the row-per-wave kernel
+int g_slab_sddmm_mfma = 0;   // "slab_sddmm_mfma": 1 = 16-bit multi-head SDDMM over a plan on the matrix cores (seg_slab_sddmm_mfma_kernel).  Exact, and
+                             // SLOWER as it stands (bf16 H=4 x F=64: 7.33 vs 5.84 ms): off - see the kernel's header
 int g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
 int g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured
                         // SLOWER than seg_slab_wrow_kernel (bf16 H=4 x F=64, weights in plan order: 4.63 vs 4.50 ms), so off: see the kernel's header
@@ -2217,6 +2225,7 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   } else {
 #define GEOT_SLAB_SDDMM(T_, E2_, E1_)                                                                        \
   do {                                                                                                        \
+    geot_internal_note_kernel((std::string(wrow ? "seg_slab_sddmm_wrow_kernel<" : "seg_slab_sddmm_kernel<") + slab_tname<T_>() + ">").c_str()); \
     if (lpr_log2 == 6) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, true>), grid, blk, lds, st, p);          \
     else if (!wrow) hipLaunchKernelGGL((seg_slab_sddmm_kernel<T_, false>), grid, blk, lds, st, p);            \
     else if (el == E2_) hipLaunchKernelGGL((seg_slab_sddmm_wrow_kernel<T_, E2_>), grid, blk, lds, st, p);     \

@@ -299,7 +299,7 @@ def test_weights_in_every_order_on_every_chunk_length(geot, dtype, H, Fh):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32)])
 def test_matrix_core_sddmm_is_exact_on_integer_data(geot, dtype, H, Fh):
-    """seg_slab_sddmm_mfma_kernel (16-bit multi-head SDDMM over a plan, v_mfma_f32_16x16x32): features in {-1, 0, 1}, so every dot
+    """seg_slab_sddmm_mfma_kernel (option slab_sddmm_mfma; 16-bit multi-head SDDMM over a plan, v_mfma_f32_16x16x32): features in {-1, 0, 1}, so every dot
     product is an integer below 2^8 - exact in fp32 and in the 16-bit result - and any slip in the operand maps (which lane holds
     which features of which edge / row, where D[m][dl(m)] sits) shows as a wrong integer, not as rounding.  Plans with at most 16
     rows per group (one 16-column operand), a hub split into pieces, rows without edges, an out-of-range source; results in plan order
@@ -332,7 +332,7 @@ def test_matrix_core_sddmm_is_exact_on_integer_data(geot, dtype, H, Fh):
             assert torch.equal(s_edge.double(), want), (mfma, float((s_edge.double() - want).abs().max()))
             outs[mfma] = s_edge
     finally:
-        geot.hip.set_option("slab_sddmm_mfma", 1)
+        geot.hip.set_option("slab_sddmm_mfma", 0)                     # (off by default: measured slower, see the kernel's header)
     assert torch.equal(outs[0], outs[1])
 
 
