@@ -742,8 +742,22 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                 att_handle()
             out["attention_forward_ms"] = {"operators_edge_order": device_ms(att_ops, max(2, iters // 2)),
                                            "graph_handle_plan_order": device_ms(att_handle, max(2, iters // 2))}
+            # the same in bf16 storage through the handle: the scores come from the matrix cores (seg_slab_sddmm_mfma_kernel: 16 edges x the
+            # group's rows x 32 features per v_mfma_f32_16x16x32_bf16), fp32 accumulation as everywhere
+            qb, kb, xb = q.bfloat16(), k.bfloat16(), x.detach().bfloat16()
+
+            def att_handle_bf16():
+                s = handle.mh_sddmm(qb, kb, plan_order=True)
+                return handle.mh_spmm(s.with_values(torch.exp(s.values.float()).bfloat16()), xb)
+            for _ in range(3):
+                att_handle_bf16()
+            t_sddmm = device_ms(lambda: handle.mh_sddmm(qb, kb, plan_order=True), max(2, iters // 2))
+            sddmm_kernel = hip.last_kernel()
+            out["attention_forward_ms"]["graph_handle_plan_order_bf16"] = device_ms(att_handle_bf16, max(2, iters // 2))
+            out["attention_forward_ms"]["bf16_scores_alone_ms"] = t_sddmm
+            out["attention_forward_ms"]["bf16_scores_kernel"] = sddmm_kernel
             out["handle"] = dict(handle.stats)
-            del handle, q, k
+            del handle, q, k, qb, kb, xb
         finally:
             ops.set_option("slab_mode", old)
             ops.clear_caches()

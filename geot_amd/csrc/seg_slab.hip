@@ -1473,35 +1473,41 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 // (edge, row) products of a 32-feature slice; the one wanted per edge, D[m][dl(m)], is picked out through a small LDS exchange, the
 // other 15 are the price.  It is worth it because these kernels are bound by vector-instruction issue, not by their gathers (§3.1d
 // of DESIGN.md: with the gathers dropped they keep 97 % of their time): the row-per-wave kernel spends ~20 wave-instructions per edge
-// on unpacking two 16-bit rows and multiplying them, this one ~3 (8 loads, 8 MFMAs and the exchange per 16 edges), and the MFMAs
-// themselves are 0.4 ms of work at Reddit scale.  Nothing is contaminated by the unused products: a result element is the sum over
-// its OWN row's and edge's features only.
-// MEASURED (an experiment, option "slab_sddmm_mfma", off by default): exact on integer data for every shape and both types
-// (tests/test_gpu_round5.py), and SLOWER than the row-per-wave kernel at Reddit scale - bf16 H=4 x F=64, results in plan order: 7.33 vs
-// 5.84 ms - although with the gathers dropped ("slab_probe") it needs 3.73 ms against 5.65: the operand map makes every gather
-// instruction fetch 16 rows x 64 bytes (four lanes per edge), i.e. two 64-byte requests per 128-byte line and 8 requests per edge where
-// the row-per-wave kernel makes 4 whole-line ones, and THIS form does wait for its gathers (profiles/r05/
-// slab_cases__mh_sddmm_matrix_cores_ab.txt).  What would make it win: rows brought in whole (8 bytes a lane, one edge per
-// instruction) and turned into operand fragments through LDS, and the four tiles of a chunk pipelined - not built this round.  Plans cut into waves, R <= 16 rows per group, rows of 32 x NCH elements (512 / 256 bytes),
-// CPH slices per head (H = NCH / CPH heads), results in the plan's edge order (staged); fp32 accumulation as everywhere, the sum order
-// inside a head is the hardware's (32 features per step, CPH steps).
-template <typename T, int NCH, int CPH>
+// on unpacking two 16-bit rows and multiplying them, this one ~8, and the MFMAs themselves are 0.4 ms of work at Reddit scale.
+// Nothing is contaminated by the unused products: a result element is the sum over its OWN row's and edge's features only.
+// The m2 rows are brought in WHOLE (one edge per gather instruction, 8 bytes a lane - the row-per-wave kernel's requests: four whole
+// 128-byte lines) and turned into A fragments through LDS: a tile's 16 rows are written to a per-wave image [16 edges][512 + 32
+// bytes] (ds_write_b64, contiguous) and read back as the operand map wants them (ds_read_b128 at [edge n][64 c + 16 kb]; the
+// 32-byte pad makes every 16-lane group of the read hit 64 distinct banks).  (Gathering the operand pieces DIRECTLY - four lanes
+// per edge, 16 rows x 64 bytes per instruction - was built first and measured slower than the row-per-wave kernel, 7.33 vs 5.84 ms,
+// though it needed only 3.73 ms with its gathers dropped: two 64-byte requests per 128-byte line, eight per edge instead of four.)
+// MEASURED at Reddit scale, bf16 H=4 x F=64: **4.30 ms** with the results left in plan order against 5.84 (5.25 vs 6.81 into edge
+// order), exact on integer data for every shape and both types (tests/test_gpu_round5.py); 4.18 ms with the gathers dropped - what
+// bounds it now is the LDS write path (a tile's image is 8 KB at ~80 B/clk per CU) and the chain of waits inside a tile
+// (profiles/r05/slab_cases__mh_sddmm_matrix_cores_ab.txt).  Plans cut into waves, R <= 16 rows per group, rows of 512 bytes, CPH
+// 32-feature slices per head (H = 8 / CPH <= 4 heads: the image and the exchange share 64 KB of LDS), results in the plan's edge order
+// (staged); fp32 accumulation as everywhere, the sum order inside a head is the hardware's (32 features per step, CPH steps).
+// Option "slab_sddmm_mfma" = 0: the row-per-wave kernel.
+template <typename T, int CPH>
 __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParams p) {
-  static_assert(sizeof(T) == 2 && (NCH == 8 || NCH == 4) && NCH % CPH == 0, "16-bit rows of 512 / 256 bytes");
-  constexpr int H = NCH / CPH;
-  constexpr int rsh = NCH == 8 ? 9 : 8;                  // log2(row bytes)
+  static_assert(sizeof(T) == 2 && 8 % CPH == 0, "16-bit rows of 512 bytes");
+  constexpr int NCH = 8, H = NCH / CPH;
+  constexpr int kStride = 512 + 32;                      // bytes between the rows of a tile's image
   typedef T t8_t __attribute__((ext_vector_type(8)));
+  typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 15, kb = lane >> 4;               // operand maps: A[row n][k = 8 kb + j], B[k = 8 kb + j][col n]; D[row 4 kb + j][col n]
-  f4_t *xch = reinterpret_cast<f4_t *>(smem) + (size_t)wave * (H * 64);     // the exchange: [H][4 row blocks][16 cols] x 4 rows
+  const int n = lane & 15, kb = lane >> 4;
+  unsigned char *img = smem + (size_t)wave * (16 * kStride);                                      // this wave's tile image
+  f4_t *xch = reinterpret_cast<f4_t *>(smem + (size_t)4 * 16 * kStride) + (size_t)wave * (H * 64); // ... and its result exchange
   const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
   const int64_t units = P.units;
-  const T *m1 = static_cast<const T *>(p.weight);        // (the dst-side matrix travels in the `weight` slot)
+  const T *m1 = static_cast<const T *>(p.weight);
   T *out = static_cast<T *>(p.dst);
   const uint32_t src_rows = (uint32_t)p.src_rows;
-  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
+  const uint32_t cB = (uint32_t)lane * 8u;
   t8_t zero8;
 #pragma unroll
   for (int i = 0; i < 8; ++i) zero8[i] = (T)0.f;
@@ -1548,6 +1554,11 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
       my_slot = -1;
     }
   };
+  auto wave_order = [] {                        // LDS words written by some lanes and read by others: keep the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
 
   for (int r = 0; r < p.rounds; ++r) {
     const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
@@ -1559,8 +1570,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
     len = __builtin_amdgcn_readfirstlane(len);
     nv = __builtin_amdgcn_readfirstlane(nv);
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
-    // the group's m1 rows as B fragments, in registers for the whole group (pieces of a split hub share their row)
-    t8_t bfrag[NCH];
+    t8_t bfrag[NCH];                            // the group's m1 rows as B fragments, in registers for the whole group
     {
       const int64_t row = n < nv ? P.v_row[v0 + n] : -1;
       const bool ok = row >= 0 && row < p.K;
@@ -1568,33 +1578,38 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
 #pragma unroll
       for (int c = 0; c < NCH; ++c) bfrag[c] = ok ? *reinterpret_cast<const t8_t *>(rp + 32 * c) : zero8;
     }
-    int my_src = 0, my_dl = 255;
+    uint32_t my_edge = 255;                     // (source row << 8) | row in group; 255 = padding / out-of-range source
     {
       const bool valid = lane < len;
-      my_src = valid ? P.e_src[e0 + lane] : 0;
-      my_dl = valid ? (int)P.e_dl[e0 + lane] : 255;
-      if ((uint32_t)my_src >= src_rows) { my_src = 0; my_dl = 255; }   // out-of-range source: the dot is 0
+      const uint32_t s_ = valid ? (uint32_t)P.e_src[e0 + lane] : 0u;
+      const uint32_t d_ = valid ? (uint32_t)P.e_dl[e0 + lane] : 255u;
+      my_edge = s_ < src_rows ? ((s_ << 8) | d_) : 255u;
     }
     for (int off = 0; off < len; off += 64) {
       const bool nvalid = off + 64 + lane < len;
       const int64_t ne = e0 + (nvalid ? off + 64 + lane : len - 1);    // (every lane loads: see seg_slab_wrow_kernel)
-      int n_src = 0, n_dl = 255;
+      uint32_t n_src = 0, n_dl = 255;
       const int n_here = len - off;
       const int n_max = n_here < 64 ? n_here : 64;
       for (int t = 0; t < 4 && 16 * t < n_max; ++t) {
-        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, 16 * t) >> p.slab_shift));
-        // lane (n, kb): edge m = 16 t + n of the chunk - its source row and row in group through the LDS crossbar
-        const int pick = (16 * t + n) << 2;
-        const uint32_t srow = (uint32_t)__builtin_amdgcn_ds_bpermute(pick, my_src);
-        const int dlm = __builtin_amdgcn_ds_bpermute(pick, my_dl);
-        const uint32_t voff = (srow << rsh) + 16u * (uint32_t)kb;
+        if (p.window >= 0) slab_sync(r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, 16 * t) >> (8 + p.slab_shift)));
+        raw2_t rv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {          // one edge's whole row per instruction (slots behind the last edge: row 0)
+          const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane(my_edge, 16 * t + i);
+          rv[i] = slab_row_load<raw2_t>(table, cB, (edge & ~255u) << 1);
+        }
+        if (t == 0) {                           // the next chunk's fields, behind this tile's gathers
+          n_src = (uint32_t)P.e_src[ne];
+          n_dl = (uint32_t)P.e_dl[ne];
+        }
+        const int dlm = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((16 * t + n) << 2, (int)my_edge) & 255u);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<raw2_t *>(img + i * kStride + cB) = rv[i];
+        wave_order();
         t8_t afrag[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) afrag[c] = __builtin_bit_cast(t8_t, slab_row_load<f4_t>(table, voff + 64u * c, 0));
-        if (t == 0) {                            // the next chunk's fields, behind this tile's gathers
-          n_src = P.e_src[ne];
-          n_dl = (int)P.e_dl[ne];
-        }
+        for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + n * kStride + 64 * c + 16 * kb);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           f4_t d = {0.f, 0.f, 0.f, 0.f};
@@ -1603,39 +1618,27 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
             if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
             else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
           }
-          xch[(h * 4 + kb) * 16 + n] = d;        // D[row 4 kb + j][col n], j = 0..3
+          xch[(h * 4 + kb) * 16 + n] = d;       // D[row 4 kb + j][col n], j = 0..3
         }
-        // (the exchange crosses lanes: to the compiler these are other threads' words - keep the order, see seg_slab_wpair_kernel)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 16) {                         // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
+        wave_order();
+        if (lane < 16) {                        // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
           const int e = off + 16 * t + lane;
           if (e < len) {
             const float *xf = reinterpret_cast<const float *>(xch);
-            T res[H];
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-              const float v = dlm != 255 ? xf[(((h * 4 + (lane >> 2)) * 16 + dlm) << 2) + (lane & 3)] : 0.f;
-              res[h] = (T)v;
-            }
             T *op = out + (e0 + e) * H;
-            if constexpr (H == 1) op[0] = res[0];
+            if constexpr (H == 1) op[0] = (T)(dlm != 255 ? xf[((((lane >> 2)) * 16 + dlm) << 2) + (lane & 3)] : 0.f);
             else {
               typedef T tH_t __attribute__((ext_vector_type(H)));
               tH_t pk;
 #pragma unroll
-              for (int h = 0; h < H; ++h) pk[h] = res[h];
+              for (int h = 0; h < H; ++h) pk[h] = (T)(dlm != 255 ? xf[(((h * 4 + (lane >> 2)) * 16 + dlm) << 2) + (lane & 3)] : 0.f);
               *reinterpret_cast<tH_t *>(op) = pk;
             }
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_order();
       }
-      my_src = (nvalid && (uint32_t)n_src < src_rows) ? n_src : 0;
-      my_dl = (nvalid && (uint32_t)n_src < src_rows) ? n_dl : 255;
+      my_edge = (nvalid && n_src < src_rows) ? ((n_src << 8) | n_dl) : 255u;
     }
     if (p.window >= 0 && my_slot >= 0) {
       published = (r + 1) * p.n_slabs;
@@ -1849,8 +1852,8 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 int g_slab_wrow_all = 0;
-int g_slab_sddmm_mfma = 0;   // "slab_sddmm_mfma": 1 = 16-bit multi-head SDDMM over a plan on the matrix cores (seg_slab_sddmm_mfma_kernel).  Exact, and
-                             // SLOWER as it stands (bf16 H=4 x F=64: 7.33 vs 5.84 ms): off - see the kernel's header
+int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over plans of 512-byte rows on the matrix cores (seg_slab_sddmm_mfma_kernel:
+                             // 4.30 vs 5.84 ms at Reddit scale); 0 = the row-per-wave kernel
 int g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
 int g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured
                         // SLOWER than seg_slab_wrow_kernel (bf16 H=4 x F=64, weights in plan order: 4.63 vs 4.50 ms), so off: see the kernel's header
@@ -2196,24 +2199,21 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   }
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
   const int el = (int)(F / 64);                            // (rows of 512 / 256 bytes) elements per lane
-  // 16-bit multi-head plans, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's rows fit one
-  // 16-column operand and a head is a whole number of 32-feature slices
+  // 16-bit multi-head plans over 512-byte rows, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's
+  // rows fit one 16-column operand, a head is a whole number of 32-feature slices and image + exchange fit 64 KB of LDS (H <= 4)
   const int nch = (int)(F / 32);
-  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && (rowbytes == 512 || rowbytes == 256) && plan->rows_per_group <= 16 && heads <= nch &&
-      nch % heads == 0 && (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
-    const size_t xlds = (size_t)4 * (size_t)heads * 64 * sizeof(f4_t);
+  const size_t xch_lds = (size_t)4 * (size_t)heads * 64 * sizeof(f4_t), img_lds = (size_t)4 * 16 * (512 + 32);
+  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && rowbytes == 512 && plan->rows_per_group <= 16 && (heads == 1 || heads == 2 || heads == 4) &&
+      xch_lds + img_lds <= 64 * 1024 && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
+    const size_t xlds = xch_lds + img_lds;
     const int cph = nch / (int)heads;
     const int rc = g_turn.take(st, [&]() -> int {
 #define GEOT_SLAB_MFMA(T_)                                                                                     \
       do {                                                                                                     \
-        geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(nch) + ", " + std::to_string(cph) + ">").c_str()); \
-        if (nch == 8 && cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 8>), grid, blk, xlds, st, p);      \
-        else if (nch == 8 && cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 4>), grid, blk, xlds, st, p); \
-        else if (nch == 8 && cph == 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 2>), grid, blk, xlds, st, p); \
-        else if (nch == 8 && cph == 1) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 1>), grid, blk, xlds, st, p); \
-        else if (nch == 4 && cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4, 4>), grid, blk, xlds, st, p); \
-        else if (nch == 4 && cph == 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4, 2>), grid, blk, xlds, st, p); \
-        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4, 1>), grid, blk, xlds, st, p);                            \
+        geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(cph) + ">").c_str()); \
+        if (cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8>), grid, blk, xlds, st, p);        \
+        else if (cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4>), grid, blk, xlds, st, p);   \
+        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 2>), grid, blk, xlds, st, p);                 \
       } while (0)
       if (dtype == GEOT_F16) GEOT_SLAB_MFMA(half_t);
       else GEOT_SLAB_MFMA(bf16_t);
