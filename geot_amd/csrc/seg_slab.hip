@@ -1487,7 +1487,10 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 // (profiles/r05/slab_cases__mh_sddmm_matrix_cores_ab.txt).  Plans cut into waves, R <= 16 rows per group, rows of 512 bytes, CPH
 // 32-feature slices per head (H = 8 / CPH <= 4 heads: the image and the exchange share 64 KB of LDS), results in the plan's edge order
 // (staged); fp32 accumulation as everywhere, the sum order inside a head is the hardware's (32 features per step, CPH steps).
-// Option "slab_sddmm_mfma" = 0: the row-per-wave kernel.
+// Option "slab_sddmm_mfma" = 0: the row-per-wave kernel.  Two refinements measured afterwards (one box, interleaved): the H exchange reads
+// made unconditional (behind a per-head branch each waited for its own LDS round trip): 4.31 -> 4.24 ms, kept; a tile's rows gathered ONE
+// TILE AHEAD (into the same registers, while the previous tile goes through the matrix cores): 4.47 vs 4.28 ms - slower (130 registers
+// instead of 108, and the gathers were not what a tile waits for), dropped.
 template <typename T, int CPH>
 __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParams p) {
   static_assert(sizeof(T) == 2 && 8 % CPH == 0, "16-bit rows of 512 bytes");
@@ -1624,14 +1627,19 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
         if (lane < 16) {                        // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
           const int e = off + 16 * t + lane;
           if (e < len) {
-            const float *xf = reinterpret_cast<const float *>(xch);
+            // (the H reads are unconditional - a padding edge reads column 0 and drops it: behind a branch each read would wait for
+            // its own LDS round trip, four in a row per tile)
+            const float *xf = reinterpret_cast<const float *>(xch) + ((((lane >> 2) * 16 + (dlm != 255 ? dlm : 0)) << 2) + (lane & 3));
+            float vals[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) vals[h] = xf[h * 256];
             T *op = out + (e0 + e) * H;
-            if constexpr (H == 1) op[0] = (T)(dlm != 255 ? xf[((((lane >> 2)) * 16 + dlm) << 2) + (lane & 3)] : 0.f);
+            if constexpr (H == 1) op[0] = (T)(dlm != 255 ? vals[0] : 0.f);
             else {
               typedef T tH_t __attribute__((ext_vector_type(H)));
               tH_t pk;
 #pragma unroll
-              for (int h = 0; h < H; ++h) pk[h] = (T)(dlm != 255 ? xf[(((h * 4 + (lane >> 2)) * 16 + dlm) << 2) + (lane & 3)] : 0.f);
+              for (int h = 0; h < H; ++h) pk[h] = (T)(dlm != 255 ? vals[h] : 0.f);
               *reinterpret_cast<tH_t *>(op) = pk;
             }
           }
