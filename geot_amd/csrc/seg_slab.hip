@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 // order), exact on integer data for every shape and both types (tests/test_gpu_round5.py); 4.18 ms with the gathers dropped - what
 // bounds it now is the LDS write path (a tile's image is 8 KB at ~80 B/clk per CU) and the chain of waits inside a tile
 // (profiles/r05/slab_cases__mh_sddmm_matrix_cores_ab.txt).  Plans cut into waves, R <= 16 rows per group, rows of 512 bytes, CPH
-// 32-feature slices per head (H = 8 / CPH <= 4 heads: the image and the exchange share 64 KB of LDS), results in the plan's edge order
+// 32-feature slices per head (H = 8 / CPH heads), results in the plan's edge order
 // (staged); fp32 accumulation as everywhere, the sum order inside a head is the hardware's (32 features per step, CPH steps).
 // Option "slab_sddmm_mfma" = 0: the row-per-wave kernel.  Two refinements measured afterwards (one box, interleaved): the H exchange reads
 // made unconditional (behind a per-head branch each waited for its own LDS round trip): 4.31 -> 4.24 ms, kept; a tile's rows gathered ONE
@@ -1502,8 +1502,11 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kb = lane >> 4;
-  unsigned char *img = smem + (size_t)wave * (16 * kStride);                                      // this wave's tile image
-  f4_t *xch = reinterpret_cast<f4_t *>(smem + (size_t)4 * 16 * kStride) + (size_t)wave * (H * 64); // ... and its result exchange
+  // this wave's LDS: the tile image [16][kStride] and - in the SAME bytes, once the fragments have been read out of it - the result
+  // exchange [H][4][16] float4 (H <= 8: 8 KB of the image's 8.5); a wave's LDS operations execute in order, the fences keep the compiler's
+  unsigned char *img = smem + (size_t)wave * (16 * kStride);
+  f4_t *xch = reinterpret_cast<f4_t *>(img);
+  static_assert(H * 64 * sizeof(f4_t) <= 16 * kStride, "the exchange fits the image");
   const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
   const int64_t units = P.units;
   const T *m1 = static_cast<const T *>(p.weight);
@@ -2208,12 +2211,11 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
   const int el = (int)(F / 64);                            // (rows of 512 / 256 bytes) elements per lane
   // 16-bit multi-head plans over 512-byte rows, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's
-  // rows fit one 16-column operand, a head is a whole number of 32-feature slices and image + exchange fit 64 KB of LDS (H <= 4)
+  // rows fit one 16-column operand and a head is a whole number of 32-feature slices (H = 1 / 2 / 4 / 8)
   const int nch = (int)(F / 32);
-  const size_t xch_lds = (size_t)4 * (size_t)heads * 64 * sizeof(f4_t), img_lds = (size_t)4 * 16 * (512 + 32);
-  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && rowbytes == 512 && plan->rows_per_group <= 16 && (heads == 1 || heads == 2 || heads == 4) &&
-      xch_lds + img_lds <= 64 * 1024 && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
-    const size_t xlds = xch_lds + img_lds;
+  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && rowbytes == 512 && plan->rows_per_group <= 16 &&
+      (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
+    const size_t xlds = (size_t)4 * 16 * (512 + 32);       // per wave: the tile image (the result exchange reuses its bytes)
     const int cph = nch / (int)heads;
     const int rc = g_turn.take(st, [&]() -> int {
 #define GEOT_SLAB_MFMA(T_)                                                                                     \
@@ -2221,7 +2223,8 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
         geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(cph) + ">").c_str()); \
         if (cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8>), grid, blk, xlds, st, p);        \
         else if (cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4>), grid, blk, xlds, st, p);   \
-        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 2>), grid, blk, xlds, st, p);                 \
+        else if (cph == 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 2>), grid, blk, xlds, st, p);   \
+        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 1>), grid, blk, xlds, st, p);                 \
       } while (0)
       if (dtype == GEOT_F16) GEOT_SLAB_MFMA(half_t);
       else GEOT_SLAB_MFMA(bf16_t);
