@@ -46,11 +46,17 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
  * "narrow" = 1 | 0 lane-per-edge kernel for fp32 rows of <= 7 elements; "xcd" = 1 | 0 XCD-contiguous tile
  * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
  * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
- * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
+ * "slab_blocks" = 1..6 (launchable: 1..4) workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
  * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free);
  * "slab_far" = n: a slowest wave more than n steps behind is not waited for (12); "slab_turn" = 1 | 0: the persistent
  * source-blocked grids of this process take turns per device (a launch waits on its stream for the event of the previous one;
  * skipped on a capturing stream); "slab_nt" = 0 | 1: experiment, non-temporal loads of the plan's streams;
+ * "slab_unroll" = 8 | 16 row loads in flight per lane of the row-per-wave kernel; "slab_tight" = 1 | 0 and "slab_stage" = 1 | 0 | 2:
+ * the window / pre-pass rules for per-call weights; "slab_wrow_all" = 0 | 1: every plan of 512 / 256-byte rows cut into waves;
+ * "slab_sddmm_mfma" = 1 | 0: 16-bit multi-head SDDMM over plans of 512-byte rows on the matrix cores | the row-per-wave kernel;
+ * "slab_pair" = 0 | 1: experiment, multi-head plans of 512-byte rows read two edges' rows per instruction (measured slower);
+ * "slab_probe" = 0 | 1: TIMING experiment - the gathered table's buffer descriptor gets zero records, every row read of the
+ * wave-row kernels is dropped by the range check (results are wrong by design; what a kernel costs without its gathers);
  * "handoff_tries" = polls of a predecessor's flag before a run is left to the second launch (0: sample once);
  * "lds_floor" = -1 | bytes: dynamic LDS a tile-kernel launch asks for at least - the cap on workgroups per CU
  * (-1: the rule; 33000 -> 4, 41000 -> 3, 54000 -> 2 per CU); "gather_grid" = tiles a gathered fp32 call is cut into
