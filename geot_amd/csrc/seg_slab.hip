@@ -2301,7 +2301,7 @@ void geot_internal_slab_option(const char *name, int value) {
   if (name && std::string(name) == "slab_pair") g_slab_pair = value != 0;
   if (name && std::string(name) == "slab_probe") g_slab_probe = value != 0;
   if (name && std::string(name) == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
-  if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 6) g_slab_blocks = value;
+  if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
 }
 
 } // extern "C"

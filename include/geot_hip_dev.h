@@ -46,7 +46,7 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
  * "narrow" = 1 | 0 lane-per-edge kernel for fp32 rows of <= 7 elements; "xcd" = 1 | 0 XCD-contiguous tile
  * ranges in the gather modes; "nt_keys" = 0 | 1 non-temporal key loads; "hub" = -1 | 0 | 1 per-window carry
  * sums for chains of tiles under one key (-1: when nnz / out_rows >= 4096, the few-key regime; 1: always);
- * "slab_blocks" = 1..6 (launchable: 1..4) workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
+ * "slab_blocks" = 1..4 workgroups per CU of the source-blocked kernel's persistent grid (plans built afterwards),
  * "slab_window" = -2 | -1 | n: how many slabs a wave may run ahead of the slowest wave of its XCD (-2 rule, -1 free);
  * "slab_far" = n: a slowest wave more than n steps behind is not waited for (12); "slab_turn" = 1 | 0: the persistent
  * source-blocked grids of this process take turns per device (a launch waits on its stream for the event of the previous one;
