@@ -726,6 +726,21 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                 hstep()
             out["with_graph_handle"] = {"forward_ms": device_ms(lambda: handle.mh_spmm(w.detach(), x.detach()), max(2, iters // 2)),
                                         "forward_backward_ms": device_ms(hstep, max(2, iters // 2))}
+            # the same step in bf16 storage (fp32 accumulation in every kernel; d/dweight on the matrix cores)
+            xb = x.detach().bfloat16().requires_grad_()
+            wb = w.detach().bfloat16().requires_grad_()
+            cotb = cot.bfloat16()
+
+            def hstep_bf16():
+                xb.grad = None
+                wb.grad = None
+                with torch.no_grad():
+                    wb.mul_(1.0)
+                handle.mh_spmm(wb, xb).backward(cotb)
+            for _ in range(3):
+                hstep_bf16()
+            out["with_graph_handle"]["bf16_forward_backward_ms"] = device_ms(hstep_bf16, max(2, iters // 2))
+            del xb, wb, cotb
             # attention: scores by the SDDMM, exp, the SpMM - per-edge tensors in edge order (operators) and in plan order (handle)
             q = torch.rand(nodes, H, F, device=dev, generator=g) / 8
             k = torch.rand(nodes, H, F, device=dev, generator=g) / 8
