@@ -424,6 +424,48 @@ def test_plan_order_attention_pipeline(geot, dtype, H, Fh):
     assert float((out_plan.double() - ref).abs().max()) <= otol * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("dtype,rows_log2", [(torch.float32, 22), (torch.bfloat16, 23)])
+def test_tables_just_below_4_gib_use_the_top_of_the_32_bit_row_offsets(geot, dtype, rows_log2):
+    """The wave-row kernels address a gathered row as (buffer base) + a 32-bit scalar row offset + the lane's offset, and an edge's
+    (source row, row in group) travel as one word: a table of 2^22 - 1 rows of 1 KiB (fp32 H=4 x F=64) / 2^23 - 1 rows of 512 bytes
+    (bf16) is 4 GiB minus one row - the largest the source-blocked kernels accept - with most sources in its last rows (bit 31 of the
+    offset set, the top bits of the packed word used).  SpMM and multi-head SDDMM (the matrix-core kernel for bf16) against float64;
+    and the library refuses one row more."""
+    from geot_amd import slab
+    H, Fh = 4, 64
+    nodes = (1 << rows_log2) - 1
+    esz = 4 if dtype == torch.float32 else 2
+    rowbytes = H * Fh * esz
+    assert nodes * rowbytes < 2 ** 32 <= (nodes + 1) * rowbytes
+    rng = np.random.default_rng(rows_log2)
+    nnz, rows_used = 400_000, 1500
+    di = np.sort(rng.integers(0, rows_used, nnz)).astype(np.int64)
+    si = np.where(rng.random(nnz) < 0.8, rng.integers(nodes - 40_000, nodes, nnz), rng.integers(0, nodes, nnz)).astype(np.int64)
+    si[:64] = nodes - 1                                                 # the very last row
+    d_si, d_di = dev(si), dev(di)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(nodes, H, Fh, device="cuda", generator=gen).to(dtype)
+    w = torch.rand(nnz, H, device="cuda", generator=gen).to(dtype)
+    plan = slab.build_plan(d_si, d_di, rows_used, nodes, rowbytes, 2, H, rows_per_group=slab.rows_per_group(2, H, dtype, rowbytes))
+    out = torch.full((rows_used, H, Fh), float("nan"), device="cuda", dtype=dtype)
+    slab.slab_spmm_out(plan, w, 2, x, out, H, Fh)
+    ref = torch.zeros(rows_used, H, Fh, device="cuda", dtype=torch.float64).index_add_(0, d_di, x[d_si].double() * w.double()[:, :, None])
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -6
+    assert float((out.double() - ref).abs().max()) <= tol * float(ref.abs().max()), geot.hip.last_kernel()
+    q = (torch.rand(rows_used, H, Fh, device="cuda", generator=gen) - 0.5).to(dtype)
+    s_edge = torch.full((nnz, H), float("nan"), device="cuda", dtype=dtype)
+    slab.slab_mh_sddmm_out(plan, q, x, s_edge)
+    if dtype == torch.bfloat16:
+        assert "seg_slab_sddmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+    want = (q.double()[d_di] * x[d_si].double()).sum(-1)
+    assert float((s_edge.double() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    del x
+    x1 = torch.empty(nodes + 1, H, Fh, device="cuda", dtype=dtype)         # one row more: 4 GiB exactly - refused, not wrapped
+    with pytest.raises(RuntimeError, match="4 GiB"):
+        slab.slab_spmm_out(plan, w, 2, x1, out, H, Fh)
+
+
+
 def test_hang_hunt_quick(tmp_path):
     """tools/hang_hunt.py stays in the suite's orbit: ten fresh-process runs of round 3's three-thread
     scenario (three workers on one dense graph, persistent source-blocked grids in flight) under the watchdog, five with the
