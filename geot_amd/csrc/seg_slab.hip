@@ -55,7 +55,7 @@ struct SlabParams {
   uint32_t rowbytes;
   int lpr_log2;
   int rounds;
-  // loose per-XCD lockstep (see slab_sync): progress words of the waves of each XCD, slab size as a shift
+  // loose per-XCD lockstep (see SlabStep): progress words of the waves of each XCD, slab size as a shift
   int *prog;            // [8][kProgSlots] current step of every registered wave (0x7f7f7f7f = not running)
   int *prog_cnt;        // [8] slot allocator (starts at 0x7f7f7f7f)
   int slab_shift;       // slab = source row >> slab_shift
@@ -70,7 +70,7 @@ struct SlabParams {
 constexpr int kProgSlots = 512;
 constexpr int kProgIdle = 0x7f7f7f7f;
 constexpr int kSyncTries = 640;  // polls of one wait (8 loads + s_sleep 16 each, ~1.5 us: ~1 ms; a slab step is ~50-100 us)
-constexpr int kSyncGiveUp = 4;   // waits that ran out in a row before a wave stops keeping step (see slab_sync)
+constexpr int kSyncGiveUp = 4;   // waits that ran out in a row before a wave stops keeping step (see SlabStep)
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
@@ -203,6 +203,75 @@ __global__ __launch_bounds__(kThreads) void slab_stage_weights_x4_kernel(const i
 // mirror image of slab_unstage_kernel - measured SLOWER than this plain gather: gws F=128 fp32 4.52 vs 4.00 ms per call,
 // profiles/r05/slab_cases__weight_prepass_through_lds.txt; three barriers per group cost more than the L2 requests they save.)
 
+// ---- loose lockstep inside an XCD (used by every source-blocked kernel) ---------------------------------------------------------
+// The natural lockstep (same start, same work) drifts like a random walk: with ~6000 edges per group the waves of an XCD spread
+// over ~+-3 % of the table (+-6 MB at 238 MB) - more than the 4 MiB L2.  So every wave publishes the step (round * slabs + slab) it
+// is working on in a per-XCD array and does not START a slab more than `window` slabs ahead of the slowest registered wave of its
+// XCD.  Only leaders ever wait, the slowest wave never does, a wave that is not resident is not registered, and every wait is
+// bounded: no deadlock by construction.  Same-XCD visibility: plain stores go through to the XCD's L2, the polls bypass L1 (nt loads).
+// Bounded in AGGREGATE too: a wait is ~1 ms at most, and a wave whose waits run out kSyncGiveUp times in a row stops keeping step for
+// the rest of the launch (it withdraws its progress word, so nobody waits for it either).  That is the situation of a grid that does
+// not have the chip to itself - another persistent grid of this process, of another process, or a replayed graph on a second stream
+// holds the CUs its slowest waves would run on: lockstep has nothing to offer there, and without this rule thousands of steps x a
+// timed-out wait each would look like a hang.  Timing only: the result never depends on the lockstep.  All members are wave-uniform.
+struct SlabStep {
+  int my_slot = -1;
+  int *xprog = nullptr;
+  int published = -1;
+  int known_min = -1;                          // a lower bound of the slowest wave's step (steps only grow)
+  int timeouts = 0;                            // consecutive waits that ran out
+
+  __device__ __forceinline__ void enter(const SlabParams &p, int lane) {
+    if (p.window < 0) return;
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;        // HW_REG_XCC_ID[3:0]
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    xprog = p.prog + xcc * kProgSlots;
+    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
+  }
+  __device__ __forceinline__ void at(const SlabParams &p, int lane, int step) {   // about to start `step`
+    if (my_slot < 0 || step <= published) return;
+    published = step;
+    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
+    if (known_min + p.window >= step) return;  // the last poll already allows this step: no memory round trip
+    bool ok = false;
+    for (int tries = 0; tries < kSyncTries; ++tries) {
+      int m = kProgIdle;
+#pragma unroll
+      for (int q = 0; q < kProgSlots / 64; ++q) {
+        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
+        m = v < m ? v : m;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o, 64);
+        m = other < m ? other : m;
+      }
+      known_min = m;
+      if (m + p.window >= step || step - m > p.far) {
+        ok = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (ok) timeouts = 0;
+    else if (++timeouts >= kSyncGiveUp) {
+      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+      my_slot = -1;
+    }
+  }
+  __device__ __forceinline__ void round_done(const SlabParams &p, int lane, int r) {   // never hold the others back
+    if (p.window >= 0 && my_slot >= 0) {
+      published = (r + 1) * p.n_slabs;
+      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
+    }
+  }
+  __device__ __forceinline__ void leave(int lane) {
+    if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  }
+};
+
 // A gathered row read of the wave-row forms: buffer_load with the table as the buffer (base + size in four SGPRs, made once per wave
 // from kernel arguments), the lane's byte offset inside the row in voffset (loop-invariant) and the ROW's byte offset - wave-uniform,
 // out of v_readlane - in soffset: no vector instruction per edge for the address (global_load wanted a 64-bit add per edge).  The
@@ -263,63 +332,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   const uint32_t c16 = (uint32_t)c * 16u;
   const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
 
-  // ---- loose lockstep inside an XCD -------------------------------------------------------------------------------
-  // The natural lockstep (same start, same work) drifts like a random walk: with ~6000 edges per group the waves of an
-  // XCD spread over ~+-3 % of the table (+-6 MB at 238 MB) - more than the 4 MiB L2.  So every wave publishes the step
-  // (round * slabs + slab) it is working on in a per-XCD array and does not START a slab more than `window` slabs
-  // ahead of the slowest registered wave of its XCD.  Only leaders ever wait, the slowest wave never does, a wave
-  // that is not resident is not registered, and every wait is bounded: no deadlock by construction.  Same-XCD
-  // visibility: plain stores go through to the XCD's L2, the polls bypass L1 (nt loads).
-  int my_slot = -1;
-  int *xprog = nullptr;
-  if (p.window >= 0) {
-    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;        // HW_REG_XCC_ID[3:0]
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    xprog = p.prog + xcc * kProgSlots;
-    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
-  }
-  int published = -1;
-  int known_min = -1;                         // a lower bound of the slowest wave's step (steps only grow)
-  int timeouts = 0;                           // consecutive waits that ran out (wave-uniform)
-  auto slab_sync = [&](int step) {            // wave-uniform
-    if (my_slot < 0 || step <= published) return;
-    published = step;
-    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
-    if (known_min + p.window >= step) return; // the last poll already allows this step: no memory round trip
-    bool ok = false;
-    for (int tries = 0; tries < kSyncTries; ++tries) {
-      int m = kProgIdle;
-#pragma unroll
-      for (int q = 0; q < kProgSlots / 64; ++q) {
-        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
-        m = v < m ? v : m;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(m, o, 64);
-        m = other < m ? other : m;
-      }
-      known_min = m;
-      if (m + p.window >= step || step - m > p.far) {
-        ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    // Bounded in AGGREGATE too: a wait is ~1 ms at most, and a wave whose waits run out kSyncGiveUp times in a row stops
-    // keeping step for the rest of the launch (it withdraws its progress word, so nobody waits for it either).  That is
-    // the situation of a grid that does not have the chip to itself - another persistent grid of this process, of another
-    // process, or a replayed graph on a second stream holds the CUs its slowest waves would run on: lockstep has nothing to
-    // offer there, and without this rule thousands of steps x a timed-out wait each would look like a hang.  Timing only:
-    // the result never depends on the lockstep.
-    if (ok) timeouts = 0;
-    else if (++timeouts >= kSyncGiveUp) {
-      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
-      my_slot = -1;
-    }
-  };
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
 
   // a unit's accumulator rows are touched by that unit's lanes only, each lane its own 16 bytes: plain LDS
   // read / write (ds_read_b128 / ds_write_b128), no atomics (LDS float atomics measured ~30x slower per byte)
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
         if (p.window >= 0) {                         // which slab does this batch start in (the wave's first unit decides)
           const int first_row = WAVE_ROW ? (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, b) >> 8) : __builtin_amdgcn_readlane(my_src, b);
           const int has_edge = __builtin_amdgcn_readfirstlane(n_here) > b;
-          if (has_edge) slab_sync(r * p.n_slabs + (first_row >> p.slab_shift));
+          if (has_edge) lock.at(p, lane, r * p.n_slabs + (first_row >> p.slab_shift));
         }
         f4_t v[kU];
         int dls[kU];
@@ -524,10 +538,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) accV[((size_t)cur * lpr + c) * NV + q] = acc[q];
     }
-    if (p.window >= 0 && my_slot >= 0) {             // done with this round: never hold the others back
-      published = (r + 1) * p.n_slabs;
-      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
-    }
+    lock.round_done(p, lane, r);
     // the group's rows: dst for whole rows, the carry buffer for the pieces of a split hub
     if (has) {
       const int64_t v0 = P.g_vrow0[pos];
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
       }
     }
   }
-  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  lock.leave(lane);
 }
 
 // Rows of 512 / 256 bytes: ONE ROW PER WAVE-INSTRUCTION, E = row elements / 64 per lane (8 or 4 bytes a lane) - the scalar path of
@@ -634,49 +645,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
     return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
   };
 
-  // ---- loose lockstep inside an XCD (as in seg_slab_kernel) ---------------------------------------------------------
-  int my_slot = -1;
-  int *xprog = nullptr;
-  if (p.window >= 0) {
-    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    xprog = p.prog + xcc * kProgSlots;
-    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
-  }
-  int published = -1, known_min = -1, timeouts = 0;
-  auto slab_sync = [&](int step) {
-    if (my_slot < 0 || step <= published) return;
-    published = step;
-    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
-    if (known_min + p.window >= step) return;
-    bool ok = false;
-    for (int tries = 0; tries < kSyncTries; ++tries) {
-      int m = kProgIdle;
-#pragma unroll
-      for (int q = 0; q < kProgSlots / 64; ++q) {
-        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
-        m = v < m ? v : m;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(m, o, 64);
-        m = other < m ? other : m;
-      }
-      known_min = m;
-      if (m + p.window >= step || step - m > p.far) {
-        ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (ok) timeouts = 0;
-    else if (++timeouts >= kSyncGiveUp) {
-      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
-      my_slot = -1;
-    }
-  };
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
   auto zero = [] {                                      // (the reduction's identity)
     accv_t z;
     if constexpr (E == 1) z = kIdent;
@@ -755,7 +725,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
       // them - a conditional load inside one shared body made every batch's last row wait for vmcnt(0))
       auto batch = [&](const int b, auto first_c) __attribute__((always_inline)) {
         constexpr bool kFirst = decltype(first_c)::value;
-        if (p.window >= 0) slab_sync(r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, b) >> (8 + p.slab_shift)));
+        if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, b) >> (8 + p.slab_shift)));
         if constexpr (WMODE == 1 || WMODE == 2) {
           // the next chunk's weights, in edge order: their place comes out of e_perm (loaded behind the first batch) - read it at the
           // TOP of the second batch, where everything outstanding is a batch old, not behind that batch's gathers
@@ -832,10 +802,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
     if (WMODE == 0 || wpo_rt) chunks(std::true_type{});
     else chunks(std::false_type{});
     if (cur != 255) accV[(size_t)cur * 64 + lane] = acc;
-    if (p.window >= 0 && my_slot >= 0) {
-      published = (r + 1) * p.n_slabs;
-      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
-    }
+    lock.round_done(p, lane, r);
     if (has) {
       const int64_t v0 = P.g_vrow0[pos];
       for (int l = 0; l < nv; ++l) {
@@ -862,7 +829,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
       }
     }
   }
-  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  lock.leave(lane);
 }
 
 // Rows of 512 bytes under multi-head weights, TWO ROWS PER WAVE-INSTRUCTION (an EXPERIMENT, option "slab_pair"; off by default): the
@@ -909,49 +876,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wpair_kernel(SlabParams p) 
   const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, rsh, p.probe);
   typedef T t4_t __attribute__((ext_vector_type(4)));
 
-  // ---- loose lockstep inside an XCD (as in seg_slab_kernel) ---------------------------------------------------------
-  int my_slot = -1;
-  int *xprog = nullptr;
-  if (p.window >= 0) {
-    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    xprog = p.prog + xcc * kProgSlots;
-    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
-  }
-  int published = -1, known_min = -1, timeouts = 0;
-  auto slab_sync = [&](int step) {
-    if (my_slot < 0 || step <= published) return;
-    published = step;
-    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
-    if (known_min + p.window >= step) return;
-    bool ok = false;
-    for (int tries = 0; tries < kSyncTries; ++tries) {
-      int m = kProgIdle;
-#pragma unroll
-      for (int q = 0; q < kProgSlots / 64; ++q) {
-        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
-        m = v < m ? v : m;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(m, o, 64);
-        m = other < m ? other : m;
-      }
-      known_min = m;
-      if (m + p.window >= step || step - m > p.far) {
-        ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (ok) timeouts = 0;
-    else if (++timeouts >= kSyncGiveUp) {
-      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
-      my_slot = -1;
-    }
-  };
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
   const f4_t z4 = {0.f, 0.f, 0.f, 0.f};
 
   for (int r = 0; r < p.rounds; ++r) {
@@ -1028,7 +954,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wpair_kernel(SlabParams p) 
       int n_max = len - off;
       n_max = n_max < 64 ? n_max : 64;
       for (int b = 0; b < n_max; b += 2 * kI) {
-        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
+        if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
         f4_t v[kI];
         int dl0[kI], dl1[kI];
         float ws[kI];
@@ -1076,10 +1002,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wpair_kernel(SlabParams p) 
     }
     hand_in(0, cur0);
     hand_in(1, cur1);
-    if (p.window >= 0 && my_slot >= 0) {
-      published = (r + 1) * p.n_slabs;
-      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
-    }
+    lock.round_done(p, lane, r);
     if (has) {                                            // the group's rows, two at a time (a half each)
       const int64_t v0 = P.g_vrow0[pos];
       for (int l0 = 0; l0 < nv; l0 += 2) {
@@ -1099,7 +1022,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wpair_kernel(SlabParams p) 
       }
     }
   }
-  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  lock.leave(lane);
 }
 
 // SDDMM over the same plan (d/dweight of gather_weight_scatter on a dense graph): out[e] = <m1[dst(e)], m2[src(e)]>.
@@ -1131,48 +1054,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
   for (int hh = p.H; hh > 1; hh >>= 1) --lph_log2;
   const int lph = 1 << lph_log2;
 
-  int my_slot = -1;
-  int *xprog = nullptr;
-  if (p.window >= 0) {
-    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    xprog = p.prog + xcc * kProgSlots;
-    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
-  }
-  int published = -1, known_min = -1, timeouts = 0;
-  auto slab_sync = [&](int step) {              // (as in seg_slab_kernel: every wait bounded, and bounded in aggregate)
-    if (my_slot < 0 || step <= published) return;
-    published = step;
-    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
-    if (known_min + p.window >= step) return;
-    bool ok = false;
-    for (int tries = 0; tries < kSyncTries; ++tries) {
-      int m = kProgIdle;
-#pragma unroll
-      for (int q = 0; q < kProgSlots / 64; ++q) {
-        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
-        m = v < m ? v : m;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(m, o, 64);
-        m = other < m ? other : m;
-      }
-      known_min = m;
-      if (m + p.window >= step || step - m > p.far) {
-        ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (ok) timeouts = 0;
-    else if (++timeouts >= kSyncGiveUp) {
-      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
-      my_slot = -1;
-    }
-  };
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
 
   for (int r = 0; r < p.rounds; ++r) {
     const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
@@ -1224,7 +1107,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
         if (p.window >= 0) {
           const int first_row = __builtin_amdgcn_readlane(my_src, b);
           const int has_edge = __builtin_amdgcn_readfirstlane(n_here) > b;
-          if (has_edge) slab_sync(r * p.n_slabs + (first_row >> p.slab_shift));
+          if (has_edge) lock.at(p, lane, r * p.n_slabs + (first_row >> p.slab_shift));
         }
         f4_t v[kU];
         int dls[kU];
@@ -1287,12 +1170,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_kernel(SlabParams p) 
       my_dl = n_dl;
       my_pe = n_pe;
     }
-    if (p.window >= 0 && my_slot >= 0) {
-      published = (r + 1) * p.n_slabs;
-      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
-    }
+    lock.round_done(p, lane, r);
   }
-  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  lock.leave(lane);
 }
 
 // The same SDDMM for rows of 512 / 256 bytes, ONE ROW PER WAVE-INSTRUCTION (E elements per lane; see seg_slab_wrow_kernel): the forward
@@ -1318,48 +1198,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
   for (int hh = p.H; hh > 1; hh >>= 1) --lph_log2;
   const int lph = 1 << lph_log2;
 
-  int my_slot = -1;
-  int *xprog = nullptr;
-  if (p.window >= 0) {
-    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    xprog = p.prog + xcc * kProgSlots;
-    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
-  }
-  int published = -1, known_min = -1, timeouts = 0;
-  auto slab_sync = [&](int step) {              // (as in seg_slab_kernel: every wait bounded, and bounded in aggregate)
-    if (my_slot < 0 || step <= published) return;
-    published = step;
-    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
-    if (known_min + p.window >= step) return;
-    bool ok = false;
-    for (int tries = 0; tries < kSyncTries; ++tries) {
-      int m = kProgIdle;
-#pragma unroll
-      for (int q = 0; q < kProgSlots / 64; ++q) {
-        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
-        m = v < m ? v : m;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(m, o, 64);
-        m = other < m ? other : m;
-      }
-      known_min = m;
-      if (m + p.window >= step || step - m > p.far) {
-        ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (ok) timeouts = 0;
-    else if (++timeouts >= kSyncGiveUp) {
-      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
-      my_slot = -1;
-    }
-  };
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
   auto raw_zero = [] {
     raw_t z;
     if constexpr (sizeof(raw_t) == 4) z = raw_t(0);
@@ -1403,7 +1243,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
       const int n_here = len - off;
       const int n_max = n_here < 64 ? n_here : 64;
       for (int b = 0; b < n_max; b += kU) {
-        if (p.window >= 0) slab_sync(r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
+        if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (__builtin_amdgcn_readlane(my_src, b) >> p.slab_shift));
         raw_t v[kU];
         int dls[kU];
 #pragma unroll
@@ -1457,12 +1297,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
       my_dl = n_dl;
       my_pe = n_pe;
     }
-    if (p.window >= 0 && my_slot >= 0) {
-      published = (r + 1) * p.n_slabs;
-      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
-    }
+    lock.round_done(p, lane, r);
   }
-  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  lock.leave(lane);
 }
 
 // The multi-head SDDMM of 16-bit plans on the MATRIX cores (round 5): out[e, h] = <m1[dst(e), h, :], m2[src(e), h, :]> is a
@@ -1518,48 +1355,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
 #pragma unroll
   for (int i = 0; i < 8; ++i) zero8[i] = (T)0.f;
 
-  int my_slot = -1;
-  int *xprog = nullptr;
-  if (p.window >= 0) {
-    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.prog_cnt + xcc, 1) - kProgIdle;
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    xprog = p.prog + xcc * kProgSlots;
-    if (slot >= 0 && slot < kProgSlots) my_slot = slot;
-  }
-  int published = -1, known_min = -1, timeouts = 0;
-  auto slab_sync = [&](int step) {              // (as in seg_slab_kernel: every wait bounded, and bounded in aggregate)
-    if (my_slot < 0 || step <= published) return;
-    published = step;
-    if (lane == 0) __builtin_nontemporal_store(step, xprog + my_slot);
-    if (known_min + p.window >= step) return;
-    bool ok = false;
-    for (int tries = 0; tries < kSyncTries; ++tries) {
-      int m = kProgIdle;
-#pragma unroll
-      for (int q = 0; q < kProgSlots / 64; ++q) {
-        const int v = __builtin_nontemporal_load(xprog + q * 64 + lane);
-        m = v < m ? v : m;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(m, o, 64);
-        m = other < m ? other : m;
-      }
-      known_min = m;
-      if (m + p.window >= step || step - m > p.far) {
-        ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    if (ok) timeouts = 0;
-    else if (++timeouts >= kSyncGiveUp) {
-      if (lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
-      my_slot = -1;
-    }
-  };
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
   auto wave_order = [] {                        // LDS words written by some lanes and read by others: keep the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1598,7 +1395,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
       const int n_here = len - off;
       const int n_max = n_here < 64 ? n_here : 64;
       for (int t = 0; t < 4 && 16 * t < n_max; ++t) {
-        if (p.window >= 0) slab_sync(r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, 16 * t) >> (8 + p.slab_shift)));
+        if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, 16 * t) >> (8 + p.slab_shift)));
         raw2_t rv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {          // one edge's whole row per instruction (slots behind the last edge: row 0)
@@ -1651,12 +1448,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
       }
       my_edge = (nvalid && n_src < src_rows) ? ((n_src << 8) | n_dl) : 255u;
     }
-    if (p.window >= 0 && my_slot >= 0) {
-      published = (r + 1) * p.n_slabs;
-      if (lane == 0) __builtin_nontemporal_store(published, xprog + my_slot);
-    }
+    lock.round_done(p, lane, r);
   }
-  if (my_slot >= 0 && lane == 0) __builtin_nontemporal_store(kProgIdle, xprog + my_slot);
+  lock.leave(lane);
 }
 
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row).  The pieces meet in FLOAT64 and are
@@ -1755,7 +1549,7 @@ __global__ __launch_bounds__(kThreads) void slab_unstage_kernel(const int64_t *_
 
 extern "C" int g_slab_turn;
 // The persistent grids are sized for the whole chip and keep step per XCD: two of them at once take each other's CUs and
-// lockstep has nothing to offer (the kernels stay correct and bounded - slab_sync gives up - but both run slower than one
+// lockstep has nothing to offer (the kernels stay correct and bounded - SlabStep gives up - but both run slower than one
 // after the other).  So the launches of this process take turns per device, whichever stream, thread or entry point (the
 // torch plugin, ctypes, a C caller) they come from: a launch waits, on ITS stream, for the event of the previous one.
 // An optimisation, not a safety net: a stream that is being captured skips it (an event recorded outside a capture cannot
