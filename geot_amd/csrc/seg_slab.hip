@@ -26,8 +26,12 @@
 // Kernels: seg_slab_kernel (all weight modes and reductions; rows of 1 KiB run one row per wave-instruction on scalar bases - group
 // bounds, row numbers, row switches in SGPRs -, 128-byte rows as lane groups of 8 lanes), seg_slab_wrow_kernel (every weight mode and multi-head
 // weights on rows of 512 / 256 bytes: the scalar path at 8 / 4 bytes per lane, a unit = a wave), seg_slab_combine_kernel,
-// seg_slab_sddmm_kernel (d/dweight over the same plan; results staged in plan order) + slab_unstage_kernel (into edge order, a group at a
-// time through LDS).  Measurements and what bounds them: DESIGN.md section 3.1d.
+// seg_slab_sddmm_kernel / seg_slab_sddmm_wrow_kernel (d/dweight and attention scores over the same plan; results staged in plan order)
+// + slab_unstage_kernel (into edge order, a group at a time through LDS), seg_slab_sddmm_mfma_kernel (the 16-bit multi-head SDDMM of
+// 512-byte rows on the matrix cores), slab_stage_weights*_kernel (per-call weights into plan order), seg_slab_wpair_kernel (an
+// experiment behind "slab_pair").  The waves of an XCD keep loose step through SlabStep.  Row gathers of the wave-row forms are
+// buffer_loads with scalar row offsets (slab_row_load); "slab_probe" drops them to time a kernel without its gathers.
+// Measurements and what bounds them (instruction issue, not the gathers): DESIGN.md section 3.1d.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
