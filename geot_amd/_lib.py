@@ -41,7 +41,7 @@ SYMBOLS = [
     "geot_csr_workspace_bytes", "geot_csr_gws", "geot_coo_to_csr",
     "geot_slab_units", "geot_slab_full_chip", "geot_slab_rows_per_group", "geot_slab_rows_per_group_dtype", "geot_slab_units_for", "geot_slab_rows_per_group_shape", "geot_slab_workspace_bytes", "geot_slab_workspace_bytes_staged", "geot_slab_spmm", "geot_slab_sddmm", "geot_slab_sddmm_staged", "geot_slab_mh_sddmm", "geot_slab_to_plan_order",
     "geot_slab_plan_scratch_bytes", "geot_slab_plan_rows", "geot_slab_plan_groups", "geot_slab_plan_edges",
-    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_tune", "geot_set_option", "geot_last_kernel",
+    "geot_profile_enable", "geot_profile_reset", "geot_profile_read", "geot_profile_box", "geot_profile_box_rows", "geot_tune", "geot_set_option", "geot_last_kernel",
 ]
 
 class SlabPlan(ctypes.Structure):
@@ -255,6 +255,7 @@ def load() -> ctypes.CDLL:
     L.geot_profile_reset.restype = None
     L.geot_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(c_i64)]
     L.geot_profile_box.argtypes = [c_vp, c_sz, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_vp]
+    L.geot_profile_box_rows.argtypes = [c_vp, c_i64, c_i64, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_vp]
     L.geot_tune.argtypes = [c_int, c_int, c_int, c_int]
     L.geot_tune.restype = None
     if L.geot_abi_version() != ABI_VERSION:

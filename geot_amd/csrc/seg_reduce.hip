@@ -1874,6 +1874,33 @@ __global__ __launch_bounds__(kThreads) void box_read_kernel(const float *__restr
   if (s[0] + s[1] + s[2] + s[3] == 123.456f) sink[0] = s[0];
 }
 
+// Uniform-random rows of `piece16 * 16` bytes out of the caller's table, 16 row reads in flight per lane, nothing else: the
+// yardstick of the per-edge gather kernels (configs[4]: a 57 GB table, every row a miss) - the streamed-read ceiling above is
+// the wrong one for them.  A group of `piece16` lanes reads one row per step; the row number is a hash of (group, step).
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void box_rows_kernel(const float *__restrict__ a, float *sink, unsigned long long rows, int piece16,
+                                                             int steps, unsigned seed) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const f4_t *p = reinterpret_cast<const f4_t *>(a);
+  const unsigned tid = blockIdx.x * kThreads + threadIdx.x;
+  const unsigned group = tid / (unsigned)piece16, lane = tid % (unsigned)piece16;
+  f4_t s = {0, 0, 0, 0};
+  unsigned long long x = ((unsigned long long)group << 32) ^ seed;
+  for (int i = 0; i < steps; i += 16) {
+    f4_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      x = x * 6364136223846793005ull + 1442695040888963407ull; // (one 64-bit LCG step per row: the top 32 bits pick it)
+      const unsigned long long r = ((x >> 32) * rows) >> 32;
+      const f4_t *q = p + r * (unsigned long long)piece16 + lane;
+      v[u] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  if (s[0] + s[1] + s[2] + s[3] == 123.456f) sink[0] = s[0];
+}
+
 __global__ void box_clock_kernel(unsigned long long *out, int spins) {
   const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
   float x = (float)threadIdx.x;
@@ -3028,6 +3055,49 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
   HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (sclk_mhz) *sclk_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0; // s_memrealtime ticks at 100 MHz
+  return GEOT_OK;
+}
+
+int geot_profile_box_rows(const void *table, int64_t rows, int64_t row_bytes, int iters, double *row_gbps, double *row_gbps_nt, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t piece16 = row_bytes / 16;
+  if (!table || rows < 1 || rows >= (int64_t(1) << 32) || row_bytes < 16 || row_bytes % 16 || piece16 > 64 || (piece16 & (piece16 - 1)) || iters < 1)
+    return fail(GEOT_EINVAL, "profile_box_rows: needs a device table of 1 .. 2^32 - 1 rows of 16 * 2^k <= 1024 bytes");
+  float *d = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Cleanup {
+    float *&d;
+    hipEvent_t &e0, &e1;
+    ~Cleanup() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (d) (void)hipFree(d);
+    }
+  } cleanup{d, e0, e1};
+  HIP_TRY(hipMalloc(&d, 64));
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  // ~16 GB of row reads a pass (a few ms): 256 CUs x 8 workgroups, every lane group 16 rows a step
+  const int grid = 256 * 8;
+  const int64_t groups = (int64_t)grid * kThreads / piece16;
+  int steps = (int)(((int64_t(16) << 30) / row_bytes / groups + 15) / 16 * 16);
+  if (steps < 16) steps = 16;
+  const double bytes = (double)groups * steps * row_bytes;
+  float best[2] = {1e30f, 1e30f};
+  for (int it = 0; it < 2 * (iters + 1); ++it) {
+    HIP_TRY(hipEventRecord(e0, st));
+    if (it & 1)
+      hipLaunchKernelGGL(box_rows_kernel<true>, dim3(grid), dim3(kThreads), 0, st, static_cast<const float *>(table), d, (unsigned long long)rows, (int)piece16, steps, 12345u + it);
+    else
+      hipLaunchKernelGGL(box_rows_kernel<false>, dim3(grid), dim3(kThreads), 0, st, static_cast<const float *>(table), d, (unsigned long long)rows, (int)piece16, steps, 12345u + it);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (it > 1 && ms < best[it & 1]) best[it & 1] = ms; // the first pass of each form warms up
+  }
+  if (row_gbps) *row_gbps = bytes / (best[0] * 1e-3) / 1e9;
+  if (row_gbps_nt) *row_gbps_nt = bytes / (best[1] * 1e-3) / 1e9;
   return GEOT_OK;
 }
 

@@ -38,6 +38,8 @@ class PlanOrdered:
     flows through it); ``with_values`` wraps the result of elementwise work; ``edge_order()`` leaves the plan's order."""
 
     def __init__(self, graph: "Graph", plan, values: torch.Tensor):
+        """``plan is None``: the graph has no plan for this shape (not dense enough, a row width the source-blocked kernels do not
+        serve) - the values are in the ORIGINAL edge order, and every method still works."""
         self.graph, self.plan, self.values = graph, plan, values
 
     def with_values(self, values: torch.Tensor) -> "PlanOrdered":
@@ -47,16 +49,18 @@ class PlanOrdered:
 
     def edge_order(self) -> torch.Tensor:
         """The values in ORIGINAL edge order (one scatter through the plan's permutation)."""
+        if self.plan is None:
+            return self.values
         return _PlanToEdge.apply(self.graph, self.plan, self.values)
 
     @property
     def dst(self) -> torch.Tensor:
-        """Destination row of every plan position (int64 [nnz]) - the key of a per-row softmax over ``values``."""
-        return self.graph._plan_endpoints(self.plan)[0]
+        """Destination row of every position (int64 [nnz]) - the key of a per-row softmax over ``values``."""
+        return self.graph.dst_index if self.plan is None else self.graph._plan_endpoints(self.plan)[0]
 
     @property
     def src(self) -> torch.Tensor:
-        return self.graph._plan_endpoints(self.plan)[1]
+        return self.graph.src_index if self.plan is None else self.graph._plan_endpoints(self.plan)[1]
 
 
 def _rows(t: torch.Tensor) -> int:
@@ -218,7 +222,7 @@ class Graph:
         po = isinstance(weight, tuple) and not via
         wmode_plan = 0 if weight is None else (2 if mh else 1)
         plan = self._plan(which, rowbytes, wmode_plan, H, x.dtype, _rows(x)) if (reduce != "prod") else None
-        if mh and (F * x.element_size()) % 16 != 0:
+        if mh and ((F * x.element_size()) % 16 != 0 or H > 16):     # (the host operator's rule too: mh_spmm_common in csrc/torch_ops.cpp)
             plan = None
         w_edge = [None]
 
@@ -336,7 +340,7 @@ class Graph:
     def _sddmm_public(self, m1, m2, plan_order):
         holder = []
         values = _SddmmFn.apply(self, m1, m2, plan_order, holder)
-        if plan_order and holder[0] is not None:
+        if plan_order:                                    # always a PlanOrdered (over no plan = edge order): the caller's code is one shape
             return PlanOrdered(self, holder[0], values)
         return values
 
@@ -352,11 +356,23 @@ class Graph:
             mh = like.dim() == 3
             H, F = (like.shape[1], like.shape[2]) if mh else (1, like.shape[1])
             plan = self._plan("fwd", H * F * like.element_size(), 2 if mh else 1, H, like.dtype, _rows(like))
-            if mh and (F * like.element_size()) % 16 != 0:
+            if mh and ((F * like.element_size()) % 16 != 0 or H > 16):
                 plan = None
             if plan is None:
                 return values
+        if plan is None:
+            return PlanOrdered(self, None, values)
         return PlanOrdered(self, plan, _EdgeToPlan.apply(self, plan, values))
+
+
+def _fit_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    """A gradient over the graph's row count brought to the row count of the tensor it belongs to: zero rows appended for trailing
+    nodes without an edge, surplus rows (all zero by construction) dropped."""
+    if t.shape[0] == rows:
+        return t
+    if t.shape[0] > rows:
+        return t[:rows].contiguous()
+    return torch.nn.functional.pad(t, [0, 0] * (t.dim() - 1) + [0, rows - t.shape[0]])
 
 
 def _kind(reduce: str) -> str:
@@ -368,6 +384,8 @@ def _split(g: Graph, weight, dims: int):
     if isinstance(weight, PlanOrdered):
         if weight.graph is not g:
             raise ValueError("PlanOrdered values of another Graph")
+        if weight.values.dim() != dims or weight.values.shape[0] != g.nnz:
+            raise RuntimeError("weight must be 1 dimensional with one value per edge" if dims == 1 else "Invalid weight size")
         return weight.plan, weight.values
     if weight.shape[0] != g.nnz or weight.dim() != dims:
         raise RuntimeError("weight must be 1 dimensional with one value per edge" if dims == 1 else "Invalid weight size")
@@ -441,7 +459,7 @@ class _SpmmFn(torch.autograd.Function):
                 def list_order(vals=vals, plan=plan):       # the weights in the transposed LIST's order (per-edge kernels, trials)
                     return hip.gather_rows_out(g._values_for_bwd(plan, None), vals, torch.empty_like(vals))
                 w_t = ("via", g._bwd_reader(plan, bwd_plan), vals, list_order) if bwd_plan is not None else list_order()
-            gx = g._spmm("bwd", w_t, grad)
+            gx = _fit_rows(g._spmm("bwd", w_t, grad), x.shape[0])     # (x may have trailing rows no edge reads: src_rows = max(src_index) + 1)
         if ctx.has_w and ctx.needs_input_grad[2]:
             wplan, gw = g._sddmm(grad, x.detach(), plan is not None)      # (plan order asked for when the weight came in plan order)
             if plan is not None and wplan is not plan:       # the scores came back in another order than the weight's: re-order once
@@ -477,8 +495,7 @@ class _SddmmFn(torch.autograd.Function):
         g1 = g2 = None
         if ctx.needs_input_grad[1]:
             g1 = g._spmm("fwd", (plan, grad) if plan is not None else grad, m2.detach())
-            if g1.shape[0] != m1.shape[0]:                   # (more rows in m1 than index[-1] + 1: the tail has no edges)
-                g1 = torch.nn.functional.pad(g1, [0, 0] * (g1.dim() - 1) + [0, m1.shape[0] - g1.shape[0]]) if g1.shape[0] < m1.shape[0] else g1[: m1.shape[0]]
+            g1 = _fit_rows(g1, m1.shape[0])                  # (more rows in m1 than index[-1] + 1: the tail has no edges)
         if ctx.needs_input_grad[2]:
             mh = m1.dim() == 3
             H, F = (m1.shape[1], m1.shape[2]) if mh else (1, m1.shape[1])
@@ -492,6 +509,5 @@ class _SddmmFn(torch.autograd.Function):
             if m1d.shape[0] < g.rows:
                 m1d = torch.nn.functional.pad(m1d, [0, 0] * (m1d.dim() - 1) + [0, g.rows - m1d.shape[0]])
             g2 = g._spmm("bwd", w_t, m1d)
-            if g2.shape[0] != m2.shape[0]:
-                g2 = torch.nn.functional.pad(g2, [0, 0] * (g2.dim() - 1) + [0, m2.shape[0] - g2.shape[0]]) if g2.shape[0] < m2.shape[0] else g2[: m2.shape[0]]
+            g2 = _fit_rows(g2, m2.shape[0])
         return None, g1, g2, None, None

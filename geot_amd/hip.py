@@ -356,6 +356,20 @@ def profile_box(buf: torch.Tensor, iters: int = 5) -> dict:
     return {"read_ceiling_gbps": g.value, "sclk_mhz": c.value}
 
 
+def profile_box_rows(table: torch.Tensor, iters: int = 3) -> dict:
+    """Random-row ceiling of THIS box on the caller's own [rows, F] table (geot_profile_box_rows): uniform-random rows, 16 reads in
+    flight per lane, nothing else - default-policy and non-temporal loads."""
+    dev = _require_gpu(table)
+    if table.dim() != 2 or not table.is_contiguous():
+        raise ValueError("profile_box_rows: a contiguous [rows, F] table")
+    a, b = ctypes.c_double(), ctypes.c_double()
+    with _on_device(dev):
+        rc = _lib.load().geot_profile_box_rows(table.data_ptr(), table.shape[0], table.shape[1] * table.element_size(), iters,
+                                               ctypes.byref(a), ctypes.byref(b), _stream_handle(dev))
+    _lib.check(rc, "geot_profile_box_rows")
+    return {"random_row_gbps": a.value, "random_row_gbps_nt": b.value, "best_gbps": max(a.value, b.value)}
+
+
 def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2: int = -1) -> None:
     _lib.load().geot_tune(edges_per_group, vec, nontemporal, lpr_log2)
     _ws_bytes.clear()  # the tile shape, hence the workspace need, follows the plan

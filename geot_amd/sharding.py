@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Tuple
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -484,12 +486,19 @@ def sharded_gather_scatter_node(src_index_shard: torch.Tensor, dst_index_shard: 
     ``timing`` receives "halo_plan" (the plan: mode, rows fetched) and, on the GPU, event pairs around the fetch ("fetch_events")."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if halo is None:
+        # The plan's compact_index REPLACES src_index_shard, so a remembered plan is used only for the very tensor OBJECT it was
+        # built from, still alive and unwritten (weak reference + version counter): an equally long shard at a recycled address
+        # (fixed-fanout sampling + the caching allocator) is a different object and misses - on every rank alike, so all ranks
+        # enter the collective build together.  A caller that makes a fresh view of its shard per step passes `halo=` instead.
         ident = _ident(src_index_shard, world, rank, tuple(node_offsets))
-        halo = _halo_seen.get(ident) if ident is not None else None
+        seen = _halo_seen.get(ident) if ident is not None else None
+        halo = seen[1] if seen is not None and seen[0]() is src_index_shard else None
         if halo is None:
             halo = HaloPlan.build(src_index_shard, node_offsets, group, all_gather_above)
             if ident is not None:
-                _halo_seen[ident] = halo
+                _halo_seen[ident] = (weakref.ref(src_index_shard), halo)
+                for k in [k for k, (ref, _) in _halo_seen.items() if ref() is None]:
+                    del _halo_seen[k]
                 if len(_halo_seen) > 16:
                     _halo_seen.pop(next(iter(_halo_seen)))
     ev = None

@@ -35,6 +35,12 @@ const char *geot_last_kernel(void);
  * Synchronous; allocates a few bytes; not capturable. */
 int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps, double *sclk_mhz, void *stream);
 
+/* The same box's RANDOM-ROW rate: uniform-random rows of `row_bytes` (16 * 2^k <= 1024) out of the caller's own table of `rows`
+ * rows, 16 row reads in flight per lane, nothing else - with default-policy loads (*row_gbps) and non-temporal ones
+ * (*row_gbps_nt).  The yardstick of the per-edge gather kernels on tables far beyond the caches (BASELINE.json configs[4]:
+ * 57 GB): bench.py quotes the kernel's own row-read rate as a fraction of it.  ~16 GB of reads per pass; synchronous. */
+int geot_profile_box_rows(const void *table, int64_t rows, int64_t row_bytes, int iters, double *row_gbps, double *row_gbps_nt, void *stream);
+
 /* Tuning knobs for experiments: edges per lane-group sub-chunk (0 = auto), forced vector
  * width in elements (0 = auto), non-temporal policy (-1 = auto; 0 = default cache policy, anything else = nt row loads AND nt
  * dst stores on streamed rows - gathered rows always use the default policy; the half-and-half forms of round 1 are no longer

@@ -14,18 +14,22 @@ from conftest import ROOT, powerlaw_index
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks_one_gpu():
+def test_bench_two_ranks_one_gpu(tmp_path):
     env = dict(os.environ, GEOT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "5", "--warmup", "2"]
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--detail-out", str(tmp_path / "detail.json")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(line) <= 3000, len(line)                               # the compact record (what the driver parses at every N)
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 1e9 and r["unit"] == "edges/s"
     assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1
-    leg = r["secondary"]["gather_scatter_cfg5"]                       # configs[4] rides along at every N (a hundredth of it where ranks share a GPU)
+    assert r["ranks_seen"] == 2 and r["boundary_exchange_ms"] > 0 and "secondary" not in r
+    assert r["extras"]["gather_scatter_cfg5_edges_per_s"] > 1e8 and r["extras"]["gather_scatter_cfg5_ms"] > 0
+    full = json.load(open(tmp_path / "detail.json"))
+    leg = full["secondary"]["gather_scatter_cfg5"]                    # configs[4] rides along at every N (a hundredth of it where ranks share a GPU)
     assert "error" not in leg and leg["n_gpus"] == 2 and leg["value"] > 1e8 and leg["scaling"] == "weak"
 
 
@@ -123,33 +127,64 @@ print("RCCL OK")
     assert p.returncode == 0 and "RCCL OK" in p.stdout, p.stderr[-2000:]
 
 
-def test_bench_json_contract_single_gpu():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2"],
+def test_bench_json_contract_single_gpu(tmp_path):
+    """The driver's command (`python3 bench.py --gpus 1 --steps K --warmup W`): the LAST stdout line is the compact record - parseable
+    out of a 2 000-byte tail (round 5's 23.8 KB line was cut by the driver's 8 KB capture: parsed null) - and the full record is in
+    the file it names."""
+    detail = tmp_path / "detail.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--detail-out", str(detail)],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line"
-    r = json.loads(lines[0])
+    assert len(lines[0]) <= 2000, len(lines[0])
+    r = json.loads(p.stdout[-2000:].strip().splitlines()[-1])          # what a reader holding only the tail of stdout sees
+    assert set(r) <= {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                      "data", "config", "roofline", "cpu_baseline", "extras", "detail", "secondary_errors"}, sorted(r)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "extras"):
         assert key in r, key
+    assert "secondary_errors" not in r, r["secondary_errors"]
     assert r["metric"] == "aggregated edges/sec + HBM GB/s, index_scatter feat=64 sorted sum" and r["unit"] == "edges/s"
     assert r["n_gpus"] == 1 and r["steps"] == 5 and r["warmup"] == 2 and r["higher_is_better"] is True
-    assert r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None and "workload" in r["config"]
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None and "configs[1]" in r["config"]["workload"]
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and 0.3 < rf["frac"] < 1.0
     assert rf["traffic"] is None or rf["traffic"] > 2.8e9
+    assert rf["kernel"] == "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"       # from the library (geot_last_kernel)
     cb = r["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["unit"] == "edges/s" and cb["cores"] >= 1 and cb["value"] > 1e6
-    assert r["value"] > 1e9 and abs(r["value"] - 10_000_000 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
-    # BASELINE.json's other configs ride along as `secondary`: configs[0], configs[2] (four stand-ins), configs[3] (two), configs[4]'s shard
-    sec = r["secondary"]
+    assert r["value"] > 1e9 and abs(r["value"] - 10_000_000 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-5
+    ex = r["extras"]                                                  # flat, numbers only, at most ten
+    assert len(ex) <= 10 and all(isinstance(v, (int, float)) for v in ex.values()), ex
+    for name in ("gws_cfg3_ms", "rocsparse_best_ms", "gws_speedup_vs_rocsparse", "mh_spmm_cfg4_ms", "mh_spmm_cfg4_bf16_ms", "gather_scatter_cfg5_ms",
+                 "gather_scatter_cfg5_edges_per_s", "cfg5_kernel_frac_of_box_random_row", "cfg1_us_per_call"):
+        assert ex.get(name, 0) > 0, (name, ex)
+    assert 0.5 < ex["cfg5_kernel_frac_of_box_random_row"] < 1.3
+    # BASELINE.json's other configs, in full, in the file: configs[0], configs[2], configs[3] (fp32 + bf16), configs[4]'s shard
+    full = json.load(open(detail))
+    assert r["detail"] and all(abs(full[k] - r[k]) <= 1e-5 * abs(full[k]) for k in ("value", "ms_per_step"))
+    sec = full["secondary"]
+    for name in ("cfg1", "gws_cfg3", "mh_spmm_cfg4", "mh_spmm_cfg4_bf16", "gather_scatter_cfg5"):
+        assert name in sec and "error" not in sec[name], (name, sec.get(name))
+        assert 0 < sec[name]["roofline"]["frac"] < 1
+    assert sec["cfg1"]["us_per_call_as_dispatched"] < 100 and sec["cfg1"]["cpu_baseline"]["value"] > 0
+    assert 0 < sec["cfg1"]["kernel_us"] < sec["cfg1"]["us_per_call_as_dispatched"] * 1.5 and "graph" in sec["cfg1"]["kernel_us_source"]
+    assert sec["gather_scatter_cfg5"]["n_gpus"] == 1 and sec["gather_scatter_cfg5"]["value"] > 1e9
+    assert sec["gather_scatter_cfg5"]["roofline"]["box_random_row_gbps"] > 1000
+
+
+def test_bench_all_secondaries_small_scale(tmp_path):
+    """`--secondary all` (profiling sessions): every stand-in lands in the detail file; the stdout line stays compact."""
+    detail = tmp_path / "detail.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.02", "--no-cpu-baseline",
+                        "--secondary", "all", "--detail-out", str(detail)], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.strip()][-1]
+    assert len(line) <= 3000 and "cpu_baseline" not in json.loads(line)
+    sec = json.load(open(detail))["secondary"]
     for name in ("cfg1", "gws_cfg3", "gws_cfg3_local", "gws_cfg3_powerlaw_src", "gws_cfg3_blockmodel", "mh_spmm_cfg4", "mh_spmm_cfg4_powerlaw_src",
+                 "mh_spmm_cfg4_coalesced", "gws_cfg3_bf16", "mh_spmm_cfg4_bf16", "gws_train_step_cfg4_graph", "mh_train_step_cfg4_graph",
                  "gather_scatter_cfg5"):
         assert name in sec and "error" not in sec[name], (name, sec.get(name))
-        assert 0 < sec[name]["roofline"]["frac"] < 1 and "traffic_source" in sec[name]["roofline"]
-    assert sec["cfg1"]["us_per_call_as_dispatched"] < 100 and sec["cfg1"]["cpu_baseline"]["value"] > 0
-    assert sec["gather_scatter_cfg5"]["n_gpus"] == 1 and sec["gather_scatter_cfg5"]["value"] > 1e9
-    assert sec["gws_cfg3_blockmodel"]["renumbered"]["speedup_vs_as_shipped"] > 1.2
-    assert r["roofline"]["kernel"] == "seg_tile_kernel<float, 4, false, 0, false, 3, 3, 16>"       # from the library (geot_last_kernel)

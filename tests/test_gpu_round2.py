@@ -461,14 +461,16 @@ def test_bench_launches_its_own_ranks():
         assert 0 < r["roofline"]["frac"] < 1
 
 
-def test_bench_secondary_object_small_scale():
+def test_bench_secondary_object_small_scale(tmp_path):
     """The `secondary` object (gws vs rocSPARSE, mh_spmm) at 2 % scale: keys and sanity of the numbers."""
     import json
     import subprocess
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--scale", "0.02",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu-baseline", "--secondary", "all", "--full", "--detail-out", str(tmp_path / "detail.json")],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])     # --full: the whole record on stdout (tools/profile_round.sh)
+    assert r == json.load(open(tmp_path / "detail.json"))
     sec = r["secondary"]
     assert "error" not in sec, sec
     g = sec["gws_cfg3"]

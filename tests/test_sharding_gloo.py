@@ -272,10 +272,24 @@ def _node_worker(rank, world, port, case, q):
                                                               halo=sharding.HaloPlan.build(t(case["si"][sl]), offs, None, above))
             plan = timing["halo_plan"]
             res[name] = (first, out.numpy().copy(), plan.mode, plan.rows_fetched, plan.table_rows)
-        # the remembered plan (no `halo=`): built on the first call, found on the second
-        a, _ = sharding.sharded_gather_scatter_node(t(case["si"][sl]), t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
-        b, _ = sharding.sharded_gather_scatter_node(t(case["si"][sl]), t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
-        assert torch.equal(a, b) and torch.equal(a, rep)
+        # the remembered plan (no `halo=`): built on the first call, found on the second - for the SAME tensor object only
+        builds = []
+        real_build = sharding.HaloPlan.build
+        sharding.HaloPlan.build = staticmethod(lambda *a, **k: (builds.append(1), real_build(*a, **k))[1])
+        si_np = case["si"][sl].copy()
+        si_t = t(si_np)
+        a, _ = sharding.sharded_gather_scatter_node(si_t, t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
+        b, _ = sharding.sharded_gather_scatter_node(si_t, t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
+        assert torch.equal(a, b) and torch.equal(a, rep) and len(builds) == 1
+        # another edge shard of the same length at the SAME address with version 0 (what the caching allocator hands a fixed-fanout
+        # sampler): a different object - the plan is rebuilt (on every rank alike), never silently the old graph's sources
+        si_np[:] = np.roll(case["si"], 17)[sl]                            # (a numpy write: no version counter sees it)
+        si_new = t(si_np)
+        assert si_new.data_ptr() == si_t.data_ptr() and si_new._version == si_t._version
+        c, _ = sharding.sharded_gather_scatter_node(si_new, t(case["dst"][sl]), x_mine, offs, weight_shard=t(case["w"][sl]), local_op=local_op)
+        want, _ = sharding.sharded_gather_scatter(si_new, t(case["dst"][sl]), t(case["x"]), weight_shard=t(case["w"][sl]), local_op=local_op)
+        assert len(builds) == 2 and torch.equal(c, want)
+        sharding.HaloPlan.build = real_build
         q.put((rank, res))
         dist.barrier()
     finally:

@@ -1,15 +1,18 @@
 #!/bin/bash
-# GPU session driver (round 4; logs under gpurun_out/r04): `gpurun --timeout 3300 -- bash tools/gpu_session.sh [steps...]`
+# GPU session driver (logs under gpurun_out/r06): `gpurun --timeout 3300 -- bash tools/gpu_session.sh [steps...]`
 # Each step writes its log under gpurun_out/r02/ and is bounded by its own timeout.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-O=gpurun_out/r04
+O=gpurun_out/r06
 mkdir -p $O
 steps="${@:-tests bench kexp unsorted soak}"
 for s in $steps; do
   echo "=== $s $(date +%T)"
   case $s in
+    r6a)      timeout 1200 python3 -m pytest tests/test_gpu_graph_handle.py tests/test_gpu_multirank.py -m gpu -x -q > $O/pytest_r6a.log 2>&1; echo "rc=$?"; tail -8 $O/pytest_r6a.log
+              ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out $O/bench_driver_detail.json > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err ) 2> $O/bench_driver_cmd.time; echo "rc=$?"
+              cat $O/bench_driver_cmd.time; wc -c $O/bench_driver_cmd.json; cat $O/bench_driver_cmd.json; tail -3 $O/bench_driver_cmd.err ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
@@ -80,7 +83,7 @@ for s in $steps; do
                  set -- $spec
                  timeout 900 python3 tools/sweep_slab.py --case $1 --dtype $2 2>&1 | grep -v amdgpu.ids > $O/sweep_slab_$1_$2_v2.txt; cat $O/sweep_slab_$1_$2_v2.txt | head -9
                done ;;
-    benchmh)  timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --only-secondary mh_spmm_cfg4,mh_spmm_cfg4_powerlaw_src,mh_spmm_cfg4_coalesced,mh_spmm_cfg4_bf16 > $O/bench_mh.json 2> $O/bench_mh.err; echo "rc=$?"; python3 -c "
+    benchmh)  timeout 900 python3 bench.py --full --steps 20 --warmup 5 --no-cpu-baseline --only-secondary mh_spmm_cfg4,mh_spmm_cfg4_powerlaw_src,mh_spmm_cfg4_coalesced,mh_spmm_cfg4_bf16 > $O/bench_mh.json 2> $O/bench_mh.err; echo "rc=$?"; python3 -c "
 import json; d=json.load(open('$O/bench_mh.json'))
 for k,v in d['secondary'].items(): print(k, {a:b for a,b in v.items() if a in ('kernel_ms','kernel','error','kernel_ms_without_content_guard')})" ;;
     mhrow)    timeout 1200 python3 -m pytest tests/test_gpu_slab.py -x -q -m gpu 2>&1 | tail -6

@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/r04/pmc_sq_bench}
 rm -rf "$OUT"; mkdir -p "$OUT"
 C1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"
-rocprofv3 --pmc $C1 --output-format csv -d "$OUT/headline" -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/headline.json" 2> "$OUT/headline.err"
+rocprofv3 --pmc $C1 --output-format csv -d "$OUT/headline" -o pmc -- python3 bench.py --full --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/headline.json" 2> "$OUT/headline.err"
 for w in gws_cfg3 gws_cfg3_local gws_cfg3_bf16 mh_spmm_cfg4; do
-  rocprofv3 --pmc $C1 --output-format csv -d "$OUT/$w" -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $w > "$OUT/$w.json" 2> "$OUT/$w.err"
+  rocprofv3 --pmc $C1 --output-format csv -d "$OUT/$w" -o pmc -- python3 bench.py --full --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $w > "$OUT/$w.json" 2> "$OUT/$w.err"
 done
 find "$OUT" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
 find "$OUT" -name "*.csv" -size +4M -delete

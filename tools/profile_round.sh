@@ -10,27 +10,27 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-python3 bench.py --steps 100 --warmup 10 > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+python3 bench.py --full --steps 100 --warmup 10 > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
 # ---- headline (BASELINE.json configs[1])
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 bench.py --full --steps 100 --warmup 10 --no-cpu-baseline --no-secondary \
     > "$OUT/bench_under_kernel_trace.json" 2> "$OUT/kt.err"
 for c in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
-  rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary \
+  rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- python3 bench.py --full --steps 5 --warmup 2 --no-cpu-baseline --no-secondary \
       > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err"
 done
 # ---- the secondary workloads, one at a time
 # (gather_scatter_cfg5 = BASELINE.json configs[4]'s one-GPU shard: bench.py selects it with `--only-secondary cfg5`)
 for w in ${WORKLOADS:-gws_cfg3 gws_cfg3_local gws_cfg3_powerlaw_src gws_cfg3_blockmodel_asis gws_cfg3_blockmodel_renum mh_spmm_cfg4 mh_spmm_cfg4_powerlaw_src gws_cfg3_bf16 mh_spmm_cfg4_bf16 gather_scatter_cfg5}; do
   sel=$w; [ $w = gather_scatter_cfg5 ] && sel=cfg5
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -o bench -- python3 bench.py --full --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
       > "$OUT/kt_$w.json" 2> "$OUT/kt_$w.err"
   for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; do
-    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${c}__$w" -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${c}__$w" -o pmc -- python3 bench.py --full --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
         > "$OUT/pmc_${c}__$w.json" 2> "$OUT/pmc_${c}__$w.err"
   done
 done
 # configs[0] is launch-bound: its kernel's own duration can only come from a trace (HIP events bracket the launch gap too)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfg1" -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --only-secondary cfg1 \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfg1" -o bench -- python3 bench.py --full --steps 2 --warmup 1 --no-cpu-baseline --only-secondary cfg1 \
     > "$OUT/kt_cfg1.json" 2> "$OUT/kt_cfg1.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/cal_$c" -o cal -- ./tools/kbench copy > "$OUT/cal_$c.txt" 2> "$OUT/cal_$c.err"
