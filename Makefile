@@ -11,7 +11,7 @@ SRC = geot_amd/csrc/seg_reduce.hip geot_amd/csrc/seg_reduce_f32.hip geot_amd/csr
       geot_amd/csrc/seg_reduce_bf16.hip geot_amd/csrc/seg_slab.hip geot_amd/csrc/seg_sort.hip geot_amd/csrc/seg_plan.hip \
       geot_amd/csrc/seg_guard.hip
 
-.PHONY: all lib tools shim oracle ref clean
+.PHONY: all lib devlib tools shim oracle ref clean
 all: lib tools
 
 # one object per source under geot_amd/csrc/.obj, the stale ones compiled side by side, one link; staleness by content
@@ -19,6 +19,11 @@ all: lib tools
 lib: $(LIB)
 $(LIB): $(SRC) include/geot_hip.h include/geot_hip_dev.h geot_amd/csrc/internal.h
 	python3 geot_amd/_lib.py lib
+
+# the DEVELOPMENT build: the same sources with -DGEOT_DEV_EXPERIMENTS (rejected kernel variants + the timing probe behind switches);
+# loaded instead of the product by processes started with GEOT_HIP_LIB=dev (tools/, tests/test_gpu_dev_variants.py)
+devlib:
+	python3 geot_amd/_lib.py devlib
 
 tools: tools/kbench
 tools/kbench: tools/kbench.cpp $(LIB) include/geot_hip.h
@@ -37,5 +42,5 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -rf $(LIB) tools/kbench geot_amd/_C.so geot_amd/*.srchash geot_amd/csrc/.obj
+	rm -rf $(LIB) geot_amd/libgeot_hip_dev.so tools/kbench geot_amd/_C.so geot_amd/*.srchash geot_amd/csrc/.obj
 	$(MAKE) -C oracle clean

@@ -898,10 +898,14 @@ def cfg5_leg(world, rank, dev, scale, steps, warmup, cuts="equal", collective="a
     # ... and its RANDOM-ROW rate on this very table (uniform-random 512-byte rows, 16 reads in flight per lane, nothing else): the
     # yardstick a per-edge gather kernel on a 57 GB table is to be read against (the streamed ceiling is not: round 5's two boxes
     # were 1 % apart on streams and 13 % apart on this kernel)
+    # ... and that rate with the operator's WRITE MIX: one output row written per `run` rows read (run = this shard's edges per dst row),
+    # nothing else - on this part a few per cent of writes among random reads cost more than their bytes (tools/kexp4.hip: 6.4 TB/s
+    # pure, 5.4 with one row written per 16 read, whatever the store policy), and that is what a gather_scatter kernel can reach
+    run = max(1, round(index.numel() / max(rows, 1)))
     try:
-        rows_box = hip.profile_box_rows(src)
+        rows_box = hip.profile_box_rows(src, out=torch.empty(rows, feat, device=dev), run=run)
     except Exception as e:  # noqa: BLE001
-        rows_box = {"random_row_gbps": None, "random_row_gbps_nt": None, "best_gbps": None, "error": repr(e)}
+        rows_box = {"random_row_gbps": None, "random_row_gbps_nt": None, "best_gbps": None, "mix_row_gbps": None, "mix_run": None, "error": repr(e)}
     uniq = int(torch.unique(src_index).numel())
     comp = index.numel() * 16 + uniq * 4 * feat + rows * 4 * feat
     # what the per-edge gather MOVES: one row read per edge (a 57 GB table is re-read from HBM every time: 256 MiB of Infinity Cache
@@ -922,6 +926,8 @@ def cfg5_leg(world, rank, dev, scale, steps, warmup, cuts="equal", collective="a
                         "box_random_row_gbps": rows_box["best_gbps"], "box_random_row_gbps_default_policy": rows_box["random_row_gbps"],
                         "box_random_row_gbps_nt": rows_box["random_row_gbps_nt"],
                         "row_gather_frac_of_box_random_row": (index.numel() * 4 * feat / ms / 1e6 / rows_box["best_gbps"]) if rows_box["best_gbps"] else None,
+                        "box_random_row_gbps_with_write_mix": rows_box["mix_row_gbps"], "write_mix_run": rows_box["mix_run"],
+                        "row_gather_frac_of_box_row_mix": (index.numel() * 4 * feat / ms / 1e6 / rows_box["mix_row_gbps"]) if rows_box["mix_row_gbps"] else None,
                         "note": "every edge's 512-byte row comes from HBM (table 57 GB >> 256 MiB Infinity Cache): the kernel runs at the part's random-"
                                 "row rate - 4.7 TB/s of row reads from any table >= 4 GB whatever the tile shape, loads in flight, in-tile source "
                                 "order or page locality (profiles/r05/cfg5_study/exp_gather_table*.txt); compulsory bytes credit a row once, the "
@@ -991,8 +997,9 @@ def compact_record(res):
     put("gather_scatter_cfg5_ms", get(sec, "gather_scatter_cfg5", "ms_per_step"))
     put("gather_scatter_cfg5_edges_per_s", get(sec, "gather_scatter_cfg5", "value"))
     put("cfg5_kernel_frac_of_box_random_row", get(sec, "gather_scatter_cfg5", "roofline", "row_gather_frac_of_box_random_row"))
-    put("cfg5_boundary_exchange_ms", get(sec, "gather_scatter_cfg5", "boundary_exchange_ms"))
+    put("cfg5_kernel_frac_of_box_row_write_mix", get(sec, "gather_scatter_cfg5", "roofline", "row_gather_frac_of_box_row_mix"))
     put("cfg1_us_per_call", get(sec, "cfg1", "us_per_call_as_dispatched"))
+    put("cfg5_boundary_exchange_ms", get(sec, "gather_scatter_cfg5", "boundary_exchange_ms"))     # (N > 1, where the entries above are absent)
     out["extras"] = ex
     errs = sorted(k for k, v in sec.items() if isinstance(v, dict) and "error" in v)
     if errs or "error" in sec:

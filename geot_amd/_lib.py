@@ -14,6 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_NAME = "libgeot_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
+# The DEVELOPMENT build: the same sources with -DGEOT_DEV_EXPERIMENTS (measured-and-rejected kernel variants and the timing probe
+# behind geot_set_option switches; include/geot_hip_dev.h).  Loaded INSTEAD of the product library by a process started with
+# GEOT_HIP_LIB=dev (tools/, the A/B tests); it carries the product's soname, so the torch plugin, which names libgeot_hip.so,
+# binds to the copy already in the process.  Nothing that imports geot_amd without that variable ever sees it.
+DEV_LIB_NAME = "libgeot_hip_dev.so"
+DEV_LIB_PATH = os.path.join(_HERE, DEV_LIB_NAME)
+DEV = os.environ.get("GEOT_HIP_LIB", "") == "dev"
 # (the longest compiles first; seg_reduce_<type>.hip are seg_reduce.hip's kernels of one storage type each - they #include it)
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("seg_reduce_f32.hip", "seg_plan.hip", "seg_reduce_f16.hip", "seg_reduce_bf16.hip",
                                                      "seg_reduce_f64.hip", "seg_slab.hip", "seg_reduce.hip", "seg_sort.hip",
@@ -87,28 +94,32 @@ def _stale(binary: str, sources) -> bool:
 
 
 def stamp(which=None) -> None:
-    """Record the content of the sources a binary was built from.  `which`: LIB_PATH or PLUGIN_PATH - the one just built; None
-    (`make shim`'s g++ recipe, which builds behind this module's back) stamps whichever exists."""
-    for binary, sources in ((LIB_PATH, LIB_INPUTS), (PLUGIN_PATH, PLUGIN_INPUTS)):
+    """Record the content of the sources a binary was built from.  `which`: LIB_PATH, DEV_LIB_PATH or PLUGIN_PATH - the one just
+    built; None (`make shim`'s g++ recipe, which builds behind this module's back) stamps whichever exists."""
+    for binary, sources in ((LIB_PATH, LIB_INPUTS), (DEV_LIB_PATH, LIB_INPUTS), (PLUGIN_PATH, PLUGIN_INPUTS)):
         if os.path.exists(binary) and which in (None, binary):
             with open(binary + ".srchash", "w") as f:
                 f.write(_digest(sources) + "\n")
 
 
-def needs_build() -> bool:
-    return _stale(LIB_PATH, LIB_INPUTS)
+def needs_build(dev: bool = False) -> bool:
+    return _stale(DEV_LIB_PATH if dev else LIB_PATH, LIB_INPUTS)
 
 
 OBJ_DIR = os.path.join(_HERE, "csrc", ".obj")        # per-source objects (git-ignored; they do not travel with a snapshot)
 HIPFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", os.path.join(_ROOT, "include")]
 
 
-def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+def build(force: bool = False, verbose: bool = False, jobs: int = 0, dev: bool = False) -> str:
     """Cross-compile the HIP library for gfx950 in-tree (works without a GPU).  One object per source, the stale ones compiled
-    side by side (the tile kernel's instantiations are one object per storage type: the longest, fp32, ~1 minute), then one link."""
-    if force or needs_build():
+    side by side (the tile kernel's instantiations are one object per storage type: the longest, fp32, ~1 minute), then one link.
+    dev=True: the development build (DEV_LIB_PATH, -DGEOT_DEV_EXPERIMENTS, its own objects)."""
+    lib_path = DEV_LIB_PATH if dev else LIB_PATH
+    obj_dir = os.path.join(OBJ_DIR, "dev") if dev else OBJ_DIR
+    flags = HIPFLAGS + (["-DGEOT_DEV_EXPERIMENTS"] if dev else [])
+    if force or needs_build(dev):
         from concurrent.futures import ThreadPoolExecutor
-        os.makedirs(OBJ_DIR, exist_ok=True)
+        os.makedirs(obj_dir, exist_ok=True)
         shared = LIB_INPUTS[len(SOURCES):]
         todo, objs = [], []
         def inputs(src):
@@ -116,14 +127,14 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
             return [src] + ([SEG_REDUCE] if part else []) + shared
 
         for src in SOURCES:
-            obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+            obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
             objs.append(obj)
             if force or _stale(obj, inputs(src)) or not os.path.exists(obj + ".srchash"):
                 todo.append((src, obj))
 
         def compile_one(job):
             src, obj = job
-            cmd = [hipcc(), *HIPFLAGS, "-c", src, "-o", obj]
+            cmd = [hipcc(), *flags, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -132,12 +143,12 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
 
         with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as pool:
             list(pool.map(compile_one, todo))
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,-soname,{LIB_NAME}", *objs, "-o", lib_path]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        stamp(LIB_PATH)
-    return LIB_PATH
+        stamp(lib_path)
+    return lib_path
 
 
 def plugin_needs_build() -> bool:
@@ -190,14 +201,16 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = DEV_LIB_PATH if DEV else LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"Could not find '{LIB_NAME}' in {_HERE}: build it with `make lib` (or "
+            f"Could not find '{os.path.basename(path)}' in {_HERE}: build it with `make {'devlib' if DEV else 'lib'}` (or "
             f"`python -c 'import __graft_entry__ as g; g.build()'`).  geot_amd has no fallback path.")
-    L = ctypes.CDLL(LIB_PATH)
+    # (RTLD_GLOBAL + the product's soname: the torch plugin's DT_NEEDED libgeot_hip.so binds to THIS copy, product or development)
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     missing = [s for s in SYMBOLS if not hasattr(L, s)]
     if missing:
-        raise ImportError(f"{LIB_PATH} does not export {missing}")
+        raise ImportError(f"{path} does not export {missing}")
     c_i64, c_int, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     L.geot_abi_version.restype = c_int
     L.geot_last_error.restype = ctypes.c_char_p
@@ -255,11 +268,14 @@ def load() -> ctypes.CDLL:
     L.geot_profile_reset.restype = None
     L.geot_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3 + [ctypes.POINTER(c_i64)]
     L.geot_profile_box.argtypes = [c_vp, c_sz, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_vp]
-    L.geot_profile_box_rows.argtypes = [c_vp, c_i64, c_i64, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_vp]
+    L.geot_profile_box_rows.argtypes = [c_vp, c_i64, c_i64, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_vp, c_i64, c_int,
+                                        ctypes.POINTER(ctypes.c_double), c_vp]
     L.geot_tune.argtypes = [c_int, c_int, c_int, c_int]
     L.geot_tune.restype = None
+    L.geot_set_option.argtypes = [ctypes.c_char_p, c_int]
+    L.geot_set_option.restype = c_int
     if L.geot_abi_version() != ABI_VERSION:
-        raise ImportError(f"{LIB_PATH}: ABI version {L.geot_abi_version()} != {ABI_VERSION}")
+        raise ImportError(f"{path}: ABI version {L.geot_abi_version()} != {ABI_VERSION}")
     _lib = L
     return L
 
@@ -278,6 +294,8 @@ if __name__ == "__main__":      # `python3 geot_amd/_lib.py [lib|plugin|stamp]` 
     what = sys.argv[1] if len(sys.argv) > 1 else "stamp"
     if what == "lib":
         build(verbose=True)
+    elif what == "devlib":
+        build(verbose=True, dev=True)
     elif what == "plugin":
         build(verbose=True)
         build_plugin(verbose=True)

@@ -4,7 +4,7 @@
 // records `msg` as the calling thread's geot_last_error() and returns `code`
 extern "C" int geot_internal_fail(int code, const char *msg);
 // experiment knobs of seg_slab.hip, forwarded by geot_set_option
-extern "C" void geot_internal_slab_option(const char *name, int value);
+extern "C" int geot_internal_slab_option(const char *name, int value);   // 1 = known name
 // records the name of the dominant kernel the calling thread's last operator call launched (geot_last_kernel)
 extern "C" void geot_internal_note_kernel(const char *name);
 #endif

@@ -1877,15 +1877,20 @@ __global__ __launch_bounds__(kThreads) void box_read_kernel(const float *__restr
 // Uniform-random rows of `piece16 * 16` bytes out of the caller's table, 16 row reads in flight per lane, nothing else: the
 // yardstick of the per-edge gather kernels (configs[4]: a 57 GB table, every row a miss) - the streamed-read ceiling above is
 // the wrong one for them.  A group of `piece16` lanes reads one row per step; the row number is a hash of (group, step).
-template <bool NT>
+template <bool NT, bool MIX>
 __global__ __launch_bounds__(kThreads) void box_rows_kernel(const float *__restrict__ a, float *sink, unsigned long long rows, int piece16,
-                                                             int steps, unsigned seed) {
+                                                             int steps, unsigned seed, int run, float *__restrict__ out, unsigned long long out_rows) {
   typedef float f4_t __attribute__((ext_vector_type(4)));
   const f4_t *p = reinterpret_cast<const f4_t *>(a);
+  f4_t *o = reinterpret_cast<f4_t *>(out);
   const unsigned tid = blockIdx.x * kThreads + threadIdx.x;
   const unsigned group = tid / (unsigned)piece16, lane = tid % (unsigned)piece16;
   f4_t s = {0, 0, 0, 0};
   unsigned long long x = ((unsigned long long)group << 32) ^ seed;
+  // MIX: the sum of every `run` rows read is written out as one row - the operator's read / write mix with trivial segment handling;
+  // a lane group's output rows are consecutive (as a dst-sorted edge range's are), starting at its own place in `out`
+  unsigned long long orow = MIX ? ((unsigned long long)group * (unsigned long long)((steps + run - 1) / (run > 0 ? run : 1))) % out_rows : 0;
+  int left = run;
   for (int i = 0; i < steps; i += 16) {
     f4_t v[16];
 #pragma unroll
@@ -1896,9 +1901,17 @@ __global__ __launch_bounds__(kThreads) void box_rows_kernel(const float *__restr
       v[u] = NT ? __builtin_nontemporal_load(q) : *q;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s += v[u];
+    for (int u = 0; u < 16; ++u) {
+      s += v[u];
+      if (MIX && --left == 0) {
+        __builtin_nontemporal_store(s, o + orow * (unsigned long long)piece16 + lane);
+        orow = orow + 1 < out_rows ? orow + 1 : 0;
+        s = f4_t{0, 0, 0, 0};
+        left = run;
+      }
+    }
   }
-  if (s[0] + s[1] + s[2] + s[3] == 123.456f) sink[0] = s[0];
+  if (!MIX && s[0] + s[1] + s[2] + s[3] == 123.456f) sink[0] = s[0];
 }
 
 __global__ void box_clock_kernel(unsigned long long *out, int spins) {
@@ -2759,7 +2772,11 @@ int geot_abi_version(void) { return GEOT_ABI_VERSION; }
 
 const char *geot_last_error(void) { return g_err.c_str(); }
 
+#ifdef GEOT_DEV_EXPERIMENTS
+const char *geot_build_info(void) { return "libgeot_hip_dev gfx950 (CDNA4) DEVELOPMENT build (experiment switches) built " __DATE__ " " __TIME__; }
+#else
 const char *geot_build_info(void) { return "libgeot_hip gfx950 (CDNA4) built " __DATE__ " " __TIME__; }
+#endif
 
 // exact need of every plan the launcher can pick for these sizes (storage alignment unknown here:
 // both vector widths are priced), so the answer is tight: cfg2 needs ~11 MB, not a 64-edge-tile bound
@@ -3058,11 +3075,13 @@ int geot_profile_box(const void *buf, size_t bytes, int iters, double *read_gbps
   return GEOT_OK;
 }
 
-int geot_profile_box_rows(const void *table, int64_t rows, int64_t row_bytes, int iters, double *row_gbps, double *row_gbps_nt, void *stream) {
+int geot_profile_box_rows(const void *table, int64_t rows, int64_t row_bytes, int iters, double *row_gbps, double *row_gbps_nt, void *out,
+                          int64_t out_rows, int run, double *mix_row_gbps, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t piece16 = row_bytes / 16;
   if (!table || rows < 1 || rows >= (int64_t(1) << 32) || row_bytes < 16 || row_bytes % 16 || piece16 > 64 || (piece16 & (piece16 - 1)) || iters < 1)
     return fail(GEOT_EINVAL, "profile_box_rows: needs a device table of 1 .. 2^32 - 1 rows of 16 * 2^k <= 1024 bytes");
+  if (mix_row_gbps && (!out || out_rows < 1 || run < 1)) return fail(GEOT_EINVAL, "profile_box_rows: the read / write mix needs an output buffer and a run length");
   float *d = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   struct Cleanup {
@@ -3083,38 +3102,58 @@ int geot_profile_box_rows(const void *table, int64_t rows, int64_t row_bytes, in
   int steps = (int)(((int64_t(16) << 30) / row_bytes / groups + 15) / 16 * 16);
   if (steps < 16) steps = 16;
   const double bytes = (double)groups * steps * row_bytes;
-  float best[2] = {1e30f, 1e30f};
-  for (int it = 0; it < 2 * (iters + 1); ++it) {
+  float best[3] = {1e30f, 1e30f, 1e30f};
+  const int forms = mix_row_gbps ? 3 : 2;
+  for (int it = 0; it < forms * (iters + 1); ++it) {
+    const int form = it % forms;
+    const float *t = static_cast<const float *>(table);
     HIP_TRY(hipEventRecord(e0, st));
-    if (it & 1)
-      hipLaunchKernelGGL(box_rows_kernel<true>, dim3(grid), dim3(kThreads), 0, st, static_cast<const float *>(table), d, (unsigned long long)rows, (int)piece16, steps, 12345u + it);
+    if (form == 0)
+      hipLaunchKernelGGL((box_rows_kernel<false, false>), dim3(grid), dim3(kThreads), 0, st, t, d, (unsigned long long)rows, (int)piece16, steps, 12345u + it, 0, nullptr, 1ull);
+    else if (form == 1)
+      hipLaunchKernelGGL((box_rows_kernel<true, false>), dim3(grid), dim3(kThreads), 0, st, t, d, (unsigned long long)rows, (int)piece16, steps, 12345u + it, 0, nullptr, 1ull);
     else
-      hipLaunchKernelGGL(box_rows_kernel<false>, dim3(grid), dim3(kThreads), 0, st, static_cast<const float *>(table), d, (unsigned long long)rows, (int)piece16, steps, 12345u + it);
+      hipLaunchKernelGGL((box_rows_kernel<true, true>), dim3(grid), dim3(kThreads), 0, st, t, d, (unsigned long long)rows, (int)piece16, steps, 12345u + it, run,
+                         static_cast<float *>(out), (unsigned long long)out_rows);
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (it > 1 && ms < best[it & 1]) best[it & 1] = ms; // the first pass of each form warms up
+    if (it >= forms && ms < best[form]) best[form] = ms; // the first pass of each form warms up
   }
   if (row_gbps) *row_gbps = bytes / (best[0] * 1e-3) / 1e9;
   if (row_gbps_nt) *row_gbps_nt = bytes / (best[1] * 1e-3) / 1e9;
+  if (mix_row_gbps) *mix_row_gbps = bytes / (best[2] * 1e-3) / 1e9;
   return GEOT_OK;
 }
 
-void geot_set_option(const char *name, int value) {
-  if (name && std::string(name) == "unroll") g_unroll = value;
-  if (name && std::string(name) == "gather_grid") g_gather_grid = value;
-  if (name && std::string(name) == "sddmm_shift") g_sddmm_shift = value;
-  if (name && std::string(name) == "lds_floor") g_lds_floor = value;
-  if (name && std::string(name) == "narrow") g_narrow = value;
-  if (name && std::string(name) == "handoff") g_handoff = value;
-  if (name && std::string(name) == "ragged") g_ragged = value != 0;
-  if (name && std::string(name) == "handoff_tries") g_handoff_tries = value;
-  if (name && std::string(name) == "hub") g_hub = value;
-  if (name && std::string(name) == "lane_e") g_lane_e = value;
-  if (name && std::string(name) == "xcd") g_xcd = value;
-  if (name && std::string(name) == "nt_keys") g_nt_keys = value;
-  geot_internal_slab_option(name, value);
+int geot_set_option(const char *name, int value) {
+  if (!name) return fail(GEOT_EINVAL, "set_option: null name");
+  const std::string n(name);
+  if (n == "unroll") g_unroll = value;
+  else if (n == "gather_grid") g_gather_grid = value;
+  else if (n == "sddmm_shift") g_sddmm_shift = value;
+  else if (n == "lds_floor") g_lds_floor = value;
+  else if (n == "narrow") g_narrow = value;
+  else if (n == "handoff") g_handoff = value;
+  else if (n == "ragged") g_ragged = value != 0;
+  else if (n == "handoff_tries") g_handoff_tries = value;
+  else if (n == "hub") g_hub = value;
+  else if (n == "lane_e") g_lane_e = value;
+  else if (n == "xcd") g_xcd = value;
+  else if (n == "nt_keys") g_nt_keys = value;
+  else if (!geot_internal_slab_option(name, value))
+    // (the switches of measured-and-rejected variants - slab_probe, slab_pair, slab_wrow_all, slab_nt, slab_tight, slab_stage,
+    // slab_unroll - exist in the development build only, geot_amd/libgeot_hip_dev.so: a name this build does not know is an error,
+    // never silently ignored)
+    return fail(GEOT_EINVAL, (std::string("set_option: unknown option '") + n + "' in this build (" +
+#ifdef GEOT_DEV_EXPERIMENTS
+                              "development"
+#else
+                              "product; experiment switches live in libgeot_hip_dev.so"
+#endif
+                              + ")").c_str());
+  return GEOT_OK;
 }
 
 void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2) {

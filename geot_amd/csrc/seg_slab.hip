@@ -281,6 +281,9 @@ struct SlabStep {
 // out of v_readlane - in soffset: no vector instruction per edge for the address (global_load wanted a 64-bit add per edge).  The
 // table is below 4 GiB (geot_slab_spmm / geot_slab_sddmm refuse more): offsets and the record count fit 32 bits.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_table_rsrc(const void *table, int64_t rows, int row_shift, int probe = 0) {
+#ifndef GEOT_DEV_EXPERIMENTS
+  probe = 0;                                  // (the timing probe that drops every row read exists in the development build only)
+#endif
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(table), 0, probe ? 0 : (int)(uint32_t)((uint64_t)rows << row_shift), 0x00020000);
 }
 template <typename RAW> __device__ __forceinline__ RAW slab_row_load(__amdgpu_buffer_rsrc_t table, uint32_t lane_bytes, uint32_t row_bytes_off) {
@@ -326,7 +329,11 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   T *dst = static_cast<T *>(p.dst);
   const int h = WMODE >= 2 ? (c * VEC) / p.Fh : 0;
   typedef T t4_t __attribute__((ext_vector_type(4)));
+#ifdef GEOT_DEV_EXPERIMENTS
   const bool ntp = p.nt_plan != 0;
+#else
+  constexpr bool ntp = false;                 // ("slab_nt" exists in the development build only: measured neutral)
+#endif
   auto load_w4 = [&](int64_t pe) { // the 4 head weights of an edge (edge-major layout, H == 4) as floats: one 16- / 8-byte read
     const t4_t x = ntp ? __builtin_nontemporal_load(reinterpret_cast<const t4_t *>(weight + pe * 4)) : *reinterpret_cast<const t4_t *>(weight + pe * 4);
     return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
@@ -836,6 +843,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
   lock.leave(lane);
 }
 
+#ifdef GEOT_DEV_EXPERIMENTS
 // Rows of 512 bytes under multi-head weights, TWO ROWS PER WAVE-INSTRUCTION (an EXPERIMENT, option "slab_pair"; off by default): the
 // plan of seg_slab_wrow_kernel (a unit = a wave, R rows per group, group bounds / row switches in SGPRs) read at 16 bytes a lane -
 // lanes 0..31 gather the row of edge 2j, lanes 32..63 the row of edge 2j+1 OF THE SAME UNIT.  The idea: fp32 rows of 512 B run at
@@ -1028,6 +1036,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wpair_kernel(SlabParams p) 
   }
   lock.leave(lane);
 }
+#endif // GEOT_DEV_EXPERIMENTS
+
 
 // SDDMM over the same plan (d/dweight of gather_weight_scatter on a dense graph): out[e] = <m1[dst(e)], m2[src(e)]>.
 // The unit's <= R rows of m1 (the dst side: shared by all edges of a row) sit in LDS where the forward kernel keeps its
@@ -1603,10 +1613,18 @@ int g_slab_window = -2;
 // for the slowest wave serialised the chip (Reddit scale, sources within +-2000 rows: 48.7 ms against 6.2 ms per edge, r03).
 // Such a wave does not wait.  On graphs without locality all waves sweep the table together and never get that far apart.
 int g_slab_far = 12;
-int g_slab_nt = 0;      // "slab_nt": experiment, see SlabParams::nt_plan
-int g_slab_unroll = 8;  // "slab_unroll": 8 | 16 row loads in flight per lane of the row-per-wave kernel (sums)
-int g_slab_tight = 1;   // "slab_tight": 1 = the window of 1 slab for per-call weights on dense graphs (the round-4 rule), 0 = always 2
-int g_slab_stage = 1;   // "slab_stage": 1 = edge-order weights are staged into plan order inside the kernel when the workspace has room, 0 = read through e_perm
+// Switches of measured-and-rejected variants: variables in the DEVELOPMENT build (-DGEOT_DEV_EXPERIMENTS -> geot_amd/libgeot_hip_dev.so,
+// what tools/ and the A/B tests load), constants in the product - their kernels are not instantiated there and geot_set_option refuses
+// the names.
+#ifdef GEOT_DEV_EXPERIMENTS
+#define GEOT_DEV_SWITCH int
+#else
+#define GEOT_DEV_SWITCH static constexpr int
+#endif
+GEOT_DEV_SWITCH g_slab_nt = 0;      // "slab_nt": experiment, see SlabParams::nt_plan
+GEOT_DEV_SWITCH g_slab_unroll = 8;  // "slab_unroll": 8 | 16 row loads in flight per lane of the row-per-wave kernel (sums)
+GEOT_DEV_SWITCH g_slab_tight = 1;   // "slab_tight": 1 = the window of 1 slab for per-call weights on dense graphs (the round-4 rule), 0 = always 2
+GEOT_DEV_SWITCH g_slab_stage = 1;   // "slab_stage": 1 = edge-order weights are staged into plan order by a pre-pass when the workspace has room, 0 = read through e_perm, 2 = multi-head weights too
 int g_slab_turn = 1;    // "slab_turn": 1 = the persistent grids of this process take turns on a device (see SlabTurn), 0 = launch freely
 
 int g_slab_blocks = 3;  // workgroups per CU of the persistent grid ("slab_blocks"; 160 KB of LDS per CU): measured 2 -> 3: -18 %, 4: same
@@ -1660,11 +1678,11 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 4.50, the SDDMM 6.86 vs 4.52: half the bytes per load instruction, and a weightless lane-group kernel already reads at the L2's
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
-int g_slab_wrow_all = 0;
+GEOT_DEV_SWITCH g_slab_wrow_all = 0;
 int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over plans of 512-byte rows on the matrix cores (seg_slab_sddmm_mfma_kernel:
                              // 4.30 vs 5.84 ms at Reddit scale); 0 = the row-per-wave kernel
-int g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
-int g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured
+GEOT_DEV_SWITCH g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
+GEOT_DEV_SWITCH g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured
                         // SLOWER than seg_slab_wrow_kernel (bf16 H=4 x F=64, weights in plan order: 4.63 vs 4.50 ms), so off: see the kernel's header
 static bool slab_wants_wrow(int weight_mode, int64_t rowbytes) {
   return slab_wrow(rowbytes) && (g_slab_wrow_all || weight_mode == 2 || weight_mode == 3 || weight_mode == 5);
@@ -1852,11 +1870,15 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, RED_>), cgrid, blk, 0, st, p);               \
   } while (0)
   // (16 loads in flight per lane: an experiment switch, "slab_unroll"; instantiated for the sums only)
+#ifdef GEOT_DEV_EXPERIMENTS
 #define GEOT_SLAB_WROW(T_, W, E_, RED_)                                                                       \
   do {                                                                                                        \
     if (RED_ == GEOT_REDUCE_SUM && g_slab_unroll == 16) GEOT_SLAB_WROW_U(T_, W, E_, GEOT_REDUCE_SUM, 16);     \
     else GEOT_SLAB_WROW_U(T_, W, E_, RED_, 8);                                                                \
   } while (0)
+#else
+#define GEOT_SLAB_WROW(T_, W, E_, RED_) GEOT_SLAB_WROW_U(T_, W, E_, RED_, 8)
+#endif
 #define GEOT_SLAB_WROW_RED(T_, W, E_)                                                                         \
   switch (reduce) {                                                                                           \
   case GEOT_REDUCE_MEAN: GEOT_SLAB_WROW(T_, W, E_, GEOT_REDUCE_MEAN); break;                                  \
@@ -1871,6 +1893,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   case 2: GEOT_SLAB_WROW(T_, 2, E_, GEOT_REDUCE_SUM); break;                                                  \
   default: GEOT_SLAB_WROW(T_, 3, E_, GEOT_REDUCE_SUM); break;                                                 \
   }
+#ifdef GEOT_DEV_EXPERIMENTS
 #define GEOT_SLAB_WPAIR(T_)                                                                                   \
   do {                                                                                                        \
     geot_internal_note_kernel((std::string("seg_slab_wpair_kernel<") + slab_tname<T_>() + (weight_mode == 2 ? ", 2>" : ", 3>")).c_str()); \
@@ -1878,12 +1901,16 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     else hipLaunchKernelGGL((seg_slab_wpair_kernel<T_, 3>), grid, blk, lds, st, p);                           \
     if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p);    \
   } while (0)
+#endif
     const int rc = g_turn.take(st, [&]() -> int {
+#ifdef GEOT_DEV_EXPERIMENTS
       if (mhrow && g_slab_pair && weight_mode >= 2 && rowbytes == 512 && feat % vec == 0) {
         if (dtype == GEOT_F32) { GEOT_SLAB_WPAIR(float); }
         else if (dtype == GEOT_F16) { GEOT_SLAB_WPAIR(half_t); }
         else { GEOT_SLAB_WPAIR(bf16_t); }
-      } else if (mhrow) {
+      } else
+#endif
+      if (mhrow) {
         if (dtype == GEOT_F32) { if (el == 2) { GEOT_SLAB_WROW_MODE(float, 2) } else { GEOT_SLAB_WROW_MODE(float, 1) } }
         else if (dtype == GEOT_F16) { if (el == 4) { GEOT_SLAB_WROW_MODE(half_t, 4) } else { GEOT_SLAB_WROW_MODE(half_t, 2) } }
         else { if (el == 4) { GEOT_SLAB_WROW_MODE(bf16_t, 4) } else { GEOT_SLAB_WROW_MODE(bf16_t, 2) } }
@@ -1894,7 +1921,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
       const hipError_t le = hipGetLastError();
       return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
     });
+#ifdef GEOT_DEV_EXPERIMENTS
 #undef GEOT_SLAB_WPAIR
+#endif
 #undef GEOT_SLAB_WROW_MODE
 #undef GEOT_SLAB_WROW_RED
 #undef GEOT_SLAB_WROW
@@ -2087,19 +2116,25 @@ int geot_slab_mh_sddmm(const geot_slab_plan *plan, const void *mat_1, const void
   return slab_sddmm_impl(plan, mat_1, mat_2, out, staging, heads, feat, rows_1, rows_2, dtype, workspace, workspace_bytes, stream);
 }
 
-void geot_internal_slab_option(const char *name, int value) {
-  if (name && std::string(name) == "slab_window") g_slab_window = value;
-  if (name && std::string(name) == "slab_turn") g_slab_turn = value != 0;
-  if (name && std::string(name) == "slab_far" && value >= 0) g_slab_far = value;
-  if (name && std::string(name) == "slab_nt") g_slab_nt = value != 0;
-  if (name && std::string(name) == "slab_unroll" && (value == 8 || value == 16)) g_slab_unroll = value;
-  if (name && std::string(name) == "slab_tight") g_slab_tight = value != 0;
-  if (name && std::string(name) == "slab_stage" && value >= 0 && value <= 2) g_slab_stage = value;
-  if (name && std::string(name) == "slab_wrow_all") g_slab_wrow_all = value != 0;
-  if (name && std::string(name) == "slab_pair") g_slab_pair = value != 0;
-  if (name && std::string(name) == "slab_probe") g_slab_probe = value != 0;
-  if (name && std::string(name) == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
-  if (name && std::string(name) == "slab_blocks" && value >= 1 && value <= 4) g_slab_blocks = value;
+int geot_internal_slab_option(const char *name, int value) {       // 1 = a name of this file (applied if the value is in range), 0 = not
+  if (!name) return 0;
+  const std::string n(name);
+  if (n == "slab_window") g_slab_window = value;
+  else if (n == "slab_turn") g_slab_turn = value != 0;
+  else if (n == "slab_far") { if (value >= 0) g_slab_far = value; }
+  else if (n == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
+  else if (n == "slab_blocks") { if (value >= 1 && value <= 4) g_slab_blocks = value; }
+#ifdef GEOT_DEV_EXPERIMENTS
+  else if (n == "slab_nt") g_slab_nt = value != 0;
+  else if (n == "slab_unroll") { if (value == 8 || value == 16) g_slab_unroll = value; }
+  else if (n == "slab_tight") g_slab_tight = value != 0;
+  else if (n == "slab_stage") { if (value >= 0 && value <= 2) g_slab_stage = value; }
+  else if (n == "slab_wrow_all") g_slab_wrow_all = value != 0;
+  else if (n == "slab_pair") g_slab_pair = value != 0;
+  else if (n == "slab_probe") g_slab_probe = value != 0;
+#endif
+  else return 0;
+  return 1;
 }
 
 } // extern "C"

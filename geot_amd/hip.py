@@ -356,18 +356,24 @@ def profile_box(buf: torch.Tensor, iters: int = 5) -> dict:
     return {"read_ceiling_gbps": g.value, "sclk_mhz": c.value}
 
 
-def profile_box_rows(table: torch.Tensor, iters: int = 3) -> dict:
+def profile_box_rows(table: torch.Tensor, iters: int = 3, out: Optional[torch.Tensor] = None, run: int = 0) -> dict:
     """Random-row ceiling of THIS box on the caller's own [rows, F] table (geot_profile_box_rows): uniform-random rows, 16 reads in
-    flight per lane, nothing else - default-policy and non-temporal loads."""
+    flight per lane, nothing else - default-policy and non-temporal loads; with `out` (a scratch [rows', F] tensor, overwritten) and
+    `run`: also the read / write MIX - one row written per `run` rows read.  All rates are GB/s of rows READ."""
     dev = _require_gpu(table)
     if table.dim() != 2 or not table.is_contiguous():
         raise ValueError("profile_box_rows: a contiguous [rows, F] table")
-    a, b = ctypes.c_double(), ctypes.c_double()
+    a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    mix = out is not None and run >= 1
+    if mix and (out.dim() != 2 or not out.is_contiguous() or out.shape[1] * out.element_size() != table.shape[1] * table.element_size()):
+        raise ValueError("profile_box_rows: `out` must be a contiguous tensor of rows as wide as the table's")
     with _on_device(dev):
         rc = _lib.load().geot_profile_box_rows(table.data_ptr(), table.shape[0], table.shape[1] * table.element_size(), iters,
-                                               ctypes.byref(a), ctypes.byref(b), _stream_handle(dev))
+                                               ctypes.byref(a), ctypes.byref(b), out.data_ptr() if mix else None, out.shape[0] if mix else 0,
+                                               int(run) if mix else 0, ctypes.byref(c) if mix else None, _stream_handle(dev))
     _lib.check(rc, "geot_profile_box_rows")
-    return {"random_row_gbps": a.value, "random_row_gbps_nt": b.value, "best_gbps": max(a.value, b.value)}
+    return {"random_row_gbps": a.value, "random_row_gbps_nt": b.value, "best_gbps": max(a.value, b.value),
+            "mix_row_gbps": c.value if mix else None, "mix_run": int(run) if mix else None}
 
 
 def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2: int = -1) -> None:
@@ -376,11 +382,10 @@ def tune(edges_per_group: int = 0, vec: int = 0, nontemporal: int = -1, lpr_log2
 
 
 def set_option(name: str, value: int) -> None:
-    """Named experiment switches of the library ("unroll": 0|8|16, "narrow": 0|1, "hub": -1|0|1, "xcd", "nt_keys")."""
-    L = _lib.load()
-    L.geot_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
-    L.geot_set_option.restype = None
-    L.geot_set_option(name.encode(), int(value))
+    """Named switches of the library (include/geot_hip_dev.h).  A name the loaded build does not know raises: the switches of
+    measured-and-rejected variants ("slab_probe", "slab_pair", ...) exist in the development build only (GEOT_HIP_LIB=dev)."""
+    rc = _lib.load().geot_set_option(name.encode(), int(value))
+    _lib.check(rc, "geot_set_option")
     _ws_bytes.clear()
 
 

@@ -44,6 +44,25 @@ def test_stable_header_has_no_experiment_switches():
     assert "#define GEOT_ABI_VERSION 2" in open(os.path.join(ROOT, "include", "geot_hip.h")).read() and _lib.ABI_VERSION == 2
 
 
+def test_product_library_carries_no_experiments():
+    """the measured-and-rejected kernel variants (two rows per instruction, ...) and the timing probe that
+    returns wrong results by design live in the DEVELOPMENT build only (libgeot_hip_dev.so, GEOT_HIP_LIB=dev).  The product exports
+    none of their symbols and geot_set_option REFUSES their names (an unknown name is an error, never silently ignored)."""
+    import subprocess
+    from geot_amd import _lib, hip
+    if _lib.DEV:
+        pytest.skip("this process runs the development build")
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for needle in ("wpair", "slab_probe", "g_slab_pair", "g_slab_nt", "g_slab_wrow_all", "g_slab_tight", "g_slab_stage", "g_slab_unroll"):
+        assert needle not in syms, needle
+    assert "DEVELOPMENT" not in hip.build_info()
+    for name in ("slab_probe", "slab_pair", "slab_wrow_all", "slab_nt", "slab_tight", "slab_stage", "slab_unroll", "no_such_switch"):
+        with pytest.raises(RuntimeError, match="unknown option"):
+            hip.set_option(name, 1)
+    for name, value in (("slab_window", -2), ("slab_far", 12), ("slab_sddmm_mfma", 1), ("unroll", 0), ("xcd", 1)):
+        hip.set_option(name, value)                                    # the product's own switches still answer
+
+
 def test_library_is_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob

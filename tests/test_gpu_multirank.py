@@ -159,9 +159,9 @@ def test_bench_json_contract_single_gpu(tmp_path):
     ex = r["extras"]                                                  # flat, numbers only, at most ten
     assert len(ex) <= 10 and all(isinstance(v, (int, float)) for v in ex.values()), ex
     for name in ("gws_cfg3_ms", "rocsparse_best_ms", "gws_speedup_vs_rocsparse", "mh_spmm_cfg4_ms", "mh_spmm_cfg4_bf16_ms", "gather_scatter_cfg5_ms",
-                 "gather_scatter_cfg5_edges_per_s", "cfg5_kernel_frac_of_box_random_row", "cfg1_us_per_call"):
+                 "gather_scatter_cfg5_edges_per_s", "cfg5_kernel_frac_of_box_random_row", "cfg5_kernel_frac_of_box_row_write_mix", "cfg1_us_per_call"):
         assert ex.get(name, 0) > 0, (name, ex)
-    assert 0.5 < ex["cfg5_kernel_frac_of_box_random_row"] < 1.3
+    assert 0.5 < ex["cfg5_kernel_frac_of_box_random_row"] < ex["cfg5_kernel_frac_of_box_row_write_mix"] < 1.3
     # BASELINE.json's other configs, in full, in the file: configs[0], configs[2], configs[3] (fp32 + bf16), configs[4]'s shard
     full = json.load(open(detail))
     assert r["detail"] and all(abs(full[k] - r[k]) <= 1e-5 * abs(full[k]) for k in ("value", "ms_per_step"))

@@ -16,6 +16,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GEOT_HIP_LIB", "dev")     # the development build: the experiment switches (--options / --ab) live there only
 from bench import device_ms, powerlaw_index  # noqa: E402
 from geot_amd import hip, slab  # noqa: E402
 

@@ -13,6 +13,9 @@ for s in $steps; do
     r6a)      timeout 1200 python3 -m pytest tests/test_gpu_graph_handle.py tests/test_gpu_multirank.py -m gpu -x -q > $O/pytest_r6a.log 2>&1; echo "rc=$?"; tail -8 $O/pytest_r6a.log
               ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out $O/bench_driver_detail.json > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err ) 2> $O/bench_driver_cmd.time; echo "rc=$?"
               cat $O/bench_driver_cmd.time; wc -c $O/bench_driver_cmd.json; cat $O/bench_driver_cmd.json; tail -3 $O/bench_driver_cmd.err ;;
+    kexp4)    timeout 600 ./tools/kexp4 > $O/kexp4_random_rows.txt 2>&1; echo "rc=$?"; cat $O/kexp4_random_rows.txt
+              ;;
+    devtests) GEOT_HIP_LIB=dev timeout 2400 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu_devlib.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu_devlib.log ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
