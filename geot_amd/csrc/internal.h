@@ -5,6 +5,7 @@
 extern "C" int geot_internal_fail(int code, const char *msg);
 // experiment knobs of seg_slab.hip, forwarded by geot_set_option
 extern "C" int geot_internal_slab_option(const char *name, int value);   // 1 = known name
+extern "C" const char *geot_last_kernel(void);
 // records the name of the dominant kernel the calling thread's last operator call launched (geot_last_kernel)
 extern "C" void geot_internal_note_kernel(const char *name);
 #endif

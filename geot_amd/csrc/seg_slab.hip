@@ -70,6 +70,8 @@ struct SlabParams {
   int w_in_plan_order;  // WMODE 1 / 2: weight[] is indexed by plan position (a static weight permuted once, scores computed in plan order), not by edge id
   int probe;            // timing experiment ("slab_probe"): the gathered table's buffer descriptor has ZERO records - every row read of the
                         // wave-row forms is dropped by the range check (returns 0, no memory traffic), the instruction stream stays
+  const int *gate;      // != NULL: the launch does its work only if (*gate != 0) == gate_want (the matrix-core SpMM and its vector-ALU
+  int gate_want;        // twin are BOTH enqueued; a word written by slab_nonfinite_kernel on the stream says which one runs)
 };
 constexpr int kProgSlots = 512;
 constexpr int kProgIdle = 0x7f7f7f7f;
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
     return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
   };
 
+  if (p.gate && ((__builtin_nontemporal_load(p.gate) != 0) != (p.gate_want != 0))) return;   // (the other twin of a gated pair runs: see SlabParams::gate)
   SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
   lock.enter(p, lane);
   auto zero = [] {                                      // (the reduction's identity)
@@ -1467,6 +1470,243 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
   lock.leave(lane);
 }
 
+// ---- the 16-bit multi-head SpMM on the MATRIX cores (round 6) ---------------------------------------------------------------------
+// out[d, h, :] = sum_e w[e, h] x[s_e, h, :] contracts over EDGES, and an edge's row lies in memory along the FEATURES: the operand the
+// MFMA wants k-major has to be transposed on the way - gfx950's ds_read_b64_tr_b16 does that for free out of a row-major LDS image.
+// Per tile of 32 edges of a group (<= 16 output rows) and per 16-feature block fb:
+//     D_fb[16 rows x 16 features] += A_h[16 rows x 32 edges] * B_fb[32 edges x 16 features]        (v_mfma_f32_16x16x32_{bf16,f16})
+//   A_h[m][k] = dl(k) == m ? w[k, h] : 0   - the selector of the edge's output row times its weight, built in registers from the
+//               tile's row-in-group bytes and weights (staged in LDS per 64-edge chunk): 4 packed masks per tile + 4 ANDs per head;
+//   B_fb[k][n] = x[src(k), 16 fb + n]      - the gathered rows, written whole to a per-wave image [32 edges][512 + 32 bytes]
+//               (ds_write_b64, one edge per instruction as it was gathered) and read back transposed, two ds_read_b64_tr_b16 per
+//               block (rows 4 kq .. 4 kq + 3 and 16 + 4 kq ..: with the 32-byte pad the eight rows a 32-lane half reads lie on
+//               64 distinct banks);
+//   D_fb stays in registers for the WHOLE group (16 blocks x 4 VGPRs): no LDS accumulators, no row switches, no unpacking, no
+//               per-edge FMA stream - the ~20 wave-instructions per edge of seg_slab_wrow_kernel become ~6.
+// The unused 15/16 of every product is the price (the MFMAs are ~0.4 ms of matrix-core time at Reddit scale).  IEEE isolation:
+// a zero of A times an Inf / NaN of ANOTHER row's source would put a NaN into this row.  So the table is checked first
+// (slab_nonfinite_kernel: one streamed read of x, ~0.03 ms for 119 MB) and the launch is GATED on the result: with a non-finite value
+// anywhere in x this kernel returns at once and its vector-ALU twin (seg_slab_wrow_kernel, enqueued behind it with the opposite gate)
+// does the call - same plan, same results as before.  Weights may be anything (an Inf weight only meets its own row's products).
+// Order of additions inside a row: the hardware's (32 edges per step in plan order); fixed by the plan, not by timing.
+// Plans cut into waves (units = waves of THIS grid: 2 workgroups per CU - the image is 17 KB a wave), R <= 16, rows of 512 bytes,
+// heads 1 / 2 / 4 / 8 with feat % 16 == 0; WMODE 0 none | 1 weight[e] | 2 weight[e * H + h] | 3 weight[h * nnz + e];
+// p.w_in_plan_order as in seg_slab_wrow_kernel.  Option "slab_spmm_mfma" = 0: the row-per-wave kernel.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t *__restrict__ x, int64_t n16, int *flag) {
+  typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+  const u4_t *p = reinterpret_cast<const u4_t *>(x);
+  // an element is Inf / NaN iff its exponent field is all ones: bf16 0x7F80, f16 0x7C00 (per halfword)
+  constexpr uint32_t kExp = __is_same(T, bf16_t) ? 0x7F807F80u : 0x7C007C00u, kInc = __is_same(T, bf16_t) ? 0x00800080u : 0x04000400u;
+  uint32_t bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kThreads) {
+    const u4_t v = __builtin_nontemporal_load(p + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bad |= ((v[q] & kExp) + kInc) & 0x80008000u;   // (0x7F80 + 0x0080 = 0x8000: bit 15 / 31 of each half, no carry across)
+  }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <typename T, int H, int WMODE>
+__global__ __launch_bounds__(kThreads) void seg_slab_spmm_mfma_kernel(SlabParams p) {
+  static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows of 512 bytes, 1 / 2 / 4 / 8 heads");
+  static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE != 1 || H == 1), "one weight per edge = one head");
+  constexpr int kStride = 512 + 32;                      // bytes between the rows of a tile's image
+  constexpr int kImg = 32 * kStride;                     // 17 408 bytes: 32 edges
+  constexpr int kWave = kImg + 2 * H * 64 * 2 + 2 * 64;  // + weights [2 chunks][H][64] of T + rows-in-group [2][64] bytes
+  constexpr int FB_PER_H = 16 / H;                       // 16-feature blocks per head
+  typedef T t8_t __attribute__((ext_vector_type(8)));
+  typedef short s4_t __attribute__((ext_vector_type(4)));
+  typedef short s8_t __attribute__((ext_vector_type(8)));
+  typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
+  typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s4_t *lds_s4_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (p.gate && ((__builtin_nontemporal_load(p.gate) != 0) != (p.gate_want != 0))) return;
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  unsigned char *img = smem + (size_t)wave * kWave;
+  uint16_t *wst = reinterpret_cast<uint16_t *>(img + kImg);          // [2][H][64]
+  unsigned char *dlb = img + kImg + 2 * H * 64 * 2;                   // [2][64]
+  float *imgf = reinterpret_cast<float *>(img);                       // (group end: the D tiles as [16 rows][256] fp32, 16 KB of the image)
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t units = P.units;
+  const T *weight = static_cast<const T *>(p.weight);
+  T *dst = static_cast<T *>(p.dst);
+  const bool wpo = p.w_in_plan_order != 0;
+  const uint32_t src_rows = (uint32_t)p.src_rows;
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
+  const uint32_t cB = (uint32_t)lane * 8u;
+  // the tile's transposed reads: lane 16 kq + 4 q + pp supplies the address of image row 4 kq + q (second read: + 16), columns 4 pp ..
+  const uint32_t tr_off = (uint32_t)((4 * kq + ((lane >> 2) & 3)) * kStride + (lane & 3) * 8);
+  constexpr uint32_t kOne = __is_same(T, bf16_t) ? 0x3F803F80u : 0x3C003C00u;   // (1, 1) in the storage type
+
+  SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
+  lock.enter(p, lane);
+  auto wave_order = [] {                        // LDS words written by some lanes and read by others: keep the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // one edge's weights as loaded (raw 16-bit words; converted never - they go to the matrix cores as they are)
+  struct WRaw { uint16_t v[H]; };
+  auto load_w = [&](int64_t pe) {
+    WRaw w;
+    const uint16_t *wp = reinterpret_cast<const uint16_t *>(weight);
+    if constexpr (WMODE == 0) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) w.v[h] = (uint16_t)(kOne & 0xFFFFu);
+    } else if constexpr (WMODE == 1) w.v[0] = wp[pe];
+    else if constexpr (WMODE == 2) {
+      if constexpr (H == 1) w.v[0] = wp[pe];
+      else if constexpr (H == 2) {
+        const uint32_t x = *reinterpret_cast<const uint32_t *>(wp + pe * 2);
+        w.v[0] = (uint16_t)x, w.v[1] = (uint16_t)(x >> 16);
+      } else if constexpr (H == 4) {
+        const raw2_t x = *reinterpret_cast<const raw2_t *>(wp + pe * 4);
+        w.v[0] = (uint16_t)x[0], w.v[1] = (uint16_t)(x[0] >> 16), w.v[2] = (uint16_t)x[1], w.v[3] = (uint16_t)(x[1] >> 16);
+      } else {
+        const u4_t x = *reinterpret_cast<const u4_t *>(wp + pe * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w.v[2 * q] = (uint16_t)x[q], w.v[2 * q + 1] = (uint16_t)(x[q] >> 16);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) w.v[h] = wp[(int64_t)h * P.nnz + pe];
+    }
+    return w;
+  };
+  auto stage = [&](int buf, const WRaw &w, bool valid, uint32_t edge) {     // this lane's edge of a chunk into the chunk's LDS arrays
+#pragma unroll
+    for (int h = 0; h < H; ++h) wst[(buf * H + h) * 64 + lane] = valid ? w.v[h] : (uint16_t)0;
+    dlb[buf * 64 + lane] = (unsigned char)(edge & 255u);
+  };
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    const bool has = pos < P.n_groups;
+    int64_t e0 = has ? P.g_begin[pos] : 0;
+    int len = has ? (int)(P.g_begin[pos + 1] - e0) : 0;
+    int nv = has ? P.g_nv[pos] : 0;
+    e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+    len = __builtin_amdgcn_readfirstlane(len);
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    f4_t D[16];
+#pragma unroll
+    for (int fb = 0; fb < 16; ++fb) D[fb] = f4_t{0.f, 0.f, 0.f, 0.f};
+    uint32_t my_edge = 255;                     // (source row << 8) | row in group; 255 = padding / out-of-range source
+    {
+      const bool valid = lane < len;
+      const uint32_t s_ = valid ? (uint32_t)P.e_src[e0 + lane] : 0u;
+      const uint32_t d_ = valid ? (uint32_t)P.e_dl[e0 + lane] : 255u;
+      my_edge = s_ < src_rows ? ((s_ << 8) | d_) : 255u;
+      int64_t pe = 0;
+      if constexpr (WMODE != 0) pe = valid ? (wpo ? e0 + lane : (int64_t)P.e_perm[e0 + lane]) : 0;
+      stage(0, load_w(pe), valid, my_edge);
+    }
+    wave_order();
+    const int ntiles = (len + 31) >> 5;
+    uint32_t nx_src = 0, nx_dl = 255, nx_pe = 0;        // the next chunk's fields, loaded under the chunk's first tile, handed over under its second
+    WRaw nx_w = load_w(0);
+    bool nx_valid = false;
+    raw2_t rv[32];
+    auto gather = [&](int t) __attribute__((always_inline)) {             // tile t's 32 rows, one edge per instruction (slots behind the last edge: row 0)
+      const int tb = (t & 1) * 32;
+      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane(my_edge, tb + i);
+        rv[i] = slab_row_load<raw2_t>(table, cB, (edge & ~255u) << 1);
+      }
+    };
+    if (ntiles > 0) gather(0);
+    for (int t = 0; t < ntiles; ++t) {
+      const int c = t >> 1, buf = c & 1, tb = (t & 1) * 32;
+      // the next chunk's fields (and its weights, where they lie in plan order), behind this tile's gathers: every lane loads (lanes
+      // behind the group's end re-read its last edge and drop the value)
+      const bool nvalid = (c + 1) * 64 + lane < len;
+      const int64_t ne = e0 + (nvalid ? (c + 1) * 64 + lane : len - 1);
+      uint32_t n_src = 0, n_dl = 255, n_pe = 0;
+      WRaw n_w;
+      if ((t & 1) == 0) {
+        n_src = (uint32_t)P.e_src[ne];
+        n_dl = (uint32_t)P.e_dl[ne];
+        if constexpr (WMODE != 0) {
+          if (wpo) n_w = load_w(ne);
+          else n_pe = (uint32_t)P.e_perm[ne];
+        }
+      }
+      // tile t into the image (the previous tile's transposed reads are ahead of these writes in the wave's LDS queue)
+#pragma unroll
+      for (int i = 0; i < 32; ++i) *reinterpret_cast<raw2_t *>(img + i * kStride + cB) = rv[i];
+      wave_order();
+      if ((t & 1) == 0) {                       // (held across the odd tile: the chunk changes there)
+        nx_src = n_src, nx_dl = n_dl, nx_pe = n_pe, nx_w = n_w, nx_valid = nvalid;
+      } else {                                  // the chunk ends with this tile: hand the next chunk over
+        if constexpr (WMODE != 0) {
+          if (!wpo) nx_w = load_w((int64_t)nx_pe);
+        } else nx_w = load_w(0);
+        my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
+        stage(buf ^ 1, nx_w, nx_valid, my_edge);
+      }
+      if (t + 1 < ntiles) gather(t + 1);        // in flight under this tile's matrix work
+      // A: selector x weight.  This lane's eight edges are the image rows 4 kq .. 4 kq + 3 and 16 + 4 kq .. 16 + 4 kq + 3 of the tile
+      const uint32_t dla = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
+      const uint32_t dlc = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 16 + 4 * kq);
+      uint32_t mk[4];
+      mk[0] = (((dla & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dla >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+      mk[1] = ((((dla >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dla >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+      mk[2] = (((dlc & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dlc >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+      mk[3] = ((((dlc >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dlc >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+      t8_t afrag[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const raw2_t wa = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 4 * kq);
+        const raw2_t wc = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 16 + 4 * kq);
+        const u4_t a = {wa[0] & mk[0], wa[1] & mk[1], wc[0] & mk[2], wc[1] & mk[3]};
+        afrag[h] = __builtin_bit_cast(t8_t, a);
+      }
+#pragma unroll
+      for (int fb = 0; fb < 16; ++fb) {
+        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + fb * 32));
+        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + 16 * kStride + fb * 32));
+        const s8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const t8_t bfrag = __builtin_bit_cast(t8_t, b);
+        if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[fb / FB_PER_H], bfrag, D[fb], 0, 0, 0);
+        else D[fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[fb / FB_PER_H], bfrag, D[fb], 0, 0, 0);
+      }
+    }
+    lock.round_done(p, lane, r);
+    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows
+    wave_order();
+#pragma unroll
+    for (int fb = 0; fb < 16; ++fb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) imgf[(4 * kq + j) * 256 + 16 * fb + m] = D[fb][j];
+    }
+    wave_order();
+    if (has) {
+      const int64_t v0 = P.g_vrow0[pos];
+      for (int l = 0; l < nv; ++l) {
+        const int64_t tg = P.v_out[v0 + l];
+        const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * 256 + lane * 4);
+        if (tg >= 0) {
+          if (tg < p.K) {
+            typedef T t4_t __attribute__((ext_vector_type(4)));
+            const t4_t o = {(T)row[0], (T)row[1], (T)row[2], (T)row[3]};                 // one rounding, here
+            *reinterpret_cast<t4_t *>(dst + tg * p.F + lane * 4) = o;
+          }
+        } else {
+          *reinterpret_cast<f4_t *>(p.carry + (-tg - 1) * p.F + lane * 4) = row;         // fp32
+        }
+      }
+    }
+    wave_order();
+  }
+  lock.leave(lane);
+}
+
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row).  The pieces meet in FLOAT64 and are
 // rounded once: a hub of 300 k edges is thousands of pieces, and with interleaved pieces (Phase A) they can all be nearly EQUAL
 // (two distinct source rows: every piece samples both in proportion) - adding thousands of equal fp32 values to a growing fp32
@@ -1679,6 +1919,8 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 GEOT_DEV_SWITCH g_slab_wrow_all = 0;
+int g_slab_spmm_mfma = 1;    // "slab_spmm_mfma": 16-bit multi-head SpMM over wave-cut plans of 512-byte rows on the matrix cores (seg_slab_spmm_mfma_kernel,
+                             // gated on a finite source table); 0 = the row-per-wave kernel
 int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over plans of 512-byte rows on the matrix cores (seg_slab_sddmm_mfma_kernel:
                              // 4.30 vs 5.84 ms at Reddit scale); 0 = the row-per-wave kernel
 GEOT_DEV_SWITCH g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
@@ -1790,6 +2032,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
   p.probe = g_slab_probe;
+  p.gate = nullptr;
+  p.gate_want = 0;
   p.w_in_plan_order = w_in_plan_order ? 1 : 0;
   // room behind the carry rows for the weights in plan order -> the kernel stages them itself (geot_slab_workspace_bytes_staged)
   void *wstage = nullptr;
@@ -1902,7 +2146,58 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p);    \
   } while (0)
 #endif
+    // 16-bit multi-head plans over 512-byte rows, sums: the matrix-core kernel, GATED on a finite source table (its header), with the
+    // row-per-wave kernel enqueued behind it under the opposite gate.  Its grid is 2 workgroups per CU (a 17 KB image per wave): the
+    // plan's groups are dealt to ITS waves (p.plan.units / p.rounds of the copy below), whatever grid the plan was cut for.
+    const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && rowbytes == 512 && reduce == GEOT_REDUCE_SUM && plan->rows_per_group <= 16 &&
+                      (heads == 1 || heads == 2 || heads == 4 || heads == 8) && feat % 16 == 0 && (weight_mode != 1 || heads == 1) &&
+                      (weight_mode == 0 || (((uintptr_t)p.weight) & (uintptr_t)(weight_mode == 2 ? heads * 2 - 1 : 1)) == 0);
     const int rc = g_turn.take(st, [&]() -> int {
+      if (mfma) {
+        int *flag = p.prog_cnt + 32;                                   // (a word of the scratch's control block nobody else uses)
+        hipError_t me = hipMemsetAsync(flag, 0, sizeof(int), st);
+        if (me != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(me));
+        SlabParams pm = p;
+        pm.gate = flag;
+        pm.gate_want = 0;
+        p.gate = flag;                                                 // the vector-ALU twin below runs iff the table holds an Inf / NaN
+        p.gate_want = 1;
+        const int64_t mwaves = (int64_t)slab_device().cus * 2 * 4;
+        pm.plan.units = (int32_t)mwaves;
+        pm.rounds = (int)((plan->n_groups + mwaves - 1) / mwaves);
+        const dim3 mgrid((unsigned)(mwaves / 4));
+        const int64_t n16 = src_rows * rowbytes / 16;
+        const int wm = weight_mode == 1 ? 1 : weight_mode;             // (one weight per edge: H == 1)
+#define GEOT_SLAB_SPMM_MFMA_W(T_, H_, W_)                                                                     \
+        do {                                                                                                  \
+          auto kfn = seg_slab_spmm_mfma_kernel<T_, H_, W_>;                                                   \
+          const size_t mlds = (size_t)4 * (32 * (512 + 32) + 2 * H_ * 64 * 2 + 2 * 64);                       \
+          static std::once_flag once_;                                                                        \
+          std::call_once(once_, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); }); \
+          geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ">").c_str()); \
+          hipLaunchKernelGGL(kfn, mgrid, blk, mlds, st, pm);                                                  \
+        } while (0)
+#define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \
+        do {                                                                                                  \
+          if (wm == 0) GEOT_SLAB_SPMM_MFMA_W(T_, H_, 0);                                                      \
+          else if (wm == 3) GEOT_SLAB_SPMM_MFMA_W(T_, H_, 3);                                                 \
+          else GEOT_SLAB_SPMM_MFMA_W(T_, H_, 2);                                                              \
+        } while (0)
+#define GEOT_SLAB_SPMM_MFMA(T_)                                                                               \
+        do {                                                                                                  \
+          hipLaunchKernelGGL((slab_nonfinite_kernel<T_>), dim3((unsigned)(slab_device().cus * 8)), blk, 0, st, static_cast<const uint32_t *>(src), n16, flag); \
+          if (heads == 1) GEOT_SLAB_SPMM_MFMA_H(T_, 1);                                                       \
+          else if (heads == 2) GEOT_SLAB_SPMM_MFMA_H(T_, 2);                                                  \
+          else if (heads == 4) GEOT_SLAB_SPMM_MFMA_H(T_, 4);                                                  \
+          else GEOT_SLAB_SPMM_MFMA_H(T_, 8);                                                                  \
+        } while (0)
+        if (dtype == GEOT_F16) GEOT_SLAB_SPMM_MFMA(half_t);
+        else GEOT_SLAB_SPMM_MFMA(bf16_t);
+#undef GEOT_SLAB_SPMM_MFMA
+#undef GEOT_SLAB_SPMM_MFMA_H
+#undef GEOT_SLAB_SPMM_MFMA_W
+      }
+      const std::string mfma_name = mfma ? std::string(geot_last_kernel()) : std::string();
 #ifdef GEOT_DEV_EXPERIMENTS
       if (mhrow && g_slab_pair && weight_mode >= 2 && rowbytes == 512 && feat % vec == 0) {
         if (dtype == GEOT_F32) { GEOT_SLAB_WPAIR(float); }
@@ -1918,6 +2213,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
       else if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
       else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
       else { GEOT_SLAB_MODE(bf16_t) }
+      if (mfma) geot_internal_note_kernel(mfma_name.c_str());         // (the twin behind it returns at once unless the table holds an Inf / NaN)
       const hipError_t le = hipGetLastError();
       return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
     });
@@ -2016,6 +2312,8 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   p.far = g_slab_far;
   p.nt_plan = g_slab_nt;
   p.probe = g_slab_probe;
+  p.gate = nullptr;
+  p.gate_want = 0;
   p.w_in_plan_order = staged ? 1 : 0;
   p.src_rows = rows_2;
   p.K = rows_1;
@@ -2123,6 +2421,7 @@ int geot_internal_slab_option(const char *name, int value) {       // 1 = a name
   else if (n == "slab_turn") g_slab_turn = value != 0;
   else if (n == "slab_far") { if (value >= 0) g_slab_far = value; }
   else if (n == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
+  else if (n == "slab_spmm_mfma") g_slab_spmm_mfma = value != 0;
   else if (n == "slab_blocks") { if (value >= 1 && value <= 4) g_slab_blocks = value; }
 #ifdef GEOT_DEV_EXPERIMENTS
   else if (n == "slab_nt") g_slab_nt = value != 0;

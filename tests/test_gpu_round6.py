@@ -1,0 +1,321 @@
+"""Round 6 (`-m gpu`): the 16-bit multi-head SpMM on the matrix cores (seg_slab_spmm_mfma_kernel) and the IEEE isolation of every
+source-blocked kernel.
+
+* the matrix-core SpMM against float64 sums for every shape / weight layout it serves, exact equality with the row-per-wave kernel on
+  integer data (any slip in the operand maps - which lane holds which edge of which row, the transposed LDS reads, the selector
+  masks - shows as a wrong integer, not as rounding);
+* a source table with Inf / NaN rows: only the destination rows that really have such a source are affected, for EVERY kernel that
+  runs a plan (the matrix-core SpMM multiplies other rows' sources by a selector's zero - 0 x Inf would be a NaN next door - so its
+  launch is gated on a finite table and a vector-ALU twin takes such calls: this test is what holds that construction to account).
+
+Reference semantics: csrc/cuda/mh_spmm_kernel.cuh:28-111 (dst[d, h, :] += w[e, h] * src[s, h, :]), test/test_mh_spmm.py:4-10.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import powerlaw_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def geot():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import geot_amd
+    return geot_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _dense_graph(rng, nodes, nnz, hub=20):
+    di = powerlaw_index(nnz, nodes, nodes + 1)
+    di[: nnz // hub] = di[nnz // hub]                                   # a hub that is split (carry slots)
+    di = np.sort(di)
+    di[di == 7] = 8                                                     # a destination without edges
+    di[-1] = nodes - 1
+    si = rng.integers(0, nodes, nnz).astype(np.int64)
+    return si, di
+
+
+def _ref(d_si, d_di, w, v, nodes):
+    """float64 sums; w [nnz, H] or None, v [nodes, H, F]."""
+    msg = v.double()[d_si]
+    if w is not None:
+        msg = msg * w.double()[:, :, None]
+    return torch.zeros(nodes, *v.shape[1:], device="cuda", dtype=torch.float64).index_add_(0, d_di, msg)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32)])
+def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtype, H, Fh):
+    """Every weight layout the kernel serves (edge-major through the permutation, head-major, plan order, none), a hub split into
+    pieces (carry rows), rows without edges, out-of-range sources (contribute nothing): float64 sums within the storage type's
+    rounding; integer data: EQUAL to the row-per-wave kernel's bits and to the exact sums."""
+    from geot_amd import slab
+    rng = np.random.default_rng(97 * H + Fh)
+    nodes, nnz = 2500, 300_000
+    si, di = _dense_graph(rng, nodes, nnz)
+    si[rng.integers(0, nnz, 50)] = nodes + 7                            # out-of-range sources
+    d_si, d_di = dev(si), dev(di)
+    ok = dev(si < nodes)
+    R = min(16, slab.rows_per_group(2, H, dtype, 512))
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, 512, 2, H, rows_per_group=R)
+    assert plan.meta["split_rows"] >= 1 and plan.meta["rows_per_group"] <= 16
+    e_perm = plan.tensors["e_perm"].long()
+    tol = 2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6
+
+    def run(weight, mode, v, mfma):
+        geot.hip.set_option("slab_spmm_mfma", mfma)
+        o = torch.full((nodes, H, Fh), float("nan"), device="cuda", dtype=dtype)
+        slab.slab_spmm_out(plan, weight, mode, v, o, H, Fh, stage_weights=False)
+        assert ("seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel()) == bool(mfma), geot.hip.last_kernel()
+        return o
+
+    try:
+        # (a) real-valued data against float64
+        v = torch.from_numpy(rng.random((nodes, H, Fh), dtype=np.float32) - 0.3).to(dtype).cuda()
+        w = torch.from_numpy(rng.random((nnz, H), dtype=np.float32) - 0.3).to(dtype).cuda()
+        wz = w * ok[:, None]
+        ref = _ref(d_si.clamp(max=nodes - 1), d_di, wz, v, nodes)
+        scale = float(ref.abs().max())
+        forms = [("edge-major", w, 2), ("head-major", w.t().contiguous(), 3), ("plan order", w[e_perm].contiguous(), 5)]
+        outs = []
+        for name, weight, mode in forms:
+            o = run(weight, mode, v, 1)
+            assert float((o.double() - ref).abs().max()) <= tol * scale, (name, float((o.double() - ref).abs().max()), scale)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])          # one order of additions, whatever the layout
+        assert torch.equal(run(w, 2, v, 1), outs[0])                                    # fixed by the plan, not by timing
+        ref0 = _ref(d_si.clamp(max=nodes - 1), d_di, ok[:, None].to(dtype).expand(nnz, H), v, nodes)
+        o0 = run(None, 0, v, 1)
+        assert float((o0.double() - ref0).abs().max()) <= tol * float(ref0.abs().max())
+        # (b) integer data: exact in fp32, so both kernels round the same number
+        vi = torch.from_numpy(rng.integers(-1, 2, (nodes, H, Fh)).astype(np.float32)).to(dtype).cuda()
+        wi = torch.from_numpy(rng.integers(-2, 3, (nnz, H)).astype(np.float32)).to(dtype).cuda()
+        exact = _ref(d_si.clamp(max=nodes - 1), d_di, wi * ok[:, None], vi, nodes)
+        a = run(wi, 2, vi, 1)
+        b = run(wi, 2, vi, 0)
+        assert torch.equal(a, b), float((a.double() - b.double()).abs().max())
+        assert torch.equal(a, exact.to(dtype))
+    finally:
+        geot.hip.set_option("slab_spmm_mfma", 1)
+
+
+def _poison(v, rows, dtype):
+    v = v.clone()
+    v[rows[0]] = float("inf")
+    v[rows[1]] = float("-inf")
+    v[rows[2]] = float("nan")
+    v[rows[3], ..., 5] = float("inf")                                   # a single element of a row
+    return v.to(dtype)
+
+
+@pytest.mark.parametrize("case", ["mh bf16 512", "mh f16 512", "mh f32 1024", "mh f32 512", "gws f32 512", "gws bf16 256", "gs f32 512"])
+def test_nonfinite_sources_touch_only_their_own_destinations(geot, case):
+    """Inf / -Inf / NaN rows (and a row with one Inf element) in the source table: a destination row is non-finite exactly where the
+    float64 reference says so, and every other row equals the result computed from the table with those rows zeroed - bit for bit on
+    the same kernel where that kernel does not depend on the data (every kernel but the gated matrix-core SpMM, whose finite twin is
+    compared within rounding).  Covers seg_slab_kernel (lane groups, whole-wave rows), seg_slab_wrow_kernel and the gated pair."""
+    from geot_amd import slab
+    kind, tname, rowbytes = case.split()
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[tname]
+    rowbytes = int(rowbytes)
+    esz = 2 if dtype != torch.float32 else 4
+    H = 4 if kind == "mh" else 1
+    Fh = rowbytes // esz // H
+    rng = np.random.default_rng(len(case) + rowbytes)
+    nodes, nnz = 2500, 300_000
+    si, di = _dense_graph(rng, nodes, nnz)
+    bad = rng.choice(nodes, 4, replace=False)
+    clean_row = int(np.setdiff1d(np.arange(nodes), bad)[0])
+    si[np.isin(si, bad)] = clean_row                                    # keep the poisoned rows RARE: three edges each
+    for b in bad:
+        si[rng.integers(0, nnz, 3)] = b
+    d_si, d_di = dev(si), dev(di)
+    wmode = {"mh": 2, "gws": 1, "gs": 0}[kind]
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, rowbytes, wmode, H, rows_per_group=min(16, slab.rows_per_group(wmode, H, dtype, rowbytes)))
+    v32 = torch.from_numpy(rng.random((nodes, H, Fh), dtype=np.float32) + 0.5).cuda()
+    w = None if kind == "gs" else (torch.from_numpy(rng.random((nnz, H), dtype=np.float32) + 0.5).to(dtype).cuda())
+    v_bad = _poison(v32, bad, dtype)
+    v_zero = v32.clone()
+    v_zero[bad] = 0
+    v_zero = v_zero.to(dtype)
+    shape = (nodes, H, Fh)
+
+    def run(v):
+        o = torch.full(shape, 7.0, device="cuda", dtype=dtype)
+        weight = None if w is None else (w if kind == "mh" else w.view(-1))
+        slab.slab_spmm_out(plan, weight, wmode, v.view(nodes, H * Fh) if kind != "mh" else v, o.view(nodes, H * Fh) if kind != "mh" else o,
+                           H, Fh, stage_weights=False)
+        return o, geot.hip.last_kernel()
+
+    got, kernel_bad = run(v_bad)
+    clean, kernel_clean = run(v_zero)
+    ref = _ref(d_si, d_di, None if w is None else w.float(), v_bad.float(), nodes)
+    touched = torch.zeros(nodes, dtype=torch.bool, device="cuda")
+    touched[d_di[torch.isin(d_si, dev(bad))]] = True
+    assert 0 < int(touched.sum()) < nodes // 4
+    # where the reference is non-finite so is the result, with the reference's kind (NaN / +Inf / -Inf); nowhere else
+    g64 = got.double()
+    assert torch.equal(torch.isnan(g64), torch.isnan(ref)), case
+    inf_ref = torch.isinf(ref)                                           # (finite sums stay below 4e4: nothing overflows the storage type)
+    assert torch.equal(torch.isinf(g64), inf_ref) and torch.equal(torch.sign(g64[inf_ref]), torch.sign(ref[inf_ref]))
+    assert not bool((~torch.isfinite(g64))[~touched].any())
+    # rows no poisoned source reaches: the values of the clean table's run
+    if "spmm_mfma" in kernel_clean:                                      # the finite call ran on the matrix cores, the poisoned one on the twin
+        assert "spmm_mfma" in kernel_bad                                 # (the label names the pair's first kernel; the gate picked the twin)
+        tol = (2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9) * float(clean.double().abs().max())
+        assert float((g64[~touched] - clean.double()[~touched]).abs().max()) <= tol
+        geot.hip.set_option("slab_spmm_mfma", 0)
+        try:
+            clean_twin, k2 = run(v_zero)
+            assert "wrow" in k2
+        finally:
+            geot.hip.set_option("slab_spmm_mfma", 1)
+        assert torch.equal(got[~touched], clean_twin[~touched])          # the twin IS the row-per-wave kernel
+    else:
+        assert torch.equal(got[~touched], clean[~touched]), case
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_nonfinite_rows_and_the_plan_sddmm(geot, dtype):
+    """The SDDMMs over a plan (row-per-wave and matrix cores): a score is non-finite exactly for the edges whose own source or
+    destination row is - nothing is contaminated by a neighbour in the tile (each product sums its OWN edge's features only)."""
+    from geot_amd import slab
+    rng = np.random.default_rng(77)
+    nodes, nnz, H = 2500, 300_000, 4
+    Fh = 64 if dtype == torch.bfloat16 else 32                           # 512-byte rows
+    si, di = _dense_graph(rng, nodes, nnz)
+    bad = rng.choice(np.arange(10, nodes - 10), 4, replace=False)
+    d_si, d_di = dev(si), dev(di)
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, 512, 2, H, rows_per_group=min(16, slab.rows_per_group(2, H, dtype, 512)))
+    q = (torch.rand(nodes, H, Fh, device="cuda") + 0.5).to(dtype)
+    k = _poison(torch.rand(nodes, H, Fh, device="cuda") + 0.5, bad, dtype)
+    s = torch.empty(nnz, H, device="cuda", dtype=dtype)
+    slab.slab_mh_sddmm_out(plan, q, k, s)
+    assert ("mfma" in geot.hip.last_kernel()) == (dtype == torch.bfloat16)
+    ref = (q.double()[d_di] * k.double()[d_si]).sum(-1)
+    hit = torch.isin(d_si, dev(bad))
+    assert torch.equal(~torch.isfinite(s.double()), ~torch.isfinite(ref)) and not bool((~torch.isfinite(s.double()))[~hit].any())
+    fin = torch.isfinite(ref)
+    tol = 2.0 ** -6 if dtype == torch.bfloat16 else 2e-5
+    assert float(((s.double() - ref)[fin]).abs().max()) <= tol * float(ref[fin].abs().max())
+
+
+def test_matrix_core_spmm_through_the_operator_and_the_handle(geot):
+    """The drop-in operator (mh_spmm on a dense graph: plan on the second sighting) and geot_amd.Graph reach the matrix-core kernel for
+    bf16 H=4 x F=64, forward and backward (d/dsrc runs the same kernel over the transposed list's plan)."""
+    from geot_amd import ops
+    nodes, nnz, H, Fh = 4000, 600_000, 4, 64
+    rng = np.random.default_rng(5)
+    si, di = _dense_graph(rng, nodes, nnz)
+    d_si, d_di = dev(si), dev(di)
+    x = (torch.rand(nodes, H, Fh, device="cuda") - 0.3).bfloat16().requires_grad_()
+    w = (torch.rand(nnz, H, device="cuda") - 0.3).bfloat16().requires_grad_()
+    ref = _ref(d_si, d_di, w.detach(), x.detach(), nodes)
+    g = geot.Graph(d_si, d_di, num_src=nodes, num_dst=nodes, slab_mode="always")
+    y = g.mh_spmm(w, x)
+    assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+    assert float((y.double() - ref).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+    up = torch.rand_like(y)
+    gx, gw = torch.autograd.grad(y, [x, w], up)
+    xr, wr = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    r = torch.zeros(nodes, H, Fh, device="cuda", dtype=torch.float64).index_add_(0, d_di, xr[d_si] * wr[:, :, None])
+    rgx, rgw = torch.autograd.grad(r, [xr, wr], up.double())
+    assert float((gx.double() - rgx).abs().max()) <= 2.0 ** -6 * float(rgx.abs().max())
+    assert float((gw.double() - rgw).abs().max()) <= 2.0 ** -5 * float(rgw.abs().max())
+    old = ops.set_option("slab_mode", "always")
+    try:
+        ops.clear_caches()
+        for _ in range(3):
+            y2 = geot.mh_spmm(d_si, d_di, w.detach(), x.detach())
+        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        assert float((y2.double() - ref).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+    finally:
+        ops.set_option("slab_mode", old)
+        ops.clear_caches()
+
+
+def _device_powerlaw(nnz, keys, seed):
+    """bench.py's generator on the device: full-size index arrays without a host round trip."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    from bench import powerlaw_index as gen
+    return gen(nnz, keys, seed, torch.device("cuda"))
+
+
+@pytest.mark.parametrize("order", ["edge", "plan"])
+def test_cfg4_full_size_bf16_properties(geot, order):
+    """BASELINE.json configs[3] at FULL size in bf16 storage (232 965 nodes, 114 615 892 edges, H=4 x F=64): the matrix-core SpMM and the
+    matrix-core score SDDMM as geot_amd.Graph dispatches them, weights in edge order and in plan order.  Size-independent properties
+    (rows without edges exactly zero, determinism, the checksum of checksums in float64 within bf16's rounding of the OUTPUT) and
+    sampled rows - the hub, the ends, 150 random rows - against the float64 sum at 2^-7 relative."""
+    nodes, nnz, H, F = 232_965, 114_615_892, 4, 64
+    di = _device_powerlaw(nnz, nodes, 11)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    w = (torch.rand(nnz, H, device="cuda", generator=g) + 0.25).bfloat16()
+    x = (torch.rand(nodes, H, F, device="cuda", generator=g) + 0.25).bfloat16()
+    handle = geot.Graph(si, di, num_src=nodes, num_dst=nodes, slab_mode="always")
+    wv = handle.plan_order(w, x) if order == "plan" else w
+    out = handle.mh_spmm(wv, x)
+    assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+    assert out.shape == (nodes, H, F) and out.dtype == torch.bfloat16
+    assert torch.equal(out, handle.mh_spmm(wv, x))                       # deterministic
+    counts = torch.bincount(di, minlength=nodes)
+    assert out[counts == 0].float().abs().sum().item() == 0              # rows without edges: exactly zero
+    offs = torch.cumsum(counts, 0) - counts
+    gen = torch.Generator().manual_seed(3)
+    pick = [int(counts.argmax()), 0, nodes - 1, nodes // 2] + torch.randint(0, nodes, (150,), generator=gen).tolist()
+    for k in pick:                                                       # comparator of test/test_mh_spmm.py:4-10, in float64
+        e = slice(int(offs[k]), int(offs[k] + counts[k]))
+        want = (x[si[e]].double() * w[e].double()[:, :, None]).sum(0)
+        assert float((out[k].double() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()) + 1e-30, k
+    # checksum of checksums: column sums of the result == (per-node, per-head total weight) contracted with x; every output element
+    # carries one bf16 rounding (relative 2^-9, random sign): the column sums over 233 k rows agree far inside 2^-9
+    cw = torch.zeros(nodes, H, dtype=torch.float64, device="cuda").index_add_(0, si, w.double())
+    want = torch.einsum("nh,nhf->hf", cw, x.double())
+    got = out.double().sum(0)
+    assert float(((got - want) / want).abs().max()) <= 2.0 ** -11, float(((got - want) / want).abs().max())
+    # the scores of an attention layer over the same plan (matrix cores), sampled edges against float64
+    q = (torch.rand(nodes, H, F, device="cuda", generator=g) / 4).bfloat16()
+    s = handle.mh_sddmm(q, x, plan_order=(order == "plan"))
+    assert "seg_slab_sddmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+    s_edge = s.edge_order() if order == "plan" else s
+    eid = torch.randint(0, nnz, (20_000,), device="cuda", generator=g)
+    ref = (q[di[eid]].double() * x[si[eid]].double()).sum(-1)
+    assert float((s_edge[eid].double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    del handle
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_full_size_bf16_properties(geot):
+    """BASELINE.json configs[2] at full size in bf16 storage (gws, 2.45 M nodes, 123.7 M edges, F=128; the per-edge tile kernel with fp32
+    accumulation): rows without edges, sampled rows against float64 at 2^-7, the checksum of checksums."""
+    nodes, nnz, F = 2_449_029, 123_718_280, 128
+    di = _device_powerlaw(nnz, nodes, 7)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    w = (torch.rand(nnz, device="cuda", generator=g) + 0.25).bfloat16()
+    x = (torch.rand(nodes, F, device="cuda", generator=g) + 0.25).bfloat16()
+    out = geot.gather_weight_scatter(si, di, w, x)
+    assert out.shape == (nodes, F) and out.dtype == torch.bfloat16 and "__bf16" in geot.hip.last_kernel()
+    counts = torch.bincount(di, minlength=nodes)
+    assert out[counts == 0].float().abs().sum().item() == 0
+    offs = torch.cumsum(counts, 0) - counts
+    gen = torch.Generator().manual_seed(4)
+    pick = [int(counts.argmax()), 0, nodes - 1, nodes // 2] + torch.randint(0, nodes, (150,), generator=gen).tolist()
+    for k in pick:
+        e = slice(int(offs[k]), int(offs[k] + counts[k]))
+        want = (x[si[e]].double() * w[e].double()[:, None]).sum(0)
+        assert float((out[k].double() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()) + 1e-30, k
+    cw = torch.zeros(nodes, dtype=torch.float64, device="cuda").index_add_(0, si, w.double())
+    want = cw @ x.double()
+    got = out.double().sum(0)
+    assert float(((got - want) / want).abs().max()) <= 2.0 ** -11

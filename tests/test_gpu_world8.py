@@ -296,7 +296,7 @@ def test_bench_cfg5_world8_node_sharded_sources():
     """`bench.py --workload cfg5 --src-sharding node`: every rank holds 1/8 of the source rows and fetches what its edge range references
     per step; the line reports the plan's mode and the bytes exchanged.  Uniform-random sources reference (almost) every row: the plan
     takes the all_gather form; the timed step includes the fetch."""
-    r = _bench(["--src-sharding", "node"])
+    r = _bench(["--src-sharding", "node", "--full"])                  # (--full: the whole record on stdout; the compact line keeps numbers only)
     assert r["ranks_seen"] == WORLD and r["src_sharding"] == "node" and r["value"] > 1e7
     f = r["source_rows_fetch"]
     assert f["mode"] in ("halo", "all_gather") and f["bytes_fetched_per_step_rank0"] > 0 and f["fetch_ms_rank0"] > 0

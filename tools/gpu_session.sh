@@ -16,6 +16,10 @@ for s in $steps; do
     kexp4)    timeout 600 ./tools/kexp4 > $O/kexp4_random_rows.txt 2>&1; echo "rc=$?"; cat $O/kexp4_random_rows.txt
               ;;
     devtests) GEOT_HIP_LIB=dev timeout 2400 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu_devlib.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu_devlib.log ;;
+    mfma)     timeout 1200 python3 -m pytest tests/test_gpu_round6.py -m gpu -x -q > $O/pytest_r6_mfma.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r6_mfma.log
+              for o in slab_spmm_mfma=1 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=0; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
+              done > $O/slab_cases_mfma_ab.txt 2>&1; cat $O/slab_cases_mfma_ab.txt ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
