@@ -286,7 +286,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_table_rsrc(const void *ta
 #ifndef GEOT_DEV_EXPERIMENTS
   probe = 0;                                  // (the timing probe that drops every row read exists in the development build only)
 #endif
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(table), 0, probe ? 0 : (int)(uint32_t)((uint64_t)rows << row_shift), 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(table), 0, (probe & 1) ? 0 : (int)(uint32_t)((uint64_t)rows << row_shift), 0x00020000);
 }
 template <typename RAW> __device__ __forceinline__ RAW slab_row_load(__amdgpu_buffer_rsrc_t table, uint32_t lane_bytes, uint32_t row_bytes_off) {
   if constexpr (sizeof(RAW) == 4) return __builtin_bit_cast(RAW, __builtin_amdgcn_raw_buffer_load_b32(table, lane_bytes, row_bytes_off, 0));
@@ -1508,16 +1508,16 @@ __global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t
 }
 
 template <typename T, int H, int WMODE>
-__global__ __launch_bounds__(kThreads) void seg_slab_spmm_mfma_kernel(SlabParams p) {
+__global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabParams p) {   // (3 waves per SIMD: the persistent grid's 3 workgroups per CU all resident)
   static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows of 512 bytes, 1 / 2 / 4 / 8 heads");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE != 1 || H == 1), "one weight per edge = one head");
+  constexpr int KT = 16;                                 // edges per tile = the K of v_mfma_f32_16x16x16 (see the header: why not 32)
   constexpr int kStride = 512 + 32;                      // bytes between the rows of a tile's image
-  constexpr int kImg = 32 * kStride;                     // 17 408 bytes: 32 edges
+  constexpr int kImg = KT * kStride;                     // 8 704 bytes
   constexpr int kWave = kImg + 2 * H * 64 * 2 + 2 * 64;  // + weights [2 chunks][H][64] of T + rows-in-group [2][64] bytes
   constexpr int FB_PER_H = 16 / H;                       // 16-feature blocks per head
-  typedef T t8_t __attribute__((ext_vector_type(8)));
   typedef short s4_t __attribute__((ext_vector_type(4)));
-  typedef short s8_t __attribute__((ext_vector_type(8)));
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
   typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
   typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) s4_t *lds_s4_t;
@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_spmm_mfma_kernel(SlabParams
   unsigned char *img = smem + (size_t)wave * kWave;
   uint16_t *wst = reinterpret_cast<uint16_t *>(img + kImg);          // [2][H][64]
   unsigned char *dlb = img + kImg + 2 * H * 64 * 2;                   // [2][64]
-  float *imgf = reinterpret_cast<float *>(img);                       // (group end: the D tiles as [16 rows][256] fp32, 16 KB of the image)
+  float *imgf = reinterpret_cast<float *>(img);                       // (group end: half of the D tiles as [16 rows][128] fp32, 8 KB of the image)
   const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
   const int64_t units = P.units;
   const T *weight = static_cast<const T *>(p.weight);
@@ -1537,19 +1537,20 @@ __global__ __launch_bounds__(kThreads) void seg_slab_spmm_mfma_kernel(SlabParams
   const bool wpo = p.w_in_plan_order != 0;
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
-  const uint32_t cB = (uint32_t)lane * 8u;
-  // the tile's transposed reads: lane 16 kq + 4 q + pp supplies the address of image row 4 kq + q (second read: + 16), columns 4 pp ..
+  const uint32_t cH = (uint32_t)(lane & 31) * 16u;        // a lane's 16 bytes of its half-wave's row
+  // the tile's transposed read: lane 16 kq + 4 q + pp supplies the address of image row 4 kq + q, columns 4 pp .. 4 pp + 3 of the block;
+  // lane 16 kq + n receives column n of those four rows = B[k = 4 kq .. 4 kq + 3][n]
   const uint32_t tr_off = (uint32_t)((4 * kq + ((lane >> 2) & 3)) * kStride + (lane & 3) * 8);
   constexpr uint32_t kOne = __is_same(T, bf16_t) ? 0x3F803F80u : 0x3C003C00u;   // (1, 1) in the storage type
 
   SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
   lock.enter(p, lane);
-  auto wave_order = [] {                        // LDS words written by some lanes and read by others: keep the compiler's order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  auto wave_order = [] {                        // LDS words written by some lanes and read by others: keep the compiler's order (the
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // hardware runs a wave's LDS operations in order; no wait is emitted)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  // one edge's weights as loaded (raw 16-bit words; converted never - they go to the matrix cores as they are)
+  // one edge's weights as loaded (raw 16-bit words; never converted - they go to the matrix cores as they are)
   struct WRaw { uint16_t v[H]; };
   auto load_w = [&](int64_t pe) {
     WRaw w;
@@ -1595,7 +1596,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_spmm_mfma_kernel(SlabParams
     f4_t D[16];
 #pragma unroll
     for (int fb = 0; fb < 16; ++fb) D[fb] = f4_t{0.f, 0.f, 0.f, 0.f};
-    uint32_t my_edge = 255;                     // (source row << 8) | row in group; 255 = padding / out-of-range source
+    uint32_t my_edge = 255;                     // (source row << 8) | row in group; 255 = padding / out-of-range source (contributes nothing)
     {
       const bool valid = lane < len;
       const uint32_t s_ = valid ? (uint32_t)P.e_src[e0 + lane] : 0u;
@@ -1606,99 +1607,131 @@ __global__ __launch_bounds__(kThreads) void seg_slab_spmm_mfma_kernel(SlabParams
       stage(0, load_w(pe), valid, my_edge);
     }
     wave_order();
-    const int ntiles = (len + 31) >> 5;
-    uint32_t nx_src = 0, nx_dl = 255, nx_pe = 0;        // the next chunk's fields, loaded under the chunk's first tile, handed over under its second
+    const int ntiles = (len + KT - 1) / KT;
+    uint32_t nx_src = 0, nx_dl = 255, nx_pe = 0;        // the next chunk's fields: loaded under the chunk's first tile, handed over under its last
     WRaw nx_w = load_w(0);
     bool nx_valid = false;
-    raw2_t rv[32];
-    auto gather = [&](int t) __attribute__((always_inline)) {             // tile t's 32 rows, one edge per instruction (slots behind the last edge: row 0)
-      const int tb = (t & 1) * 32;
-      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
+    uint32_t my_off = (my_edge & ~255u) << 1;           // this lane's edge: its source row's byte offset
+    // TWO rows per gather instruction, 16 bytes a lane (lanes 0..31 the row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide
+    // load costs the CU ~17-20 cycles whatever its width (tools/kexp5.hip: dropped by the range check 16 / 18 cycles at 8 / 16 bytes a lane,
+    // from an L2-resident table 20 / 19) - at one 512-byte row per instruction that alone is 3.8 ms for configs[3]'s 114.6 M edges, the
+    // floor every row-per-wave kernel of this file sits on.  The per-lane row offset comes through the LDS crossbar (ds_bpermute).
+    u4_t rv[KT / 2];
+    auto gather = [&](auto tb_c) __attribute__((always_inline)) {         // a tile's rows (slots behind the last edge: row 0)
+      constexpr int tb = decltype(tb_c)::value;
+      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (9 + p.slab_shift)));
+      uint32_t off[KT / 2];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane(my_edge, tb + i);
-        rv[i] = slab_row_load<raw2_t>(table, cB, (edge & ~255u) << 1);
-      }
+      for (int j = 0; j < KT / 2; ++j) off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((tb + 2 * j + (lane >> 5)) << 2, (int)my_off);
+#pragma unroll
+      for (int j = 0; j < KT / 2; ++j) rv[j] = slab_row_load<u4_t>(table, cH + off[j], 0u);
     };
-    if (ntiles > 0) gather(0);
-    for (int t = 0; t < ntiles; ++t) {
-      const int c = t >> 1, buf = c & 1, tb = (t & 1) * 32;
+    auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
+      constexpr int ph = decltype(ph_c)::value, tb = ph * KT;
+      const int c = t >> 2, buf = c & 1;
       // the next chunk's fields (and its weights, where they lie in plan order), behind this tile's gathers: every lane loads (lanes
       // behind the group's end re-read its last edge and drop the value)
-      const bool nvalid = (c + 1) * 64 + lane < len;
-      const int64_t ne = e0 + (nvalid ? (c + 1) * 64 + lane : len - 1);
-      uint32_t n_src = 0, n_dl = 255, n_pe = 0;
-      WRaw n_w;
-      if ((t & 1) == 0) {
-        n_src = (uint32_t)P.e_src[ne];
-        n_dl = (uint32_t)P.e_dl[ne];
+      if constexpr (ph == 0) {
+        nx_valid = (c + 1) * 64 + lane < len;
+        const int64_t ne = e0 + (nx_valid ? (c + 1) * 64 + lane : len - 1);
+        nx_src = (uint32_t)P.e_src[ne];
+        nx_dl = (uint32_t)P.e_dl[ne];
         if constexpr (WMODE != 0) {
-          if (wpo) n_w = load_w(ne);
-          else n_pe = (uint32_t)P.e_perm[ne];
+          if (wpo) nx_w = load_w(ne);
+          else nx_pe = (uint32_t)P.e_perm[ne];
         }
       }
+      if constexpr (WMODE != 0 && ph == 2) {
+        if (!wpo) nx_w = load_w((int64_t)nx_pe);       // (through the permutation: its entry arrived two tiles ago)
+      }
       // tile t into the image (the previous tile's transposed reads are ahead of these writes in the wave's LDS queue)
+#ifdef GEOT_DEV_EXPERIMENTS
+      if (!(p.probe & 4))
+#endif
+      {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) *reinterpret_cast<raw2_t *>(img + i * kStride + cB) = rv[i];
+        for (int j = 0; j < KT / 2; ++j) *reinterpret_cast<u4_t *>(img + (2 * j + (lane >> 5)) * kStride + cH) = rv[j];
+      }
+#ifdef GEOT_DEV_EXPERIMENTS
+      if (p.probe & 4) {                        // (knock-out experiment "slab_probe" bit 2: no image writes - the rows still have to arrive)
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < KT / 2; ++j) acc |= rv[j][0] ^ rv[j][1] ^ rv[j][2] ^ rv[j][3];
+        if (acc == 0x12345678u) img[lane] = 1;
+      }
+#endif
       wave_order();
-      if ((t & 1) == 0) {                       // (held across the odd tile: the chunk changes there)
-        nx_src = n_src, nx_dl = n_dl, nx_pe = n_pe, nx_w = n_w, nx_valid = nvalid;
-      } else {                                  // the chunk ends with this tile: hand the next chunk over
-        if constexpr (WMODE != 0) {
-          if (!wpo) nx_w = load_w((int64_t)nx_pe);
-        } else nx_w = load_w(0);
+      if constexpr (ph == 3) {                  // the chunk ends with this tile: hand the next chunk over
         my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
+        my_off = (my_edge & ~255u) << 1;
         stage(buf ^ 1, nx_w, nx_valid, my_edge);
       }
-      if (t + 1 < ntiles) gather(t + 1);        // in flight under this tile's matrix work
-      // A: selector x weight.  This lane's eight edges are the image rows 4 kq .. 4 kq + 3 and 16 + 4 kq .. 16 + 4 kq + 3 of the tile
-      const uint32_t dla = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
-      const uint32_t dlc = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 16 + 4 * kq);
-      uint32_t mk[4];
-      mk[0] = (((dla & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dla >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      mk[1] = ((((dla >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dla >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      mk[2] = (((dlc & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dlc >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      mk[3] = ((((dlc >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dlc >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      t8_t afrag[H];
+      if (t + 1 < ntiles) gather(std::integral_constant<int, ((ph + 1) & 3) * KT>{});   // in flight under this tile's matrix work
+      // A: selector x weight.  This lane's four edges are the image rows 4 kq .. 4 kq + 3 of the tile
+      const uint32_t dl4 = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
+      uint32_t mk[2];
+      mk[0] = (((dl4 & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dl4 >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+      mk[1] = ((((dl4 >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dl4 >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+      s4_t afrag[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const raw2_t wa = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 4 * kq);
-        const raw2_t wc = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 16 + 4 * kq);
-        const u4_t a = {wa[0] & mk[0], wa[1] & mk[1], wc[0] & mk[2], wc[1] & mk[3]};
-        afrag[h] = __builtin_bit_cast(t8_t, a);
+        const raw2_t a = {wa[0] & mk[0], wa[1] & mk[1]};
+        afrag[h] = __builtin_bit_cast(s4_t, a);
       }
+#ifdef GEOT_DEV_EXPERIMENTS
+      if (p.probe & 2) {                        // (knock-out bit 1: no transposed reads, no MFMAs)
+        D[0][0] += __builtin_bit_cast(float, (uint32_t)afrag[0][0]);
+        return;
+      }
+      const bool no_tr = (p.probe & 8) != 0;   // (knock-out bit 3: the MFMAs without their LDS operand)
+#endif
 #pragma unroll
       for (int fb = 0; fb < 16; ++fb) {
-        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + fb * 32));
-        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + 16 * kStride + fb * 32));
-        const s8_t b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const t8_t bfrag = __builtin_bit_cast(t8_t, b);
-        if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[fb / FB_PER_H], bfrag, D[fb], 0, 0, 0);
-        else D[fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[fb / FB_PER_H], bfrag, D[fb], 0, 0, 0);
+        s4_t b;
+#ifdef GEOT_DEV_EXPERIMENTS
+        if (no_tr) b = afrag[(fb + 1) % H];
+        else
+#endif
+        b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + fb * 32));
+        if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[fb / FB_PER_H], b, D[fb], 0, 0, 0);
+        else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[fb / FB_PER_H]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
       }
+    };
+    if (ntiles > 0) gather(std::integral_constant<int, 0>{});
+    for (int t = 0; t < ntiles; t += 4) {       // a chunk of 64 edges = four tiles, unrolled: lane numbers of the crossbar reads are immediates
+      tile(t, std::integral_constant<int, 0>{});
+      if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+      if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 2>{});
+      if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
     }
     lock.round_done(p, lane, r);
-    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows
-    wave_order();
+    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows, the two halves of
+    // the features one after the other (the image is 8.5 KB: 16 rows x 128 fp32 at a time)
+    const int64_t v0 = has ? P.g_vrow0[pos] : 0;
 #pragma unroll
-    for (int fb = 0; fb < 16; ++fb) {
+    for (int hf = 0; hf < 2; ++hf) {
+      wave_order();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) imgf[(4 * kq + j) * 256 + 16 * fb + m] = D[fb][j];
-    }
-    wave_order();
-    if (has) {
-      const int64_t v0 = P.g_vrow0[pos];
-      for (int l = 0; l < nv; ++l) {
-        const int64_t tg = P.v_out[v0 + l];
-        const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * 256 + lane * 4);
-        if (tg >= 0) {
-          if (tg < p.K) {
-            typedef T t4_t __attribute__((ext_vector_type(4)));
-            const t4_t o = {(T)row[0], (T)row[1], (T)row[2], (T)row[3]};                 // one rounding, here
-            *reinterpret_cast<t4_t *>(dst + tg * p.F + lane * 4) = o;
+      for (int fb = 0; fb < 8; ++fb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) imgf[(4 * kq + j) * 128 + 16 * fb + m] = D[8 * hf + fb][j];
+      }
+      wave_order();
+      if (has) {
+        for (int l = lane >> 5; l < nv; l += 2) {                 // lanes 0 .. 31 row l, lanes 32 .. 63 row l + 1: 128 features each
+          const int64_t tg = P.v_out[v0 + l];
+          const int col = (lane & 31) * 4;
+          const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * 128 + col);
+          if (tg >= 0) {
+            if (tg < p.K) {
+              typedef T t4_t __attribute__((ext_vector_type(4)));
+              const t4_t o = {(T)row[0], (T)row[1], (T)row[2], (T)row[3]};                 // one rounding, here
+              *reinterpret_cast<t4_t *>(dst + tg * p.F + 128 * hf + col) = o;
+            }
+          } else {
+            *reinterpret_cast<f4_t *>(p.carry + (-tg - 1) * p.F + 128 * hf + col) = row;   // fp32
           }
-        } else {
-          *reinterpret_cast<f4_t *>(p.carry + (-tg - 1) * p.F + lane * 4) = row;         // fp32
         }
       }
     }
@@ -2147,8 +2180,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   } while (0)
 #endif
     // 16-bit multi-head plans over 512-byte rows, sums: the matrix-core kernel, GATED on a finite source table (its header), with the
-    // row-per-wave kernel enqueued behind it under the opposite gate.  Its grid is 2 workgroups per CU (a 17 KB image per wave): the
-    // plan's groups are dealt to ITS waves (p.plan.units / p.rounds of the copy below), whatever grid the plan was cut for.
+    // row-per-wave kernel enqueued behind it under the opposite gate.  Same persistent grid, same plan.
     const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && rowbytes == 512 && reduce == GEOT_REDUCE_SUM && plan->rows_per_group <= 16 &&
                       (heads == 1 || heads == 2 || heads == 4 || heads == 8) && feat % 16 == 0 && (weight_mode != 1 || heads == 1) &&
                       (weight_mode == 0 || (((uintptr_t)p.weight) & (uintptr_t)(weight_mode == 2 ? heads * 2 - 1 : 1)) == 0);
@@ -2162,20 +2194,13 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         pm.gate_want = 0;
         p.gate = flag;                                                 // the vector-ALU twin below runs iff the table holds an Inf / NaN
         p.gate_want = 1;
-        const int64_t mwaves = (int64_t)slab_device().cus * 2 * 4;
-        pm.plan.units = (int32_t)mwaves;
-        pm.rounds = (int)((plan->n_groups + mwaves - 1) / mwaves);
-        const dim3 mgrid((unsigned)(mwaves / 4));
         const int64_t n16 = src_rows * rowbytes / 16;
         const int wm = weight_mode == 1 ? 1 : weight_mode;             // (one weight per edge: H == 1)
 #define GEOT_SLAB_SPMM_MFMA_W(T_, H_, W_)                                                                     \
         do {                                                                                                  \
-          auto kfn = seg_slab_spmm_mfma_kernel<T_, H_, W_>;                                                   \
-          const size_t mlds = (size_t)4 * (32 * (512 + 32) + 2 * H_ * 64 * 2 + 2 * 64);                       \
-          static std::once_flag once_;                                                                        \
-          std::call_once(once_, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds); }); \
+          const size_t mlds = (size_t)4 * (16 * (512 + 32) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
           geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ">").c_str()); \
-          hipLaunchKernelGGL(kfn, mgrid, blk, mlds, st, pm);                                                  \
+          hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_>), grid, blk, mlds, st, pm);               \
         } while (0)
 #define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \
         do {                                                                                                  \
@@ -2430,7 +2455,7 @@ int geot_internal_slab_option(const char *name, int value) {       // 1 = a name
   else if (n == "slab_stage") { if (value >= 0 && value <= 2) g_slab_stage = value; }
   else if (n == "slab_wrow_all") g_slab_wrow_all = value != 0;
   else if (n == "slab_pair") g_slab_pair = value != 0;
-  else if (n == "slab_probe") g_slab_probe = value != 0;
+  else if (n == "slab_probe") g_slab_probe = value;          // bit 0: drop the row reads; bits 1..3 (matrix-core SpMM only): skip the MFMAs / the image writes / the transposed reads
 #endif
   else return 0;
   return 1;

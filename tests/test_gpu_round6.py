@@ -80,26 +80,31 @@ def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtyp
         w = torch.from_numpy(rng.random((nnz, H), dtype=np.float32) - 0.3).to(dtype).cuda()
         wz = w * ok[:, None]
         ref = _ref(d_si.clamp(max=nodes - 1), d_di, wz, v, nodes)
-        scale = float(ref.abs().max())
+        mag = _ref(d_si.clamp(max=nodes - 1), d_di, wz.abs(), v.abs(), nodes)          # per element: the sum of |contributions|
         forms = [("edge-major", w, 2), ("head-major", w.t().contiguous(), 3), ("plan order", w[e_perm].contiguous(), 5)]
         outs = []
         for name, weight, mode in forms:
             o = run(weight, mode, v, 1)
-            assert float((o.double() - ref).abs().max()) <= tol * scale, (name, float((o.double() - ref).abs().max()), scale)
+            assert bool(((o.double() - ref).abs() <= tol * mag + 1e-30).all()), (name, float(((o.double() - ref).abs() / (mag + 1e-30)).max()))
             outs.append(o)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])          # one order of additions, whatever the layout
         assert torch.equal(run(w, 2, v, 1), outs[0])                                    # fixed by the plan, not by timing
-        ref0 = _ref(d_si.clamp(max=nodes - 1), d_di, ok[:, None].to(dtype).expand(nnz, H), v, nodes)
+        ones = ok[:, None].to(dtype).expand(nnz, H)
+        ref0, mag0 = _ref(d_si.clamp(max=nodes - 1), d_di, ones, v, nodes), _ref(d_si.clamp(max=nodes - 1), d_di, ones, v.abs(), nodes)
         o0 = run(None, 0, v, 1)
-        assert float((o0.double() - ref0).abs().max()) <= tol * float(ref0.abs().max())
+        assert bool(((o0.double() - ref0).abs() <= tol * mag0 + 1e-30).all())
         # (b) integer data: exact in fp32, so both kernels round the same number
         vi = torch.from_numpy(rng.integers(-1, 2, (nodes, H, Fh)).astype(np.float32)).to(dtype).cuda()
         wi = torch.from_numpy(rng.integers(-2, 3, (nnz, H)).astype(np.float32)).to(dtype).cuda()
         exact = _ref(d_si.clamp(max=nodes - 1), d_di, wi * ok[:, None], vi, nodes)
         a = run(wi, 2, vi, 1)
         b = run(wi, 2, vi, 0)
-        assert torch.equal(a, b), float((a.double() - b.double()).abs().max())
-        assert torch.equal(a, exact.to(dtype))
+        assert torch.equal(a, exact.to(dtype))                                          # an out-of-range source contributes NOTHING here
+        # (the row-per-wave kernel reads row 0 for such an edge - indices out of range are outside the contract, csrc/gather_scatter.cpp:25-34
+        # checks nothing; both are memory-safe): the two kernels agree bit for bit on every row that has no such edge
+        clean_rows = torch.ones(nodes, dtype=torch.bool, device="cuda")
+        clean_rows[d_di[~ok]] = False
+        assert torch.equal(a[clean_rows], b[clean_rows]), float((a.double() - b.double())[clean_rows].abs().max())
     finally:
         geot.hip.set_option("slab_spmm_mfma", 1)
 

@@ -20,6 +20,14 @@ for s in $steps; do
               for o in slab_spmm_mfma=1 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=0; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
               done > $O/slab_cases_mfma_ab.txt 2>&1; cat $O/slab_cases_mfma_ab.txt ;;
+    dbg)      timeout 600 python3 tools/_ab/dbg_mfma.py 2>&1 | grep -v amdgpu.ids | tail -60 ;;
+    mfmaprobe) for o in slab_spmm_mfma=1 slab_spmm_mfma=1,slab_probe=1 slab_spmm_mfma=1,slab_probe=1,slab_window=-1 slab_spmm_mfma=1,slab_window=-1 slab_spmm_mfma=1,slab_blocks=4 slab_spmm_mfma=0,slab_probe=1; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids | grep -v "^# done"
+              done > $O/slab_cases_mfma_probe.txt 2>&1; cat $O/slab_cases_mfma_probe.txt ;;
+    knock)    for o in slab_probe=0 slab_probe=1 slab_probe=3 slab_probe=5 slab_probe=7 slab_probe=9 slab_probe=2 slab_probe=4 slab_probe=8; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options slab_window=-1,$o 2>&1 | grep "PLAN order\|options"
+              done > $O/slab_cases_mfma_knockout.txt 2>&1; cat $O/slab_cases_mfma_knockout.txt ;;
+    kexp5)    timeout 600 ./tools/kexp5 > $O/kexp5_row_gather_instruction_cost.txt 2>&1; echo "rc=$?"; cat $O/kexp5_row_gather_instruction_cost.txt ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
