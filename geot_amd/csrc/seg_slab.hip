@@ -1617,18 +1617,22 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
     // from an L2-resident table 20 / 19) - at one 512-byte row per instruction that alone is 3.8 ms for configs[3]'s 114.6 M edges, the
     // floor every row-per-wave kernel of this file sits on.  The per-lane row offset comes through the LDS crossbar (ds_bpermute).
     u4_t rv[KT / 2];
+    uint32_t off[KT / 2];
+    auto offsets = [&](auto tb_c) __attribute__((always_inline)) {        // the per-lane row offsets of a tile's gathers (LDS crossbar: no memory)
+      constexpr int tb = decltype(tb_c)::value;
+#pragma unroll
+      for (int j = 0; j < KT / 2; ++j) off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((tb + 2 * j + (lane >> 5)) << 2, (int)my_off);
+    };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {         // a tile's rows (slots behind the last edge: row 0)
       constexpr int tb = decltype(tb_c)::value;
       if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (9 + p.slab_shift)));
-      uint32_t off[KT / 2];
-#pragma unroll
-      for (int j = 0; j < KT / 2; ++j) off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((tb + 2 * j + (lane >> 5)) << 2, (int)my_off);
 #pragma unroll
       for (int j = 0; j < KT / 2; ++j) rv[j] = slab_row_load<u4_t>(table, cH + off[j], 0u);
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
-      constexpr int ph = decltype(ph_c)::value, tb = ph * KT;
+      constexpr int ph = decltype(ph_c)::value, tb = ph * KT, tbn = ((ph + 1) & 3) * KT;
       const int c = t >> 2, buf = c & 1;
+      const bool more = t + 1 < ntiles;
       // the next chunk's fields (and its weights, where they lie in plan order), behind this tile's gathers: every lane loads (lanes
       // behind the group's end re-read its last edge and drop the value)
       if constexpr (ph == 0) {
@@ -1644,6 +1648,18 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       if constexpr (WMODE != 0 && ph == 2) {
         if (!wpo) nx_w = load_w((int64_t)nx_pe);       // (through the permutation: its entry arrived two tiles ago)
       }
+      // Everything that needs only the LDS crossbar / the chunk's staged arrays goes FIRST, ahead of the wait for this tile's rows: the
+      // hand-over of the next chunk (its fields arrived tiles ago), the next tile's gather offsets, this tile's selector bytes and weights
+      if constexpr (ph == 3) {                  // the chunk ends with this tile: the next chunk's edges become this lane's
+        my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
+        my_off = (my_edge & ~255u) << 1;
+        stage(buf ^ 1, nx_w, nx_valid, my_edge);
+      }
+      if (more) offsets(std::integral_constant<int, tbn>{});
+      const uint32_t dl4 = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
+      raw2_t wa[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) wa[h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 4 * kq);
       // tile t into the image (the previous tile's transposed reads are ahead of these writes in the wave's LDS queue)
 #ifdef GEOT_DEV_EXPERIMENTS
       if (!(p.probe & 4))
@@ -1661,22 +1677,15 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       }
 #endif
       wave_order();
-      if constexpr (ph == 3) {                  // the chunk ends with this tile: hand the next chunk over
-        my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
-        my_off = (my_edge & ~255u) << 1;
-        stage(buf ^ 1, nx_w, nx_valid, my_edge);
-      }
-      if (t + 1 < ntiles) gather(std::integral_constant<int, ((ph + 1) & 3) * KT>{});   // in flight under this tile's matrix work
+      if (more) gather(std::integral_constant<int, tbn>{});              // in flight under this tile's matrix work
       // A: selector x weight.  This lane's four edges are the image rows 4 kq .. 4 kq + 3 of the tile
-      const uint32_t dl4 = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
       uint32_t mk[2];
       mk[0] = (((dl4 & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dl4 >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
       mk[1] = ((((dl4 >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dl4 >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
       s4_t afrag[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const raw2_t wa = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 4 * kq);
-        const raw2_t a = {wa[0] & mk[0], wa[1] & mk[1]};
+        const raw2_t a = {wa[h][0] & mk[0], wa[h][1] & mk[1]};
         afrag[h] = __builtin_bit_cast(s4_t, a);
       }
 #ifdef GEOT_DEV_EXPERIMENTS
@@ -1698,6 +1707,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
         else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[fb / FB_PER_H]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
       }
     };
+    if (ntiles > 0) offsets(std::integral_constant<int, 0>{});
     if (ntiles > 0) gather(std::integral_constant<int, 0>{});
     for (int t = 0; t < ntiles; t += 4) {       // a chunk of 64 edges = four tiles, unrolled: lane numbers of the crossbar reads are immediates
       tile(t, std::integral_constant<int, 0>{});
