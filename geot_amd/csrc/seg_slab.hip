@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 // TILE AHEAD (into the same registers, while the previous tile goes through the matrix cores): 4.47 vs 4.28 ms - slower (130 registers
 // instead of 108, and the gathers were not what a tile waits for), dropped.
 template <typename T, int CPH>
-__global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParams p) {
+__global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabParams p) {   // (3 waves per SIMD: the persistent grid's 3 workgroups per CU all resident)
   static_assert(sizeof(T) == 2 && 8 % CPH == 0, "16-bit rows of 512 bytes");
   constexpr int NCH = 8, H = NCH / CPH;
   constexpr int kStride = 512 + 32;                      // bytes between the rows of a tile's image
@@ -1367,7 +1367,8 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
   T *out = static_cast<T *>(p.dst);
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
-  const uint32_t cB = (uint32_t)lane * 8u;
+  typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+  const uint32_t cH = (uint32_t)(lane & 31) * 16u;        // a lane's 16 bytes of its half-wave's row
   t8_t zero8;
 #pragma unroll
   for (int i = 0; i < 8; ++i) zero8[i] = (T)0.f;
@@ -1405,65 +1406,89 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_mfma_kernel(SlabParam
       const uint32_t d_ = valid ? (uint32_t)P.e_dl[e0 + lane] : 255u;
       my_edge = s_ < src_rows ? ((s_ << 8) | d_) : 255u;
     }
-    for (int off = 0; off < len; off += 64) {
-      const bool nvalid = off + 64 + lane < len;
-      const int64_t ne = e0 + (nvalid ? off + 64 + lane : len - 1);    // (every lane loads: see seg_slab_wrow_kernel)
-      uint32_t n_src = 0, n_dl = 255;
-      const int n_here = len - off;
-      const int n_max = n_here < 64 ? n_here : 64;
-      for (int t = 0; t < 4 && 16 * t < n_max; ++t) {
-        if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, 16 * t) >> (8 + p.slab_shift)));
-        raw2_t rv[16];
+    // Tiles of 16 edges, the four tiles of a 64-edge chunk unrolled.  TWO rows per gather instruction, 16 bytes a lane (lanes 0..31 the
+    // row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide load costs the CU ~17-20 cycles whatever its width
+    // (tools/kexp5.hip) - one 512-byte row per instruction was this kernel's floor (4.18 of its 4.30 ms with the gathers dropped, round
+    // 5).  The per-lane row offsets come through the LDS crossbar, ahead of the wait for the current tile's rows, and the NEXT tile's
+    // rows are gathered as soon as the current tile is in the image: in flight under its matrix work and its result exchange.
+    const int ntiles = (len + 15) >> 4;
+    uint32_t nx_src = 0, nx_dl = 255;
+    bool nx_valid = false;
+    u4_t rv[8];
+    uint32_t goff[8];
+    auto offsets = [&](auto tb_c) __attribute__((always_inline)) {
+      constexpr int tb = decltype(tb_c)::value;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {          // one edge's whole row per instruction (slots behind the last edge: row 0)
-          const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane(my_edge, 16 * t + i);
-          rv[i] = slab_row_load<raw2_t>(table, cB, (edge & ~255u) << 1);
-        }
-        if (t == 0) {                           // the next chunk's fields, behind this tile's gathers
-          n_src = (uint32_t)P.e_src[ne];
-          n_dl = (uint32_t)P.e_dl[ne];
-        }
-        const int dlm = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((16 * t + n) << 2, (int)my_edge) & 255u);
+      for (int j = 0; j < 8; ++j) goff[j] = ((uint32_t)__builtin_amdgcn_ds_bpermute((tb + 2 * j + (lane >> 5)) << 2, (int)my_edge) & ~255u) << 1;
+    };
+    auto gather = [&](auto tb_c) __attribute__((always_inline)) {
+      constexpr int tb = decltype(tb_c)::value;
+      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<raw2_t *>(img + i * kStride + cB) = rv[i];
-        wave_order();
-        t8_t afrag[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + n * kStride + 64 * c + 16 * kb);
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          f4_t d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int cc = 0; cc < CPH; ++cc) {
-            if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
-            else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
-          }
-          xch[(h * 4 + kb) * 16 + n] = d;       // D[row 4 kb + j][col n], j = 0..3
-        }
-        wave_order();
-        if (lane < 16) {                        // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
-          const int e = off + 16 * t + lane;
-          if (e < len) {
-            // (the H reads are unconditional - a padding edge reads column 0 and drops it: behind a branch each read would wait for
-            // its own LDS round trip, four in a row per tile)
-            const float *xf = reinterpret_cast<const float *>(xch) + ((((lane >> 2) * 16 + (dlm != 255 ? dlm : 0)) << 2) + (lane & 3));
-            float vals[H];
-#pragma unroll
-            for (int h = 0; h < H; ++h) vals[h] = xf[h * 256];
-            T *op = out + (e0 + e) * H;
-            if constexpr (H == 1) op[0] = (T)(dlm != 255 ? vals[0] : 0.f);
-            else {
-              typedef T tH_t __attribute__((ext_vector_type(H)));
-              tH_t pk;
-#pragma unroll
-              for (int h = 0; h < H; ++h) pk[h] = (T)(dlm != 255 ? vals[h] : 0.f);
-              *reinterpret_cast<tH_t *>(op) = pk;
-            }
-          }
-        }
-        wave_order();
+      for (int j = 0; j < 8; ++j) rv[j] = slab_row_load<u4_t>(table, cH + goff[j], 0u);
+    };
+    auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
+      constexpr int ph = decltype(ph_c)::value, tb = ph * 16, tbn = ((ph + 1) & 3) * 16;
+      const bool more = t + 1 < ntiles;
+      if constexpr (ph == 0) {                  // the next chunk's fields, behind this tile's gathers (every lane loads: see seg_slab_wrow_kernel)
+        const int c = t >> 2;
+        nx_valid = (c + 1) * 64 + lane < len;
+        const int64_t ne = e0 + (nx_valid ? (c + 1) * 64 + lane : len - 1);
+        nx_src = (uint32_t)P.e_src[ne];
+        nx_dl = (uint32_t)P.e_dl[ne];
       }
-      my_edge = (nvalid && n_src < src_rows) ? ((n_src << 8) | n_dl) : 255u;
+      const int dlm = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((tb + n) << 2, (int)my_edge) & 255u);
+      if constexpr (ph == 3) my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;   // (the chunk ends with this tile)
+      if (more) offsets(std::integral_constant<int, tbn>{});
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<u4_t *>(img + (2 * j + (lane >> 5)) * kStride + cH) = rv[j];
+      wave_order();
+      if (more) gather(std::integral_constant<int, tbn>{});
+      t8_t afrag[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + n * kStride + 64 * c + 16 * kb);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        f4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < CPH; ++cc) {
+          if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
+          else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
+        }
+        xch[(h * 4 + kb) * 16 + n] = d;         // D[row 4 kb + j][col n], j = 0..3
+      }
+      wave_order();
+      if (lane < 16) {                          // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
+        const int e = t * 16 + lane;
+        if (e < len) {
+          // (the H reads are unconditional - a padding edge reads column 0 and drops it: behind a branch each read would wait for
+          // its own LDS round trip, four in a row per tile)
+          const float *xf = reinterpret_cast<const float *>(xch) + ((((lane >> 2) * 16 + (dlm != 255 ? dlm : 0)) << 2) + (lane & 3));
+          float vals[H];
+#pragma unroll
+          for (int h = 0; h < H; ++h) vals[h] = xf[h * 256];
+          T *op = out + (e0 + e) * H;
+          if constexpr (H == 1) op[0] = (T)(dlm != 255 ? vals[0] : 0.f);
+          else {
+            typedef T tH_t __attribute__((ext_vector_type(H)));
+            tH_t pk;
+#pragma unroll
+            for (int h = 0; h < H; ++h) pk[h] = (T)(dlm != 255 ? vals[h] : 0.f);
+            *reinterpret_cast<tH_t *>(op) = pk;
+          }
+        }
+      }
+      wave_order();
+    };
+    if (ntiles > 0) {
+      offsets(std::integral_constant<int, 0>{});
+      gather(std::integral_constant<int, 0>{});
+    }
+    for (int t = 0; t < ntiles; t += 4) {
+      tile(t, std::integral_constant<int, 0>{});
+      if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+      if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 2>{});
+      if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
     }
     lock.round_done(p, lane, r);
   }

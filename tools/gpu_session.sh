@@ -28,6 +28,10 @@ for s in $steps; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options slab_window=-1,$o 2>&1 | grep "PLAN order\|options"
               done > $O/slab_cases_mfma_knockout.txt 2>&1; cat $O/slab_cases_mfma_knockout.txt ;;
     kexp5)    timeout 600 ./tools/kexp5 > $O/kexp5_row_gather_instruction_cost.txt 2>&1; echo "rc=$?"; cat $O/kexp5_row_gather_instruction_cost.txt ;;
+    sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
+              for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
+              done > $O/slab_cases_sddmm_mfma_b128.txt 2>&1; cat $O/slab_cases_sddmm_mfma_b128.txt ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
