@@ -24,7 +24,7 @@ geot/gather_weight_scatter.py:31-51.
 """
 from __future__ import annotations
 
-from typing import Optional, Union
+from typing import Optional, Tuple, Union
 
 import torch
 
@@ -437,42 +437,51 @@ class _SpmmFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        g, plan = ctx.g, ctx.plan
         values, x = ctx.saved_tensors
-        if ctx.reduce not in ("sum", "mean"):
-            raise NotImplementedError(f"geot_amd.Graph: backward is implemented for reduce='sum' and 'mean' only (got '{ctx.reduce}')")
-        grad = grad.contiguous()
-        if ctx.reduce == "mean":
-            deg = g.degree().clamp(min=1.0).to(grad.dtype)
-            grad = grad / deg.view(-1, *([1] * (grad.dim() - 1)))
-        gx = gw = None
-        if ctx.needs_input_grad[3]:
-            w_t = None
-            if ctx.has_w:
-                mh = x.dim() == 3
-                H, F = (x.shape[1], x.shape[2]) if mh else (1, x.shape[1])
-                bwd_plan = g._plan("bwd", H * F * x.element_size(), 2 if mh else 1, H, x.dtype, _rows(grad))
-                if bwd_plan is not None and not g._verdict.get((id(bwd_plan), "spmm"), True):
-                    bwd_plan = None                       # (lost its trial: the per-edge kernels read the transposed list's order)
-                vals = values.detach().contiguous()
+        gx, gw = _spmm_backward(ctx.g, ctx.plan, values if ctx.has_w else None, x, grad, ctx.reduce, ctx.needs_input_grad[3],
+                                ctx.has_w and ctx.needs_input_grad[2])
+        return None, None, gw, gx, None
 
-                def list_order(vals=vals, plan=plan):       # the weights in the transposed LIST's order (per-edge kernels, trials)
-                    return hip.gather_rows_out(g._values_for_bwd(plan, None), vals, torch.empty_like(vals))
-                w_t = ("via", g._bwd_reader(plan, bwd_plan), vals, list_order) if bwd_plan is not None else list_order()
-            gx = _fit_rows(g._spmm("bwd", w_t, grad), x.shape[0])     # (x may have trailing rows no edge reads: src_rows = max(src_index) + 1)
-        if ctx.has_w and ctx.needs_input_grad[2]:
-            wplan, gw = g._sddmm(grad, x.detach(), plan is not None)      # (plan order asked for when the weight came in plan order)
-            if plan is not None and wplan is not plan:       # the scores came back in another order than the weight's: re-order once
-                gw_edge = gw
-                if wplan is not None:
-                    gw_edge = torch.empty_like(gw)
-                    gw_edge[wplan.tensors["e_perm"].long()] = gw
-                gw = gw_edge[plan.tensors["e_perm"].long()].contiguous()
-            elif plan is None and wplan is not None:
+
+def _spmm_backward(g: "Graph", plan, values, x, grad, reduce: str, need_x: bool, need_w: bool):
+    """(d/dx, d/dweight) of out = g._spmm('fwd', weight, x): d/dx = the same operator over the transposed list with the weights read in
+    ITS order; d/dweight = the (multi-head) SDDMM, returned in the order the weight came in (``plan``: plan order; None: edge order).
+    Shared by the handle's autograd.Function and the ``geot::graph_spmm`` operator of a rewritten exported program."""
+    if reduce not in ("sum", "mean"):
+        raise NotImplementedError(f"geot_amd.Graph: backward is implemented for reduce='sum' and 'mean' only (got '{reduce}')")
+    has_w = values is not None
+    grad = grad.contiguous()
+    if reduce == "mean":
+        deg = g.degree().clamp(min=1.0).to(grad.dtype)
+        grad = grad / deg.view(-1, *([1] * (grad.dim() - 1)))
+    gx = gw = None
+    if need_x:
+        w_t = None
+        if has_w:
+            mh = x.dim() == 3
+            H, F = (x.shape[1], x.shape[2]) if mh else (1, x.shape[1])
+            bwd_plan = g._plan("bwd", H * F * x.element_size(), 2 if mh else 1, H, x.dtype, _rows(grad))
+            if bwd_plan is not None and not g._verdict.get((id(bwd_plan), "spmm"), True):
+                bwd_plan = None                       # (lost its trial: the per-edge kernels read the transposed list's order)
+            vals = values.detach().contiguous()
+
+            def list_order(vals=vals, plan=plan):       # the weights in the transposed LIST's order (per-edge kernels, trials)
+                return hip.gather_rows_out(g._values_for_bwd(plan, None), vals, torch.empty_like(vals))
+            w_t = ("via", g._bwd_reader(plan, bwd_plan), vals, list_order) if bwd_plan is not None else list_order()
+        gx = _fit_rows(g._spmm("bwd", w_t, grad), x.shape[0])     # (x may have trailing rows no edge reads: src_rows = max(src_index) + 1)
+    if has_w and need_w:
+        wplan, gw = g._sddmm(grad, x.detach(), plan is not None)      # (plan order asked for when the weight came in plan order)
+        if plan is not None and wplan is not plan:       # the scores came back in another order than the weight's: re-order once
+            gw_edge = gw
+            if wplan is not None:
                 gw_edge = torch.empty_like(gw)
                 gw_edge[wplan.tensors["e_perm"].long()] = gw
-                gw = gw_edge
-        return None, None, gw, gx, None
+            gw = gw_edge[plan.tensors["e_perm"].long()].contiguous()
+        elif plan is None and wplan is not None:
+            gw_edge = torch.empty_like(gw)
+            gw_edge[wplan.tensors["e_perm"].long()] = gw
+            gw = gw_edge
+    return gx, gw
 
 
 class _SddmmFn(torch.autograd.Function):
@@ -511,3 +520,70 @@ class _SddmmFn(torch.autograd.Function):
             g2 = g._spmm("bwd", w_t, m1d)
             g2 = _fit_rows(g2, m2.shape[0])
         return None, g1, g2, None, None
+
+
+# ---- handles inside an exported program (geot_amd.match_replace.pattern_transform(..., static_graph=True)) -------------------------------
+# An FX graph carries tensors and numbers, not Python objects: the rewritten program names its Graph by an integer, and two operators
+# defined here (where the reference defines its own, geot/gather_weight_scatter.py:15-51: torch.library.custom_op + register_fake +
+# register_autograd) run the handle's kernels - no index tensors in the call, so no fingerprint, no cache lookup, no row rule.
+_HANDLES: dict = {}
+_NEXT_HANDLE = [1]
+
+
+def register_graph(g: Graph) -> int:
+    """Keep ``g`` alive under a fresh integer (what ``geot::graph_spmm`` takes); ``release_graph`` drops it."""
+    h = _NEXT_HANDLE[0]
+    _NEXT_HANDLE[0] += 1
+    _HANDLES[h] = g
+    return h
+
+
+def release_graph(handle: int) -> None:
+    _HANDLES.pop(int(handle), None)
+
+
+def _handle(handle: int) -> Graph:
+    g = _HANDLES.get(int(handle))
+    if g is None:
+        raise RuntimeError(f"geot::graph_spmm: no geot_amd.Graph is registered under handle {handle} (released, or another process)")
+    return g
+
+
+@torch.library.custom_op("geot::graph_spmm", mutates_args=())
+def graph_spmm(handle: int, weight: Optional[torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """dst[d] = sum over the registered graph's edges into d of (w_e) x[s_e]; x [N, F] with weight None | [nnz], or [N, H, F] with
+    weight [nnz, H] (gather_scatter / gather_weight_scatter / mh_spmm over a static graph)."""
+    return _handle(handle)._spmm("fwd", None if weight is None else weight.contiguous(), x)
+
+
+@graph_spmm.register_fake
+def _(handle, weight, x):
+    return x.new_empty((_handle(handle).rows,) + tuple(x.shape[1:]))
+
+
+@torch.library.custom_op("geot::graph_spmm_backward", mutates_args=())
+def graph_spmm_backward(handle: int, weight: Optional[torch.Tensor], x: torch.Tensor, grad: torch.Tensor, need_x: bool,
+                        need_w: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    gx, gw = _spmm_backward(_handle(handle), None, weight, x, grad, "sum", need_x, need_w and weight is not None)
+    return (gx if gx is not None else x.new_empty(0)), (gw if gw is not None else x.new_empty(0))
+
+
+@graph_spmm_backward.register_fake
+def _(handle, weight, x, grad, need_x, need_w):
+    return (x.new_empty(x.shape) if need_x else x.new_empty(0)), (weight.new_empty(weight.shape) if (need_w and weight is not None) else x.new_empty(0))
+
+
+def _graph_spmm_setup(ctx, inputs, output):
+    handle, weight, x = inputs
+    ctx.handle, ctx.has_w = handle, weight is not None
+    ctx.save_for_backward(weight if weight is not None else x.new_empty(0), x)
+
+
+def _graph_spmm_bwd(ctx, grad):
+    weight, x = ctx.saved_tensors
+    need_x, need_w = ctx.needs_input_grad[2], ctx.has_w and ctx.needs_input_grad[1]
+    gx, gw = torch.ops.geot.graph_spmm_backward(ctx.handle, weight if ctx.has_w else None, x, grad, need_x, need_w)
+    return None, (gw if need_w else None), (gx if need_x else None)
+
+
+torch.library.register_autograd("geot::graph_spmm", _graph_spmm_bwd, setup_context=_graph_spmm_setup)

@@ -32,6 +32,7 @@ import torch.fx as fx
 from torch.export import ExportedProgram, export
 
 from . import ops  # noqa: F401  (registers torch.ops.geot.*)
+from . import graph as _graph_ops  # noqa: F401  (registers geot::graph_spmm)
 
 aten = torch.ops.aten
 _ZEROS = {aten.new_zeros.default, aten.zeros.default, aten.zeros_like.default}
@@ -152,9 +153,97 @@ def rewrite_graph(gm: fx.GraphModule, sort_edges: bool = False) -> int:
     return fused
 
 
-def pattern_transform(model: torch.nn.Module, args, sort_edges: bool = False, **kwargs) -> ExportedProgram:
+def _placeholder_values(exported: ExportedProgram, args) -> dict:
+    """placeholder name -> concrete tensor, for the exported graph's lifted parameters / buffers / constants and the user's inputs."""
+    import torch.utils._pytree as pytree
+    from torch.export.graph_signature import InputKind
+    flat_user = list(pytree.tree_leaves(tuple(args)))
+    values, user_i = {}, 0
+    for spec in exported.graph_signature.input_specs:
+        name = getattr(spec.arg, "name", None)
+        if spec.kind == InputKind.USER_INPUT:
+            values[name] = flat_user[user_i]
+            user_i += 1
+        elif spec.kind == InputKind.PARAMETER:
+            values[name] = exported.state_dict[spec.target]
+        elif spec.kind == InputKind.BUFFER:
+            values[name] = exported.state_dict[spec.target] if spec.target in exported.state_dict else exported.constants[spec.target]
+        else:
+            values[name] = exported.constants.get(spec.target)
+    return values
+
+
+def _evaluate(node, known: dict, depth: int = 0):
+    """The concrete value of ``node`` on the example inputs: placeholders from ``known``, call_function nodes by calling their target on
+    the evaluated arguments (the edge list of a layer is a select / slice / index of an input: a handful of nodes)."""
+    if not isinstance(node, fx.Node):
+        return node
+    if node.name in known:
+        return known[node.name]
+    if node.op != "call_function" or depth > 32:
+        raise RuntimeError(f"static_graph: cannot evaluate {node.format_node()} at export time")
+    a = fx.node.map_arg(node.args, lambda n: _evaluate(n, known, depth + 1))
+    k = fx.node.map_arg(node.kwargs, lambda n: _evaluate(n, known, depth + 1))
+    known[node.name] = node.target(*a, **k)
+    return known[node.name]
+
+
+def bind_static_graphs(exported: ExportedProgram, args, slab_mode: str = "auto") -> list:
+    """Second pass of ``pattern_transform(..., static_graph=True)``: every fused ``geot::*_rows(col, row, [w,] x, rows)`` node whose edge
+    list can be evaluated on the example inputs becomes ``geot::graph_spmm(handle, w, x)`` over ONE ``geot_amd.Graph`` per distinct edge
+    list, built HERE - outside ``forward``.  The rewritten program then never reads its index tensors for these nodes: no content
+    fingerprint, no cache lookup, no read-back of the row rule per call (the host layer's guard re-reads 3.7 GB per call at configs[3]).
+    THE CALLER'S PROMISE: the program is run on the graph it was exported with (a static graph - full-batch training, inference on one
+    graph); other inputs of the same shapes would silently use the exported graph's edges.  Returns the handles
+    (``geot_amd.graph.release_graph`` frees one)."""
+    from . import graph as _graph
+    gm = exported.graph_module
+    known = _placeholder_values(exported, args)
+    fused = {torch.ops.geot.gather_scatter_rows.default: False, torch.ops.geot.gather_weight_scatter_rows.default: True,
+             torch.ops.geot.mh_spmm_rows.default: True}
+    graphs, handles, bound = {}, [], 0
+    for node in list(gm.graph.nodes):
+        if node.op != "call_function" or node.target not in fused:
+            continue
+        has_w = fused[node.target]
+        col, row = node.args[0], node.args[1]
+        w = node.args[2] if has_w else None
+        x, rows = node.args[-2], node.args[-1]
+        xs = _shape(x)
+        if not isinstance(rows, int) or xs is None or not isinstance(xs[0], int):
+            continue                                       # (symbolic sizes: the node keeps its tensor-based form)
+        key = (col.name if isinstance(col, fx.Node) else id(col), row.name if isinstance(row, fx.Node) else id(row), rows, xs[0])
+        if key not in graphs:
+            col_t, row_t = _evaluate(col, known), _evaluate(row, known)
+            if not (torch.is_tensor(col_t) and col_t.is_cuda):
+                raise RuntimeError("pattern_transform(static_graph=True): the example edge list must live on the GPU (geot_amd.Graph has no CPU path)")
+            if row_t.numel() > 1 and bool((row_t[1:] < row_t[:-1]).any()):
+                raise ValueError("pattern_transform(static_graph=True): the index_add index (edge_index[0]) must ascend - sort the edge list by "
+                                 "destination once, or use sort_edges / the default tensor-based rewrite")
+            g = _graph.Graph(col_t, row_t, num_src=xs[0], num_dst=rows, slab_mode=slab_mode)
+            graphs[key] = _graph.register_graph(g)
+            handles.append(graphs[key])
+        with gm.graph.inserting_before(node):
+            new = gm.graph.call_function(torch.ops.geot.graph_spmm.default, (graphs[key], w, x))
+        new.meta["val"] = node.meta.get("val")
+        node.replace_all_uses_with(new)
+        gm.graph.erase_node(node)
+        bound += 1
+    if bound:
+        gm.graph.eliminate_dead_code()
+        gm.graph.lint()
+        gm.recompile()
+    exported.geot_static_nodes = bound
+    return handles
+
+
+def pattern_transform(model: torch.nn.Module, args, sort_edges: bool = False, static_graph: bool = False, slab_mode: str = "auto",
+                      **kwargs) -> ExportedProgram:
     """Export ``model`` on ``args`` and fuse its message-passing patterns (same call shape as the
-    reference's ``pattern_transform(model, args, **kwargs)``; extra keyword ``sort_edges``)."""
+    reference's ``pattern_transform(model, args, **kwargs)``, geot/match_replace/match_replace.py:8-32; extra keywords ``sort_edges``,
+    ``static_graph``).  ``static_graph=True``: the fused nodes are bound to ``geot_amd.Graph`` handles built here, once, from the example
+    inputs' edge list (see :func:`bind_static_graphs` for the promise that goes with it); ``exported.geot_graphs`` lists the handles."""
     exported = export(model, args, **kwargs)
-    exported.geot_fused_nodes = rewrite_graph(exported.graph_module, sort_edges=sort_edges)
+    exported.geot_fused_nodes = rewrite_graph(exported.graph_module, sort_edges=sort_edges and not static_graph)
+    exported.geot_graphs = bind_static_graphs(exported, args, slab_mode=slab_mode) if static_graph else []
     return exported

@@ -149,3 +149,79 @@ def test_rewritten_and_compiled_models_match_eager(name):
         assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-4, atol=1e-4), name
         comp = torch.compile(mod)(*args)
         assert torch.allclose(comp, ref, rtol=1e-4, atol=1e-4), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ZOO))
+def test_static_graph_rewrite_matches_eager_and_touches_no_cache(name):
+    """`pattern_transform(model, args, static_graph=True)`: the fused nodes run over ONE geot_amd.Graph built at
+    export time - `geot::graph_spmm(handle, w, x)` - so a call neither fingerprints the index tensors nor looks anything up: the host
+    layer's counters do not move across steps.  Results equal the eager layer; also under torch.compile."""
+    from geot_amd import ops
+    from geot_amd.graph import release_graph
+    from geot_amd.match_replace import pattern_transform
+    torch._dynamo.reset()
+    make, fused, _ = ZOO[name]
+    torch.manual_seed(0)
+    model = make().cuda()
+    args = _graph(5000, 120_000, 16, 2, "cuda")
+    with torch.no_grad():
+        ref = model(*args).double()
+        ep = pattern_transform(model, args, static_graph=True)
+        assert ep.geot_fused_nodes == fused and ep.geot_static_nodes == fused and len(ep.geot_graphs) == 1       # one edge list -> one handle
+        targets = [n.target for n in ep.graph_module.graph.nodes if n.op == "call_function"]
+        assert targets.count(torch.ops.geot.graph_spmm.default) == fused
+        assert not any(getattr(t, "__name__", "").endswith("_rows.default") or "_rows" in str(t) for t in targets if "geot" in str(t))
+        mod = ep.module()
+        ops.clear_caches()
+        got = mod(*args)
+        st0 = ops.stats()
+        for _ in range(3):
+            got = mod(*args)
+        assert ops.stats() == st0, "a static-graph program must not touch the host layer's caches / guards"
+        scale = float(ref.abs().max())
+        assert got.shape == ref.shape and float((got.double() - ref).abs().max()) <= 1e-5 * scale, name
+        comp = torch.compile(mod)(*args)
+        assert float((comp.double() - ref).abs().max()) <= 1e-5 * scale, name
+    for h in ep.geot_graphs:
+        release_graph(h)
+    with pytest.raises(RuntimeError, match="no geot_amd.Graph is registered"):
+        mod(*args)
+
+
+@pytest.mark.gpu
+def test_static_graph_rewrite_trains():
+    """Gradients flow through `geot::graph_spmm` (register_autograd -> geot::graph_spmm_backward: d/dx over the transposed list, d/dweight
+    by the SDDMM): a rewritten GAT and GCN take optimiser steps and follow the eager model's parameters."""
+    from geot_amd.match_replace import pattern_transform
+    for make in (lambda: GAT(16, 8, 4), lambda: GCN(16, 32)):
+        torch.manual_seed(0)
+        eager = make().cuda()
+        args = _graph(3000, 90_000, 16, 5, "cuda")
+        twin = make().cuda()
+        twin.load_state_dict(eager.state_dict())
+        ep = pattern_transform(twin, args, static_graph=True)
+        mod = ep.module()
+        opt_e = torch.optim.SGD(eager.parameters(), lr=0.05)
+        opt_m = torch.optim.SGD(mod.parameters(), lr=0.05)
+        target = torch.rand_like(eager(*args))
+        for _ in range(3):
+            for m, opt in ((eager, opt_e), (mod, opt_m)):
+                opt.zero_grad()
+                loss = ((m(*args) - target) ** 2).mean()
+                loss.backward()
+                opt.step()
+        pe = dict(eager.named_parameters())
+        for k, v in mod.named_parameters():
+            ref = pe[k]
+            assert float((v - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6, k
+
+
+@pytest.mark.gpu
+def test_static_graph_rewrite_refuses_an_unsorted_edge_list():
+    from geot_amd.match_replace import pattern_transform
+    torch.manual_seed(0)
+    x, ei = _graph(500, 4000, 16, 3, "cuda")
+    ei = ei[:, torch.randperm(ei.shape[1], device="cuda")]
+    with pytest.raises(ValueError, match="must ascend"):
+        pattern_transform(GIN(16, 16).cuda(), (x, ei), static_graph=True)

@@ -209,12 +209,14 @@ def _dense_graph(rng, nodes, nnz):
 
 
 @pytest.mark.parametrize("dtype,F", [(torch.float32, 128), (torch.float32, 64), (torch.bfloat16, 256), (torch.float16, 128)])
-def test_row_per_wave_kernels_every_weight_mode_and_reduction(geot, oracle, dtype, F):
+def test_row_per_wave_kernels_every_weight_mode_and_reduction(geot, oracle, dtype, F, request):
     """seg_slab_wrow_kernel for weight modes 0 / 1 / 4 - a plan cut into WAVES runs one row per wave-instruction under any weight
     mode (the library's own rule keeps lane groups for these modes: measured faster, profiles/r05/slab_cases__row_per_wave_*): sum /
     mean / max / min against the oracle in float64, split hub, empty row, deterministic; edge-order weights staged inside the kernel
     and read through the permutation give the same bits."""
     from geot_amd import slab
+    geot.hip.set_option("slab_spmm_mfma", 0)                            # (this test is about the row-per-wave kernel; the matrix-core kernel
+    request.addfinalizer(lambda: geot.hip.set_option("slab_spmm_mfma", 1))   #  that serves 16-bit 512-byte plans by default: tests/test_gpu_round6.py)
     rng = np.random.default_rng(F)
     nodes, nnz = 3000, 400_000
     si, di = _dense_graph(rng, nodes, nnz)

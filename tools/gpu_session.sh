@@ -32,6 +32,7 @@ for s in $steps; do
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
               done > $O/slab_cases_sddmm_mfma_b128.txt 2>&1; cat $O/slab_cases_sddmm_mfma_b128.txt ;;
+    compile)  timeout 1500 python3 -m pytest tests/test_compile_models.py tests/test_match_replace.py tests/test_gpu_graph_handle.py -m gpu -x -q 2>&1 | tail -25 ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
