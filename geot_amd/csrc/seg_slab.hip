@@ -1532,15 +1532,26 @@ __global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t
   if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-template <typename T, int H, int WMODE>
-__global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabParams p) {   // (3 waves per SIMD: the persistent grid's 3 workgroups per CU all resident)
+// FS = 1: a wave owns a group's whole rows (3 workgroups per CU).  FS = 2: a PAIR of waves owns a group, each wave one half of the
+// features (256 bytes of every row: four edges per gather instruction, half the accumulators, half the image) - under 128 registers,
+// so 4 workgroups per CU are resident: the tile body is a chain of latencies (crossbar -> rows -> image -> transposed reads -> MFMAs)
+// and more waves per SIMD is what hides them.  The two waves of a pair share nothing but the plan's streams (the second reader hits L1 / L2).
+template <typename T, int H, int WMODE, int FS>
+__global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_kernel(SlabParams p) {
   static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows of 512 bytes, 1 / 2 / 4 / 8 heads");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE != 1 || H == 1), "one weight per edge = one head");
+  static_assert(FS == 1 || FS == 2, "whole rows or halves");
   constexpr int KT = 16;                                 // edges per tile = the K of v_mfma_f32_16x16x16 (see the header: why not 32)
-  constexpr int kStride = 512 + 32;                      // bytes between the rows of a tile's image
-  constexpr int kImg = KT * kStride;                     // 8 704 bytes
+  constexpr int RB = 512 / FS;                           // bytes of a row this wave reads
+  constexpr int LPR = RB / 16;                           // lanes per row of a gather instruction (16 bytes a lane)
+  constexpr int RPI = 64 / LPR;                          // rows per gather instruction: 2 | 4
+  constexpr int NL = KT / RPI;                           // gather instructions per tile: 8 | 4
+  constexpr int NFB = 16 / FS;                           // 16-feature blocks of this wave
+  constexpr int kStride = RB + 32;                       // bytes between the rows of a tile's image
+  constexpr int kImg = KT * kStride;                     // 8 704 | 4 608 bytes
   constexpr int kWave = kImg + 2 * H * 64 * 2 + 2 * 64;  // + weights [2 chunks][H][64] of T + rows-in-group [2][64] bytes
   constexpr int FB_PER_H = 16 / H;                       // 16-feature blocks per head
+  constexpr int HL = H >= FS ? H / FS : 1;               // heads this wave touches
   typedef short s4_t __attribute__((ext_vector_type(4)));
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
   typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
@@ -1554,15 +1565,19 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
   unsigned char *img = smem + (size_t)wave * kWave;
   uint16_t *wst = reinterpret_cast<uint16_t *>(img + kImg);          // [2][H][64]
   unsigned char *dlb = img + kImg + 2 * H * 64 * 2;                   // [2][64]
-  float *imgf = reinterpret_cast<float *>(img);                       // (group end: half of the D tiles as [16 rows][128] fp32, 8 KB of the image)
-  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  float *imgf = reinterpret_cast<float *>(img);                       // (group end: half of this wave's D tiles as [16 rows][128 | 64] fp32: 8 | 4 KB of the image)
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t unit = gw / FS;                           // (FS = 2: waves 2 u and 2 u + 1 are unit u)
+  const int half = (int)(gw % FS);
+  const int hbase = H >= FS ? half * HL : 0;              // this wave's first head
   const int64_t units = P.units;
   const T *weight = static_cast<const T *>(p.weight);
   T *dst = static_cast<T *>(p.dst);
   const bool wpo = p.w_in_plan_order != 0;
   const uint32_t src_rows = (uint32_t)p.src_rows;
   const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
-  const uint32_t cH = (uint32_t)(lane & 31) * 16u;        // a lane's 16 bytes of its half-wave's row
+  const uint32_t cL = (uint32_t)(lane % LPR) * 16u;       // a lane's 16 bytes inside the image row ...
+  const uint32_t cH = cL + (uint32_t)half * RB;           // ... and inside the table's row
   // the tile's transposed read: lane 16 kq + 4 q + pp supplies the address of image row 4 kq + q, columns 4 pp .. 4 pp + 3 of the block;
   // lane 16 kq + n receives column n of those four rows = B[k = 4 kq .. 4 kq + 3][n]
   const uint32_t tr_off = (uint32_t)((4 * kq + ((lane >> 2) & 3)) * kStride + (lane & 3) * 8);
@@ -1618,9 +1633,9 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
     e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
     len = __builtin_amdgcn_readfirstlane(len);
     nv = __builtin_amdgcn_readfirstlane(nv);
-    f4_t D[16];
+    f4_t D[NFB];
 #pragma unroll
-    for (int fb = 0; fb < 16; ++fb) D[fb] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int fb = 0; fb < NFB; ++fb) D[fb] = f4_t{0.f, 0.f, 0.f, 0.f};
     uint32_t my_edge = 255;                     // (source row << 8) | row in group; 255 = padding / out-of-range source (contributes nothing)
     {
       const bool valid = lane < len;
@@ -1641,18 +1656,18 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
     // load costs the CU ~17-20 cycles whatever its width (tools/kexp5.hip: dropped by the range check 16 / 18 cycles at 8 / 16 bytes a lane,
     // from an L2-resident table 20 / 19) - at one 512-byte row per instruction that alone is 3.8 ms for configs[3]'s 114.6 M edges, the
     // floor every row-per-wave kernel of this file sits on.  The per-lane row offset comes through the LDS crossbar (ds_bpermute).
-    u4_t rv[KT / 2];
-    uint32_t off[KT / 2];
+    u4_t rv[NL];
+    uint32_t off[NL];
     auto offsets = [&](auto tb_c) __attribute__((always_inline)) {        // the per-lane row offsets of a tile's gathers (LDS crossbar: no memory)
       constexpr int tb = decltype(tb_c)::value;
 #pragma unroll
-      for (int j = 0; j < KT / 2; ++j) off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((tb + 2 * j + (lane >> 5)) << 2, (int)my_off);
+      for (int j = 0; j < NL; ++j) off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((tb + RPI * j + lane / LPR) << 2, (int)my_off);
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {         // a tile's rows (slots behind the last edge: row 0)
       constexpr int tb = decltype(tb_c)::value;
       if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (9 + p.slab_shift)));
 #pragma unroll
-      for (int j = 0; j < KT / 2; ++j) rv[j] = slab_row_load<u4_t>(table, cH + off[j], 0u);
+      for (int j = 0; j < NL; ++j) rv[j] = slab_row_load<u4_t>(table, cH + off[j], 0u);
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
       constexpr int ph = decltype(ph_c)::value, tb = ph * KT, tbn = ((ph + 1) & 3) * KT;
@@ -1682,22 +1697,22 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       }
       if (more) offsets(std::integral_constant<int, tbn>{});
       const uint32_t dl4 = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
-      raw2_t wa[H];
+      raw2_t wa[HL];
 #pragma unroll
-      for (int h = 0; h < H; ++h) wa[h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 4 * kq);
+      for (int h = 0; h < HL; ++h) wa[h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + hbase + h) * 64 + tb + 4 * kq);
       // tile t into the image (the previous tile's transposed reads are ahead of these writes in the wave's LDS queue)
 #ifdef GEOT_DEV_EXPERIMENTS
       if (!(p.probe & 4))
 #endif
       {
 #pragma unroll
-        for (int j = 0; j < KT / 2; ++j) *reinterpret_cast<u4_t *>(img + (2 * j + (lane >> 5)) * kStride + cH) = rv[j];
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<u4_t *>(img + (RPI * j + lane / LPR) * kStride + cL) = rv[j];
       }
 #ifdef GEOT_DEV_EXPERIMENTS
       if (p.probe & 4) {                        // (knock-out experiment "slab_probe" bit 2: no image writes - the rows still have to arrive)
         uint32_t acc = 0;
 #pragma unroll
-        for (int j = 0; j < KT / 2; ++j) acc |= rv[j][0] ^ rv[j][1] ^ rv[j][2] ^ rv[j][3];
+        for (int j = 0; j < NL; ++j) acc |= rv[j][0] ^ rv[j][1] ^ rv[j][2] ^ rv[j][3];
         if (acc == 0x12345678u) img[lane] = 1;
       }
 #endif
@@ -1707,9 +1722,9 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       uint32_t mk[2];
       mk[0] = (((dl4 & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dl4 >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
       mk[1] = ((((dl4 >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dl4 >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      s4_t afrag[H];
+      s4_t afrag[HL];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
+      for (int h = 0; h < HL; ++h) {
         const raw2_t a = {wa[h][0] & mk[0], wa[h][1] & mk[1]};
         afrag[h] = __builtin_bit_cast(s4_t, a);
       }
@@ -1721,15 +1736,17 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       const bool no_tr = (p.probe & 8) != 0;   // (knock-out bit 3: the MFMAs without their LDS operand)
 #endif
 #pragma unroll
-      for (int fb = 0; fb < 16; ++fb) {
+      for (int fb = 0; fb < NFB; ++fb) {
+        constexpr int kOneHead = FB_PER_H >= NFB;            // (a head spans all of this wave's blocks)
+        const int hl = kOneHead ? 0 : fb / FB_PER_H;
         s4_t b;
 #ifdef GEOT_DEV_EXPERIMENTS
-        if (no_tr) b = afrag[(fb + 1) % H];
+        if (no_tr) b = afrag[(hl + 1) % HL];
         else
 #endif
         b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + fb * 32));
-        if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[fb / FB_PER_H], b, D[fb], 0, 0, 0);
-        else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[fb / FB_PER_H]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
+        if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[hl], b, D[fb], 0, 0, 0);
+        else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[hl]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
       }
     };
     if (ntiles > 0) offsets(std::integral_constant<int, 0>{});
@@ -1741,31 +1758,33 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
     }
     lock.round_done(p, lane, r);
-    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows, the two halves of
-    // the features one after the other (the image is 8.5 KB: 16 rows x 128 fp32 at a time)
+    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows, this wave's blocks
+    // in two passes (the image is 8.5 | 4.5 KB: 16 rows x 128 | 64 fp32 at a time)
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
+    constexpr int PB = NFB / 2, PF = PB * 16, LR = PF / 4;     // blocks and floats of a pass, lanes that cover a row's part
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       wave_order();
 #pragma unroll
-      for (int fb = 0; fb < 8; ++fb) {
+      for (int fb = 0; fb < PB; ++fb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) imgf[(4 * kq + j) * 128 + 16 * fb + m] = D[8 * hf + fb][j];
+        for (int j = 0; j < 4; ++j) imgf[(4 * kq + j) * PF + 16 * fb + m] = D[PB * hf + fb][j];
       }
       wave_order();
       if (has) {
-        for (int l = lane >> 5; l < nv; l += 2) {                 // lanes 0 .. 31 row l, lanes 32 .. 63 row l + 1: 128 features each
+        for (int l = lane / LR; l < nv; l += 64 / LR) {          // 64 / LR rows at a time
           const int64_t tg = P.v_out[v0 + l];
-          const int col = (lane & 31) * 4;
-          const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * 128 + col);
+          const int colp = (lane % LR) * 4;
+          const int col = half * (256 / FS) + PF * hf + colp;
+          const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * PF + colp);
           if (tg >= 0) {
             if (tg < p.K) {
               typedef T t4_t __attribute__((ext_vector_type(4)));
               const t4_t o = {(T)row[0], (T)row[1], (T)row[2], (T)row[3]};                 // one rounding, here
-              *reinterpret_cast<t4_t *>(dst + tg * p.F + 128 * hf + col) = o;
+              *reinterpret_cast<t4_t *>(dst + tg * p.F + col) = o;
             }
           } else {
-            *reinterpret_cast<f4_t *>(p.carry + (-tg - 1) * p.F + 128 * hf + col) = row;   // fp32
+            *reinterpret_cast<f4_t *>(p.carry + (-tg - 1) * p.F + col) = row;             // fp32
           }
         }
       }
@@ -2231,11 +2250,22 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         p.gate_want = 1;
         const int64_t n16 = src_rows * rowbytes / 16;
         const int wm = weight_mode == 1 ? 1 : weight_mode;             // (one weight per edge: H == 1)
+        // "slab_spmm_mfma" = 2: pairs of waves, each one half of the features, 4 workgroups per CU - the plan's groups are dealt to THIS
+        // grid's units (waves / 2), whatever grid the plan was cut for
+        const int fs = g_slab_spmm_mfma == 2 ? 2 : 1;
+        dim3 mgrid = grid;
+        if (fs == 2) {
+          const int64_t mwaves = (int64_t)slab_device().cus * 4 * 4;
+          pm.plan.units = (int32_t)(mwaves / 2);
+          pm.rounds = (int)((plan->n_groups + pm.plan.units - 1) / pm.plan.units);
+          mgrid = dim3((unsigned)(mwaves / 4));
+        }
 #define GEOT_SLAB_SPMM_MFMA_W(T_, H_, W_)                                                                     \
         do {                                                                                                  \
-          const size_t mlds = (size_t)4 * (16 * (512 + 32) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
-          geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ">").c_str()); \
-          hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_>), grid, blk, mlds, st, pm);               \
+          const size_t mlds = (size_t)4 * (16 * (512 / fs + 32) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
+          geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(fs) + ">").c_str()); \
+          if (fs == 2) hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 2>), mgrid, blk, mlds, st, pm); \
+          else hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 1>), mgrid, blk, mlds, st, pm);      \
         } while (0)
 #define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \
         do {                                                                                                  \
@@ -2481,7 +2511,7 @@ int geot_internal_slab_option(const char *name, int value) {       // 1 = a name
   else if (n == "slab_turn") g_slab_turn = value != 0;
   else if (n == "slab_far") { if (value >= 0) g_slab_far = value; }
   else if (n == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
-  else if (n == "slab_spmm_mfma") g_slab_spmm_mfma = value != 0;
+  else if (n == "slab_spmm_mfma") { if (value >= 0 && value <= 2) g_slab_spmm_mfma = value; }   // 1: a wave per group, 2: a pair of waves per group (feature halves)
   else if (n == "slab_blocks") { if (value >= 1 && value <= 4) g_slab_blocks = value; }
 #ifdef GEOT_DEV_EXPERIMENTS
   else if (n == "slab_nt") g_slab_nt = value != 0;

@@ -17,7 +17,7 @@ for s in $steps; do
               ;;
     devtests) GEOT_HIP_LIB=dev timeout 2400 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu_devlib.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu_devlib.log ;;
     mfma)     timeout 1200 python3 -m pytest tests/test_gpu_round6.py -m gpu -x -q > $O/pytest_r6_mfma.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r6_mfma.log
-              for o in slab_spmm_mfma=1 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=0; do
+              for o in slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
               done > $O/slab_cases_mfma_ab.txt 2>&1; cat $O/slab_cases_mfma_ab.txt ;;
     dbg)      timeout 600 python3 tools/_ab/dbg_mfma.py 2>&1 | grep -v amdgpu.ids | tail -60 ;;
@@ -33,6 +33,7 @@ for s in $steps; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
               done > $O/slab_cases_sddmm_mfma_b128.txt 2>&1; cat $O/slab_cases_sddmm_mfma_b128.txt ;;
     compile)  timeout 1500 python3 -m pytest tests/test_compile_models.py tests/test_match_replace.py tests/test_gpu_graph_handle.py -m gpu -x -q 2>&1 | tail -25 ;;
+    pmcmfma)  bash tools/pmc_spmm_mfma.sh $O/pmc_spmm_mfma 2>&1 | tail -40 ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt

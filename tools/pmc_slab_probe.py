@@ -15,7 +15,9 @@ for d in sorted(glob.glob(os.path.join(out, "*_1"))):
         f = glob.glob(os.path.join(out, name + "_" + n, "**", "*counter_collection.csv"), recursive=True)
         if not f:
             continue
-        rows = [r for r in csv.DictReader(open(f[0])) if "seg_slab_w" in r["Kernel_Name"] or "seg_slab_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f[0])) if "seg_slab_w" in r["Kernel_Name"] or "seg_slab_kernel" in r["Kernel_Name"] or "seg_slab_spmm_mfma" in r["Kernel_Name"]]
+        if any("seg_slab_spmm_mfma" in r["Kernel_Name"] for r in rows):      # (its gated vector-ALU twin is launched behind it and returns at once)
+            rows = [r for r in rows if "seg_slab_spmm_mfma" in r["Kernel_Name"]]
         if not rows:
             continue
         last = max(int(r["Dispatch_Id"]) for r in rows)
