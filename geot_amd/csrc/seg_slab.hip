@@ -2252,7 +2252,11 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         const int wm = weight_mode == 1 ? 1 : weight_mode;             // (one weight per edge: H == 1)
         // "slab_spmm_mfma" = 2: pairs of waves, each one half of the features, 4 workgroups per CU - the plan's groups are dealt to THIS
         // grid's units (waves / 2), whatever grid the plan was cut for
+#ifdef GEOT_DEV_EXPERIMENTS
         const int fs = g_slab_spmm_mfma == 2 ? 2 : 1;
+#else
+        constexpr int fs = 1;                                          // (the pair form measured slower, 3.87 vs 3.71 ms: development build only)
+#endif
         dim3 mgrid = grid;
         if (fs == 2) {
           const int64_t mwaves = (int64_t)slab_device().cus * 4 * 4;
@@ -2260,12 +2264,17 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
           pm.rounds = (int)((plan->n_groups + pm.plan.units - 1) / pm.plan.units);
           mgrid = dim3((unsigned)(mwaves / 4));
         }
+#ifdef GEOT_DEV_EXPERIMENTS
+#define GEOT_SLAB_SPMM_MFMA_FS2(T_, H_, W_) if (fs == 2) hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 2>), mgrid, blk, mlds, st, pm); else
+#else
+#define GEOT_SLAB_SPMM_MFMA_FS2(T_, H_, W_)
+#endif
 #define GEOT_SLAB_SPMM_MFMA_W(T_, H_, W_)                                                                     \
         do {                                                                                                  \
           const size_t mlds = (size_t)4 * (16 * (512 / fs + 32) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
           geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(fs) + ">").c_str()); \
-          if (fs == 2) hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 2>), mgrid, blk, mlds, st, pm); \
-          else hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 1>), mgrid, blk, mlds, st, pm);      \
+          GEOT_SLAB_SPMM_MFMA_FS2(T_, H_, W_)                                                                 \
+          hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 1>), mgrid, blk, mlds, st, pm);           \
         } while (0)
 #define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \
         do {                                                                                                  \
@@ -2286,6 +2295,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 #undef GEOT_SLAB_SPMM_MFMA
 #undef GEOT_SLAB_SPMM_MFMA_H
 #undef GEOT_SLAB_SPMM_MFMA_W
+#undef GEOT_SLAB_SPMM_MFMA_FS2
       }
       const std::string mfma_name = mfma ? std::string(geot_last_kernel()) : std::string();
 #ifdef GEOT_DEV_EXPERIMENTS
@@ -2511,7 +2521,11 @@ int geot_internal_slab_option(const char *name, int value) {       // 1 = a name
   else if (n == "slab_turn") g_slab_turn = value != 0;
   else if (n == "slab_far") { if (value >= 0) g_slab_far = value; }
   else if (n == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
-  else if (n == "slab_spmm_mfma") { if (value >= 0 && value <= 2) g_slab_spmm_mfma = value; }   // 1: a wave per group, 2: a pair of waves per group (feature halves)
+#ifdef GEOT_DEV_EXPERIMENTS
+  else if (n == "slab_spmm_mfma") { if (value >= 0 && value <= 2) g_slab_spmm_mfma = value; }   // 1: a wave per group, 2 (development build): a pair of waves per group (feature halves)
+#else
+  else if (n == "slab_spmm_mfma") { if (value >= 0 && value <= 1) g_slab_spmm_mfma = value; }
+#endif
   else if (n == "slab_blocks") { if (value >= 1 && value <= 4) g_slab_blocks = value; }
 #ifdef GEOT_DEV_EXPERIMENTS
   else if (n == "slab_nt") g_slab_nt = value != 0;

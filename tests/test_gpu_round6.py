@@ -107,10 +107,11 @@ def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtyp
         assert torch.equal(a[clean_rows], b[clean_rows]), float((a.double() - b.double())[clean_rows].abs().max())
         # the other form of the kernel - a PAIR of waves per group, each wave one half of the features ("slab_spmm_mfma" = 2) - adds in the
         # same order: the same bits, for every weight layout
-        for name, weight, mode in forms:
-            assert torch.equal(run(weight, mode, v, 2), outs[0]), name
-        assert torch.equal(run(None, 0, v, 2), o0) and torch.equal(run(wi, 2, vi, 2), a)
-        assert geot.hip.last_kernel().endswith(", 2>"), geot.hip.last_kernel()
+        if "DEVELOPMENT" in geot.hip.build_info():                                      # (measured slower: the development build only)
+            for name, weight, mode in forms:
+                assert torch.equal(run(weight, mode, v, 2), outs[0]), name
+            assert torch.equal(run(None, 0, v, 2), o0) and torch.equal(run(wi, 2, vi, 2), a)
+            assert geot.hip.last_kernel().endswith(", 2>"), geot.hip.last_kernel()
     finally:
         geot.hip.set_option("slab_spmm_mfma", 1)
 

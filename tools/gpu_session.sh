@@ -33,7 +33,19 @@ for s in $steps; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
               done > $O/slab_cases_sddmm_mfma_b128.txt 2>&1; cat $O/slab_cases_sddmm_mfma_b128.txt ;;
     compile)  timeout 1500 python3 -m pytest tests/test_compile_models.py tests/test_match_replace.py tests/test_gpu_graph_handle.py -m gpu -x -q 2>&1 | tail -25 ;;
-    pmcmfma)  bash tools/pmc_spmm_mfma.sh $O/pmc_spmm_mfma 2>&1 | tail -40 ;;
+    pmcmfma)  GEOT_HIP_LIB=product bash tools/pmc_spmm_mfma.sh $O/pmc_spmm_mfma 2>&1 | tail -40 ;;
+    mfmaprod) for o in slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0; do
+                GEOT_HIP_LIB=product timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
+              done > $O/slab_cases_mfma_ab_product_lib.txt 2>&1; cat $O/slab_cases_mfma_ab_product_lib.txt ;;
+    benchall) timeout 1500 python3 bench.py --steps 20 --warmup 5 --secondary all --detail-out $O/bench_all_detail.json > $O/bench_all.json 2> $O/bench_all.err; echo "rc=$?"; cat $O/bench_all.json; tail -2 $O/bench_all.err
+              python3 - <<PY
+import json
+d=json.load(open("$O/bench_all_detail.json"))
+for k,v in d["secondary"].items():
+    keep={a:b for a,b in v.items() if a in ("kernel_ms","kernel","error","kernel_ms_without_content_guard","kernel_ms_with_graph_handle","rocsparse_best_ms","speedup_vs_rocsparse_best","us_per_call_as_dispatched","kernel_us","ms_per_step","attention_forward_ms","as_dispatched","with_graph_handle","without_content_guard","per_edge_kernels")}
+    print(k, json.dumps(keep)[:700])
+PY
+              ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
