@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_round")
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r06"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 COPY_BYTES = 2_684_354_560            # tools/kbench copy: 160 Mi float4 elements
@@ -138,7 +138,9 @@ WORKLOADS = {
     # (rocprofv3 leaves the __bf16 instantiations mangled: DF16b)
     "gather_scatter_cfg5": [("", r"seg_tile_kernel<float, 4, true, 0,")],
     "gws_cfg3_bf16": [("", r"seg_tile_kernel(<" + T16 + r", 8, true, 1,|IDF16bLi8ELb1ELi1E)")],
-    "mh_spmm_cfg4_bf16": [("", r"seg_slab_wrow_kernel(<" + T16 + r", 2, 4|IDF16bLi2ELi4E)"),
+    # (round 6: the matrix-core SpMM serves this workload; its gated vector-ALU twin is launched behind it and returns at once)
+    "mh_spmm_cfg4_bf16": [("", r"seg_slab_spmm_mfma_kernel"), ("/gated twin (returns at once)", r"seg_slab_wrow_kernel(<" + T16 + r", 2, 4|IDF16bLi2ELi4E)"),
+                          ("/finite-table check", r"slab_nonfinite_kernel"),
                           ("/per-edge [nnz,H]", r"seg_tile_kernel(<" + T16 + r", 8, true, 2,|IDF16bLi8ELb1ELi2E)")],
 }
 gather = {}

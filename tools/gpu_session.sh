@@ -46,6 +46,13 @@ for k,v in d["secondary"].items():
     print(k, json.dumps(keep)[:700])
 PY
               ;;
+    mfmaR)    for R in 11 12 13 14; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --rows-per-group $R 2>&1 | grep "mh_\|options" | cut -c1-170
+              done > $O/slab_cases_mfma_rows_per_group.txt 2>&1; cat $O/slab_cases_mfma_rows_per_group.txt ;;
+    mfmastage) for o in slab_stage=1 slab_stage=2; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16,fp32 --options $o 2>&1 | grep "mh_spmm\|options" | cut -c1-170
+              done > $O/slab_cases_mh_weight_prepass.txt 2>&1; cat $O/slab_cases_mh_weight_prepass.txt ;;
+    cfg5box)  bash tools/cfg5_box.sh ${CFG5_TAG:-box_$(date +%H%M%S)} 2>&1 | tail -14 ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt

@@ -10,7 +10,9 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
-python3 bench.py --full --steps 100 --warmup 10 > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+python3 bench.py --full --secondary all --steps 100 --warmup 10 > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+# ... and the driver's own command, as the driver sees it (the compact last line)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out "$OUT/bench_driver_detail.json" > "$OUT/bench_driver_cmd.json" 2> "$OUT/bench_driver_cmd.err"
 # ---- headline (BASELINE.json configs[1])
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 bench.py --full --steps 100 --warmup 10 --no-cpu-baseline --no-secondary \
     > "$OUT/bench_under_kernel_trace.json" 2> "$OUT/kt.err"
@@ -20,7 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
 done
 # ---- the secondary workloads, one at a time
 # (gather_scatter_cfg5 = BASELINE.json configs[4]'s one-GPU shard: bench.py selects it with `--only-secondary cfg5`)
-for w in ${WORKLOADS:-gws_cfg3 gws_cfg3_local gws_cfg3_powerlaw_src gws_cfg3_blockmodel_asis gws_cfg3_blockmodel_renum mh_spmm_cfg4 mh_spmm_cfg4_powerlaw_src gws_cfg3_bf16 mh_spmm_cfg4_bf16 gather_scatter_cfg5}; do
+for w in ${WORKLOADS:-gws_cfg3 gws_cfg3_local mh_spmm_cfg4 gws_cfg3_bf16 mh_spmm_cfg4_bf16 gather_scatter_cfg5}; do
   sel=$w; [ $w = gather_scatter_cfg5 ] && sel=cfg5
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -o bench -- python3 bench.py --full --steps 2 --warmup 1 --no-cpu-baseline --only-secondary $sel \
       > "$OUT/kt_$w.json" 2> "$OUT/kt_$w.err"
