@@ -144,8 +144,18 @@ WORKLOADS = {
                           ("/per-edge [nnz,H]", r"seg_tile_kernel(<" + T16 + r", 8, true, 2,|IDF16bLi8ELb1ELi2E)")],
 }
 gather = {}
+# (gpurun MERGES a session's files into gpurun_out/: what an earlier round's session left there under other workload names must not be
+#  taken for this session's - everything older than the session's first file by more than a minute is ignored)
+session_t0 = os.path.getmtime(os.path.join(src, "bench_unprofiled.json")) - 60
+for name in ("bench_driver_cmd.json", "bench_driver_detail.json"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 for w, wanted in WORKLOADS.items():
-    kt = kernel_times(os.path.join(src, f"kt_{w}", "bench_kernel_stats.csv"))
+    ktp = os.path.join(src, f"kt_{w}", "bench_kernel_stats.csv")
+    if os.path.exists(ktp) and os.path.getmtime(ktp) < session_t0:
+        print(f"# {w}: stale files of an earlier session ignored", file=sys.stderr)
+        continue
+    kt = kernel_times(ktp)
     if not kt:
         continue
     shutil.copy(os.path.join(src, f"kt_{w}", "bench_kernel_stats.csv"), os.path.join(dst, f"kernel_stats__{w}.csv"))

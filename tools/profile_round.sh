@@ -41,4 +41,4 @@ done
 find "$OUT" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.txt" ! -name "*.err" -delete
 find "$OUT" -name "*.csv" -size +4M -delete
 du -sh "$OUT"; find "$OUT" -name "*.csv" | wc -l
-tail -2 "$OUT"/*.err | grep -v "^$" | head -40
+for f in "$OUT"/*.err; do tail -n 2 "$f"; done | grep -v "^$" | head -40
