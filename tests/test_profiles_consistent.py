@@ -47,6 +47,29 @@ def _evidence_us():
             pool += [rec["ms_per_step"] * 1e3, rec["roofline"]["kernel_ms"] * 1e3]
             pool += [v * 1e3 for k, v in rec.get("extras", {}).items() if k.endswith("_ms")]
             pool += [v for k, v in rec.get("extras", {}).items() if k.endswith("_us_per_call")]
+    def unit_of(key, inherited):
+        if re.search(r"(^|_)ms($|_)", key):
+            return 1e3
+        if re.search(r"(^|_)us($|_)", key):
+            return 1.0
+        return inherited
+
+    def walk(node, unit=None):                                # the bench records of the session: every leaf under a key that names a duration
+        if isinstance(node, dict):
+            for k, v in node.items():
+                u = unit_of(k, unit)
+                if isinstance(v, (dict, list)):
+                    walk(v, u)
+                elif isinstance(v, (int, float)) and not isinstance(v, bool) and u:
+                    pool.append(v * u)
+        elif isinstance(node, list):
+            for v in node:
+                walk(v, unit)
+    import json
+    for name in ("bench_all_secondaries_detail.json", "bench_driver_detail.json", "bench_unprofiled.json"):
+        path = os.path.join(ROOT, "profiles", RND, name)
+        if os.path.exists(path):
+            walk(json.loads(open(path).read()))
     for path in glob.glob(os.path.join(ROOT, "profiles", RND, "**", "*.txt"), recursive=True):
         for m in DUR.finditer(open(path, errors="replace").read()):
             pool.append(_num(m.group(1)) * (1e3 if m.group(2) == "ms" else 1.0))
