@@ -53,6 +53,12 @@ PY
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16,fp32 --options $o 2>&1 | grep "mh_spmm\|options" | cut -c1-170
               done > $O/slab_cases_mh_weight_prepass.txt 2>&1; cat $O/slab_cases_mh_weight_prepass.txt ;;
     cfg5box)  bash tools/cfg5_box.sh ${CFG5_TAG:-box_$(date +%H%M%S)} 2>&1 | tail -14 ;;
+    soak6)    for seed in 301 302 303 304 305 306; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 200 --seed $seed --ops mh,mh,mh,gws,gs,is > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; tail -1 $O/soak_seed$seed.log | cut -c1-200
+              done
+              timeout 900 python3 tools/hang_hunt.py --scenario threads --runs 20 --slab-turn 1 --T 60 > $O/hunt_threads20.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_threads20.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario procs --runs 10 --T 90 > $O/hunt_procs10.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_procs10.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 10 --T 90 > $O/hunt_graphs10.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_graphs10.txt ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
