@@ -8,4 +8,9 @@ extern "C" int geot_internal_slab_option(const char *name, int value);   // 1 = 
 extern "C" const char *geot_last_kernel(void);
 // records the name of the dominant kernel the calling thread's last operator call launched (geot_last_kernel)
 extern "C" void geot_internal_note_kernel(const char *name);
+// fills `bytes` (a multiple of 4, 4-byte aligned) with the 32-bit `word` by a KERNEL on `stream` (hipStream_t).  Used instead of
+// hipMemsetAsync wherever a call may be captured into a graph: a memset node of a graph captured through PyTorch was seen to write a
+// repeating 16-byte pattern (another kernel's argument block) instead of its value from the SECOND replay on (round 6; a bare HIP
+// program does not show it: tools/kexp6.hip).  A kernel node replays as captured.
+extern "C" int geot_internal_fill(void *p, unsigned long bytes, unsigned int word, void *stream);
 #endif

@@ -1914,6 +1914,19 @@ __global__ __launch_bounds__(kThreads) void box_rows_kernel(const float *__restr
   if (!MIX && s[0] + s[1] + s[2] + s[3] == 123.456f) sink[0] = s[0];
 }
 
+// geot_internal_fill (internal.h): 16 bytes a lane where the buffer allows, words otherwise
+__global__ __launch_bounds__(kThreads) void fill_quads_kernel(uint32_t *p, size_t words, uint32_t value) {
+  typedef uint32_t u4f_t __attribute__((ext_vector_type(4)));
+  const size_t quads = words >> 2;
+  u4f_t *q = reinterpret_cast<u4f_t *>(p);
+  const u4f_t v = {value, value, value, value};
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < quads; i += (size_t)gridDim.x * kThreads) q[i] = v;
+  if (blockIdx.x == 0 && threadIdx.x < (words & 3)) p[(quads << 2) + threadIdx.x] = value;
+}
+__global__ __launch_bounds__(kThreads) void fill_words_kernel(uint32_t *p, size_t words, uint32_t value) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < words; i += (size_t)gridDim.x * kThreads) p[i] = value;
+}
+
 __global__ void box_clock_kernel(unsigned long long *out, int spins) {
   const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
   float x = (float)threadIdx.x;
@@ -2467,7 +2480,11 @@ int run_segment_op(int mode, bool sorted, const int64_t *src_index, const int64_
     rec.e0 = prof_event(); rec.e1 = prof_event(); rec.e2 = prof_event(); rec.e3 = prof_event();
   }
   if (prof) HIP_TRY(hipEventRecord(rec.e0, st));
-  if (nnz == 0 || !sorted) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)K * (size_t)F * sizeof(T), st));
+  if (nnz == 0 || !sorted) {                                   // (a kernel, not a memset node: internal.h geot_internal_fill)
+    const size_t zb = (size_t)K * (size_t)F * sizeof(T);
+    if ((zb & 3) == 0 && (((uintptr_t)dst) & 3) == 0) { if (geot_internal_fill(dst, zb, 0u, st) != GEOT_OK) return GEOT_ELAUNCH; }
+    else HIP_TRY(hipMemsetAsync(dst, 0, zb, st));
+  }
   if (prof) HIP_TRY(hipEventRecord(rec.e1, st));
 
   int rc = GEOT_OK;
@@ -2742,8 +2759,8 @@ int run_select_backward(const int64_t *si, const int64_t *di, const void *w, con
                                void *gsrc, void *gw, int64_t nnz, int64_t F, int64_t src_rows, int64_t K, hipStream_t st) {
   if (nnz < 0 || F < 0 || src_rows < 0 || K < 0) return fail(GEOT_EINVAL, "negative size");
   if (!gsrc || !ties || (nnz > 0 && (!si || !di || !x || !out || !grad))) return fail(GEOT_EINVAL, "null pointer");
-  HIP_TRY(hipMemsetAsync(gsrc, 0, (size_t)src_rows * (size_t)F * sizeof(T), st));
-  HIP_TRY(hipMemsetAsync(ties, 0, (size_t)K * (size_t)F * sizeof(T), st));
+  if (geot_internal_fill(gsrc, (size_t)src_rows * (size_t)F * sizeof(T), 0u, st) != GEOT_OK) return GEOT_ELAUNCH;   // (fp32 / fp64: whole words)
+  if (geot_internal_fill(ties, (size_t)K * (size_t)F * sizeof(T), 0u, st) != GEOT_OK) return GEOT_ELAUNCH;
   if (nnz == 0 || F == 0) return GEOT_OK;
   int l = ceil_log2(F);
   if (l > 6) l = 6;
@@ -2765,6 +2782,21 @@ int run_select_backward(const int64_t *si, const int64_t *di, const void *w, con
 extern "C" {
 
 int geot_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+int geot_internal_fill(void *p, unsigned long bytes, unsigned int word, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bytes == 0) return GEOT_OK;
+  if (!p || (bytes & 3) || (((uintptr_t)p) & 3)) return fail(GEOT_EINVAL, "internal: fill wants whole, aligned 32-bit words");
+  const size_t words = bytes / 4;
+  const bool quads = (((uintptr_t)p) & 15) == 0 && words >= 4;
+  size_t blocks = ((quads ? words / 4 : words) + kThreads - 1) / kThreads;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (quads) hipLaunchKernelGGL(fill_quads_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, static_cast<uint32_t *>(p), words, (uint32_t)word);
+  else hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, static_cast<uint32_t *>(p), words, (uint32_t)word);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GEOT_OK : fail(GEOT_ELAUNCH, hipGetErrorString(e));
+}
+
 void geot_internal_note_kernel(const char *name) { t_last_kernel = name ? name : ""; }
 const char *geot_last_kernel(void) { return t_last_kernel.c_str(); }
 
@@ -2945,7 +2977,7 @@ int geot_index_probe(const int64_t *index, int64_t nnz, int64_t *out2, void *str
     HIP_TRY(hipGetLastError());
     return GEOT_OK;
   }
-  HIP_TRY(hipMemsetAsync(out2, 0, 2 * sizeof(int64_t), st));
+  if (geot_internal_fill(out2, 2 * sizeof(int64_t), 0u, st) != GEOT_OK) return GEOT_ELAUNCH;
   int64_t blocks = (nnz + kThreads * 4 - 1) / (kThreads * 4);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(index_probe_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, index, nnz, out2);
@@ -2992,7 +3024,7 @@ int geot_coo_to_csr(const int64_t *coo_row, int64_t nnz, int64_t nrow, int32_t *
     hipLaunchKernelGGL(coo_sorted_to_csr_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, coo_row, nnz, nrow, rowptr);
   } else {
     // hist into rowptr[1..nrow], the caller turns it into an inclusive prefix sum
-    HIP_TRY(hipMemsetAsync(rowptr, 0, (size_t)(nrow + 1) * sizeof(int32_t), st));
+    if (geot_internal_fill(rowptr, (size_t)(nrow + 1) * sizeof(int32_t), 0u, st) != GEOT_OK) return GEOT_ELAUNCH;
     hipLaunchKernelGGL(coo_hist_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, coo_row, nnz, nrow, rowptr + 1);
   }
   HIP_TRY(hipGetLastError());

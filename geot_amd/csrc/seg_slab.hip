@@ -294,6 +294,14 @@ template <typename RAW> __device__ __forceinline__ RAW slab_row_load(__amdgpu_bu
   else return __builtin_bit_cast(RAW, __builtin_amdgcn_raw_buffer_load_b128(table, lane_bytes, row_bytes_off, 0));
 }
 
+// The word that picks one kernel of a gated pair (SlabParams::gate) is written by kernels EARLIER ON THE STREAM (a memset, then
+// slab_nonfinite_kernel's atomicOr) and read by every wave of the pair, on all eight XCDs.  An XCD's L2 is not coherent with the
+// others': a plain (or non-temporal) load may be served a line its own L2 kept from the LAST launch - between eager launches the
+// runtime's kernel-boundary invalidate hides that, between the kernel nodes of a replayed HIP graph it does not (seen: replay n + 1 of
+// a captured call read replay n's word on some XCDs, so those waves of BOTH kernels took the wrong turn).  An agent-scope atomic load
+// (sc1: served at the memory side) is coherent by construction.
+__device__ __forceinline__ int slab_gate_word(const int *gate) { return __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // WMODE: 0 none, 1 weight[e], 2 weight[e*H + h], 3 weight[h*nnz + e]
 // WAVE_ROW: rows of 1 KiB - the whole wave is one unit, edge fields are read with v_readlane (scalar row bases)
 //
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_wrow_kernel(SlabParams p) {
     return f4_t{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
   };
 
-  if (p.gate && ((__builtin_nontemporal_load(p.gate) != 0) != (p.gate_want != 0))) return;   // (the other twin of a gated pair runs: see SlabParams::gate)
+  if (p.gate && ((slab_gate_word(p.gate) != 0) != (p.gate_want != 0))) return;   // (the other twin of a gated pair runs: see SlabParams::gate)
   SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
   lock.enter(p, lane);
   auto zero = [] {                                      // (the reduction's identity)
@@ -1558,7 +1566,7 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
   typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) s4_t *lds_s4_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (p.gate && ((__builtin_nontemporal_load(p.gate) != 0) != (p.gate_want != 0))) return;
+  if (p.gate && ((slab_gate_word(p.gate) != 0) != (p.gate_want != 0))) return;
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
@@ -1895,6 +1903,12 @@ extern "C" int g_slab_turn;
 // torch plugin, ctypes, a C caller) they come from: a launch waits, on ITS stream, for the event of the previous one.
 // An optimisation, not a safety net: a stream that is being captured skips it (an event recorded outside a capture cannot
 // be waited for inside one; replayed graphs on two streams may overlap), and so does another process on the same GPU.
+// (fills - the output's rows without edges, the lockstep's words, the gate word - go through geot_internal_fill: a kernel, not a
+// hipMemsetAsync node; see csrc/seg_reduce.hip)
+static hipError_t slab_fill(void *p, size_t bytes, uint32_t word, hipStream_t st) {
+  return geot_internal_fill(p, bytes, word, st) == GEOT_OK ? hipSuccess : hipErrorUnknown;
+}
+
 struct SlabTurn {
   std::mutex mu;
   std::map<int, hipEvent_t> last; // per device
@@ -2141,10 +2155,10 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   p.lpr_log2 = lpr_log2;
   p.rounds = (int)((plan->n_groups + plan->units - 1) / plan->units);
 
-  hipError_t e = hipMemsetAsync(dst, 0, (size_t)out_rows * (size_t)rowbytes, st); // rows without edges
+  hipError_t e = slab_fill(dst, (size_t)out_rows * (size_t)rowbytes, 0u, st); // rows without edges
   if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   if (p.window >= 0) {
-    e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);                              // every word = kProgIdle
+    e = slab_fill(p.prog, kSyncBytes, (uint32_t)kProgIdle, st);                              // every word = kProgIdle
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   }
   if (wstage) {   // the weights into plan order first; the row loop then streams them (p.w_in_plan_order)
@@ -2241,7 +2255,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     const int rc = g_turn.take(st, [&]() -> int {
       if (mfma) {
         int *flag = p.prog_cnt + 32;                                   // (a word of the scratch's control block nobody else uses)
-        hipError_t me = hipMemsetAsync(flag, 0, sizeof(int), st);
+        hipError_t me = slab_fill(flag, sizeof(int), 0u, st);
         if (me != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(me));
         SlabParams pm = p;
         pm.gate = flag;
@@ -2430,7 +2444,7 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   p.window = (plan->slab_shift > 0 && plan->n_slabs > 1) ? (g_slab_window == -2 ? 2 : g_slab_window) : -1;
   hipError_t e = hipSuccess;
   if (p.window >= 0) {
-    e = hipMemsetAsync(p.prog, 0x7f, kSyncBytes, st);
+    e = slab_fill(p.prog, kSyncBytes, (uint32_t)kProgIdle, st);
     if (e != hipSuccess) return geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(e));
   }
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);

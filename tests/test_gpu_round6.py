@@ -331,3 +331,78 @@ def test_cfg3_full_size_bf16_properties(geot):
     want = cw @ x.double()
     got = out.double().sum(0)
     assert float(((got - want) / want).abs().max()) <= 2.0 ** -11
+
+
+def test_gated_pair_inside_a_captured_graph(geot):
+    """The matrix-core SpMM and its vector-ALU twin are BOTH enqueued and a word written on the stream picks one: inside a captured HIP
+    graph the choice is therefore made at every REPLAY from the table's content of that moment - finite data runs on the matrix cores, a
+    NaN written into the source table before the next replay sends that replay to the twin, and only the NaN's destinations change."""
+    from geot_amd import slab
+    rng = np.random.default_rng(12)
+    nodes, nnz, H, Fh = 2500, 300_000, 4, 64
+    si, di = _dense_graph(rng, nodes, nnz)
+    d_si, d_di = dev(si), dev(di)
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, 512, 2, H, rows_per_group=min(16, slab.rows_per_group(2, H, torch.bfloat16, 512)))
+    v = (torch.rand(nodes, H, Fh, device="cuda") + 0.5).bfloat16()
+    w = (torch.rand(nnz, H, device="cuda") + 0.5).bfloat16()
+    out = torch.empty(nodes, H, Fh, device="cuda", dtype=torch.bfloat16)
+    slab.slab_spmm_out(plan, w, 2, v, out, H, Fh, stage_weights=False)          # (eager once: workspace, first-launch costs)
+    eager = out.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        slab.slab_spmm_out(plan, w, 2, v, out, H, Fh, stage_weights=False)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        slab.slab_spmm_out(plan, w, 2, v, out, H, Fh, stage_weights=False)
+    out.fill_(7)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    bad_row = int(si[1234])
+    v[bad_row, 1, 3] = float("nan")                                              # the table changes between replays
+    g.replay()
+    torch.cuda.synchronize()
+    touched = torch.zeros(nodes, dtype=torch.bool, device="cuda")
+    touched[d_di[d_si == bad_row]] = True
+    assert bool(torch.isnan(out[touched][:, 1, 3]).all()) and int(touched.sum()) > 0
+    assert not bool(torch.isnan(out[~touched]).any())
+    ref = _ref(d_si, d_di, w, v, nodes)
+    fin = torch.isfinite(ref)
+    err = torch.where(fin, (out.double() - ref).abs(), torch.zeros_like(ref))
+    assert float(err.max()) <= 2.0 ** -6 * float(ref[fin].abs().max())
+    v[bad_row, 1, 3] = 1.0
+    g.replay()
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(out).any())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rows_without_edges_stay_zero_on_every_replay(geot, dtype):
+    """A captured source-blocked call zero-fills its output (rows without edges rely on it) with a KERNEL: the hipMemsetAsync node it
+    used to capture wrote a repeating 16-byte pattern - another kernel's argument block - into the output from the SECOND replay of a
+    graph captured through PyTorch on, whenever an ordinary kernel ran between the replays (found in round 6 by the test above; every
+    earlier capture test replayed once, or had an edge in every row).  Five replays with a fill of the output in between, 127 rows
+    without edges: the eager result every time."""
+    from geot_amd import slab
+    rng = np.random.default_rng(21)
+    nodes, nnz, H, Fh = 2500, 300_000, 4, (64 if dtype == torch.bfloat16 else 32)
+    si, di = _dense_graph(rng, nodes, nnz)
+    d_si, d_di = dev(si), dev(di)
+    assert int((torch.bincount(d_di, minlength=nodes) == 0).sum()) > 100
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, 512, 2, H, rows_per_group=min(16, slab.rows_per_group(2, H, dtype, 512)))
+    v = (torch.rand(nodes, H, Fh, device="cuda") + 0.5).to(dtype)
+    w = (torch.rand(nnz, H, device="cuda") + 0.5).to(dtype)
+    out = torch.empty(nodes, H, Fh, device="cuda", dtype=dtype)
+    slab.slab_spmm_out(plan, w, 2, v, out, H, Fh, stage_weights=False)
+    eager = out.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        slab.slab_spmm_out(plan, w, 2, v, out, H, Fh, stage_weights=False)
+    for rep in range(5):
+        out.fill_(7)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager), (rep, int((out != eager).sum()))

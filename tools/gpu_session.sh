@@ -20,7 +20,7 @@ for s in $steps; do
               for o in slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
               done > $O/slab_cases_mfma_ab.txt 2>&1; cat $O/slab_cases_mfma_ab.txt ;;
-    dbg)      timeout 600 python3 tools/_ab/dbg_mfma.py 2>&1 | grep -v amdgpu.ids | tail -60 ;;
+    dbg)      timeout 600 python3 tools/_ab/dbg_gate2.py 2>&1 | grep -v amdgpu.ids | tail -60 ;;
     mfmaprobe) for o in slab_spmm_mfma=1 slab_spmm_mfma=1,slab_probe=1 slab_spmm_mfma=1,slab_probe=1,slab_window=-1 slab_spmm_mfma=1,slab_window=-1 slab_spmm_mfma=1,slab_blocks=4 slab_spmm_mfma=0,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids | grep -v "^# done"
               done > $O/slab_cases_mfma_probe.txt 2>&1; cat $O/slab_cases_mfma_probe.txt ;;
@@ -59,6 +59,7 @@ PY
               timeout 900 python3 tools/hang_hunt.py --scenario threads --runs 20 --slab-turn 1 --T 60 > $O/hunt_threads20.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_threads20.txt
               timeout 900 python3 tools/hang_hunt.py --scenario procs --runs 10 --T 90 > $O/hunt_procs10.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_procs10.txt
               timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 10 --T 90 > $O/hunt_graphs10.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt_graphs10.txt ;;
+    kexp6)    timeout 300 ./tools/kexp6 > $O/kexp6_memset_node_under_replay.txt 2>&1; echo "rc=$?"; cat $O/kexp6_memset_node_under_replay.txt ;;
     tests)    timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu.log ;;
     w8)       timeout 1500 python3 -m pytest tests/test_gpu_world8.py tests/test_gpu_multirank.py -m gpu -q --durations=12 > $O/pytest_w8.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_w8.log ;;
     hunt)     timeout 1500 python3 tools/hang_hunt.py --scenario lockstep --runs 3 --slab-turn 0 --T 90 > $O/hunt_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -5 $O/hunt_lockstep_turn0.txt
