@@ -60,6 +60,7 @@ def test_two_rows_per_instruction_kernel_gives_the_sums(geot, dtype, H, Fh):
     ref = torch.zeros(nodes, H, Fh, device="cuda", dtype=torch.float64).index_add_(0, d_di, v.double()[d_si] * w.double()[:, :, None])
     tol = 1e-5 if dtype == torch.float32 else (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6)
     outs = {}
+    geot.hip.set_option("slab_spmm_mfma", 0)                            # (the comparison is with the row-per-wave kernel, not the matrix-core one)
     try:
         for pair in (1, 0):
             geot.hip.set_option("slab_pair", pair)
@@ -78,6 +79,7 @@ def test_two_rows_per_instruction_kernel_gives_the_sums(geot, dtype, H, Fh):
         assert torch.equal(again, outs[1])
     finally:
         geot.hip.set_option("slab_pair", 0)
+        geot.hip.set_option("slab_spmm_mfma", 1)
     assert float((outs[1].double() - outs[0].double()).abs().max()) <= 2 * tol * float(ref.abs().max())
 
 
