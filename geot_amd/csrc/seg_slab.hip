@@ -1364,11 +1364,8 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kb = lane >> 4;
-  // this wave's LDS: the tile image [16][kStride] and - in the SAME bytes, once the fragments have been read out of it - the result
-  // exchange [H][4][16] float4 (H <= 8: 8 KB of the image's 8.5); a wave's LDS operations execute in order, the fences keep the compiler's
+  // this wave's LDS: the tile image [16][kStride]; a wave's LDS operations execute in order, the fences keep the compiler's
   unsigned char *img = smem + (size_t)wave * (16 * kStride);
-  f4_t *xch = reinterpret_cast<f4_t *>(img);
-  static_assert(H * 64 * sizeof(f4_t) <= 16 * kStride, "the exchange fits the image");
   const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
   const int64_t units = P.units;
   const T *m1 = static_cast<const T *>(p.weight);
@@ -1418,7 +1415,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
     // row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide load costs the CU ~17-20 cycles whatever its width
     // (tools/kexp5.hip) - one 512-byte row per instruction was this kernel's floor (4.18 of its 4.30 ms with the gathers dropped, round
     // 5).  The per-lane row offsets come through the LDS crossbar, ahead of the wait for the current tile's rows, and the NEXT tile's
-    // rows are gathered as soon as the current tile is in the image: in flight under its matrix work and its result exchange.
+    // rows are gathered as soon as the current tile is in the image: in flight under its matrix work and its stores.
     const int ntiles = (len + 15) >> 4;
     uint32_t nx_src = 0, nx_dl = 255;
     bool nx_valid = false;
@@ -1455,33 +1452,35 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
       t8_t afrag[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + n * kStride + 64 * c + 16 * kb);
+      // The group's rows are the M side of the product and the tile's edges the N side (both operands have the same lane map, so this is
+      // only the order of the arguments): lane 16 kb + n then holds D[row 4 kb + j][edge n], j = 0..3 - the four lanes n, 16 + n, 32 + n,
+      // 48 + n own all sixteen (row, edge n) products between them, and edge n's one wanted product, row dl(n), sits in lane
+      // 16 (dl >> 2) + n, element dl & 3.  That lane stores it: no exchange through LDS, nothing in the image for the next tile to wait
+      // for but the fragment reads above (the first form - edges as M, D written to LDS and picked up by lanes 0..15 - cost two more
+      // fences and 2 H LDS operations per tile, and kept the image busy until the pick-up: 3.81 ms at configs[3]'s graph).
+      float vals[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         f4_t d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < CPH; ++cc) {
-          if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
-          else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[h * CPH + cc], bfrag[h * CPH + cc], d, 0, 0, 0);
+          if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[h * CPH + cc], afrag[h * CPH + cc], d, 0, 0, 0);
+          else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfrag[h * CPH + cc], afrag[h * CPH + cc], d, 0, 0, 0);
         }
-        xch[(h * 4 + kb) * 16 + n] = d;         // D[row 4 kb + j][col n], j = 0..3
+        const float lo = (dlm & 1) ? d[1] : d[0], hi = (dlm & 1) ? d[3] : d[2];
+        vals[h] = (dlm & 2) ? hi : lo;
       }
-      wave_order();
-      if (lane < 16) {                          // lane m: edge m of the tile, its H results = D_h[m][dl(m)]
-        const int e = t * 16 + lane;
-        if (e < len) {
-          // (the H reads are unconditional - a padding edge reads column 0 and drops it: behind a branch each read would wait for
-          // its own LDS round trip, four in a row per tile)
-          const float *xf = reinterpret_cast<const float *>(xch) + ((((lane >> 2) * 16 + (dlm != 255 ? dlm : 0)) << 2) + (lane & 3));
-          float vals[H];
-#pragma unroll
-          for (int h = 0; h < H; ++h) vals[h] = xf[h * 256];
+      {
+        const int e = t * 16 + n;
+        const bool real = dlm != 255;                                   // (padding / out-of-range source: a zero, written by the kb = 0 lane)
+        if (e < len && (real ? (dlm >> 2) == kb : kb == 0)) {
           T *op = out + (e0 + e) * H;
-          if constexpr (H == 1) op[0] = (T)(dlm != 255 ? vals[0] : 0.f);
+          if constexpr (H == 1) op[0] = (T)(real ? vals[0] : 0.f);
           else {
             typedef T tH_t __attribute__((ext_vector_type(H)));
             tH_t pk;
 #pragma unroll
-            for (int h = 0; h < H; ++h) pk[h] = (T)(dlm != 255 ? vals[h] : 0.f);
+            for (int h = 0; h < H; ++h) pk[h] = (T)(real ? vals[h] : 0.f);
             *reinterpret_cast<tH_t *>(op) = pk;
           }
         }
@@ -2454,7 +2453,7 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   const int nch = (int)(F / 32);
   if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && rowbytes == 512 && plan->rows_per_group <= 16 &&
       (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
-    const size_t xlds = (size_t)4 * 16 * (512 + 32);       // per wave: the tile image (the result exchange reuses its bytes)
+    const size_t xlds = (size_t)4 * 16 * (512 + 32);       // per wave: the tile image
     const int cph = nch / (int)heads;
     const int rc = g_turn.take(st, [&]() -> int {
 #define GEOT_SLAB_MFMA(T_)                                                                                     \
