@@ -1329,11 +1329,12 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 
 // The multi-head SDDMM of 16-bit plans on the MATRIX cores (round 5): out[e, h] = <m1[dst(e), h, :], m2[src(e), h, :]> is a
 // contraction over FEATURES, and that is the K dimension of an MFMA with both operands in the layout memory already has them in:
-// v_mfma_f32_16x16x32_{bf16,f16} takes A[16 edges][32 features] with lane l holding 8 consecutive features (16 bytes) of edge l & 15
-// - a 16-byte piece of a gathered m2 row - and B[32 features][16 rows] with lane l holding 8 consecutive features of row l & 15 - a
-// piece of one of the group's <= 16 m1 rows, which stay in registers for the whole group.  One instruction forms all 16 x 16
-// (edge, row) products of a 32-feature slice; the one wanted per edge, D[m][dl(m)], is picked out through a small LDS exchange, the
-// other 15 are the price.  It is worth it because these kernels are bound by vector-instruction issue, not by their gathers (§3.1d
+// v_mfma_f32_16x16x32_{bf16,f16} takes A[16 rows][32 features] with lane l holding 8 consecutive features (16 bytes) of row l & 15
+// - a piece of one of the group's <= 16 m1 rows, which stay in registers for the whole group - and B[32 features][16 edges] with lane
+// l holding 8 consecutive features of edge l & 15 - a 16-byte piece of a gathered m2 row.  One instruction forms all 16 x 16
+// (row, edge) products of a 32-feature slice; the one wanted per edge, D[dl(n)][n], lies in ONE lane's result registers and that lane
+// stores it (round 6; round 5 had the edges on the M side and picked the products up through an LDS exchange), the other 15 are the
+// price.  It is worth it because these kernels are bound by vector-instruction issue, not by their gathers (§3.1d
 // of DESIGN.md: with the gathers dropped they keep 97 % of their time): the row-per-wave kernel spends ~20 wave-instructions per edge
 // on unpacking two 16-bit rows and multiplying them, this one ~8, and the MFMAs themselves are 0.4 ms of work at Reddit scale.
 // Nothing is contaminated by the unused products: a result element is the sum over its OWN row's and edge's features only.
@@ -1352,7 +1353,9 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
 // Option "slab_sddmm_mfma" = 0: the row-per-wave kernel.  Two refinements measured afterwards (one box, interleaved): the H exchange reads
 // made unconditional (behind a per-head branch each waited for its own LDS round trip): 4.31 -> 4.24 ms, kept; a tile's rows gathered ONE
 // TILE AHEAD (into the same registers, while the previous tile goes through the matrix cores): 4.47 vs 4.28 ms - slower (130 registers
-// instead of 108, and the gathers were not what a tile waits for), dropped.
+// instead of 108, and the gathers were not what a tile waits for), dropped.  Round 6: two rows per gather instruction with the next
+// tile's rows in flight 4.24 -> 3.81 ms; the operands exchanged (no result exchange through LDS) 3.81 -> 3.39 ms
+// (profiles/r06/slab_cases__mh_bf16_sddmm_*.txt).
 template <typename T, int CPH>
 __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabParams p) {   // (3 waves per SIMD: the persistent grid's 3 workgroups per CU all resident)
   static_assert(sizeof(T) == 2 && 8 % CPH == 0, "16-bit rows of 512 bytes");
