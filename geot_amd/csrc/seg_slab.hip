@@ -39,6 +39,7 @@
 #include <mutex>
 #include <string>
 #include <type_traits>
+#include <utility>
 
 #include "geot_hip.h"
 #include "internal.h"
@@ -1327,6 +1328,16 @@ __global__ __launch_bounds__(kThreads) void seg_slab_sddmm_wrow_kernel(SlabParam
   lock.leave(lane);
 }
 
+// a compile-time loop (the DPP controls below are instruction immediates) and the row broadcast: every lane of each 16-lane row
+// receives lane C of ITS row (DPP row_newbcast, gfx90a+): a vector-ALU move, no LDS crossbar
+template <class F, int... J>
+__device__ __forceinline__ void slab_static_for(F &&f, std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
+template <int C>
+__device__ __forceinline__ uint32_t slab_row_bcast(uint32_t v) {
+  static_assert(C >= 0 && C < 16, "a lane of the row");
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + C, 0xF, 0xF, false);
+}
+
 // The multi-head SDDMM of 16-bit plans on the MATRIX cores (round 5): out[e, h] = <m1[dst(e), h, :], m2[src(e), h, :]> is a
 // contraction over FEATURES, and that is the K dimension of an MFMA with both operands in the layout memory already has them in:
 // v_mfma_f32_16x16x32_{bf16,f16} takes A[16 rows][32 features] with lane l holding 8 consecutive features (16 bytes) of row l & 15
@@ -1377,6 +1388,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
   const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
   typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
   const uint32_t cH = (uint32_t)(lane & 31) * 16u;        // a lane's 16 bytes of its half-wave's row
+  const uint32_t po_idx = (uint32_t)(16 * (n >> 3) + 2 * (n & 7) + (kb >> 1)) << 2;   // (the broadcast register's layout, see the gathers)
   t8_t zero8;
 #pragma unroll
   for (int i = 0; i < 8; ++i) zero8[i] = (T)0.f;
@@ -1417,23 +1429,24 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
     // Tiles of 16 edges, the four tiles of a 64-edge chunk unrolled.  TWO rows per gather instruction, 16 bytes a lane (lanes 0..31 the
     // row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide load costs the CU ~17-20 cycles whatever its width
     // (tools/kexp5.hip) - one 512-byte row per instruction was this kernel's floor (4.18 of its 4.30 ms with the gathers dropped, round
-    // 5).  The per-lane row offsets come through the LDS crossbar, ahead of the wait for the current tile's rows, and the NEXT tile's
-    // rows are gathered as soon as the current tile is in the image: in flight under its matrix work and its stores.
+    // 5).  The NEXT tile's rows are gathered as soon as the current tile is in the image: in flight under its matrix work and its
+    // stores.  The per-lane row offsets: one crossbar read per TWO tiles lays their edges' offsets out for DPP row broadcasts (lane
+    // 8 tt + j of row r: what row r's lanes fetch in instruction j of tile tt - see seg_slab_spmm_mfma_kernel).
     const int ntiles = (len + 15) >> 4;
     uint32_t nx_src = 0, nx_dl = 255;
     bool nx_valid = false;
     u4_t rv[8];
-    uint32_t goff[8];
-    auto offsets = [&](auto tb_c) __attribute__((always_inline)) {
-      constexpr int tb = decltype(tb_c)::value;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) goff[j] = ((uint32_t)__builtin_amdgcn_ds_bpermute((tb + 2 * j + (lane >> 5)) << 2, (int)my_edge) & ~255u) << 1;
+    uint32_t po = 0;
+    auto pair_up = [&](int gen) __attribute__((always_inline)) {
+      po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)po_idx + gen * 128, (int)((my_edge & ~255u) << 1));
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {
-      constexpr int tb = decltype(tb_c)::value;
+      constexpr int tb = decltype(tb_c)::value, k0 = ((tb >> 4) & 1) * 8;
       if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rv[j] = slab_row_load<u4_t>(table, cH + goff[j], 0u);
+      slab_static_for([&](auto j_c) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_c)::value;
+        rv[j] = slab_row_load<u4_t>(table, cH + slab_row_bcast<k0 + j>(po), 0u);
+      }, std::make_integer_sequence<int, 8>{});
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
       constexpr int ph = decltype(ph_c)::value, tb = ph * 16, tbn = ((ph + 1) & 3) * 16;
@@ -1446,8 +1459,10 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
         nx_dl = (uint32_t)P.e_dl[ne];
       }
       const int dlm = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((tb + n) << 2, (int)my_edge) & 255u);
-      if constexpr (ph == 3) my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;   // (the chunk ends with this tile)
-      if (more) offsets(std::integral_constant<int, tbn>{});
+      if constexpr (ph == 3) {                  // the chunk ends with this tile: the next chunk's edges become this lane's
+        my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
+        pair_up(0);
+      } else if constexpr (ph == 1) pair_up(1);
 #pragma unroll
       for (int j = 0; j < 8; ++j) *reinterpret_cast<u4_t *>(img + (2 * j + (lane >> 5)) * kStride + cH) = rv[j];
       wave_order();
@@ -1490,10 +1505,8 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
       }
       wave_order();
     };
-    if (ntiles > 0) {
-      offsets(std::integral_constant<int, 0>{});
-      gather(std::integral_constant<int, 0>{});
-    }
+    pair_up(0);
+    if (ntiles > 0) gather(std::integral_constant<int, 0>{});
     for (int t = 0; t < ntiles; t += 4) {
       tile(t, std::integral_constant<int, 0>{});
       if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
@@ -1556,6 +1569,7 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
   constexpr int LPR = RB / 16;                           // lanes per row of a gather instruction (16 bytes a lane)
   constexpr int RPI = 64 / LPR;                          // rows per gather instruction: 2 | 4
   constexpr int NL = KT / RPI;                           // gather instructions per tile: 8 | 4
+  constexpr int TPR = 16 / NL;                           // tiles whose row offsets one broadcast register holds: 2 | 4
   constexpr int NFB = 16 / FS;                           // 16-feature blocks of this wave
   constexpr int kStride = RB + 32;                       // bytes between the rows of a tile's image
   constexpr int kImg = KT * kStride;                     // 8 704 | 4 608 bytes
@@ -1592,6 +1606,8 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
   // lane 16 kq + n receives column n of those four rows = B[k = 4 kq .. 4 kq + 3][n]
   const uint32_t tr_off = (uint32_t)((4 * kq + ((lane >> 2) & 3)) * kStride + (lane & 3) * 8);
   constexpr uint32_t kOne = __is_same(T, bf16_t) ? 0x3F803F80u : 0x3C003C00u;   // (1, 1) in the storage type
+  // the broadcast register's layout (see the gathers): lane 16 r + k reads the chunk's lane KT (k / NL) + RPI (k % NL) + r RPI / 4
+  const uint32_t po_idx = (uint32_t)(KT * (m / NL) + RPI * (m % NL) + (kq * RPI) / 4) << 2;
 
   SlabStep lock;                               // the loose lockstep of the XCD's waves (see SlabStep)
   lock.enter(p, lane);
@@ -1665,19 +1681,23 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
     // TWO rows per gather instruction, 16 bytes a lane (lanes 0..31 the row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide
     // load costs the CU ~17-20 cycles whatever its width (tools/kexp5.hip: dropped by the range check 16 / 18 cycles at 8 / 16 bytes a lane,
     // from an L2-resident table 20 / 19) - at one 512-byte row per instruction that alone is 3.8 ms for configs[3]'s 114.6 M edges, the
-    // floor every row-per-wave kernel of this file sits on.  The per-lane row offset comes through the LDS crossbar (ds_bpermute).
+    // floor every row-per-wave kernel of this file sits on.
+    // The per-lane row offsets: ONE crossbar read (ds_bpermute) lays the offsets of TPR tiles' edges out so that lane k of every 16-lane
+    // row holds what that row's lanes need for one gather instruction (row r, lane k = NL tt + j: the edge of tile tt, instruction j,
+    // that row r's lanes fetch); the instruction's offsets are then a DPP row broadcast of lane k - vector-ALU work, folded into the add
+    // of the lane's column.  (First form: one ds_bpermute per gather instruction, 8 of a tile's 38 LDS operations.)
     u4_t rv[NL];
-    uint32_t off[NL];
-    auto offsets = [&](auto tb_c) __attribute__((always_inline)) {        // the per-lane row offsets of a tile's gathers (LDS crossbar: no memory)
-      constexpr int tb = decltype(tb_c)::value;
-#pragma unroll
-      for (int j = 0; j < NL; ++j) off[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((tb + RPI * j + lane / LPR) << 2, (int)my_off);
+    uint32_t po = 0;
+    auto pair_up = [&](int gen) __attribute__((always_inline)) {
+      po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)po_idx + gen * (TPR * KT * 4), (int)my_off);
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {         // a tile's rows (slots behind the last edge: row 0)
-      constexpr int tb = decltype(tb_c)::value;
+      constexpr int tb = decltype(tb_c)::value, k0 = ((tb / KT) % TPR) * NL;
       if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (9 + p.slab_shift)));
-#pragma unroll
-      for (int j = 0; j < NL; ++j) rv[j] = slab_row_load<u4_t>(table, cH + off[j], 0u);
+      slab_static_for([&](auto j_c) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_c)::value;
+        rv[j] = slab_row_load<u4_t>(table, cH + slab_row_bcast<k0 + j>(po), 0u);
+      }, std::make_integer_sequence<int, NL>{});
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
       constexpr int ph = decltype(ph_c)::value, tb = ph * KT, tbn = ((ph + 1) & 3) * KT;
@@ -1704,8 +1724,8 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
         my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
         my_off = (my_edge & ~255u) << 1;
         stage(buf ^ 1, nx_w, nx_valid, my_edge);
-      }
-      if (more) offsets(std::integral_constant<int, tbn>{});
+        pair_up(0);
+      } else if constexpr ((ph + 1) % TPR == 0) pair_up((ph + 1) / TPR);      // (the next tile opens the register's next generation)
       const uint32_t dl4 = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
       raw2_t wa[HL];
 #pragma unroll
@@ -1759,7 +1779,7 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
         else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[hl]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
       }
     };
-    if (ntiles > 0) offsets(std::integral_constant<int, 0>{});
+    pair_up(0);
     if (ntiles > 0) gather(std::integral_constant<int, 0>{});
     for (int t = 0; t < ntiles; t += 4) {       // a chunk of 64 edges = four tiles, unrolled: lane numbers of the crossbar reads are immediates
       tile(t, std::integral_constant<int, 0>{});
