@@ -303,7 +303,7 @@ extern std::list<SlabEntry> &g_slab;
 extern std::list<std::pair<ContentKey, ContentKey>> g_sightings, g_declined;
 bool slab_worthwhile(int64_t nnz, int64_t out_rows, int64_t src_rows, int64_t rowbytes, int dtype = GEOT_F32);
 std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Tensor &di, int64_t rows, const at::Tensor &src, int wmode,
-                                              int64_t heads);
+                                              int64_t heads, int red = GEOT_REDUCE_SUM);
 // false: the plan's arrays have been released (a trial on another thread rejected it) - the caller runs the per-edge kernels
 bool run_slab(SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
               int red = GEOT_REDUCE_SUM);

@@ -1367,28 +1367,35 @@ __device__ __forceinline__ uint32_t slab_row_bcast(uint32_t v) {
 // instead of 108, and the gathers were not what a tile waits for), dropped.  Round 6: two rows per gather instruction with the next
 // tile's rows in flight 4.24 -> 3.81 ms; the operands exchanged (no result exchange through LDS) 3.81 -> 3.39 ms
 // (profiles/r06/slab_cases__mh_bf16_sddmm_*.txt).
-template <typename T, int CPH>
+template <typename T, int CPH, int ROWB>
 __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabParams p) {   // (3 waves per SIMD: the persistent grid's 3 workgroups per CU all resident)
-  static_assert(sizeof(T) == 2 && 8 % CPH == 0, "16-bit rows of 512 bytes");
-  constexpr int NCH = 8, H = NCH / CPH;
-  constexpr int kStride = 512 + 32;                      // bytes between the rows of a tile's image
+  static_assert(ROWB == 512 || ROWB == 256, "rows of 512 or 256 bytes");
+  constexpr int NCH = ROWB / 64;                         // 32-feature slices of a row: 8 | 4
+  static_assert(sizeof(T) == 2 && NCH % CPH == 0, "16-bit rows, a head is whole 32-feature slices");
+  constexpr int H = NCH / CPH;
+  constexpr int LOGB = ROWB == 512 ? 9 : 8;
+  constexpr int KS = 512 / ROWB;                         // 16-edge blocks (the N side of a product) per tile: 1 | 2
+  constexpr int KT = 16 * KS;                            // edges per tile: 16 | 32 - eight gather instructions, 8 KB, either way
+  constexpr int PH = 64 / KT;                            // tiles per 64-edge chunk: 4 | 2
+  constexpr int LPR = ROWB / 16, RPI = 64 / LPR;         // lanes per row of a gather instruction, rows per instruction: 32, 2 | 16, 4
+  constexpr int kStride = ROWB + 32;                     // bytes between the rows of a tile's image
   typedef T t8_t __attribute__((ext_vector_type(8)));
   typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, kb = lane >> 4;
-  // this wave's LDS: the tile image [16][kStride]; a wave's LDS operations execute in order, the fences keep the compiler's
-  unsigned char *img = smem + (size_t)wave * (16 * kStride);
+  // this wave's LDS: the tile image [KT][kStride]; a wave's LDS operations execute in order, the fences keep the compiler's
+  unsigned char *img = smem + (size_t)wave * (KT * kStride);
   const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
   const int64_t units = P.units;
   const T *m1 = static_cast<const T *>(p.weight);
   T *out = static_cast<T *>(p.dst);
   const uint32_t src_rows = (uint32_t)p.src_rows;
-  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, LOGB, p.probe);
   typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-  const uint32_t cH = (uint32_t)(lane & 31) * 16u;        // a lane's 16 bytes of its half-wave's row
-  const uint32_t po_idx = (uint32_t)(16 * (n >> 3) + 2 * (n & 7) + (kb >> 1)) << 2;   // (the broadcast register's layout, see the gathers)
+  const uint32_t cH = (uint32_t)(lane % LPR) * 16u;       // a lane's 16 bytes of its lane group's row
+  const uint32_t po_idx = (uint32_t)(KT * (n >> 3) + RPI * (n & 7) + (kb * RPI) / 4) << 2;   // (the broadcast register's layout, see the gathers)
   t8_t zero8;
 #pragma unroll
   for (int i = 0; i < 8; ++i) zero8[i] = (T)0.f;
@@ -1411,7 +1418,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
     len = __builtin_amdgcn_readfirstlane(len);
     nv = __builtin_amdgcn_readfirstlane(nv);
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
-    t8_t bfrag[NCH];                            // the group's m1 rows as B fragments, in registers for the whole group
+    t8_t bfrag[NCH];                            // the group's m1 rows as operand fragments, in registers for the whole group
     {
       const int64_t row = n < nv ? P.v_row[v0 + n] : -1;
       const bool ok = row >= 0 && row < p.K;
@@ -1426,22 +1433,23 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
       const uint32_t d_ = valid ? (uint32_t)P.e_dl[e0 + lane] : 255u;
       my_edge = s_ < src_rows ? ((s_ << 8) | d_) : 255u;
     }
-    // Tiles of 16 edges, the four tiles of a 64-edge chunk unrolled.  TWO rows per gather instruction, 16 bytes a lane (lanes 0..31 the
-    // row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide load costs the CU ~17-20 cycles whatever its width
-    // (tools/kexp5.hip) - one 512-byte row per instruction was this kernel's floor (4.18 of its 4.30 ms with the gathers dropped, round
-    // 5).  The NEXT tile's rows are gathered as soon as the current tile is in the image: in flight under its matrix work and its
-    // stores.  The per-lane row offsets: one crossbar read per TWO tiles lays their edges' offsets out for DPP row broadcasts (lane
-    // 8 tt + j of row r: what row r's lanes fetch in instruction j of tile tt - see seg_slab_spmm_mfma_kernel).
-    const int ntiles = (len + 15) >> 4;
+    // Tiles of 16 | 32 edges, the tiles of a 64-edge chunk unrolled.  SEVERAL rows per gather instruction, 16 bytes a lane (512-byte
+    // rows: lanes 0..31 the row of edge 2 j, lanes 32..63 that of edge 2 j + 1; 256-byte rows: 16 lanes an edge): a wave-wide load costs
+    // the CU ~17-20 cycles whatever its width (tools/kexp5.hip) - one 512-byte row per instruction was this kernel's floor (4.18 of
+    // its 4.30 ms with the gathers dropped, round 5).  The NEXT tile's rows are gathered as soon as the current tile is in the image:
+    // in flight under its matrix work and its stores.  The per-lane row offsets: one crossbar read per TWO tiles lays their edges'
+    // offsets out for DPP row broadcasts (lane 8 tt + j of row r: what row r's lanes fetch in instruction j of tile tt - see
+    // seg_slab_spmm_mfma_kernel).
+    const int ntiles = (len + KT - 1) / KT;
     uint32_t nx_src = 0, nx_dl = 255;
     bool nx_valid = false;
     u4_t rv[8];
     uint32_t po = 0;
     auto pair_up = [&](int gen) __attribute__((always_inline)) {
-      po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)po_idx + gen * 128, (int)((my_edge & ~255u) << 1));
+      po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)po_idx + gen * (2 * KT * 4), (int)((my_edge & ~255u) << (LOGB - 8)));
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {
-      constexpr int tb = decltype(tb_c)::value, k0 = ((tb >> 4) & 1) * 8;
+      constexpr int tb = decltype(tb_c)::value, k0 = ((tb / KT) & 1) * 8;
       if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
       slab_static_for([&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
@@ -1449,49 +1457,52 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
       }, std::make_integer_sequence<int, 8>{});
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
-      constexpr int ph = decltype(ph_c)::value, tb = ph * 16, tbn = ((ph + 1) & 3) * 16;
+      constexpr int ph = decltype(ph_c)::value, tb = ph * KT, tbn = ((ph + 1) % PH) * KT;
       const bool more = t + 1 < ntiles;
       if constexpr (ph == 0) {                  // the next chunk's fields, behind this tile's gathers (every lane loads: see seg_slab_wrow_kernel)
-        const int c = t >> 2;
+        const int c = t / PH;
         nx_valid = (c + 1) * 64 + lane < len;
         const int64_t ne = e0 + (nx_valid ? (c + 1) * 64 + lane : len - 1);
         nx_src = (uint32_t)P.e_src[ne];
         nx_dl = (uint32_t)P.e_dl[ne];
       }
-      const int dlm = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((tb + n) << 2, (int)my_edge) & 255u);
-      if constexpr (ph == 3) {                  // the chunk ends with this tile: the next chunk's edges become this lane's
+      int dlm[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dlm[ks] = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((tb + 16 * ks + n) << 2, (int)my_edge) & 255u);
+      if constexpr (ph == PH - 1) {             // the chunk ends with this tile: the next chunk's edges become this lane's
         my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
         pair_up(0);
-      } else if constexpr (ph == 1) pair_up(1);
+      } else if constexpr ((ph & 1) == 1) pair_up((ph + 1) / 2);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) *reinterpret_cast<u4_t *>(img + (2 * j + (lane >> 5)) * kStride + cH) = rv[j];
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<u4_t *>(img + (RPI * j + lane / LPR) * kStride + cH) = rv[j];
       wave_order();
       if (more) gather(std::integral_constant<int, tbn>{});
-      t8_t afrag[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + n * kStride + 64 * c + 16 * kb);
       // The group's rows are the M side of the product and the tile's edges the N side (both operands have the same lane map, so this is
       // only the order of the arguments): lane 16 kb + n then holds D[row 4 kb + j][edge n], j = 0..3 - the four lanes n, 16 + n, 32 + n,
       // 48 + n own all sixteen (row, edge n) products between them, and edge n's one wanted product, row dl(n), sits in lane
       // 16 (dl >> 2) + n, element dl & 3.  That lane stores it: no exchange through LDS, nothing in the image for the next tile to wait
-      // for but the fragment reads above (the first form - edges as M, D written to LDS and picked up by lanes 0..15 - cost two more
-      // fences and 2 H LDS operations per tile, and kept the image busy until the pick-up: 3.81 ms at configs[3]'s graph).
-      float vals[H];
+      // for but the fragment reads (the first form - edges as M, D written to LDS and picked up by lanes 0..15 - cost two more fences
+      // and 2 H LDS operations per tile, and kept the image busy until the pick-up: 3.81 ms at configs[3]'s graph).
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        f4_t d = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < KS; ++ks) {
+        t8_t afrag[NCH];
 #pragma unroll
-        for (int cc = 0; cc < CPH; ++cc) {
-          if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[h * CPH + cc], afrag[h * CPH + cc], d, 0, 0, 0);
-          else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfrag[h * CPH + cc], afrag[h * CPH + cc], d, 0, 0, 0);
+        for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + (16 * ks + n) * kStride + 64 * c + 16 * kb);
+        float vals[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          f4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < CPH; ++cc) {
+            if constexpr (__is_same(T, bf16_t)) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[h * CPH + cc], afrag[h * CPH + cc], d, 0, 0, 0);
+            else d = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfrag[h * CPH + cc], afrag[h * CPH + cc], d, 0, 0, 0);
+          }
+          const float lo = (dlm[ks] & 1) ? d[1] : d[0], hi = (dlm[ks] & 1) ? d[3] : d[2];
+          vals[h] = (dlm[ks] & 2) ? hi : lo;
         }
-        const float lo = (dlm & 1) ? d[1] : d[0], hi = (dlm & 1) ? d[3] : d[2];
-        vals[h] = (dlm & 2) ? hi : lo;
-      }
-      {
-        const int e = t * 16 + n;
-        const bool real = dlm != 255;                                   // (padding / out-of-range source: a zero, written by the kb = 0 lane)
-        if (e < len && (real ? (dlm >> 2) == kb : kb == 0)) {
+        const int e = t * KT + 16 * ks + n;
+        const bool real = dlm[ks] != 255;                               // (padding / out-of-range source: a zero, written by the kb = 0 lane)
+        if (e < len && (real ? (dlm[ks] >> 2) == kb : kb == 0)) {
           T *op = out + (e0 + e) * H;
           if constexpr (H == 1) op[0] = (T)(real ? vals[0] : 0.f);
           else {
@@ -1507,11 +1518,13 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
     };
     pair_up(0);
     if (ntiles > 0) gather(std::integral_constant<int, 0>{});
-    for (int t = 0; t < ntiles; t += 4) {
+    for (int t = 0; t < ntiles; t += PH) {
       tile(t, std::integral_constant<int, 0>{});
       if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
-      if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 2>{});
-      if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
+      if constexpr (PH == 4) {
+        if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
+      }
     }
     lock.round_done(p, lane, r);
   }
@@ -1521,24 +1534,23 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
 // ---- the 16-bit multi-head SpMM on the MATRIX cores (round 6) ---------------------------------------------------------------------
 // out[d, h, :] = sum_e w[e, h] x[s_e, h, :] contracts over EDGES, and an edge's row lies in memory along the FEATURES: the operand the
 // MFMA wants k-major has to be transposed on the way - gfx950's ds_read_b64_tr_b16 does that for free out of a row-major LDS image.
-// Per tile of 32 edges of a group (<= 16 output rows) and per 16-feature block fb:
-//     D_fb[16 rows x 16 features] += A_h[16 rows x 32 edges] * B_fb[32 edges x 16 features]        (v_mfma_f32_16x16x32_{bf16,f16})
+// Per step of 16 edges of a group (<= 16 output rows) and per 16-feature block fb:
+//     D_fb[16 rows x 16 features] += A_h[16 rows x 16 edges] * B_fb[16 edges x 16 features]        (v_mfma_f32_16x16x16_{bf16,f16})
 //   A_h[m][k] = dl(k) == m ? w[k, h] : 0   - the selector of the edge's output row times its weight, built in registers from the
-//               tile's row-in-group bytes and weights (staged in LDS per 64-edge chunk): 4 packed masks per tile + 4 ANDs per head;
-//   B_fb[k][n] = x[src(k), 16 fb + n]      - the gathered rows, written whole to a per-wave image [32 edges][512 + 32 bytes]
-//               (ds_write_b64, one edge per instruction as it was gathered) and read back transposed, two ds_read_b64_tr_b16 per
-//               block (rows 4 kq .. 4 kq + 3 and 16 + 4 kq ..: with the 32-byte pad the eight rows a 32-lane half reads lie on
-//               64 distinct banks);
-//   D_fb stays in registers for the WHOLE group (16 blocks x 4 VGPRs): no LDS accumulators, no row switches, no unpacking, no
-//               per-edge FMA stream - the ~20 wave-instructions per edge of seg_slab_wrow_kernel become ~6.
-// The unused 15/16 of every product is the price (the MFMAs are ~0.4 ms of matrix-core time at Reddit scale).  IEEE isolation:
-// a zero of A times an Inf / NaN of ANOTHER row's source would put a NaN into this row.  So the table is checked first
-// (slab_nonfinite_kernel: one streamed read of x, ~0.03 ms for 119 MB) and the launch is GATED on the result: with a non-finite value
+//               step's row-in-group bytes and weights (staged in LDS per 64-edge chunk): 2 packed masks per step + 2 ANDs per head;
+//   B_fb[k][n] = x[src(k), 16 fb + n]      - the gathered rows, written whole to a per-wave image [edges][row bytes + 32]
+//               (ds_write_b128, several edges per instruction as they were gathered) and read back transposed, one ds_read_b64_tr_b16
+//               per block (image rows 4 kq .. 4 kq + 3: with the 32-byte pad the rows a 16-lane group reads lie on distinct banks);
+//   D_fb stays in registers for the WHOLE group (16 | 8 blocks x 4 VGPRs): no LDS accumulators, no row switches, no unpacking, no
+//               per-edge FMA stream - the ~20 wave-instructions per edge of seg_slab_wrow_kernel become ~9.
+// The unused 15/16 of every product is the price (the MFMAs are ~0.75 ms of matrix-core time at Reddit scale, under the gathers).  IEEE
+// isolation: a zero of A times an Inf / NaN of ANOTHER row's source would put a NaN into this row.  So the table is checked first
+// (slab_nonfinite_kernel: one streamed read of x, ~0.02 ms for 119 MB) and the launch is GATED on the result: with a non-finite value
 // anywhere in x this kernel returns at once and its vector-ALU twin (seg_slab_wrow_kernel, enqueued behind it with the opposite gate)
 // does the call - same plan, same results as before.  Weights may be anything (an Inf weight only meets its own row's products).
-// Order of additions inside a row: the hardware's (32 edges per step in plan order); fixed by the plan, not by timing.
-// Plans cut into waves (units = waves of THIS grid: 2 workgroups per CU - the image is 17 KB a wave), R <= 16, rows of 512 bytes,
-// heads 1 / 2 / 4 / 8 with feat % 16 == 0; WMODE 0 none | 1 weight[e] | 2 weight[e * H + h] | 3 weight[h * nnz + e];
+// Order of additions inside a row: the hardware's (16 edges per step in plan order); fixed by the plan, not by timing.
+// Plans cut into waves (units = waves: 3 workgroups per CU - image + staged weights are ~10 KB a wave), R <= 16, rows of 512 or 256
+// bytes, heads 1 / 2 / 4 / 8 with feat % 16 == 0; WMODE 0 none | 1 weight[e] | 2 weight[e * H + h] | 3 weight[h * nnz + e];
 // p.w_in_plan_order as in seg_slab_wrow_kernel.  Option "slab_spmm_mfma" = 0: the row-per-wave kernel.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t *__restrict__ x, int64_t n16, int *flag) {
@@ -1555,27 +1567,29 @@ __global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t
   if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-// FS = 1: a wave owns a group's whole rows (3 workgroups per CU).  FS = 2: a PAIR of waves owns a group, each wave one half of the
-// features (256 bytes of every row: four edges per gather instruction, half the accumulators, half the image) - under 128 registers,
-// so 4 workgroups per CU are resident: the tile body is a chain of latencies (crossbar -> rows -> image -> transposed reads -> MFMAs)
-// and more waves per SIMD is what hides them.  The two waves of a pair share nothing but the plan's streams (the second reader hits L1 / L2).
-template <typename T, int H, int WMODE, int FS>
-__global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_kernel(SlabParams p) {
-  static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows of 512 bytes, 1 / 2 / 4 / 8 heads");
+// ROWB = 512: tiles of 16 edges (one K = 16 step), two rows per gather instruction.  ROWB = 256: tiles of 32 edges (two K = 16 steps
+// over one image), four rows per gather instruction - the same eight instructions, 8 KB, in flight per tile and the same image size.
+// (A PAIR of waves per group of 512-byte rows, each one half of the features with 4 workgroups per CU, was built and measured slower,
+// 3.87 against 3.71 ms, and is gone: profiles/r06/slab_cases__mh_bf16_spmm_matrix_cores_ab__product_library.txt.)
+template <typename T, int H, int WMODE, int ROWB>
+__global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabParams p) {
+  static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows, 1 / 2 / 4 / 8 heads");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE != 1 || H == 1), "one weight per edge = one head");
-  static_assert(FS == 1 || FS == 2, "whole rows or halves");
-  constexpr int KT = 16;                                 // edges per tile = the K of v_mfma_f32_16x16x16 (see the header: why not 32)
-  constexpr int RB = 512 / FS;                           // bytes of a row this wave reads
-  constexpr int LPR = RB / 16;                           // lanes per row of a gather instruction (16 bytes a lane)
+  static_assert(ROWB == 512 || ROWB == 256, "rows of 512 or 256 bytes");
+  constexpr int LOGB = ROWB == 512 ? 9 : 8;
+  constexpr int KS = 512 / ROWB;                         // K = 16 steps per tile: 1 | 2
+  constexpr int KT = 16 * KS;                            // edges per tile: 16 | 32
+  constexpr int PH = 64 / KT;                            // tiles per 64-edge chunk: 4 | 2
+  constexpr int LPR = ROWB / 16;                         // lanes per row of a gather instruction (16 bytes a lane): 32 | 16
   constexpr int RPI = 64 / LPR;                          // rows per gather instruction: 2 | 4
-  constexpr int NL = KT / RPI;                           // gather instructions per tile: 8 | 4
-  constexpr int TPR = 16 / NL;                           // tiles whose row offsets one broadcast register holds: 2 | 4
-  constexpr int NFB = 16 / FS;                           // 16-feature blocks of this wave
-  constexpr int kStride = RB + 32;                       // bytes between the rows of a tile's image
-  constexpr int kImg = KT * kStride;                     // 8 704 | 4 608 bytes
+  constexpr int NL = KT / RPI;                           // gather instructions per tile: 8
+  constexpr int TPR = 16 / NL;                           // tiles whose row offsets one broadcast register holds: 2
+  constexpr int NFB = ROWB / 32;                         // 16-feature blocks of a row: 16 | 8
+  constexpr int kStride = ROWB + 32;                     // bytes between the rows of a tile's image
+  constexpr int kImg = KT * kStride;                     // 8 704 | 9 216 bytes
   constexpr int kWave = kImg + 2 * H * 64 * 2 + 2 * 64;  // + weights [2 chunks][H][64] of T + rows-in-group [2][64] bytes
-  constexpr int FB_PER_H = 16 / H;                       // 16-feature blocks per head
-  constexpr int HL = H >= FS ? H / FS : 1;               // heads this wave touches
+  constexpr int FB_PER_H = NFB / H;                      // 16-feature blocks per head
+  static_assert(NL == 8 && TPR == 2 && FB_PER_H >= 1, "eight gather instructions per tile; a head is whole 16-feature blocks");
   typedef short s4_t __attribute__((ext_vector_type(4)));
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
   typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
@@ -1589,19 +1603,15 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
   unsigned char *img = smem + (size_t)wave * kWave;
   uint16_t *wst = reinterpret_cast<uint16_t *>(img + kImg);          // [2][H][64]
   unsigned char *dlb = img + kImg + 2 * H * 64 * 2;                   // [2][64]
-  float *imgf = reinterpret_cast<float *>(img);                       // (group end: half of this wave's D tiles as [16 rows][128 | 64] fp32: 8 | 4 KB of the image)
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t unit = gw / FS;                           // (FS = 2: waves 2 u and 2 u + 1 are unit u)
-  const int half = (int)(gw % FS);
-  const int hbase = H >= FS ? half * HL : 0;              // this wave's first head
+  float *imgf = reinterpret_cast<float *>(img);                       // (group end: eight D tiles as [16 rows][128] fp32: 8 KB of the image)
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
   const int64_t units = P.units;
   const T *weight = static_cast<const T *>(p.weight);
   T *dst = static_cast<T *>(p.dst);
   const bool wpo = p.w_in_plan_order != 0;
   const uint32_t src_rows = (uint32_t)p.src_rows;
-  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, 9, p.probe);
-  const uint32_t cL = (uint32_t)(lane % LPR) * 16u;       // a lane's 16 bytes inside the image row ...
-  const uint32_t cH = cL + (uint32_t)half * RB;           // ... and inside the table's row
+  const __amdgpu_buffer_rsrc_t table = slab_table_rsrc(p.src, p.src_rows, LOGB, p.probe);
+  const uint32_t cL = (uint32_t)(lane % LPR) * 16u;       // a lane's 16 bytes inside the row (table and image)
   // the tile's transposed read: lane 16 kq + 4 q + pp supplies the address of image row 4 kq + q, columns 4 pp .. 4 pp + 3 of the block;
   // lane 16 kq + n receives column n of those four rows = B[k = 4 kq .. 4 kq + 3][n]
   const uint32_t tr_off = (uint32_t)((4 * kq + ((lane >> 2) & 3)) * kStride + (lane & 3) * 8);
@@ -1677,15 +1687,16 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
     uint32_t nx_src = 0, nx_dl = 255, nx_pe = 0;        // the next chunk's fields: loaded under the chunk's first tile, handed over under its last
     WRaw nx_w = load_w(0);
     bool nx_valid = false;
-    uint32_t my_off = (my_edge & ~255u) << 1;           // this lane's edge: its source row's byte offset
-    // TWO rows per gather instruction, 16 bytes a lane (lanes 0..31 the row of edge 2 j, lanes 32..63 that of edge 2 j + 1): a wave-wide
-    // load costs the CU ~17-20 cycles whatever its width (tools/kexp5.hip: dropped by the range check 16 / 18 cycles at 8 / 16 bytes a lane,
-    // from an L2-resident table 20 / 19) - at one 512-byte row per instruction that alone is 3.8 ms for configs[3]'s 114.6 M edges, the
-    // floor every row-per-wave kernel of this file sits on.
-    // The per-lane row offsets: ONE crossbar read (ds_bpermute) lays the offsets of TPR tiles' edges out so that lane k of every 16-lane
-    // row holds what that row's lanes need for one gather instruction (row r, lane k = NL tt + j: the edge of tile tt, instruction j,
+    uint32_t my_off = (my_edge & ~255u) << (LOGB - 8);  // this lane's edge: its source row's byte offset
+    // SEVERAL rows per gather instruction, 16 bytes a lane (512-byte rows: lanes 0..31 the row of edge 2 j, lanes 32..63 that of edge
+    // 2 j + 1; 256-byte rows: 16 lanes an edge, 4 j .. 4 j + 3): a wave-wide load costs the CU ~17-20 cycles whatever its width
+    // (tools/kexp5.hip: dropped by the range check 16 / 18 cycles at 8 / 16 bytes a lane, from an L2-resident table 20 / 19) - at one
+    // 512-byte row per instruction that alone is 3.8 ms for configs[3]'s 114.6 M edges, the floor every row-per-wave kernel of this file
+    // sits on.
+    // The per-lane row offsets: ONE crossbar read (ds_bpermute) lays the offsets of two tiles' edges out so that lane k of every 16-lane
+    // row holds what that row's lanes need for one gather instruction (row r, lane k = 8 tt + j: the edge of tile tt, instruction j,
     // that row r's lanes fetch); the instruction's offsets are then a DPP row broadcast of lane k - vector-ALU work, folded into the add
-    // of the lane's column.  (First form: one ds_bpermute per gather instruction, 8 of a tile's 38 LDS operations.)
+    // of the lane's column.  (First form: one ds_bpermute per gather instruction, 8 of a tile's 38 LDS operations: 3.72 -> 3.45 ms.)
     u4_t rv[NL];
     uint32_t po = 0;
     auto pair_up = [&](int gen) __attribute__((always_inline)) {
@@ -1693,15 +1704,15 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {         // a tile's rows (slots behind the last edge: row 0)
       constexpr int tb = decltype(tb_c)::value, k0 = ((tb / KT) % TPR) * NL;
-      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (9 + p.slab_shift)));
+      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (LOGB + p.slab_shift)));
       slab_static_for([&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
-        rv[j] = slab_row_load<u4_t>(table, cH + slab_row_bcast<k0 + j>(po), 0u);
+        rv[j] = slab_row_load<u4_t>(table, cL + slab_row_bcast<k0 + j>(po), 0u);
       }, std::make_integer_sequence<int, NL>{});
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
-      constexpr int ph = decltype(ph_c)::value, tb = ph * KT, tbn = ((ph + 1) & 3) * KT;
-      const int c = t >> 2, buf = c & 1;
+      constexpr int ph = decltype(ph_c)::value, tb = ph * KT, tbn = ((ph + 1) % PH) * KT;
+      const int c = t / PH, buf = c & 1;
       const bool more = t + 1 < ntiles;
       // the next chunk's fields (and its weights, where they lie in plan order), behind this tile's gathers: every lane loads (lanes
       // behind the group's end re-read its last edge and drop the value)
@@ -1715,21 +1726,25 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
           else nx_pe = (uint32_t)P.e_perm[ne];
         }
       }
-      if constexpr (WMODE != 0 && ph == 2) {
+      if constexpr (WMODE != 0 && PH == 4 && ph == 2) {
         if (!wpo) nx_w = load_w((int64_t)nx_pe);       // (through the permutation: its entry arrived two tiles ago)
       }
       // Everything that needs only the LDS crossbar / the chunk's staged arrays goes FIRST, ahead of the wait for this tile's rows: the
       // hand-over of the next chunk (its fields arrived tiles ago), the next tile's gather offsets, this tile's selector bytes and weights
-      if constexpr (ph == 3) {                  // the chunk ends with this tile: the next chunk's edges become this lane's
+      if constexpr (ph == PH - 1) {             // the chunk ends with this tile: the next chunk's edges become this lane's
         my_edge = (nx_valid && nx_src < src_rows) ? ((nx_src << 8) | nx_dl) : 255u;
-        my_off = (my_edge & ~255u) << 1;
+        my_off = (my_edge & ~255u) << (LOGB - 8);
         stage(buf ^ 1, nx_w, nx_valid, my_edge);
         pair_up(0);
       } else if constexpr ((ph + 1) % TPR == 0) pair_up((ph + 1) / TPR);      // (the next tile opens the register's next generation)
-      const uint32_t dl4 = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 4 * kq);
-      raw2_t wa[HL];
+      uint32_t dl4[KS];
+      raw2_t wa[KS][H];
 #pragma unroll
-      for (int h = 0; h < HL; ++h) wa[h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + hbase + h) * 64 + tb + 4 * kq);
+      for (int ks = 0; ks < KS; ++ks) {
+        dl4[ks] = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 16 * ks + 4 * kq);
+#pragma unroll
+        for (int h = 0; h < H; ++h) wa[ks][h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 16 * ks + 4 * kq);
+      }
       // tile t into the image (the previous tile's transposed reads are ahead of these writes in the wave's LDS queue)
 #ifdef GEOT_DEV_EXPERIMENTS
       if (!(p.probe & 4))
@@ -1748,52 +1763,61 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
 #endif
       wave_order();
       if (more) gather(std::integral_constant<int, tbn>{});              // in flight under this tile's matrix work
-      // A: selector x weight.  This lane's four edges are the image rows 4 kq .. 4 kq + 3 of the tile
-      uint32_t mk[2];
-      mk[0] = (((dl4 & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dl4 >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      mk[1] = ((((dl4 >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dl4 >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-      s4_t afrag[HL];
-#pragma unroll
-      for (int h = 0; h < HL; ++h) {
-        const raw2_t a = {wa[h][0] & mk[0], wa[h][1] & mk[1]};
-        afrag[h] = __builtin_bit_cast(s4_t, a);
-      }
 #ifdef GEOT_DEV_EXPERIMENTS
-      if (p.probe & 2) {                        // (knock-out bit 1: no transposed reads, no MFMAs)
-        D[0][0] += __builtin_bit_cast(float, (uint32_t)afrag[0][0]);
-        return;
-      }
       const bool no_tr = (p.probe & 8) != 0;   // (knock-out bit 3: the MFMAs without their LDS operand)
 #endif
 #pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) {
-        constexpr int kOneHead = FB_PER_H >= NFB;            // (a head spans all of this wave's blocks)
-        const int hl = kOneHead ? 0 : fb / FB_PER_H;
-        s4_t b;
+      for (int ks = 0; ks < KS; ++ks) {
+        // A: selector x weight.  This lane's four edges are the image rows 16 ks + 4 kq .. + 3 of the tile
+        uint32_t mk[2];
+        mk[0] = (((dl4[ks] & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dl4[ks] >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+        mk[1] = ((((dl4[ks] >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dl4[ks] >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
+        s4_t afrag[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const raw2_t a = {wa[ks][h][0] & mk[0], wa[ks][h][1] & mk[1]};
+          afrag[h] = __builtin_bit_cast(s4_t, a);
+        }
 #ifdef GEOT_DEV_EXPERIMENTS
-        if (no_tr) b = afrag[(hl + 1) % HL];
-        else
+        if (p.probe & 2) {                      // (knock-out bit 1: no transposed reads, no MFMAs)
+          D[0][0] += __builtin_bit_cast(float, (uint32_t)afrag[0][0]);
+          continue;
+        }
 #endif
-        b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + fb * 32));
-        if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[hl], b, D[fb], 0, 0, 0);
-        else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[hl]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          const int hl = fb / FB_PER_H;
+          s4_t b;
+#ifdef GEOT_DEV_EXPERIMENTS
+          if (no_tr) b = afrag[(hl + 1) % H];
+          else
+#endif
+          b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + ks * 16 * kStride + fb * 32));
+          if constexpr (__is_same(T, bf16_t)) D[fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afrag[hl], b, D[fb], 0, 0, 0);
+          else D[fb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4_t, afrag[hl]), __builtin_bit_cast(h4_t, b), D[fb], 0, 0, 0);
+        }
+      }
+      if constexpr (WMODE != 0 && PH == 2 && ph == 0) {
+        if (!wpo) nx_w = load_w((int64_t)nx_pe);       // (two tiles a chunk: the permutation's entry arrived under this tile's matrix work)
       }
     };
     pair_up(0);
     if (ntiles > 0) gather(std::integral_constant<int, 0>{});
-    for (int t = 0; t < ntiles; t += 4) {       // a chunk of 64 edges = four tiles, unrolled: lane numbers of the crossbar reads are immediates
+    for (int t = 0; t < ntiles; t += PH) {      // a chunk of 64 edges = PH tiles, unrolled: lane numbers of the crossbar reads are immediates
       tile(t, std::integral_constant<int, 0>{});
       if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
-      if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 2>{});
-      if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
+      if constexpr (PH == 4) {
+        if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 2>{});
+        if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
+      }
     }
     lock.round_done(p, lane, r);
-    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows, this wave's blocks
-    // in two passes (the image is 8.5 | 4.5 KB: 16 rows x 128 | 64 fp32 at a time)
+    // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows, eight blocks
+    // (128 features, 16 rows x 512 bytes of fp32 = 8 KB of the image) at a time
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
-    constexpr int PB = NFB / 2, PF = PB * 16, LR = PF / 4;     // blocks and floats of a pass, lanes that cover a row's part
+    constexpr int PB = 8, PF = PB * 16, LR = PF / 4;           // blocks and floats of a pass, lanes that cover a row's part
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < NFB / PB; ++hf) {
       wave_order();
 #pragma unroll
       for (int fb = 0; fb < PB; ++fb) {
@@ -1805,7 +1829,7 @@ __global__ __launch_bounds__(kThreads, FS == 1 ? 3 : 4) void seg_slab_spmm_mfma_
         for (int l = lane / LR; l < nv; l += 64 / LR) {          // 64 / LR rows at a time
           const int64_t tg = P.v_out[v0 + l];
           const int colp = (lane % LR) * 4;
-          const int col = half * (256 / FS) + PF * hf + colp;
+          const int col = PF * hf + colp;
           const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * PF + colp);
           if (tg >= 0) {
             if (tg < p.K) {
@@ -2042,7 +2066,7 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 GEOT_DEV_SWITCH g_slab_wrow_all = 0;
-int g_slab_spmm_mfma = 1;    // "slab_spmm_mfma": 16-bit multi-head SpMM over wave-cut plans of 512-byte rows on the matrix cores (seg_slab_spmm_mfma_kernel,
+int g_slab_spmm_mfma = 1;    // "slab_spmm_mfma": 16-bit SpMM over wave-cut plans of 512- / 256-byte rows on the matrix cores (seg_slab_spmm_mfma_kernel,
                              // gated on a finite source table); 0 = the row-per-wave kernel
 int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over plans of 512-byte rows on the matrix cores (seg_slab_sddmm_mfma_kernel:
                              // 4.30 vs 5.84 ms at Reddit scale); 0 = the row-per-wave kernel
@@ -2063,6 +2087,9 @@ int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, in
   const size_t hw = weight_mode == 0 ? 0 : ((weight_mode == 1 || weight_mode == 4) ? 1 : (size_t)heads);
   int r = 32;
   while (r > 1 && (size_t)4 * r * row + (size_t)4 * 2 * 64 * hw * sizeof(float) > budget) --r;
+  // 16-bit rows: at most the 16 rows of a matrix-core operand, so that the plan can be run by seg_slab_spmm_mfma_kernel /
+  // seg_slab_sddmm_mfma_kernel (512-byte rows end below 16 by the LDS bound above; 256-byte rows would get 24)
+  if (dtype != GEOT_F32 && r > 16) r = 16;
   return r;
 }
 
@@ -2269,9 +2296,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p);    \
   } while (0)
 #endif
-    // 16-bit multi-head plans over 512-byte rows, sums: the matrix-core kernel, GATED on a finite source table (its header), with the
+    // 16-bit plans cut into waves over 512- / 256-byte rows, sums: the matrix-core kernel, GATED on a finite source table (its header), with the
     // row-per-wave kernel enqueued behind it under the opposite gate.  Same persistent grid, same plan.
-    const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && rowbytes == 512 && reduce == GEOT_REDUCE_SUM && plan->rows_per_group <= 16 &&
+    const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && (rowbytes == 512 || rowbytes == 256) && reduce == GEOT_REDUCE_SUM && plan->rows_per_group <= 16 &&
                       (heads == 1 || heads == 2 || heads == 4 || heads == 8) && feat % 16 == 0 && (weight_mode != 1 || heads == 1) &&
                       (weight_mode == 0 || (((uintptr_t)p.weight) & (uintptr_t)(weight_mode == 2 ? heads * 2 - 1 : 1)) == 0);
     const int rc = g_turn.take(st, [&]() -> int {
@@ -2286,31 +2313,12 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         p.gate_want = 1;
         const int64_t n16 = src_rows * rowbytes / 16;
         const int wm = weight_mode == 1 ? 1 : weight_mode;             // (one weight per edge: H == 1)
-        // "slab_spmm_mfma" = 2: pairs of waves, each one half of the features, 4 workgroups per CU - the plan's groups are dealt to THIS
-        // grid's units (waves / 2), whatever grid the plan was cut for
-#ifdef GEOT_DEV_EXPERIMENTS
-        const int fs = g_slab_spmm_mfma == 2 ? 2 : 1;
-#else
-        constexpr int fs = 1;                                          // (the pair form measured slower, 3.87 vs 3.71 ms: development build only)
-#endif
-        dim3 mgrid = grid;
-        if (fs == 2) {
-          const int64_t mwaves = (int64_t)slab_device().cus * 4 * 4;
-          pm.plan.units = (int32_t)(mwaves / 2);
-          pm.rounds = (int)((plan->n_groups + pm.plan.units - 1) / pm.plan.units);
-          mgrid = dim3((unsigned)(mwaves / 4));
-        }
-#ifdef GEOT_DEV_EXPERIMENTS
-#define GEOT_SLAB_SPMM_MFMA_FS2(T_, H_, W_) if (fs == 2) hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 2>), mgrid, blk, mlds, st, pm); else
-#else
-#define GEOT_SLAB_SPMM_MFMA_FS2(T_, H_, W_)
-#endif
 #define GEOT_SLAB_SPMM_MFMA_W(T_, H_, W_)                                                                     \
         do {                                                                                                  \
-          const size_t mlds = (size_t)4 * (16 * (512 / fs + 32) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
-          geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(fs) + ">").c_str()); \
-          GEOT_SLAB_SPMM_MFMA_FS2(T_, H_, W_)                                                                 \
-          hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 1>), mgrid, blk, mlds, st, pm);           \
+          const size_t mlds = (size_t)4 * ((rowbytes == 512 ? 16 * (512 + 32) : 32 * (256 + 32)) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
+          geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(rowbytes) + ">").c_str()); \
+          if (rowbytes == 512) hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 512>), grid, blk, mlds, st, pm); \
+          else hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 256>), grid, blk, mlds, st, pm);       \
         } while (0)
 #define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \
         do {                                                                                                  \
@@ -2331,7 +2339,6 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 #undef GEOT_SLAB_SPMM_MFMA
 #undef GEOT_SLAB_SPMM_MFMA_H
 #undef GEOT_SLAB_SPMM_MFMA_W
-#undef GEOT_SLAB_SPMM_MFMA_FS2
       }
       const std::string mfma_name = mfma ? std::string(geot_last_kernel()) : std::string();
 #ifdef GEOT_DEV_EXPERIMENTS
@@ -2471,25 +2478,31 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   }
   const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
   const int el = (int)(F / 64);                            // (rows of 512 / 256 bytes) elements per lane
-  // 16-bit multi-head plans over 512-byte rows, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's
+  // 16-bit plans cut into waves over 512- / 256-byte rows, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's
   // rows fit one 16-column operand and a head is a whole number of 32-feature slices (H = 1 / 2 / 4 / 8)
   const int nch = (int)(F / 32);
-  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && rowbytes == 512 && plan->rows_per_group <= 16 &&
-      (heads == 1 || heads == 2 || heads == 4 || heads == 8) && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
-    const size_t xlds = (size_t)4 * 16 * (512 + 32);       // per wave: the tile image
+  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && (rowbytes == 512 || rowbytes == 256) && plan->rows_per_group <= 16 &&
+      (heads == 1 || heads == 2 || heads == 4 || heads == 8) && nch % (int)heads == 0 && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
+    const size_t xlds = (size_t)4 * (rowbytes == 512 ? 16 * (512 + 32) : 32 * (256 + 32));   // per wave: the tile image
     const int cph = nch / (int)heads;
     const int rc = g_turn.take(st, [&]() -> int {
+#define GEOT_SLAB_MFMA_B(T_, C_)                                                                               \
+      do {                                                                                                     \
+        if (rowbytes == 512) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, C_, 512>), grid, blk, xlds, st, p); \
+        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, C_, 256>), grid, blk, xlds, st, p);           \
+      } while (0)
 #define GEOT_SLAB_MFMA(T_)                                                                                     \
       do {                                                                                                     \
-        geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(cph) + ">").c_str()); \
-        if (cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8>), grid, blk, xlds, st, p);        \
-        else if (cph == 4) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 4>), grid, blk, xlds, st, p);   \
-        else if (cph == 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 2>), grid, blk, xlds, st, p);   \
-        else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 1>), grid, blk, xlds, st, p);                 \
+        geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(cph) + ", " + std::to_string(rowbytes) + ">").c_str()); \
+        if (cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 512>), grid, blk, xlds, st, p);   /* (one head over 512-byte rows) */ \
+        else if (cph == 4) GEOT_SLAB_MFMA_B(T_, 4);                                                            \
+        else if (cph == 2) GEOT_SLAB_MFMA_B(T_, 2);                                                            \
+        else GEOT_SLAB_MFMA_B(T_, 1);                                                                          \
       } while (0)
       if (dtype == GEOT_F16) GEOT_SLAB_MFMA(half_t);
       else GEOT_SLAB_MFMA(bf16_t);
 #undef GEOT_SLAB_MFMA
+#undef GEOT_SLAB_MFMA_B
       const hipError_t le = hipGetLastError();
       return le == hipSuccess ? GEOT_OK : geot_internal_fail(GEOT_ELAUNCH, hipGetErrorString(le));
     });
@@ -2557,11 +2570,7 @@ int geot_internal_slab_option(const char *name, int value) {       // 1 = a name
   else if (n == "slab_turn") g_slab_turn = value != 0;
   else if (n == "slab_far") { if (value >= 0) g_slab_far = value; }
   else if (n == "slab_sddmm_mfma") g_slab_sddmm_mfma = value != 0;
-#ifdef GEOT_DEV_EXPERIMENTS
-  else if (n == "slab_spmm_mfma") { if (value >= 0 && value <= 2) g_slab_spmm_mfma = value; }   // 1: a wave per group, 2 (development build): a pair of waves per group (feature halves)
-#else
-  else if (n == "slab_spmm_mfma") { if (value >= 0 && value <= 1) g_slab_spmm_mfma = value; }
-#endif
+  else if (n == "slab_spmm_mfma") g_slab_spmm_mfma = value != 0;
   else if (n == "slab_blocks") { if (value >= 1 && value <= 4) g_slab_blocks = value; }
 #ifdef GEOT_DEV_EXPERIMENTS
   else if (n == "slab_nt") g_slab_nt = value != 0;

@@ -423,7 +423,7 @@ at::Tensor gather_common(const char *op, const at::Tensor &si, const at::Tensor 
     };
     std::shared_ptr<SlabPlanHolder> plan;
     if (red != GEOT_REDUCE_PROD && !e.permuted)        // dense graphs: sum / mean / max / min on the source-blocked kernel
-      plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1);
+      plan = slab_plan_for(e.si, e.di, rows, x, has_w ? 1 : 0, 1, red);
     if (plan) {
       auto run_plan = [&](at::Tensor &o) -> bool {
         const void *wptr = has_w ? e.w.data_ptr() : nullptr;

@@ -126,14 +126,17 @@ class Graph:
             self._deg = hip.index_scatter_out(self.dst_index, ones, torch.empty(self.rows, 1, dtype=torch.float32, device=ones.device)).view(-1)
         return self._deg
 
-    def _plan(self, which: str, rowbytes: int, wmode: int, heads: int, dtype: torch.dtype, table_rows: int):
+    def _plan(self, which: str, rowbytes: int, wmode: int, heads: int, dtype: torch.dtype, table_rows: int, reduce: str = "sum"):
         if self.slab_mode == "never" or dtype not in _SLAB_DTYPES or rowbytes not in (256, 512, 1024) or self.nnz >= 2 ** 31:
             return None
         si, di, rows = self._edges(which)
         if table_rows * rowbytes >= 2 ** 32:
             return None
-        R = slab.rows_per_group(wmode, heads, dtype, rowbytes)
-        units = int(slab._lib.load().geot_slab_units_for(wmode, rowbytes))
+        # (the host operator's rule, csrc/host_plan.cpp slab_plan_for: 16-bit sums over 256-byte rows with one weight per edge or none
+        #  take the multi-head cut - waves, <= 16 rows per group - which the matrix-core kernels run)
+        cut = 2 if (dtype != torch.float32 and rowbytes == 256 and reduce == "sum" and wmode in (0, 1)) else wmode
+        R = slab.rows_per_group(cut, heads, dtype, rowbytes)
+        units = int(slab._lib.load().geot_slab_units_for(cut, rowbytes))
         key = (which, rowbytes, R, units)
         if key not in self._plans:
             plan = None
@@ -221,7 +224,7 @@ class Graph:
         via = isinstance(weight, tuple) and len(weight) == 4          # ("via", twin plan, values, list-order fallback): see _bwd_reader
         po = isinstance(weight, tuple) and not via
         wmode_plan = 0 if weight is None else (2 if mh else 1)
-        plan = self._plan(which, rowbytes, wmode_plan, H, x.dtype, _rows(x)) if (reduce != "prod") else None
+        plan = self._plan(which, rowbytes, wmode_plan, H, x.dtype, _rows(x), reduce) if (reduce != "prod") else None
         if mh and ((F * x.element_size()) % 16 != 0 or H > 16):     # (the host operator's rule too: mh_spmm_common in csrc/torch_ops.cpp)
             plan = None
         w_edge = [None]

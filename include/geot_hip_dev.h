@@ -64,8 +64,8 @@ void geot_tune(int edges_per_group, int vec, int nontemporal, int lpr_log2);
  * "slab_far" = n: a slowest wave more than n steps behind is not waited for (12); "slab_turn" = 1 | 0: the persistent
  * source-blocked grids of this process take turns per device (a launch waits on its stream for the event of the previous one;
  * skipped on a capturing stream);
- * "slab_sddmm_mfma" = 1 | 0 and "slab_spmm_mfma" = 1 | 0: 16-bit multi-head SDDMM / SpMM over plans of 512-byte rows on the matrix
- * cores | the row-per-wave kernels;
+ * "slab_sddmm_mfma" = 1 | 0 and "slab_spmm_mfma" = 1 | 0: 16-bit SDDMM / SpMM over plans cut into waves of 512- / 256-byte rows on the
+ * matrix cores | the row-per-wave kernels;
  * "handoff_tries" = polls of a predecessor's flag before a run is left to the second launch (0: sample once);
  * "lds_floor" = -1 | bytes: dynamic LDS a tile-kernel launch asks for at least - the cap on workgroups per CU
  * (-1: the rule; 33000 -> 4, 41000 -> 3, 54000 -> 2 per CU); "gather_grid" = tiles a gathered fp32 call is cut into

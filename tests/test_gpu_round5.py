@@ -299,7 +299,7 @@ def test_weights_in_every_order_on_every_chunk_length(geot, dtype, H, Fh):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32)])
+@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32)])   # rows of 512 and (round 6) of 256 bytes
 def test_matrix_core_sddmm_is_exact_on_integer_data(geot, dtype, H, Fh):
     """seg_slab_sddmm_mfma_kernel (16-bit multi-head SDDMM over a plan of 512-byte rows, v_mfma_f32_16x16x32): features in {-1, 0, 1}, so every dot product is an integer below 2^8 - exact in fp32 and in the 16-bit result -
     and any slip in the operand maps (which lane holds which features of which edge / row, where D[m][dl(m)] sits, the padded LDS
@@ -315,7 +315,7 @@ def test_matrix_core_sddmm_is_exact_on_integer_data(geot, dtype, H, Fh):
     q = torch.from_numpy(rng.integers(-1, 2, (nodes, H, Fh)).astype(np.float32)).to(dtype).cuda()
     k = torch.from_numpy(rng.integers(-1, 2, (nodes, H, Fh)).astype(np.float32)).to(dtype).cuda()
     d_si, d_di = dev(si), dev(di)
-    R = min(16, slab.rows_per_group(2, H, dtype, rowbytes))
+    R = slab.rows_per_group(2, H, dtype, rowbytes)                      # (the rule keeps 16-bit plans within a matrix-core operand's 16 rows)
     plan = slab.build_plan(d_si, d_di, nodes, nodes, rowbytes, 2, H, rows_per_group=R)
     assert plan.meta["split_rows"] >= 1 and plan.meta["rows_per_group"] <= 16
     ok = dev((si < nodes))

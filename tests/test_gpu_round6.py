@@ -49,7 +49,7 @@ def _ref(d_si, d_di, w, v, nodes):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32)])
+@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32), (8, 16)])   # rows of 512 and of 256 bytes
 def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtype, H, Fh):
     """Every weight layout the kernel serves (edge-major through the permutation, head-major, plan order, none), a hub split into
     pieces (carry rows), rows without edges, out-of-range sources (contribute nothing): float64 sums within the storage type's
@@ -61,8 +61,9 @@ def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtyp
     si[rng.integers(0, nnz, 50)] = nodes + 7                            # out-of-range sources
     d_si, d_di = dev(si), dev(di)
     ok = dev(si < nodes)
-    R = min(16, slab.rows_per_group(2, H, dtype, 512))
-    plan = slab.build_plan(d_si, d_di, nodes, nodes, 512, 2, H, rows_per_group=R)
+    rowbytes = H * Fh * 2
+    R = slab.rows_per_group(2, H, dtype, rowbytes)                      # (the rule keeps 16-bit plans within a matrix-core operand's 16 rows)
+    plan = slab.build_plan(d_si, d_di, nodes, nodes, rowbytes, 2, H, rows_per_group=R)
     assert plan.meta["split_rows"] >= 1 and plan.meta["rows_per_group"] <= 16
     e_perm = plan.tensors["e_perm"].long()
     tol = 2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6
@@ -105,13 +106,6 @@ def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtyp
         clean_rows = torch.ones(nodes, dtype=torch.bool, device="cuda")
         clean_rows[d_di[~ok]] = False
         assert torch.equal(a[clean_rows], b[clean_rows]), float((a.double() - b.double())[clean_rows].abs().max())
-        # the other form of the kernel - a PAIR of waves per group, each wave one half of the features ("slab_spmm_mfma" = 2) - adds in the
-        # same order: the same bits, for every weight layout
-        if "DEVELOPMENT" in geot.hip.build_info():                                      # (measured slower: the development build only)
-            for name, weight, mode in forms:
-                assert torch.equal(run(weight, mode, v, 2), outs[0]), name
-            assert torch.equal(run(None, 0, v, 2), o0) and torch.equal(run(wi, 2, vi, 2), a)
-            assert geot.hip.last_kernel().endswith(", 2>"), geot.hip.last_kernel()
     finally:
         geot.hip.set_option("slab_spmm_mfma", 1)
 
@@ -249,6 +243,63 @@ def test_matrix_core_spmm_through_the_operator_and_the_handle(geot):
     finally:
         ops.set_option("slab_mode", old)
         ops.clear_caches()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_single_head_sums_over_256_byte_rows_reach_the_matrix_cores(geot, dtype):
+    """16-bit F = 128 (256-byte rows) on a dense graph, through the drop-in operators and through geot_amd.Graph: sums - weighted,
+    unweighted, and the SDDMM of the weighted op's backward - run on plans cut into WAVES (the multi-head cut: csrc/host_plan.cpp
+    slab_plan_for) by the matrix-core kernels; mean keeps its lane-group plan and vector-ALU kernel; fp32 keeps lane groups.  Values
+    against float64."""
+    from geot_amd import ops
+    nodes, nnz, F = 4000, 600_000, 128
+    rng = np.random.default_rng(11)
+    si, di = _dense_graph(rng, nodes, nnz)
+    d_si, d_di = dev(si), dev(di)
+    x = (torch.rand(nodes, F, device="cuda") - 0.3).to(dtype)
+    w = (torch.rand(nnz, device="cuda") - 0.3).to(dtype)
+    tol = 2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9
+    ref_w = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, d_di, x.double()[d_si] * w.double()[:, None])
+    ref_1 = torch.zeros(nodes, F, device="cuda", dtype=torch.float64).index_add_(0, d_di, x.double()[d_si])
+    cnt = torch.bincount(d_di, minlength=nodes).clamp(min=1).double()[:, None]
+
+    def close(y, ref):
+        return float((y.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+
+    old = ops.set_option("slab_mode", "always")
+    try:
+        ops.clear_caches()
+        for _ in range(3):
+            y = geot.gather_weight_scatter(d_si, d_di, w, x)
+        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel() and ", 256>" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        assert close(y, ref_w)
+        for _ in range(2):
+            y = geot.gather_scatter(d_si, d_di, x, "sum")
+        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        assert close(y, ref_1)
+        for _ in range(3):
+            y = geot.gather_scatter(d_si, d_di, x, "mean")
+        assert geot.hip.last_kernel().startswith("seg_slab_kernel<"), geot.hip.last_kernel()       # lane groups, vector ALUs
+        assert close(y, ref_1 / cnt)
+        # the weighted op's backward: d/dweight is the SDDMM over the same wave-cut plan
+        xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+        up = torch.rand(nodes, F, device="cuda").to(dtype)
+        gx, gw = torch.autograd.grad(geot.gather_weight_scatter(d_si, d_di, wg, xg), [xg, wg], up)
+        assert close(gw, (up.double()[d_di] * x.double()[d_si]).sum(-1))
+        sc = ops.sddmm_coo_impl(d_si, d_di, up, x)
+        assert "seg_slab_sddmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        assert close(sc, (up.double()[d_di] * x.double()[d_si]).sum(-1))
+        x32 = x.float()
+        for _ in range(3):
+            y = geot.gather_scatter(d_si, d_di, x32[:, :64].contiguous(), "sum")             # fp32 rows of 256 bytes: lane groups
+        assert geot.hip.last_kernel().startswith("seg_slab_kernel<float"), geot.hip.last_kernel()
+    finally:
+        ops.set_option("slab_mode", old)
+        ops.clear_caches()
+    g = geot.Graph(d_si, d_di, num_src=nodes, num_dst=nodes, slab_mode="always")
+    y = g.gather_weight_scatter(w, x)
+    assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+    assert close(y, ref_w)
 
 
 def _device_powerlaw(nnz, keys, seed):

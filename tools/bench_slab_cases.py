@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # (the development build - the experiment switches live there only - when the command line names one of them; the product otherwise:
 #  the development build's kernels carry knock-out branches and time a few per cent slower)
-if any(n in " ".join(sys.argv) for n in ("slab_probe", "slab_pair", "slab_wrow_all", "slab_nt", "slab_tight", "slab_stage", "slab_unroll", "slab_spmm_mfma=2")):
+if any(n in " ".join(sys.argv) for n in ("slab_probe", "slab_pair", "slab_wrow_all", "slab_nt", "slab_tight", "slab_stage", "slab_unroll")):
     os.environ.setdefault("GEOT_HIP_LIB", "dev")
 from bench import device_ms, powerlaw_index  # noqa: E402
 from geot_amd import hip, slab  # noqa: E402
@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--rows-per-group", type=int, default=0, help="R of every plan (0 = the library's rule): fewer rows = more rounds")
     ap.add_argument("--mh-lane-groups", action="store_true", help="multi-head plans over 512 / 256-byte rows cut into lane groups (16 bytes a lane) "
                                                                   "instead of waves")
+    ap.add_argument("--mh-shape", default="4,64", help="heads,features per head of the multi-head cases (configs[3]: 4,64)")
+    ap.add_argument("--gws-wave-cut", action="store_true", help="single-weight / weightless plans over 512 / 256-byte rows cut into WAVES (what the "
+                                                                "matrix-core kernels run) instead of the rule's lane groups")
     a = ap.parse_args()
     dev = torch.device("cuda")
     for item in filter(None, a.options.split(",")):
@@ -55,6 +58,9 @@ def main():
         if a.mh_lane_groups and wmode == 2 and rowbytes in (256, 512):
             R = slab.rows_per_group(wmode, H, dtype)
             units = int(slab._lib.load().geot_slab_units_for(0, rowbytes))
+        if a.gws_wave_cut and wmode != 2 and rowbytes in (256, 512):
+            R = slab.rows_per_group(2, 1, dtype, rowbytes)
+            units = int(slab._lib.load().geot_slab_units_for(2, rowbytes))
         R = a.rows_per_group or R
         key = (rowbytes, R, units)
         if key not in plans:
@@ -73,24 +79,24 @@ def main():
         esz = 4 if dtype == torch.float32 else 2
         # ---- multi-head SpMM, H = 4 x F = 64 (configs[3])
         if not only or "mh" in only:
-            H, Fh = 4, 64
+            H, Fh = (int(v) for v in a.mh_shape.split(","))
             x = torch.rand(nodes, H, Fh, device=dev, generator=g).to(dtype)
             w = torch.rand(nnz, H, device=dev, generator=g).to(dtype)
             out = torch.empty(nodes, H, Fh, device=dev, dtype=dtype)
             plan = plan_for(H * Fh * esz, 2, H, dtype)
-            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, as the ABI serves them", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh),
+            line(f"mh_spmm H={H} F={Fh} {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, as the ABI serves them", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh),
                  f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} units={plan.meta['units']}")
-            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, through e_perm", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh, stage_weights=False))
+            line(f"mh_spmm H={H} F={Fh} {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, through e_perm", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh, stage_weights=False))
             wp = w[plan.tensors["e_perm"].long()].contiguous()
-            line(f"mh_spmm H=4 F=64 {tname} rows {H * Fh * esz} B, weights in PLAN order (mode 5)", lambda: slab.slab_spmm_out(plan, wp, 5, x, out, H, Fh))
+            line(f"mh_spmm H={H} F={Fh} {tname} rows {H * Fh * esz} B, weights in PLAN order (mode 5)", lambda: slab.slab_spmm_out(plan, wp, 5, x, out, H, Fh))
             del wp
             if not only or "sddmm" in only:
                 q = torch.rand(nodes, H, Fh, device=dev, generator=g).to(dtype)
                 s_edge = torch.empty(nnz, H, device=dev, dtype=dtype)
                 staging = torch.empty(nnz, H, device=dev, dtype=dtype)
-                line(f"mh_sddmm H=4 F=64 {tname}, results in edge order (staged + unstage)", lambda: slab.slab_mh_sddmm_out(plan, q, x, s_edge, staging))
-                line(f"mh_sddmm H=4 F=64 {tname}, results left in plan order", lambda: slab.slab_mh_sddmm_out(plan, q, x, None, staging))
-                line(f"mh_sddmm H=4 F=64 {tname}, per-edge kernel", lambda: hip.mh_sddmm_coo_out(si, di, q, x, s_edge, False))
+                line(f"mh_sddmm H={H} F={Fh} {tname}, results in edge order (staged + unstage)", lambda: slab.slab_mh_sddmm_out(plan, q, x, s_edge, staging))
+                line(f"mh_sddmm H={H} F={Fh} {tname}, results left in plan order", lambda: slab.slab_mh_sddmm_out(plan, q, x, None, staging))
+                line(f"mh_sddmm H={H} F={Fh} {tname}, per-edge kernel", lambda: hip.mh_sddmm_coo_out(si, di, q, x, s_edge, False))
                 del q, s_edge, staging
             del x, w, out
         # ---- single weight / no weight, F = 128 and F = 64

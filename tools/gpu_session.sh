@@ -17,7 +17,7 @@ for s in $steps; do
               ;;
     devtests) GEOT_HIP_LIB=dev timeout 2400 python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu_devlib.log 2>&1; echo "rc=$?"; tail -5 $O/pytest_gpu_devlib.log ;;
     mfma)     timeout 1200 python3 -m pytest tests/test_gpu_round6.py -m gpu -x -q > $O/pytest_r6_mfma.log 2>&1; echo "rc=$?"; tail -25 $O/pytest_r6_mfma.log
-              for o in slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0; do
+              for o in slab_spmm_mfma=1 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=0; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
               done > $O/slab_cases_mfma_ab.txt 2>&1; cat $O/slab_cases_mfma_ab.txt ;;
     dbg)      timeout 600 python3 tools/_ab/dbg_gate2.py 2>&1 | grep -v amdgpu.ids | tail -60 ;;
@@ -28,13 +28,20 @@ for s in $steps; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options slab_window=-1,$o 2>&1 | grep "PLAN order\|options"
               done > $O/slab_cases_mfma_knockout.txt 2>&1; cat $O/slab_cases_mfma_knockout.txt ;;
     kexp5)    timeout 600 ./tools/kexp5 > $O/kexp5_row_gather_instruction_cost.txt 2>&1; echo "rc=$?"; cat $O/kexp5_row_gather_instruction_cost.txt ;;
+    slabmatrix) timeout 1500 python3 tools/bench_slab_cases.py 2>&1 | grep -v amdgpu.ids > $O/slab_cases_matrix.txt; cat $O/slab_cases_matrix.txt ;;
+    rows256)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q 2>&1 | tail -4
+              { for o in slab_spmm_mfma=1,slab_sddmm_mfma=1 slab_spmm_mfma=0,slab_sddmm_mfma=0; do
+                  timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --mh-shape 2,64 --options $o 2>&1 | grep -v amdgpu.ids
+                  timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --mh-shape 4,32 --options $o 2>&1 | grep -v amdgpu.ids
+                  timeout 600 python3 tools/bench_slab_cases.py --only gws,sddmm --dtypes bf16 --gws-wave-cut --options $o 2>&1 | grep -v amdgpu.ids
+                done; timeout 600 python3 tools/bench_slab_cases.py --only gws,sddmm --dtypes bf16 2>&1 | grep -v amdgpu.ids; } > $O/slab_cases_rows256.txt 2>&1; cat $O/slab_cases_rows256.txt ;;
     sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
               done > $O/slab_cases_sddmm_mfma_b128.txt 2>&1; cat $O/slab_cases_sddmm_mfma_b128.txt ;;
     compile)  timeout 1500 python3 -m pytest tests/test_compile_models.py tests/test_match_replace.py tests/test_gpu_graph_handle.py -m gpu -x -q 2>&1 | tail -25 ;;
     pmcmfma)  GEOT_HIP_LIB=product bash tools/pmc_spmm_mfma.sh $O/pmc_spmm_mfma 2>&1 | tail -40 ;;
-    mfmaprod) for o in slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=2 slab_spmm_mfma=0; do
+    mfmaprod) for o in slab_spmm_mfma=1 slab_spmm_mfma=0 slab_spmm_mfma=1 slab_spmm_mfma=0; do
                 GEOT_HIP_LIB=product timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --options $o 2>&1 | grep -v amdgpu.ids
               done > $O/slab_cases_mfma_ab_product_lib.txt 2>&1; cat $O/slab_cases_mfma_ab_product_lib.txt ;;
     benchall) timeout 1500 python3 bench.py --steps 20 --warmup 5 --secondary all --detail-out $O/bench_all_detail.json > $O/bench_all.json 2> $O/bench_all.err; echo "rc=$?"; cat $O/bench_all.json; tail -2 $O/bench_all.err

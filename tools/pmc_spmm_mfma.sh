@@ -11,7 +11,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 C1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"
 C2="SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM"
 C3="SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA"
-for opt in ${OPTS:-"slab_spmm_mfma=1" "slab_spmm_mfma=2" "slab_spmm_mfma=0"}; do
+for opt in ${OPTS:-"slab_spmm_mfma=1" "slab_spmm_mfma=0"}; do
   tag=$(echo "$opt" | tr ',=' '__')
   for n in 1 2 3; do
     eval "C=\$C$n"

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # (the development build - the experiment switches live there only - when the command line names one of them; the product otherwise:
 #  the development build's kernels carry knock-out branches and time a few per cent slower)
-if any(n in " ".join(sys.argv) for n in ("slab_probe", "slab_pair", "slab_wrow_all", "slab_nt", "slab_tight", "slab_stage", "slab_unroll", "slab_spmm_mfma=2")):
+if any(n in " ".join(sys.argv) for n in ("slab_probe", "slab_pair", "slab_wrow_all", "slab_nt", "slab_tight", "slab_stage", "slab_unroll")):
     os.environ.setdefault("GEOT_HIP_LIB", "dev")
 from bench import device_ms, powerlaw_index  # noqa: E402
 from geot_amd import hip, slab  # noqa: E402
