@@ -384,8 +384,8 @@ def test_multi_head_plans_on_narrow_rows_random_shapes(geot):
         assert plan.meta["split_rows"] >= 1 and plan.meta["units"] == slab._lib.load().geot_slab_units_for(2, rowbytes)
         out = torch.full((nodes, H, Fh), float("nan"), dtype=dtype, device="cuda")
         slab.slab_spmm_out(plan, d_w, 2, d_x, out, H, Fh)
-        # (round 6: 16-bit plans of 512-byte rows with 1 / 2 / 4 / 8 heads of whole 16-feature blocks go to the matrix cores)
-        mfma = esz == 2 and rowbytes == 512 and H in (1, 2, 4, 8) and Fh % 16 == 0 and plan.meta["rows_per_group"] <= 16
+        # (round 6: 16-bit plans of 512- / 256-byte rows with 1 / 2 / 4 / 8 heads of whole 16-feature blocks go to the matrix cores)
+        mfma = esz == 2 and H in (1, 2, 4, 8) and Fh % 16 == 0 and plan.meta["rows_per_group"] <= 16
         assert ("seg_slab_spmm_mfma_kernel" if mfma else "seg_slab_wrow_kernel") in geot.hip.last_kernel(), geot.hip.last_kernel()
         want = torch.zeros(nodes, H, Fh, dtype=torch.float64, device="cuda")
         want.index_add_(0, d_di, d_x.double()[d_si] * d_w.double()[:, :, None])
