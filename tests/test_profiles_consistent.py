@@ -66,7 +66,7 @@ def _evidence_us():
             for v in node:
                 walk(v, unit)
     import json
-    for name in ("bench_all_secondaries_detail.json", "bench_driver_detail.json", "bench_unprofiled.json"):
+    for name in ("bench_driver_detail.json", "bench_unprofiled.json"):
         path = os.path.join(ROOT, "profiles", RND, name)
         if os.path.exists(path):
             walk(json.loads(open(path).read()))
