@@ -357,6 +357,18 @@ def secondary(dev, scale=1.0, iters=5, only=None):
                  "roofline": {"bound": "hbm", "achieved": comp / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": comp / ms / 1e6 / HBM_PEAK_GBPS, **profiled(name)},
                  "gathered_row_bytes": nnz * esize * F, "gathered_row_gbps": nnz * esize * F / ms / 1e6}
+        if kind == "uniform":
+            # the yardstick of a per-edge gather over THIS table (configs[4]'s, bench_cfg5): the box's own rate for uniform-random rows of
+            # it with nothing else going on, and with one row written per `run` rows read (run = edges per output row) - the table is
+            # 1.25 GB (0.63 in bf16), so a part of every probe's reads comes out of the 256 MiB Infinity Cache, as the kernel's do
+            try:
+                rb = hip.profile_box_rows(x, out=torch.empty_like(out), run=max(1, round(nnz / max(nodes, 1))))
+                rate = nnz * esize * F / ms / 1e6
+                entry["roofline"].update(box_random_row_gbps=rb["best_gbps"], box_random_row_gbps_with_write_mix=rb["mix_row_gbps"],
+                                         row_gather_frac_of_box_random_row=rate / rb["best_gbps"] if rb["best_gbps"] else None,
+                                         row_gather_frac_of_box_row_mix=rate / rb["mix_row_gbps"] if rb["mix_row_gbps"] else None)
+            except Exception as e:  # noqa: BLE001
+                entry["roofline"]["box_random_row_error"] = repr(e)
         if dtype == torch.float32:
             try:
                 best, table, y = rocsparse.best_csr_spmm(di, si, w, x, nodes, iters=max(2, iters // 2))

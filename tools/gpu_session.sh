@@ -35,6 +35,9 @@ for s in $steps; do
                   timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --mh-shape 4,32 --options $o 2>&1 | grep -v amdgpu.ids
                   timeout 600 python3 tools/bench_slab_cases.py --only gws,sddmm --dtypes bf16 --gws-wave-cut --options $o 2>&1 | grep -v amdgpu.ids
                 done; timeout 600 python3 tools/bench_slab_cases.py --only gws,sddmm --dtypes bf16 2>&1 | grep -v amdgpu.ids; } > $O/slab_cases_rows256.txt 2>&1; cat $O/slab_cases_rows256.txt ;;
+    mfmaslab) for mib in 0.5 1 1.5 2 3; do for w in 0 1 2 3; do
+                timeout 300 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --slab-mib $mib --options slab_window=$w 2>&1 | grep "PLAN order\|left in plan\|^# lib" | sed "s/^# lib.*options=/# /"
+              done; done > $O/slab_cases_mfma_slab_sweep.txt 2>&1; cat $O/slab_cases_mfma_slab_sweep.txt ;;
     sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
