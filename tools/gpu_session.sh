@@ -56,8 +56,8 @@ for k,v in d["secondary"].items():
     print(k, json.dumps(keep)[:700])
 PY
               ;;
-    mfmaR)    for R in 11 12 13 14; do
-                timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --rows-per-group $R 2>&1 | grep "mh_\|options" | cut -c1-170
+    mfmaR)    for R in 8 11 12 13 14 15 16; do
+                timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --rows-per-group $R 2>&1 | grep "mh_\|options" | cut -c1-170
               done > $O/slab_cases_mfma_rows_per_group.txt 2>&1; cat $O/slab_cases_mfma_rows_per_group.txt ;;
     mfmastage) for o in slab_stage=1 slab_stage=2; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh --dtypes bf16,fp32 --options $o 2>&1 | grep "mh_spmm\|options" | cut -c1-170
