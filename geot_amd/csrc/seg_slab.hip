@@ -1942,6 +1942,61 @@ __global__ __launch_bounds__(kThreads) void slab_unstage_kernel(const int64_t *_
   }
 }
 
+// The mirror image of slab_unstage_kernel, for per-call multi-head WEIGHTS in the caller's edge order (weight_mode 2, heads x element
+// size = 8 bytes: four 16-bit heads): a group's weights - a contiguous range of the edge-order array unless the group holds a piece
+// of a split hub - come in as whole lines, go through LDS and leave in the plan's order (staged[e0 + i] = weight[e_perm[e0 + i]]).
+// Read through the permutation inside the persistent kernel every one of those 8-byte reads is a 64-byte sector of its own from
+// beyond the L2 (the gathers turn an XCD's 4 MiB over every few microseconds): 1.2 ms at configs[3]'s graph; this pre-pass takes
+// 0.76 ms (rocprofv3) - bf16 H=4 x F=64 with per-call weights 4.58 -> 4.21 ms.  1 024 threads a workgroup, every load of a phase
+// issued before the first is used (a loop around a non-temporal load is not unrolled by itself: one load in flight per thread);
+// the pieces of split hubs (their edges interleave inside the hub's range) are read directly.  Measured and NOT adopted: the same
+// for 16-byte weights (four fp32 heads, a 128 KB tile: 7.27 against 7.20 ms through the permutation), this shape for the unstage
+// kernel (1.25 against 0.95 ms), and both moves without a tile, positions dealt to the XCDs in contiguous ranges so that one L2
+// sees all of a group (stage 0.97, unstage 1.33 ms) - profiles/r06/slab_cases__mh_weights_staged_a_group_at_a_time.txt.
+constexpr int kStageThreads = 1024, kStageIters = 8, kStageTileBytes = 64 * 1024;   // tiles of at most 8 192 edges
+template <typename T>
+__global__ __launch_bounds__(kStageThreads) void slab_stage_kernel(const int64_t *__restrict__ g_begin, const int32_t *__restrict__ e_perm,
+                                                                   const T *__restrict__ weight, T *__restrict__ staged, int64_t n_groups) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T *tile = reinterpret_cast<T *>(smem);
+  constexpr int kTileElems = kStageTileBytes / (int)sizeof(T);
+  static_assert(kTileElems >= kStageIters * kStageThreads, "a tile holds what a workgroup loads in one phase");
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t e0 = g_begin[g];
+    const int len = (int)(g_begin[g + 1] - e0);
+    if (len <= kStageIters * kStageThreads) {
+      int32_t pe[kStageIters];
+      T v[kStageIters];
+#pragma unroll
+      for (int k = 0; k < kStageIters; ++k) {
+        const int i = threadIdx.x + k * kStageThreads;
+        if (i < len) {
+          pe[k] = e_perm[e0 + i];
+          v[k] = __builtin_nontemporal_load(weight + e0 + i);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kStageIters; ++k) {
+        const int i = threadIdx.x + k * kStageThreads;
+        if (i < len) tile[i] = v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kStageIters; ++k) {
+        const int i = threadIdx.x + k * kStageThreads;
+        if (i < len) {
+          const int64_t at = (int64_t)pe[k] - e0;
+          const T w = (at >= 0 && at < len) ? tile[at] : weight[pe[k]];      // (a hub's piece: its edges lie elsewhere)
+          __builtin_nontemporal_store(w, staged + e0 + i);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < len; i += kStageThreads) staged[e0 + i] = weight[e_perm[e0 + i]];
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int g_slab_turn;
 // The persistent grids are sized for the whole chip and keep step per XCD: two of them at once take each other's CUs and
 // lockstep has nothing to offer (the kernels stay correct and bounded - SlabStep gives up - but both run slower than one
@@ -2103,8 +2158,11 @@ size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total)
 size_t geot_slab_workspace_bytes_staged(const geot_slab_plan *plan, int64_t feat_total, int weight_mode, int64_t heads, int dtype) {
   if (!plan) return 0;
   const size_t base = geot_slab_workspace_bytes(plan, feat_total);
-  if (weight_mode != 1 && !(weight_mode == 2 && g_slab_stage == 2)) return base;   // (multi-head weights: staged on request only, see geot_slab_spmm)
-  return base + (size_t)plan->nnz * (size_t)(weight_mode == 1 ? 1 : heads) * (dtype == GEOT_F32 ? 4 : 2);
+  // (one weight per edge, or 8 bytes of heads an edge in edge-major layout: what the pre-passes of geot_slab_spmm serve; "slab_stage"
+  //  = 2, development build: every multi-head layout through the plain gather)
+  const size_t wb = (size_t)(weight_mode == 1 ? 1 : heads) * (dtype == GEOT_F32 ? 4 : 2);
+  if (weight_mode != 1 && !(weight_mode == 2 && (wb == 8 || g_slab_stage == 2))) return base;
+  return base + (size_t)plan->nnz * wb;
 }
 
 int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mode, const void *src, void *dst,
@@ -2191,7 +2249,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   // (measured at configs[3]'s graph, profiles/r05/slab_cases__lane_groups__weights_staged_by_a_prepass.txt: one weight per edge - gws
   //  F=128 fp32 4.50 -> 3.98 ms, F=64 3.40 -> 2.74, bf16 F=128 3.19 -> 2.79; four heads of weights: the pre-pass moves 4 GB and costs more
   //  than the permuted reads - fp32 7.18 -> 7.51, bf16 5.24 -> 5.61: multi-head weights are staged only on request, "slab_stage" = 2)
-  if (!w_in_plan_order && (weight_mode == 1 || (weight_mode == 2 && g_slab_stage == 2)) && g_slab_stage && plan->n_groups > 0 &&
+  //  Round 6: four 16-bit heads (8 bytes an edge) go through LDS a GROUP at a time instead (slab_stage_kernel) - bf16 4.58 -> 4.21 ms.
+  if (!w_in_plan_order && (weight_mode == 1 || (weight_mode == 2 && (wbytes == 8 || g_slab_stage == 2))) && g_slab_stage && plan->n_groups > 0 &&
       (wbytes == 2 || wbytes == 4 || wbytes == 8 || wbytes == 16) && (((uintptr_t)weight) & (wbytes - 1)) == 0 &&
       workspace_bytes >= geot_slab_workspace_bytes_staged(plan, F, weight_mode, heads, dtype))
     wstage = static_cast<char *>(workspace) + need;
@@ -2216,6 +2275,11 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
     const dim3 sgrid((unsigned)(sblocks > 0 ? sblocks : 1)), sblk(kThreads);
     const bool x4 = (((uintptr_t)wstage | (uintptr_t)plan->e_perm) & 15) == 0 && plan->nnz >= 4;
+    if (weight_mode == 2 && wbytes == 8 && g_slab_stage != 2) {            // a group at a time through LDS, two workgroups per CU
+      const unsigned gb = (unsigned)(plan->n_groups < (int64_t)slab_device().cus * 2 ? plan->n_groups : (int64_t)slab_device().cus * 2);
+      hipLaunchKernelGGL((slab_stage_kernel<uint64_t>), dim3(gb), dim3(kStageThreads), kStageTileBytes, st, plan->g_begin, plan->e_perm,
+                         static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(wstage), plan->n_groups);
+    } else
     if (wbytes == 2 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
     else if (wbytes == 4 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->nnz);
     else if (wbytes == 2) hipLaunchKernelGGL((slab_stage_weights_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);

@@ -283,10 +283,11 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /
 int geot_slab_units_for(int weight_mode, int64_t rowbytes);
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes);
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
-/* ... plus room for the call's weights in plan order (nnz x heads elements; weight modes 1 / 2 only, otherwise the same number).
- * Given that much, geot_slab_spmm stages EDGE-order weights into plan order inside the kernel - every unit its own group's, at the
- * start of its round - instead of reading each one through the edge permutation in the row loop (gws F=128 fp32 at Reddit scale:
- * 4.50 -> see profiles/r05/slab_cases_*; the permuted reads cost ~15 GB of 64-byte lines for 1.8 GB of weights under 4 heads). */
+/* ... plus room for the call's weights in plan order (nnz x heads elements: weight mode 1, and weight mode 2 with four 16-bit heads
+ * - 8 bytes an edge; otherwise the same number).  Given that much, geot_slab_spmm brings EDGE-order weights into plan order by a
+ * pre-pass of its own ahead of the persistent kernel instead of reading each one through the edge permutation in the row loop (gws
+ * F=128 fp32 at Reddit scale 4.50 -> 3.98 ms, profiles/r05/slab_cases_*; bf16 H=4 x F=64, a group at a time through LDS, 4.60 ->
+ * 4.25 ms, profiles/r06/slab_cases__mh_weights_staged_a_group_at_a_time.txt; four fp32 heads: measured, no gain, not staged). */
 size_t geot_slab_workspace_bytes_staged(const geot_slab_plan *plan, int64_t feat_total, int weight_mode, int64_t heads, int dtype);
 /* dst[d, h, :] = reduce_e w(e, h) * src[s[e], h, :] over the plan's edges.  weight_mode: 0 none (gather_scatter),
  * 1 weight[e] (gather_weight_scatter, heads = 1), 2 weight[e*heads + h], 3 weight[h*nnz + e] (mh_spmm layouts),

@@ -38,6 +38,19 @@ for s in $steps; do
     mfmaslab) for mib in 0.5 1 1.5 2 3; do for w in 0 1 2 3; do
                 timeout 300 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --slab-mib $mib --options slab_window=$w 2>&1 | grep "PLAN order\|left in plan\|^# lib" | sed "s/^# lib.*options=/# /"
               done; done > $O/slab_cases_mfma_slab_sweep.txt 2>&1; cat $O/slab_cases_mfma_slab_sweep.txt ;;
+    stagemh)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py tests/test_gpu_round4.py tests/test_gpu_slab.py -m gpu -x -q 2>&1 | tail -4
+              timeout 900 python3 tools/bench_slab_cases.py --only mh,sddmm 2>&1 | grep -v amdgpu.ids > $O/slab_cases_mh_group_local_staging.txt; cat $O/slab_cases_mh_group_local_staging.txt ;;
+    stagetrace) export TMPDIR=/tmp; rm -rf $O/st; rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -o st -- python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 > $O/st.log 2>&1; tail -3 $O/st.log
+              python3 - <<PY > $O/stage_unstage_kernel_trace.txt
+import csv, glob
+f = glob.glob('$O/st/**/*kernel_stats.csv', recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if any(k in r['Name'] for k in ('stage', 'mfma', 'fill', 'nonfinite', 'combine')):
+        print(f"{r['Name'][:90]:90s} calls {r['Calls']:>4s}  avg {float(r['AverageNs'])/1e6:8.3f} ms  min {float(r['MinNs'])/1e6:8.3f}  max {float(r['MaxNs'])/1e6:8.3f}")
+PY
+              cat $O/stage_unstage_kernel_trace.txt; rm -rf $O/st ;;
+    stageab)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py tests/test_gpu_round4.py tests/test_gpu_slab.py -m gpu -x -q 2>&1 | tail -3
+              for m in direct tile direct tile; do echo "# GEOT_PERMUTE=$m"; GEOT_PERMUTE=$m timeout 900 python3 tools/bench_slab_cases.py --only mh,sddmm 2>&1 | grep "as the ABI\|unstage"; done > $O/slab_cases_permute_ab.txt; cat $O/slab_cases_permute_ab.txt ;;
     sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
