@@ -1952,7 +1952,8 @@ __global__ __launch_bounds__(kThreads) void slab_unstage_kernel(const int64_t *_
 // the pieces of split hubs (their edges interleave inside the hub's range) are read directly.  Measured and NOT adopted: the same
 // for 16-byte weights (four fp32 heads, a 128 KB tile: 7.27 against 7.20 ms through the permutation), this shape for the unstage
 // kernel (1.25 against 0.95 ms), and both moves without a tile, positions dealt to the XCDs in contiguous ranges so that one L2
-// sees all of a group (stage 0.97, unstage 1.33 ms) - profiles/r06/slab_cases__mh_weights_staged_a_group_at_a_time.txt.
+// sees all of a group (stage 0.97, unstage 1.33 ms); and this kernel for ONE weight per edge in place of the plain gather pre-pass
+// (fp32 3.80 against 3.88 ms, bf16 2.75 against 2.59) - profiles/r06/slab_cases__mh_weights_staged_a_group_at_a_time.txt.
 constexpr int kStageThreads = 1024, kStageIters = 8, kStageTileBytes = 64 * 1024;   // tiles of at most 8 192 edges
 template <typename T>
 __global__ __launch_bounds__(kStageThreads) void slab_stage_kernel(const int64_t *__restrict__ g_begin, const int32_t *__restrict__ e_perm,
