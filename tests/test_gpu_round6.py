@@ -245,15 +245,16 @@ def test_matrix_core_spmm_through_the_operator_and_the_handle(geot):
         ops.clear_caches()
 
 
+@pytest.mark.parametrize("F", [128, 256])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_single_head_sums_over_256_byte_rows_reach_the_matrix_cores(geot, dtype):
-    """16-bit F = 128 (256-byte rows) on a dense graph, through the drop-in operators and through geot_amd.Graph: sums - weighted,
+def test_single_head_16_bit_sums_reach_the_matrix_cores(geot, dtype, F):
+    """16-bit F = 128 / 256 (256- / 512-byte rows) on a dense graph, through the drop-in operators and through geot_amd.Graph: sums - weighted,
     unweighted, and the SDDMM of the weighted op's backward - run on plans cut into WAVES (the multi-head cut: csrc/host_plan.cpp
     slab_plan_for) by the matrix-core kernels; mean keeps its lane-group plan and vector-ALU kernel; fp32 keeps lane groups.  Values
     against float64."""
     from geot_amd import ops
-    nodes, nnz, F = 4000, 600_000, 128
-    rng = np.random.default_rng(11)
+    nodes, nnz = 4000, 600_000
+    rng = np.random.default_rng(11 + F)
     si, di = _dense_graph(rng, nodes, nnz)
     d_si, d_di = dev(si), dev(di)
     x = (torch.rand(nodes, F, device="cuda") - 0.3).to(dtype)
@@ -271,7 +272,7 @@ def test_single_head_sums_over_256_byte_rows_reach_the_matrix_cores(geot, dtype)
         ops.clear_caches()
         for _ in range(3):
             y = geot.gather_weight_scatter(d_si, d_di, w, x)
-        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel() and ", 256>" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel() and f", {2 * F}>" in geot.hip.last_kernel(), geot.hip.last_kernel()
         assert close(y, ref_w)
         for _ in range(2):
             y = geot.gather_scatter(d_si, d_di, x, "sum")
@@ -291,7 +292,7 @@ def test_single_head_sums_over_256_byte_rows_reach_the_matrix_cores(geot, dtype)
         assert close(sc, (up.double()[d_di] * x.double()[d_si]).sum(-1))
         x32 = x.float()
         for _ in range(3):
-            y = geot.gather_scatter(d_si, d_di, x32[:, :64].contiguous(), "sum")             # fp32 rows of 256 bytes: lane groups
+            y = geot.gather_scatter(d_si, d_di, x32[:, :F // 2].contiguous(), "sum")         # fp32 rows of the same width: lane groups
         assert geot.hip.last_kernel().startswith("seg_slab_kernel<float"), geot.hip.last_kernel()
     finally:
         ops.set_option("slab_mode", old)

@@ -100,10 +100,10 @@ def main():
                 del q, s_edge, staging
             del x, w, out
         # ---- single weight / no weight, F = 128 and F = 64
-        for F in (128, 64):
+        for F in (256, 128, 64):
             if only and "gws" not in only:
                 break
-            if F * esz < 256:
+            if F * esz < 256 or F * esz > 512:
                 continue
             x = torch.rand(nodes, F, device=dev, generator=g).to(dtype)
             w = torch.rand(nnz, device=dev, generator=g).to(dtype)
