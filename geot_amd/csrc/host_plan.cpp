@@ -304,13 +304,13 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
   if (g_opt.slab_mode != 1 && !slab_worthwhile(nnz, rows, src.size(0), rowbytes, dt)) return nullptr;
   ContentKey k1, k2;
   if (!may_remember({&si, &di}) || !content_key(si, &k1) || !content_key(di, &k2)) return nullptr;
-  // The plan's cut.  16-bit SUMS over 256- / 512-byte rows with one weight per edge or none take the multi-head rule's cut - waves, at
-  // most 16 rows per group - because that is the plan the matrix-core kernels run (seg_slab_spmm_mfma_kernel / seg_slab_sddmm_mfma_kernel;
-  // bf16 at configs[3]'s graph, weighted / no weight / the SDDMM of the backward pass: F = 128 1.79 / 1.72 / 2.38 ms against the
-  // lane-group kernel's 2.28 / 2.16 / 3.26, F = 256 3.26 / 3.16 / 3.79 against 4.03 / 3.88 / 5.48 - profiles/r06/slab_cases__rows_of_256_bytes.txt,
-  // slab_cases__rows_of_512_bytes_one_head.txt); mean / max / min keep lane groups (their vector-ALU kernels are faster there: F = 128
-  // 2.17 against 3.40 ms, F = 256 3.93 against 4.31)
-  const int cut_wmode = (!f32 && (rowbytes == 256 || rowbytes == 512) && red == GEOT_REDUCE_SUM && (wmode == 0 || wmode == 1)) ? 2 : wmode;
+  // The plan's cut.  16-bit SUMS and MEANS over 256- / 512-byte rows with one weight per edge or none take the multi-head rule's cut -
+  // waves, at most 16 rows per group - because that is the plan the matrix-core kernels run (seg_slab_spmm_mfma_kernel /
+  // seg_slab_sddmm_mfma_kernel; bf16 at configs[3]'s graph, weighted / no weight / mean / the SDDMM of the backward pass: F = 128
+  // 1.78 / 1.72 / 1.74 / 2.37 ms against the lane-group kernels' 2.30 / 2.17 / 2.18 / 3.27, F = 256 3.26 / 3.17 / 3.19 / 3.79 against
+  // 4.03 / 3.88 / 3.91 / 5.48 - profiles/r06/slab_cases__rows_of_256_bytes.txt, slab_cases__rows_of_512_bytes_one_head.txt); max / min
+  // keep lane groups (no matrix-core form, and the row-per-wave kernel that would run a wave-cut plan is slower than the lane-group one)
+  const int cut_wmode = (!f32 && (rowbytes == 256 || rowbytes == 512) && (red == GEOT_REDUCE_SUM || red == GEOT_REDUCE_MEAN) && (wmode == 0 || wmode == 1)) ? 2 : wmode;
   const int rpg = geot_slab_rows_per_group_shape(cut_wmode, heads, dt, rowbytes);
   const int64_t units = geot_slab_units_for(cut_wmode, rowbytes);
   {

@@ -1571,9 +1571,10 @@ __global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t
 // over one image), four rows per gather instruction - the same eight instructions, 8 KB, in flight per tile and the same image size.
 // (A PAIR of waves per group of 512-byte rows, each one half of the features with 4 workgroups per CU, was built and measured slower,
 // 3.87 against 3.71 ms, and is gone: profiles/r06/slab_cases__mh_bf16_spmm_matrix_cores_ab__product_library.txt.)
-template <typename T, int H, int WMODE, int ROWB>
+template <typename T, int H, int WMODE, int ROWB, int RED = GEOT_REDUCE_SUM>
 __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabParams p) {
   static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows, 1 / 2 / 4 / 8 heads");
+  static_assert(RED == GEOT_REDUCE_SUM || (RED == GEOT_REDUCE_MEAN && H == 1), "sums; the mean of a single-head aggregation");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE != 1 || H == 1), "one weight per edge = one head");
   static_assert(ROWB == 512 || ROWB == 256, "rows of 512 or 256 bytes");
   constexpr int LOGB = ROWB == 512 ? 9 : 8;
@@ -1830,8 +1831,13 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
           const int64_t tg = P.v_out[v0 + l];
           const int colp = (lane % LR) * 4;
           const int col = PF * hf + colp;
-          const f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * PF + colp);
+          f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * PF + colp);
           if (tg >= 0) {
+            if constexpr (RED == GEOT_REDUCE_MEAN) {                    // (pieces of a split row are divided after the combine)
+              const float tot = (float)P.v_total[v0 + l];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) row[i] = row[i] / tot;
+            }
             if (tg < p.K) {
               typedef T t4_t __attribute__((ext_vector_type(4)));
               const t4_t o = {(T)row[0], (T)row[1], (T)row[2], (T)row[3]};                 // one rounding, here
@@ -2040,6 +2046,18 @@ struct SlabTurn {
 SlabTurn g_turn;
 
 } // namespace
+
+// (the mean exists for one head only: inside a template the other instantiations are never formed)
+template <typename T, int H, int W, int ROWB>
+static void slab_launch_spmm_mfma(int reduce, dim3 grid, dim3 blk, size_t lds, hipStream_t st, const SlabParams &pm) {
+  if constexpr (H == 1 && W != 3) {
+    if (reduce == GEOT_REDUCE_MEAN) {
+      hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T, H, W, ROWB, GEOT_REDUCE_MEAN>), grid, blk, lds, st, pm);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T, H, W, ROWB, GEOT_REDUCE_SUM>), grid, blk, lds, st, pm);
+}
 
 extern "C" {
 
@@ -2363,7 +2381,8 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 #endif
     // 16-bit plans cut into waves over 512- / 256-byte rows, sums: the matrix-core kernel, GATED on a finite source table (its header), with the
     // row-per-wave kernel enqueued behind it under the opposite gate.  Same persistent grid, same plan.
-    const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && (rowbytes == 512 || rowbytes == 256) && reduce == GEOT_REDUCE_SUM && plan->rows_per_group <= 16 &&
+    const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && (rowbytes == 512 || rowbytes == 256) &&
+                      (reduce == GEOT_REDUCE_SUM || (reduce == GEOT_REDUCE_MEAN && heads == 1)) && plan->rows_per_group <= 16 &&
                       (heads == 1 || heads == 2 || heads == 4 || heads == 8) && feat % 16 == 0 && (weight_mode != 1 || heads == 1) &&
                       (weight_mode == 0 || (((uintptr_t)p.weight) & (uintptr_t)(weight_mode == 2 ? heads * 2 - 1 : 1)) == 0);
     const int rc = g_turn.take(st, [&]() -> int {
@@ -2382,8 +2401,10 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         do {                                                                                                  \
           const size_t mlds = (size_t)4 * ((rowbytes == 512 ? 16 * (512 + 32) : 32 * (256 + 32)) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
           geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(rowbytes) + ">").c_str()); \
-          if (rowbytes == 512) hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 512>), grid, blk, mlds, st, pm); \
-          else hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T_, H_, W_, 256>), grid, blk, mlds, st, pm);       \
+          if (reduce == GEOT_REDUCE_MEAN)                                                                     \
+            geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(rowbytes) + ", mean>").c_str()); \
+          if (rowbytes == 512) slab_launch_spmm_mfma<T_, H_, W_, 512>(reduce, grid, blk, mlds, st, pm);       \
+          else slab_launch_spmm_mfma<T_, H_, W_, 256>(reduce, grid, blk, mlds, st, pm);                       \
         } while (0)
 #define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \
         do {                                                                                                  \

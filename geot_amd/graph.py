@@ -134,7 +134,7 @@ class Graph:
             return None
         # (the host operator's rule, csrc/host_plan.cpp slab_plan_for: 16-bit sums over 256- / 512-byte rows with one weight per edge or
         #  none take the multi-head cut - waves, <= 16 rows per group - which the matrix-core kernels run)
-        cut = 2 if (dtype != torch.float32 and rowbytes in (256, 512) and reduce == "sum" and wmode in (0, 1)) else wmode
+        cut = 2 if (dtype != torch.float32 and rowbytes in (256, 512) and reduce in ("sum", "mean") and wmode in (0, 1)) else wmode
         R = slab.rows_per_group(cut, heads, dtype, rowbytes)
         units = int(slab._lib.load().geot_slab_units_for(cut, rowbytes))
         key = (which, rowbytes, R, units)

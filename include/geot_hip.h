@@ -281,10 +281,10 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /
  * geot_slab_sddmm read the form off the plan's `units` (a plan cut into waves runs row-per-wave under any weight mode; measured
  * slower than lane groups except under multi-head weights: profiles/r05/slab_cases__row_per_wave_*).
  * Round 6: a 16-bit plan cut into waves with at most 16 rows per group (geot_slab_rows_per_group_shape caps 16-bit wave-cut plans
- * there) is run on the matrix cores - SUMS by geot_slab_spmm under any weight mode, geot_slab_sddmm / geot_slab_mh_sddmm with their
+ * there) is run on the matrix cores - SUMS (one head: MEANS too) by geot_slab_spmm under any weight mode, geot_slab_sddmm / geot_slab_mh_sddmm with their
  * results staged - and there it is FASTER than lane groups for one weight per edge or none over 256- / 512-byte rows too (bf16 at
- * Reddit scale: F = 128 1.79 against 2.28 ms, F = 256 3.26 against 4.03, profiles/r06/slab_cases__rows_of_*): ask for weight_mode 2's units and rows for
- * such a plan (the host layer and geot_amd.Graph do; mean / max / min are faster on lane groups). */
+ * Reddit scale: F = 128 1.78 against 2.30 ms, F = 256 3.26 against 4.03, profiles/r06/slab_cases__rows_of_*): ask for weight_mode 2's units and rows for
+ * such a plan (the host layer and geot_amd.Graph do; max / min are faster on lane groups). */
 int geot_slab_units_for(int weight_mode, int64_t rowbytes);
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes);
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);

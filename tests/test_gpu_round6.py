@@ -250,8 +250,8 @@ def test_matrix_core_spmm_through_the_operator_and_the_handle(geot):
 def test_single_head_16_bit_sums_reach_the_matrix_cores(geot, dtype, F):
     """16-bit F = 128 / 256 (256- / 512-byte rows) on a dense graph, through the drop-in operators and through geot_amd.Graph: sums - weighted,
     unweighted, and the SDDMM of the weighted op's backward - run on plans cut into WAVES (the multi-head cut: csrc/host_plan.cpp
-    slab_plan_for) by the matrix-core kernels; mean keeps its lane-group plan and vector-ALU kernel; fp32 keeps lane groups.  Values
-    against float64."""
+    slab_plan_for) by the matrix-core kernels, and so does the mean (the row's sum divided by its edge count where the row is written);
+    max keeps its lane-group plan and vector-ALU kernel; fp32 keeps lane groups.  Values against float64."""
     from geot_amd import ops
     nodes, nnz = 4000, 600_000
     rng = np.random.default_rng(11 + F)
@@ -280,8 +280,24 @@ def test_single_head_16_bit_sums_reach_the_matrix_cores(geot, dtype, F):
         assert close(y, ref_1)
         for _ in range(3):
             y = geot.gather_scatter(d_si, d_di, x, "mean")
-        assert geot.hip.last_kernel().startswith("seg_slab_kernel<"), geot.hip.last_kernel()       # lane groups, vector ALUs
+        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel() and "mean" in geot.hip.last_kernel(), geot.hip.last_kernel()
         assert close(y, ref_1 / cnt)
+        y_mean_w = geot.gather_weight_scatter(d_si, d_di, w, x, "mean")
+        assert "mean" in geot.hip.last_kernel() and close(y_mean_w, ref_w / cnt)
+        geot.hip.set_option("slab_spmm_mfma", 0)                             # the vector-ALU twin on the same plan: the same division
+        try:
+            y_twin = geot.gather_scatter(d_si, d_di, x, "mean")
+            assert "seg_slab_wrow_kernel" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        finally:
+            geot.hip.set_option("slab_spmm_mfma", 1)
+        assert close(y_twin, ref_1 / cnt)
+        for _ in range(3):
+            y = geot.gather_scatter(d_si, d_di, x, "max")
+        assert geot.hip.last_kernel().startswith("seg_slab_kernel<"), geot.hip.last_kernel()       # max / min: lane groups, vector ALUs
+        big = torch.full((nodes, F), float("-inf"), device="cuda", dtype=torch.float64)
+        ref_max = big.scatter_reduce(0, d_di[:, None].expand(-1, F), x.double()[d_si], "amax", include_self=True)
+        has = torch.bincount(d_di, minlength=nodes) > 0
+        assert torch.equal(y.double()[has], ref_max[has])
         # the weighted op's backward: d/dweight is the SDDMM over the same wave-cut plan
         xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
         up = torch.rand(nodes, F, device="cuda").to(dtype)
