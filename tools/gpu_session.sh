@@ -52,6 +52,9 @@ PY
     stageab)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py tests/test_gpu_round4.py tests/test_gpu_slab.py -m gpu -x -q 2>&1 | tail -3
               for m in direct tile direct tile; do echo "# GEOT_PERMUTE=$m"; GEOT_PERMUTE=$m timeout 900 python3 tools/bench_slab_cases.py --only mh,sddmm 2>&1 | grep "as the ABI\|unstage"; done > $O/slab_cases_permute_ab.txt; cat $O/slab_cases_permute_ab.txt ;;
     rows512)  { timeout 600 python3 tools/bench_slab_cases.py --only gws,sddmm --dtypes bf16 --gws-wave-cut 2>&1 | grep -v amdgpu.ids; timeout 600 python3 tools/bench_slab_cases.py --only gws,sddmm --dtypes bf16 2>&1 | grep -v amdgpu.ids; } | grep "rows 512\|F=256\|^# lib" > $O/slab_cases_rows512_single_head.txt; cat $O/slab_cases_rows512_single_head.txt ;;
+    soak16)   for seed in 311 312 313 314; do
+                timeout 900 python3 tools/soak_fuzz.py --iters 200 --seed $seed --ops gws,gs,gws,gs,mh,is > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; grep -c "dtype=" $O/soak_seed$seed.log; tail -1 $O/soak_seed$seed.log | cut -c1-400
+              done ;;
     sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"

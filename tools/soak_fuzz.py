@@ -51,7 +51,7 @@ def main():
     covered = {}
     for it in range(a.iters):
         nnz = int(rng.choice([70_000, 300_000, 1_000_000, int(rng.integers(50_000, 3_000_000))]))
-        F = int(rng.choice([1, 2, 4, 5, 8, 16, 31, 32, 64, 100, 128]))
+        F = int(rng.choice([1, 2, 4, 5, 8, 16, 31, 32, 64, 100, 128, 128, 256]))
         if nnz * F > 120_000_000:
             nnz = 120_000_000 // F
         index = big_index(rng, nnz)
@@ -229,6 +229,31 @@ def main():
                     hi = oracle.gather_scatter(si, index, x, acc64=True)
                     mag = oracle.gather_scatter(si, index, np.abs(x), acc64=True)
                 ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= 2e-5 * mag + 1e-30) and np.all(out[mag == 0] == 0)
+            elif red in ("sum", "mean") and rng.integers(0, 3) == 0:
+                # round 6: 16-bit storage through the gather operators - with slab_always and rows of 256 / 512 bytes (F = 128 / 256) the
+                # plan is cut into waves and the matrix-core kernels run it (sums and means; one rounding of the fp32 result)
+                dt = str(rng.choice(["bf16", "f16"]))
+                covered[(op + "_" + dt, red)] = covered.get((op + "_" + dt, red), 0) + 1
+                tag += " dtype=" + dt
+                tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[dt]
+                t_x = t(x if dt != "f16" else x / 8).to(tdt)
+                t_w = t(w).to(tdt) if w is not None else None
+                xs = t_x.double().cpu().numpy()
+                ws = t_w.double().cpu().numpy() if w is not None else None
+                out = (geot.gather_scatter(t(si), t(index), t_x, red) if w is None
+                       else geot.gather_weight_scatter(t(si), t(index), t_w, t_x, red)).double().cpu().numpy()
+                rows_o = out.shape[0]
+                msg = xs[si] if ws is None else xs[si] * ws[:, None]
+                hi = np.zeros((rows_o, F)); np.add.at(hi, index, msg)
+                mag = np.zeros((rows_o, F)); np.add.at(mag, index, np.abs(msg))
+                if red == "mean":
+                    cnt = np.maximum(np.bincount(index, minlength=rows_o), 1)[:, None]
+                    hi, mag = hi / cnt, mag / cnt
+                eps = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}[dt]
+                floor = 2.0 ** -24 if dt == "f16" else 0.0
+                ok = out.shape == hi.shape and np.all(np.abs(out - hi) <= eps * np.abs(hi) + 2e-5 * mag + floor + 1e-30)
+                if dt == "f16" and mag.max() > 6e4:
+                    ok = True                                          # (beyond float16's range: not checked)
             elif red == "sum":
                 if op == "gws":
                     out = geot.gather_weight_scatter(t(si), t(index), t(w), t(x)).cpu().numpy()
