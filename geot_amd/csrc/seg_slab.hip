@@ -318,6 +318,7 @@ __global__ __launch_bounds__(kThreads) void seg_slab_kernel(SlabParams p) {
   constexpr float kIdent = RED == GEOT_REDUCE_MAX ? -INFINITY : (RED == GEOT_REDUCE_MIN ? INFINITY : 0.f);
   constexpr int VEC = SlabVec<T>::VEC, NV = SlabVec<T>::NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (p.gate && ((slab_gate_word(p.gate) != 0) != (p.gate_want != 0))) return;     // (the twin of a gated pair: 16-bit rows of 1 KiB)
   const geot_slab_plan &P = p.plan;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lpr = WAVE_ROW ? 64 : (1 << p.lpr_log2);
@@ -1576,20 +1577,27 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
   static_assert(sizeof(T) == 2 && (H == 1 || H == 2 || H == 4 || H == 8), "16-bit rows, 1 / 2 / 4 / 8 heads");
   static_assert(RED == GEOT_REDUCE_SUM || (RED == GEOT_REDUCE_MEAN && H == 1), "sums; the mean of a single-head aggregation");
   static_assert(WMODE >= 0 && WMODE <= 3 && (WMODE != 1 || H == 1), "one weight per edge = one head");
-  static_assert(ROWB == 512 || ROWB == 256, "rows of 512 or 256 bytes");
-  constexpr int LOGB = ROWB == 512 ? 9 : 8;
-  constexpr int KS = 512 / ROWB;                         // K = 16 steps per tile: 1 | 2
+  static_assert(ROWB == 1024 || ROWB == 512 || ROWB == 256, "rows of 1024, 512 or 256 bytes");
+  static_assert(ROWB != 1024 || (H >= 2 && RED == GEOT_REDUCE_SUM), "1-KiB rows: two passes of whole heads");
+  // rows of 1 KiB: TWO PASSES over the group's edges, each the 512-byte form on one half of every row (the first H / 2 heads, then the
+  // others) - 512 features x 16 rows of fp32 accumulators are 128 registers a lane, a pass holds 64.  The edge fields and weights are
+  // walked twice (13 bytes an edge against 1 KiB of row), the rows' bytes are gathered once each as before.
+  constexpr int PASSES = ROWB == 1024 ? 2 : 1;
+  constexpr int PBYTES = ROWB / PASSES;                  // bytes of a row a pass works on: 512 | 512 | 256
+  constexpr int HP = H / PASSES;                         // heads of a pass
+  constexpr int LOGB = ROWB == 1024 ? 10 : (ROWB == 512 ? 9 : 8);
+  constexpr int KS = 512 / PBYTES;                       // K = 16 steps per tile: 1 | 2
   constexpr int KT = 16 * KS;                            // edges per tile: 16 | 32
   constexpr int PH = 64 / KT;                            // tiles per 64-edge chunk: 4 | 2
-  constexpr int LPR = ROWB / 16;                         // lanes per row of a gather instruction (16 bytes a lane): 32 | 16
+  constexpr int LPR = PBYTES / 16;                         // lanes per row of a gather instruction (16 bytes a lane): 32 | 16
   constexpr int RPI = 64 / LPR;                          // rows per gather instruction: 2 | 4
   constexpr int NL = KT / RPI;                           // gather instructions per tile: 8
   constexpr int TPR = 16 / NL;                           // tiles whose row offsets one broadcast register holds: 2
-  constexpr int NFB = ROWB / 32;                         // 16-feature blocks of a row: 16 | 8
-  constexpr int kStride = ROWB + 32;                     // bytes between the rows of a tile's image
+  constexpr int NFB = PBYTES / 32;                         // 16-feature blocks of a row: 16 | 8
+  constexpr int kStride = PBYTES + 32;                     // bytes between the rows of a tile's image
   constexpr int kImg = KT * kStride;                     // 8 704 | 9 216 bytes
   constexpr int kWave = kImg + 2 * H * 64 * 2 + 2 * 64;  // + weights [2 chunks][H][64] of T + rows-in-group [2][64] bytes
-  constexpr int FB_PER_H = NFB / H;                      // 16-feature blocks per head
+  constexpr int FB_PER_H = NFB / HP;                     // 16-feature blocks per head
   static_assert(NL == 8 && TPR == 2 && FB_PER_H >= 1, "eight gather instructions per tile; a head is whole 16-feature blocks");
   typedef short s4_t __attribute__((ext_vector_type(4)));
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
@@ -1670,6 +1678,10 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
     e0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
     len = __builtin_amdgcn_readfirstlane(len);
     nv = __builtin_amdgcn_readfirstlane(nv);
+    for (int pass = 0; pass < PASSES; ++pass) {
+    const int hbase = pass * HP;                // this pass's first head ...
+    const uint32_t cP = cL + (uint32_t)pass * PBYTES;   // ... and this lane's 16 bytes inside the table's row
+    const int vr = r * PASSES + pass;           // the lockstep's round: a pass sweeps the slabs once
     f4_t D[NFB];
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) D[fb] = f4_t{0.f, 0.f, 0.f, 0.f};
@@ -1705,10 +1717,10 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {         // a tile's rows (slots behind the last edge: row 0)
       constexpr int tb = decltype(tb_c)::value, k0 = ((tb / KT) % TPR) * NL;
-      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (LOGB + p.slab_shift)));
+      if (p.window >= 0) lock.at(p, lane, vr * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_off, tb) >> (LOGB + p.slab_shift)));
       slab_static_for([&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
-        rv[j] = slab_row_load<u4_t>(table, cL + slab_row_bcast<k0 + j>(po), 0u);
+        rv[j] = slab_row_load<u4_t>(table, cP + slab_row_bcast<k0 + j>(po), 0u);
       }, std::make_integer_sequence<int, NL>{});
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
@@ -1739,12 +1751,12 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
         pair_up(0);
       } else if constexpr ((ph + 1) % TPR == 0) pair_up((ph + 1) / TPR);      // (the next tile opens the register's next generation)
       uint32_t dl4[KS];
-      raw2_t wa[KS][H];
+      raw2_t wa[KS][HP];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         dl4[ks] = *reinterpret_cast<const uint32_t *>(dlb + buf * 64 + tb + 16 * ks + 4 * kq);
 #pragma unroll
-        for (int h = 0; h < H; ++h) wa[ks][h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + h) * 64 + tb + 16 * ks + 4 * kq);
+        for (int h = 0; h < HP; ++h) wa[ks][h] = *reinterpret_cast<const raw2_t *>(wst + (buf * H + hbase + h) * 64 + tb + 16 * ks + 4 * kq);
       }
       // tile t into the image (the previous tile's transposed reads are ahead of these writes in the wave's LDS queue)
 #ifdef GEOT_DEV_EXPERIMENTS
@@ -1773,9 +1785,9 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
         uint32_t mk[2];
         mk[0] = (((dl4[ks] & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | ((((dl4[ks] >> 8) & 255u) == (uint32_t)m) ? 0xFFFF0000u : 0u);
         mk[1] = ((((dl4[ks] >> 16) & 255u) == (uint32_t)m) ? 0xFFFFu : 0u) | (((dl4[ks] >> 24) == (uint32_t)m) ? 0xFFFF0000u : 0u);
-        s4_t afrag[H];
+        s4_t afrag[HP];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < HP; ++h) {
           const raw2_t a = {wa[ks][h][0] & mk[0], wa[ks][h][1] & mk[1]};
           afrag[h] = __builtin_bit_cast(s4_t, a);
         }
@@ -1790,7 +1802,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
           const int hl = fb / FB_PER_H;
           s4_t b;
 #ifdef GEOT_DEV_EXPERIMENTS
-          if (no_tr) b = afrag[(hl + 1) % H];
+          if (no_tr) b = afrag[(hl + 1) % HP];
           else
 #endif
           b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(img + tr_off + ks * 16 * kStride + fb * 32));
@@ -1812,7 +1824,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
         if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
       }
     }
-    lock.round_done(p, lane, r);
+    lock.round_done(p, lane, vr);
     // the group's rows out: D_fb holds (row 4 kq + j, feature 16 fb + m) in element j - through LDS into whole rows, eight blocks
     // (128 features, 16 rows x 512 bytes of fp32 = 8 KB of the image) at a time
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
@@ -1830,7 +1842,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
         for (int l = lane / LR; l < nv; l += 64 / LR) {          // 64 / LR rows at a time
           const int64_t tg = P.v_out[v0 + l];
           const int colp = (lane % LR) * 4;
-          const int col = PF * hf + colp;
+          const int col = pass * (PBYTES / 2) + PF * hf + colp;
           f4_t row = *reinterpret_cast<const f4_t *>(imgf + l * PF + colp);
           if (tg >= 0) {
             if constexpr (RED == GEOT_REDUCE_MEAN) {                    // (pieces of a split row are divided after the combine)
@@ -1850,6 +1862,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
       }
     }
     wave_order();
+    }                                           // pass
   }
   lock.leave(lane);
 }
@@ -2050,13 +2063,17 @@ SlabTurn g_turn;
 // (the mean exists for one head only: inside a template the other instantiations are never formed)
 template <typename T, int H, int W, int ROWB>
 static void slab_launch_spmm_mfma(int reduce, dim3 grid, dim3 blk, size_t lds, hipStream_t st, const SlabParams &pm) {
-  if constexpr (H == 1 && W != 3) {
-    if (reduce == GEOT_REDUCE_MEAN) {
-      hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T, H, W, ROWB, GEOT_REDUCE_MEAN>), grid, blk, lds, st, pm);
-      return;
+  if constexpr (ROWB == 1024 && H < 2) {
+    (void)reduce, (void)grid, (void)blk, (void)lds, (void)st, (void)pm;      // (never dispatched: 1-KiB rows are two passes of whole heads)
+  } else {
+    if constexpr (H == 1 && W != 3) {
+      if (reduce == GEOT_REDUCE_MEAN) {
+        hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T, H, W, ROWB, GEOT_REDUCE_MEAN>), grid, blk, lds, st, pm);
+        return;
+      }
     }
+    hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T, H, W, ROWB, GEOT_REDUCE_SUM>), grid, blk, lds, st, pm);
   }
-  hipLaunchKernelGGL((seg_slab_spmm_mfma_kernel<T, H, W, ROWB, GEOT_REDUCE_SUM>), grid, blk, lds, st, pm);
 }
 
 extern "C" {
@@ -2381,8 +2398,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
 #endif
     // 16-bit plans cut into waves over 512- / 256-byte rows, sums: the matrix-core kernel, GATED on a finite source table (its header), with the
     // row-per-wave kernel enqueued behind it under the opposite gate.  Same persistent grid, same plan.
-    const bool mfma = g_slab_spmm_mfma && mhrow && tsize == 2 && (rowbytes == 512 || rowbytes == 256) &&
-                      (reduce == GEOT_REDUCE_SUM || (reduce == GEOT_REDUCE_MEAN && heads == 1)) && plan->rows_per_group <= 16 &&
+    const bool mfma = g_slab_spmm_mfma && tsize == 2 && plan->rows_per_group <= 16 &&
+                      ((mhrow && (rowbytes == 512 || rowbytes == 256) && (reduce == GEOT_REDUCE_SUM || (reduce == GEOT_REDUCE_MEAN && heads == 1))) ||
+                       (rowbytes == 1024 && heads >= 2 && reduce == GEOT_REDUCE_SUM && plan->units == (int64_t)geot_slab_units())) &&
                       (heads == 1 || heads == 2 || heads == 4 || heads == 8) && feat % 16 == 0 && (weight_mode != 1 || heads == 1) &&
                       (weight_mode == 0 || (((uintptr_t)p.weight) & (uintptr_t)(weight_mode == 2 ? heads * 2 - 1 : 1)) == 0);
     const int rc = g_turn.take(st, [&]() -> int {
@@ -2399,11 +2417,12 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         const int wm = weight_mode == 1 ? 1 : weight_mode;             // (one weight per edge: H == 1)
 #define GEOT_SLAB_SPMM_MFMA_W(T_, H_, W_)                                                                     \
         do {                                                                                                  \
-          const size_t mlds = (size_t)4 * ((rowbytes == 512 ? 16 * (512 + 32) : 32 * (256 + 32)) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
+          const size_t mlds = (size_t)4 * ((rowbytes >= 512 ? 16 * (512 + 32) : 32 * (256 + 32)) + 2 * H_ * 64 * 2 + 2 * 64);   /* per wave: image + staged weights + rows in group */ \
           geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(rowbytes) + ">").c_str()); \
           if (reduce == GEOT_REDUCE_MEAN)                                                                     \
             geot_internal_note_kernel((std::string("seg_slab_spmm_mfma_kernel<") + slab_tname<T_>() + ", " #H_ ", " #W_ ", " + std::to_string(rowbytes) + ", mean>").c_str()); \
           if (rowbytes == 512) slab_launch_spmm_mfma<T_, H_, W_, 512>(reduce, grid, blk, mlds, st, pm);       \
+          else if (rowbytes == 1024) slab_launch_spmm_mfma<T_, H_, W_, 1024>(reduce, grid, blk, mlds, st, pm); \
           else slab_launch_spmm_mfma<T_, H_, W_, 256>(reduce, grid, blk, mlds, st, pm);                       \
         } while (0)
 #define GEOT_SLAB_SPMM_MFMA_H(T_, H_)                                                                         \

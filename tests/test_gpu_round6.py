@@ -49,7 +49,7 @@ def _ref(d_si, d_di, w, v, nodes):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32), (8, 16)])   # rows of 512 and of 256 bytes
+@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32), (8, 16), (8, 64), (4, 128), (2, 256)])   # rows of 512, 256 and 1024 bytes
 def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtype, H, Fh):
     """Every weight layout the kernel serves (edge-major through the permutation, head-major, plan order, none), a hub split into
     pieces (carry rows), rows without edges, out-of-range sources (contribute nothing): float64 sums within the storage type's
