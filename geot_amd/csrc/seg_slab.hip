@@ -1370,16 +1370,20 @@ __device__ __forceinline__ uint32_t slab_row_bcast(uint32_t v) {
 // (profiles/r06/slab_cases__mh_bf16_sddmm_*.txt).
 template <typename T, int CPH, int ROWB>
 __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabParams p) {   // (3 waves per SIMD: the persistent grid's 3 workgroups per CU all resident)
-  static_assert(ROWB == 512 || ROWB == 256, "rows of 512 or 256 bytes");
-  constexpr int NCH = ROWB / 64;                         // 32-feature slices of a row: 8 | 4
+  static_assert(ROWB == 1024 || ROWB == 512 || ROWB == 256, "rows of 1024, 512 or 256 bytes");
+  // rows of 1 KiB: TWO PASSES over the group's edges, each the 512-byte form on one half of every row - the first half of the heads,
+  // then the others (see seg_slab_spmm_mfma_kernel; a head never straddles the halves: at least two heads)
+  constexpr int PASSES = ROWB == 1024 ? 2 : 1;
+  constexpr int PBYTES = ROWB / PASSES;                  // bytes of a row a pass works on: 512 | 512 | 256
+  constexpr int NCH = PBYTES / 64;                       // 32-feature slices of a pass: 8 | 8 | 4
   static_assert(sizeof(T) == 2 && NCH % CPH == 0, "16-bit rows, a head is whole 32-feature slices");
-  constexpr int H = NCH / CPH;
-  constexpr int LOGB = ROWB == 512 ? 9 : 8;
-  constexpr int KS = 512 / ROWB;                         // 16-edge blocks (the N side of a product) per tile: 1 | 2
+  constexpr int HP = NCH / CPH, H = HP * PASSES;         // heads of a pass, heads of a row
+  constexpr int LOGB = ROWB == 1024 ? 10 : (ROWB == 512 ? 9 : 8);
+  constexpr int KS = 512 / PBYTES;                       // 16-edge blocks (the N side of a product) per tile: 1 | 2
   constexpr int KT = 16 * KS;                            // edges per tile: 16 | 32 - eight gather instructions, 8 KB, either way
   constexpr int PH = 64 / KT;                            // tiles per 64-edge chunk: 4 | 2
-  constexpr int LPR = ROWB / 16, RPI = 64 / LPR;         // lanes per row of a gather instruction, rows per instruction: 32, 2 | 16, 4
-  constexpr int kStride = ROWB + 32;                     // bytes between the rows of a tile's image
+  constexpr int LPR = PBYTES / 16, RPI = 64 / LPR;         // lanes per row of a gather instruction, rows per instruction: 32, 2 | 16, 4
+  constexpr int kStride = PBYTES + 32;                     // bytes between the rows of a tile's image
   typedef T t8_t __attribute__((ext_vector_type(8)));
   typedef uint32_t raw2_t __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1419,11 +1423,14 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
     len = __builtin_amdgcn_readfirstlane(len);
     nv = __builtin_amdgcn_readfirstlane(nv);
     const int64_t v0 = has ? P.g_vrow0[pos] : 0;
+    for (int pass = 0; pass < PASSES; ++pass) {
+    const uint32_t cP = cH + (uint32_t)pass * PBYTES;       // this lane's 16 bytes inside the table's row
+    const int vr = r * PASSES + pass;           // the lockstep's round: a pass sweeps the slabs once
     t8_t bfrag[NCH];                            // the group's m1 rows as operand fragments, in registers for the whole group
     {
       const int64_t row = n < nv ? P.v_row[v0 + n] : -1;
       const bool ok = row >= 0 && row < p.K;
-      const T *rp = m1 + (ok ? row : 0) * p.F + 8 * kb;
+      const T *rp = m1 + (ok ? row : 0) * p.F + pass * (PBYTES / 2) + 8 * kb;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) bfrag[c] = ok ? *reinterpret_cast<const t8_t *>(rp + 32 * c) : zero8;
     }
@@ -1451,10 +1458,10 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
     };
     auto gather = [&](auto tb_c) __attribute__((always_inline)) {
       constexpr int tb = decltype(tb_c)::value, k0 = ((tb / KT) & 1) * 8;
-      if (p.window >= 0) lock.at(p, lane, r * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
+      if (p.window >= 0) lock.at(p, lane, vr * p.n_slabs + (int)((uint32_t)__builtin_amdgcn_readlane(my_edge, tb) >> (8 + p.slab_shift)));
       slab_static_for([&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
-        rv[j] = slab_row_load<u4_t>(table, cH + slab_row_bcast<k0 + j>(po), 0u);
+        rv[j] = slab_row_load<u4_t>(table, cP + slab_row_bcast<k0 + j>(po), 0u);
       }, std::make_integer_sequence<int, 8>{});
     };
     auto tile = [&](int t, auto ph_c) __attribute__((always_inline)) {
@@ -1489,9 +1496,9 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
         t8_t afrag[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) afrag[c] = *reinterpret_cast<const t8_t *>(img + (16 * ks + n) * kStride + 64 * c + 16 * kb);
-        float vals[H];
+        float vals[HP];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
+        for (int h = 0; h < HP; ++h) {
           f4_t d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int cc = 0; cc < CPH; ++cc) {
@@ -1504,13 +1511,13 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
         const int e = t * KT + 16 * ks + n;
         const bool real = dlm[ks] != 255;                               // (padding / out-of-range source: a zero, written by the kb = 0 lane)
         if (e < len && (real ? (dlm[ks] >> 2) == kb : kb == 0)) {
-          T *op = out + (e0 + e) * H;
-          if constexpr (H == 1) op[0] = (T)(real ? vals[0] : 0.f);
+          T *op = out + (e0 + e) * H + pass * HP;
+          if constexpr (HP == 1) op[0] = (T)(real ? vals[0] : 0.f);
           else {
-            typedef T tH_t __attribute__((ext_vector_type(H)));
+            typedef T tH_t __attribute__((ext_vector_type(HP)));
             tH_t pk;
 #pragma unroll
-            for (int h = 0; h < H; ++h) pk[h] = (T)(real ? vals[h] : 0.f);
+            for (int h = 0; h < HP; ++h) pk[h] = (T)(real ? vals[h] : 0.f);
             *reinterpret_cast<tH_t *>(op) = pk;
           }
         }
@@ -1527,7 +1534,8 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
         if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 3>{});
       }
     }
-    lock.round_done(p, lane, r);
+    lock.round_done(p, lane, vr);
+    }                                           // pass
   }
   lock.leave(lane);
 }
@@ -1867,6 +1875,71 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
   lock.leave(lane);
 }
 
+// The vector-ALU twin of seg_slab_spmm_mfma_kernel for 16-bit rows of 1 KiB.  Plans of such rows are cut for the matrix-core kernel
+// - up to 16 rows a group, whose 512 features x 16 rows of fp32 sums seg_slab_kernel's LDS cannot hold (it takes 4-5 rows: 21-26
+// rounds, each a sweep of the table through every L2) - so a source table with an Inf / NaN in it (the gate, see
+// slab_nonfinite_kernel) and the option "slab_spmm_mfma" = 0 are served by THIS kernel: the same plan, the same grid, no lockstep,
+// nothing in flight - kSub rows of accumulators in LDS at a time, the group's edges walked once per kSub rows, one edge at a time.
+// Correct and slow by design (the path a diverged model takes); out-of-range sources contribute nothing, as in the matrix-core kernel.
+// WMODE 0 none | 2 weight[e * H + h] | 3 weight[h * nnz + e]; p.w_in_plan_order as everywhere.
+template <typename T, int WMODE>
+__global__ __launch_bounds__(kThreads) void seg_slab_twin1k_kernel(SlabParams p) {
+  static_assert(sizeof(T) == 2 && (WMODE == 0 || WMODE == 2 || WMODE == 3), "16-bit rows of 1 KiB, multi-head weights or none");
+  constexpr int kSub = 4;                                  // rows of fp32 accumulators in LDS at a time: 4 x 2 KB a wave
+  typedef T t8_t __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (p.gate && ((slab_gate_word(p.gate) != 0) != (p.gate_want != 0))) return;
+  const geot_slab_plan &P = p.plan;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *acc = reinterpret_cast<float *>(smem) + (size_t)wave * kSub * 512;          // [kSub][512]
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave, units = P.units;
+  const T *weight = static_cast<const T *>(p.weight);
+  const T *src = static_cast<const T *>(p.src);
+  T *dst = static_cast<T *>(p.dst);
+  const bool wpo = p.w_in_plan_order != 0;
+  const int head = (lane * 8) / p.Fh;                      // the head of this lane's eight features (Fh = 512 / H >= 64)
+  for (int r = 0; r < p.rounds; ++r) {
+    const int64_t pos = (int64_t)r * units + ((r & 1) ? units - 1 - unit : unit);
+    if (pos >= P.n_groups) continue;
+    const int64_t e0 = P.g_begin[pos];
+    const int len = (int)(P.g_begin[pos + 1] - e0), nv = P.g_nv[pos];
+    const int64_t v0 = P.g_vrow0[pos];
+    for (int lo = 0; lo < nv; lo += kSub) {
+#pragma unroll
+      for (int q = 0; q < kSub * 8; ++q) acc[q * 64 + lane] = 0.f;
+      for (int i = 0; i < len; ++i) {
+        const int dl = (int)P.e_dl[e0 + i];
+        const uint32_t s_ = (uint32_t)P.e_src[e0 + i];
+        if (dl < lo || dl >= lo + kSub || s_ >= (uint32_t)p.src_rows) continue;      // (wave-uniform)
+        float w = 1.f;
+        if constexpr (WMODE != 0) {
+          const int64_t pe = wpo ? e0 + i : (int64_t)P.e_perm[e0 + i];
+          w = (float)(WMODE == 2 ? weight[pe * p.H + head] : weight[(int64_t)head * P.nnz + pe]);
+        }
+        const t8_t x = *reinterpret_cast<const t8_t *>(src + (int64_t)s_ * 512 + lane * 8);
+        float *a = acc + (size_t)(dl - lo) * 512 + lane * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += w * (float)x[q];
+      }
+      for (int l = lo; l < nv && l < lo + kSub; ++l) {
+        const int64_t tg = P.v_out[v0 + l];
+        const float *a = acc + (size_t)(l - lo) * 512 + lane * 8;
+        if (tg >= 0) {
+          if (tg < p.K) {
+            t8_t o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (T)a[q];                              // one rounding, here
+            *reinterpret_cast<t8_t *>(dst + tg * p.F + lane * 8) = o;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) p.carry[(-tg - 1) * p.F + lane * 8 + q] = a[q];   // fp32
+        }
+      }
+    }
+  }
+}
+
 // split hubs: dst[row] = sum of its carry slots, in slot order (one lane group per split row).  The pieces meet in FLOAT64 and are
 // rounded once: a hub of 300 k edges is thousands of pieces, and with interleaved pieces (Phase A) they can all be nearly EQUAL
 // (two distinct source rows: every piece samples both in proportion) - adding thousands of equal fp32 values to a growing fp32
@@ -2172,6 +2245,12 @@ int geot_slab_units_for(int weight_mode, int64_t rowbytes) {
   return geot_slab_units() * (int)(1024 / rowbytes);
 }
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes) {
+  // 16-bit multi-head plans over rows of 1 KiB: the 16 rows of a matrix-core operand (seg_slab_spmm_mfma_kernel /
+  // seg_slab_sddmm_mfma_kernel run them in two passes; bf16 H=8 x F=64 at configs[3]'s graph: 6 rounds instead of the 26 that the 4
+  // rows seg_slab_kernel's LDS holds would need - 6.95 against 11.45 ms; seg_slab_twin1k_kernel serves what those two cannot)
+  if (g_slab_spmm_mfma && g_slab_sddmm_mfma && rowbytes == 1024 && dtype != GEOT_F32 && (heads == 2 || heads == 4 || heads == 8) &&
+      (weight_mode == 2 || weight_mode == 3 || weight_mode == 5))
+    return 16;
   if (!slab_wants_wrow(weight_mode, rowbytes)) return geot_slab_rows_per_group_dtype(weight_mode, heads, dtype);
   const size_t row = (size_t)(rowbytes / (dtype == GEOT_F32 ? 4 : 2)) * sizeof(float);   // a group row's accumulators
   const size_t budget = g_slab_blocks <= 2 ? 64 * 1024 : (slab_device().lds - 4 * 1024) / g_slab_blocks / 1024 * 1024;
@@ -2329,7 +2408,11 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     const size_t hw_lds = weight_mode == 0 ? 0 : (weight_mode == 1 ? 1 : (size_t)heads);
     const size_t lds = mhrow ? (size_t)4 * plan->rows_per_group * 64 * el * sizeof(float) + (size_t)4 * 2 * 64 * hw_lds * sizeof(float)
                              : slab_lds_bytes(plan->rows_per_group, weight_mode, heads, nv);
-    if (lds > 64 * 1024) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_shape)");
+    // (16-bit multi-head plans over rows of 1 KiB are cut for the matrix-core kernel - up to 16 rows a group, which seg_slab_kernel's
+    //  LDS cannot hold: seg_slab_twin1k_kernel stands in for it, see there)
+    const bool big1k = lds > 64 * 1024 && rowbytes == 1024 && tsize == 2 && plan->rows_per_group <= 16 && heads >= 2 && reduce == GEOT_REDUCE_SUM &&
+                       (weight_mode == 0 || weight_mode == 2 || weight_mode == 3) && plan->units == (int64_t)geot_slab_units();
+    if (lds > 64 * 1024 && !big1k) return geot_internal_fail(GEOT_EINVAL, "slab_spmm: rows_per_group exceeds the LDS budget (geot_slab_rows_per_group_shape)");
     const dim3 grid((unsigned)(waves / 4)), blk(kThreads);
     const bool wave_row = lpr_log2 == 6;
     int64_t cblocks = (plan->n_split + (kThreads >> lpr_log2) - 1) / (kThreads >> lpr_log2);
@@ -2457,6 +2540,20 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         if (dtype == GEOT_F32) { if (el == 2) { GEOT_SLAB_WROW_MODE(float, 2) } else { GEOT_SLAB_WROW_MODE(float, 1) } }
         else if (dtype == GEOT_F16) { if (el == 4) { GEOT_SLAB_WROW_MODE(half_t, 4) } else { GEOT_SLAB_WROW_MODE(half_t, 2) } }
         else { if (el == 4) { GEOT_SLAB_WROW_MODE(bf16_t, 4) } else { GEOT_SLAB_WROW_MODE(bf16_t, 2) } }
+      }
+      else if (big1k) {
+        const size_t tlds = (size_t)4 * 4 * 512 * sizeof(float);       // four rows of fp32 sums a wave
+#define GEOT_SLAB_TWIN1K(T_)                                                                                  \
+        do {                                                                                                  \
+          geot_internal_note_kernel((std::string("seg_slab_twin1k_kernel<") + slab_tname<T_>() + ", " + std::to_string(weight_mode) + ">").c_str()); \
+          if (weight_mode == 0) hipLaunchKernelGGL((seg_slab_twin1k_kernel<T_, 0>), grid, blk, tlds, st, p);  \
+          else if (weight_mode == 2) hipLaunchKernelGGL((seg_slab_twin1k_kernel<T_, 2>), grid, blk, tlds, st, p); \
+          else hipLaunchKernelGGL((seg_slab_twin1k_kernel<T_, 3>), grid, blk, tlds, st, p);                   \
+          if (combine) hipLaunchKernelGGL((seg_slab_combine_kernel<T_, GEOT_REDUCE_SUM>), cgrid, blk, 0, st, p); \
+        } while (0)
+        if (dtype == GEOT_F16) GEOT_SLAB_TWIN1K(half_t);
+        else GEOT_SLAB_TWIN1K(bf16_t);
+#undef GEOT_SLAB_TWIN1K
       }
       else if (dtype == GEOT_F32) { GEOT_SLAB_MODE(float) }
       else if (dtype == GEOT_F16) { GEOT_SLAB_MODE(half_t) }
@@ -2586,20 +2683,23 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
   // 16-bit plans cut into waves over 512- / 256-byte rows, results in plan order: the matrix-core kernel (seg_slab_sddmm_mfma_kernel) when the group's
   // rows fit one 16-column operand and a head is a whole number of 32-feature slices (H = 1 / 2 / 4 / 8)
   const int nch = (int)(F / 32);
-  if (g_slab_sddmm_mfma && wrow && staged && tsize == 2 && (rowbytes == 512 || rowbytes == 256) && plan->rows_per_group <= 16 &&
+  const bool mfma_1k = rowbytes == 1024 && (heads == 2 || heads == 4 || heads == 8) && plan->units == (int64_t)geot_slab_units();   // (two passes of whole heads)
+  if (g_slab_sddmm_mfma && staged && tsize == 2 && ((wrow && (rowbytes == 512 || rowbytes == 256)) || mfma_1k) && plan->rows_per_group <= 16 &&
       (heads == 1 || heads == 2 || heads == 4 || heads == 8) && nch % (int)heads == 0 && (((uintptr_t)mat_1 | (uintptr_t)staging) & 15) == 0) {
-    const size_t xlds = (size_t)4 * (rowbytes == 512 ? 16 * (512 + 32) : 32 * (256 + 32));   // per wave: the tile image
+    const size_t xlds = (size_t)4 * (rowbytes >= 512 ? 16 * (512 + 32) : 32 * (256 + 32));   // per wave: the tile image
     const int cph = nch / (int)heads;
     const int rc = g_turn.take(st, [&]() -> int {
 #define GEOT_SLAB_MFMA_B(T_, C_)                                                                               \
       do {                                                                                                     \
         if (rowbytes == 512) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, C_, 512>), grid, blk, xlds, st, p); \
+        else if (rowbytes == 1024) { if constexpr (C_ >= 2) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, (C_ >= 2 ? C_ : 2), 1024>), grid, blk, xlds, st, p); } \
         else hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, C_, 256>), grid, blk, xlds, st, p);           \
       } while (0)
 #define GEOT_SLAB_MFMA(T_)                                                                                     \
       do {                                                                                                     \
         geot_internal_note_kernel((std::string("seg_slab_sddmm_mfma_kernel<") + slab_tname<T_>() + ", " + std::to_string(cph) + ", " + std::to_string(rowbytes) + ">").c_str()); \
-        if (cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 512>), grid, blk, xlds, st, p);   /* (one head over 512-byte rows) */ \
+        if (cph == 8 && rowbytes == 1024) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 1024>), grid, blk, xlds, st, p);   /* (two heads over 1-KiB rows) */ \
+        else if (cph == 8) hipLaunchKernelGGL((seg_slab_sddmm_mfma_kernel<T_, 8, 512>), grid, blk, xlds, st, p);   /* (one head over 512-byte rows) */ \
         else if (cph == 4) GEOT_SLAB_MFMA_B(T_, 4);                                                            \
         else if (cph == 2) GEOT_SLAB_MFMA_B(T_, 2);                                                            \
         else GEOT_SLAB_MFMA_B(T_, 1);                                                                          \
@@ -2613,6 +2713,11 @@ static int slab_sddmm_impl(const geot_slab_plan *plan, const void *mat_1, const 
     });
     if (rc != GEOT_OK || !unstage) return rc;
   } else {
+  // (a plan cut for the matrix-core kernels - 16 rows of 1 KiB a group - has no vector-ALU SDDMM: the group's mat_1 rows would take
+  //  64 KB of LDS a workgroup, and the persistent grid's workgroups must all be resident)
+  if (lds * (size_t)g_slab_blocks > slab_device().lds)
+    return geot_internal_fail(GEOT_EUNSUPPORTED, "slab_sddmm: this plan's groups (geot_slab_rows_per_group_shape: cut for the matrix-core kernel) need the "
+                                                 "staged 16-bit multi-head form (geot_slab_mh_sddmm with slab_sddmm_mfma = 1)");
 #define GEOT_SLAB_SDDMM(T_, E2_, E1_)                                                                        \
   do {                                                                                                        \
     geot_internal_note_kernel((std::string(wrow ? "seg_slab_sddmm_wrow_kernel<" : "seg_slab_sddmm_kernel<") + slab_tname<T_>() + ">").c_str()); \

@@ -299,7 +299,7 @@ def test_weights_in_every_order_on_every_chunk_length(geot, dtype, H, Fh):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32)])   # rows of 512 and (round 6) of 256 bytes
+@pytest.mark.parametrize("H,Fh", [(4, 64), (1, 256), (2, 128), (8, 32), (1, 128), (2, 64), (4, 32), (8, 64), (4, 128), (2, 256)])   # rows of 512 and (round 6) of 256 and 1024 bytes
 def test_matrix_core_sddmm_is_exact_on_integer_data(geot, dtype, H, Fh):
     """seg_slab_sddmm_mfma_kernel (16-bit multi-head SDDMM over a plan of 512-byte rows, v_mfma_f32_16x16x32): features in {-1, 0, 1}, so every dot product is an integer below 2^8 - exact in fp32 and in the 16-bit result -
     and any slip in the operand maps (which lane holds which features of which edge / row, where D[m][dl(m)] sits, the padded LDS
@@ -325,6 +325,11 @@ def test_matrix_core_sddmm_is_exact_on_integer_data(geot, dtype, H, Fh):
     try:
         for mfma in (1, 0):
             geot.hip.set_option("slab_sddmm_mfma", mfma)
+            if not mfma and rowbytes == 1024:                           # a plan of 16 rows of 1 KiB is cut for the matrix cores: no vector-ALU form
+                with pytest.raises(RuntimeError, match="matrix-core"):
+                    slab.slab_mh_sddmm_out(plan, q, k, None)
+                outs[0] = outs[1]
+                continue
             s_plan = slab.slab_mh_sddmm_out(plan, q, k, None)
             assert ("seg_slab_sddmm_mfma_kernel" in geot.hip.last_kernel()) == bool(mfma), geot.hip.last_kernel()
             s_edge = torch.full((nnz, H), float("nan"), device="cuda", dtype=dtype)

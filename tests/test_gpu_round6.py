@@ -119,12 +119,12 @@ def _poison(v, rows, dtype):
     return v.to(dtype)
 
 
-@pytest.mark.parametrize("case", ["mh bf16 512", "mh f16 512", "mh f32 1024", "mh f32 512", "gws f32 512", "gws bf16 256", "gs f32 512"])
+@pytest.mark.parametrize("case", ["mh bf16 512", "mh f16 512", "mh f32 1024", "mh f32 512", "gws f32 512", "gws bf16 256", "gs f32 512", "mh bf16 1024", "mh f16 256"])
 def test_nonfinite_sources_touch_only_their_own_destinations(geot, case):
     """Inf / -Inf / NaN rows (and a row with one Inf element) in the source table: a destination row is non-finite exactly where the
     float64 reference says so, and every other row equals the result computed from the table with those rows zeroed - bit for bit on
     the same kernel where that kernel does not depend on the data (every kernel but the gated matrix-core SpMM, whose finite twin is
-    compared within rounding).  Covers seg_slab_kernel (lane groups, whole-wave rows), seg_slab_wrow_kernel and the gated pair."""
+    compared within rounding).  Covers seg_slab_kernel (lane groups, whole-wave rows), seg_slab_wrow_kernel, seg_slab_twin1k_kernel and the gated pairs."""
     from geot_amd import slab
     kind, tname, rowbytes = case.split()
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[tname]
@@ -178,10 +178,10 @@ def test_nonfinite_sources_touch_only_their_own_destinations(geot, case):
         geot.hip.set_option("slab_spmm_mfma", 0)
         try:
             clean_twin, k2 = run(v_zero)
-            assert "wrow" in k2
+            assert ("twin1k" if rowbytes == 1024 else "wrow") in k2, k2
         finally:
             geot.hip.set_option("slab_spmm_mfma", 1)
-        assert torch.equal(got[~touched], clean_twin[~touched])          # the twin IS the row-per-wave kernel
+        assert torch.equal(got[~touched], clean_twin[~touched])          # the twin IS the row-per-wave kernel (rows of 1 KiB: seg_slab_twin1k_kernel)
     else:
         assert torch.equal(got[~touched], clean[~touched]), case
 
@@ -211,11 +211,13 @@ def test_nonfinite_rows_and_the_plan_sddmm(geot, dtype):
     assert float(((s.double() - ref)[fin]).abs().max()) <= tol * float(ref[fin].abs().max())
 
 
-def test_matrix_core_spmm_through_the_operator_and_the_handle(geot):
+@pytest.mark.parametrize("H,Fh", [(4, 64), (8, 64)])                   # rows of 512 bytes, rows of 1 KiB (two passes)
+def test_matrix_core_spmm_through_the_operator_and_the_handle(geot, H, Fh):
     """The drop-in operator (mh_spmm on a dense graph: plan on the second sighting) and geot_amd.Graph reach the matrix-core kernel for
-    bf16 H=4 x F=64, forward and backward (d/dsrc runs the same kernel over the transposed list's plan)."""
+    bf16 H=4 x F=64 and H=8 x F=64, forward and backward (d/dsrc runs the same kernel over the transposed list's plan, d/dweight the
+    matrix-core SDDMM)."""
     from geot_amd import ops
-    nodes, nnz, H, Fh = 4000, 600_000, 4, 64
+    nodes, nnz = 4000, 600_000
     rng = np.random.default_rng(5)
     si, di = _dense_graph(rng, nodes, nnz)
     d_si, d_di = dev(si), dev(di)
