@@ -280,7 +280,9 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /
  * one row per wave-instruction (8 / 4 bytes per lane): there a unit is a wave and a group holds more rows.  geot_slab_spmm /
  * geot_slab_sddmm read the form off the plan's `units` (a plan cut into waves runs row-per-wave under any weight mode; measured
  * slower than lane groups except under multi-head weights: profiles/r05/slab_cases__row_per_wave_*).
- * Round 6: a 16-bit plan cut into waves with at most 16 rows per group (geot_slab_rows_per_group_shape caps 16-bit wave-cut plans
+ * Round 6: 16-bit multi-head plans over rows of 1 KiB get 16 rows per group (the matrix-core kernels run them in two passes; the
+ * vector-ALU kernels cannot: a non-finite source table is served by a slow stand-in, geot_slab_sddmm refuses the unstaged form).
+ * A 16-bit plan cut into waves with at most 16 rows per group (geot_slab_rows_per_group_shape caps 16-bit wave-cut plans
  * there) is run on the matrix cores - SUMS (one head: MEANS too) by geot_slab_spmm under any weight mode, geot_slab_sddmm / geot_slab_mh_sddmm with their
  * results staged - and there it is FASTER than lane groups for one weight per edge or none over 256- / 512-byte rows too (bf16 at
  * Reddit scale: F = 128 1.78 against 2.30 ms, F = 256 3.26 against 4.03, profiles/r06/slab_cases__rows_of_*): ask for weight_mode 2's units and rows for

@@ -55,6 +55,11 @@ PY
     soak16)   for seed in 311 312 313 314; do
                 timeout 900 python3 tools/soak_fuzz.py --iters 200 --seed $seed --ops gws,gs,gws,gs,mh,is > $O/soak_seed$seed.log 2>&1; echo "seed $seed rc=$?"; grep -c "dtype=" $O/soak_seed$seed.log; tail -1 $O/soak_seed$seed.log | cut -c1-400
               done ;;
+    rows1k)   { for sh in 8,64 4,128 2,256; do timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --mh-shape $sh 2>&1 | grep -v amdgpu.ids; done
+                echo "# the same with the matrix-core kernels off when the plans are built: the vector-ALU kernels on the plans their LDS allows (4-5 rows a group)"
+                for sh in 8,64 4,128; do timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --mh-shape $sh --options slab_spmm_mfma=0,slab_sddmm_mfma=0 2>&1 | grep -v amdgpu.ids; done
+                echo "# seg_slab_twin1k_kernel, the stand-in on a 16-row plan (a source table with an Inf / NaN in it; here: forced by the option)"
+                timeout 900 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --mh-shape 8,64 --rows-per-group 16 --options slab_spmm_mfma=0 --iters 2 2>&1 | grep -v amdgpu.ids; } > $O/slab_cases_rows1k_16bit.txt 2>&1; cat $O/slab_cases_rows1k_16bit.txt ;;
     sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
