@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_sddmm_mfma_kernel(SlabPa
 // does the call - same plan, same results as before.  Weights may be anything (an Inf weight only meets its own row's products).
 // Order of additions inside a row: the hardware's (16 edges per step in plan order); fixed by the plan, not by timing.
 // Plans cut into waves (units = waves: 3 workgroups per CU - image + staged weights are ~10 KB a wave), R <= 16, rows of 512 or 256
-// bytes, heads 1 / 2 / 4 / 8 with feat % 16 == 0; WMODE 0 none | 1 weight[e] | 2 weight[e * H + h] | 3 weight[h * nnz + e];
+// bytes (1 KiB: two passes, at least two heads), heads 1 / 2 / 4 / 8 with feat % 16 == 0; WMODE 0 none | 1 weight[e] | 2 weight[e * H + h] | 3 weight[h * nnz + e];
 // p.w_in_plan_order as in seg_slab_wrow_kernel.  Option "slab_spmm_mfma" = 0: the row-per-wave kernel.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void slab_nonfinite_kernel(const uint32_t *__restrict__ x, int64_t n16, int *flag) {
@@ -2230,9 +2230,9 @@ int geot_slab_rows_per_group(int weight_mode, int64_t heads) { return geot_slab_
 // 18.7 TB/s.  So geot_slab_units_for keeps round 4's split; option "slab_wrow_all" = 1 makes every plan of such rows row-per-wave.
 static bool slab_wrow(int64_t rowbytes) { return rowbytes == 512 || rowbytes == 256; }
 GEOT_DEV_SWITCH g_slab_wrow_all = 0;
-int g_slab_spmm_mfma = 1;    // "slab_spmm_mfma": 16-bit SpMM over wave-cut plans of 512- / 256-byte rows on the matrix cores (seg_slab_spmm_mfma_kernel,
+int g_slab_spmm_mfma = 1;    // "slab_spmm_mfma": 16-bit SpMM over wave-cut plans of 256- / 512-byte / 1-KiB rows on the matrix cores (seg_slab_spmm_mfma_kernel,
                              // gated on a finite source table); 0 = the row-per-wave kernel
-int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit multi-head SDDMM over plans of 512-byte rows on the matrix cores (seg_slab_sddmm_mfma_kernel:
+int g_slab_sddmm_mfma = 1;   // "slab_sddmm_mfma": 16-bit SDDMM over wave-cut plans of 256- / 512-byte / 1-KiB rows on the matrix cores (seg_slab_sddmm_mfma_kernel:
                              // 4.30 vs 5.84 ms at Reddit scale); 0 = the row-per-wave kernel
 GEOT_DEV_SWITCH g_slab_probe = 0;   // "slab_probe": see SlabParams::probe (results are wrong by design)
 GEOT_DEV_SWITCH g_slab_pair = 0;    // "slab_pair": 1 = multi-head plans over 512-byte rows run seg_slab_wpair_kernel (two rows per instruction).  Measured

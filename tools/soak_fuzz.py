@@ -171,7 +171,7 @@ def main():
             # multi-head SpMM (round 4: its own source-blocked kernels - one row per wave-instruction for rows of 1 KiB / 512 / 256
             # bytes): heads x width that make such rows or not, three storage types, both weight layouts, per-edge or slab-forced
             H = int(rng.choice([2, 4, 8]))
-            Fh = int(rng.choice([8, 16, 32, 64]))
+            Fh = int(rng.choice([8, 16, 32, 64, 64, 128]))
             dt = str(rng.choice(["f32", "f32", "bf16", "f16"]))
             tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dt]
             if nnz * H * Fh > 100_000_000:
