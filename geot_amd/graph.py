@@ -67,6 +67,23 @@ def _rows(t: torch.Tensor) -> int:
     return int(t.shape[0])
 
 
+_GATHER_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
+
+
+def _rows_at(values: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """``values[index]`` (int64 ``index``, rows of ``values``) by the library's row gather (geot_gather_rows).  NOT torch's advanced
+    indexing: on this stack ``t[idx]`` of a [115 M, 8] bfloat16 tensor came back with garbage in its last 2^26 rows, different on
+    every call (found by the full-size test of eight heads: tests/test_gpu_round6.py); ``t[idx] = v`` goes through the same
+    machinery - the scatters of this module are gathers through the inverse permutation instead."""
+    v = values.contiguous()
+    if not (v.is_cuda and v.dtype in _GATHER_DTYPES and index.dtype == torch.int64 and v.shape[0] > 0):
+        return v[index]
+    out = torch.empty((index.numel(),) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+    if index.numel():
+        hip.gather_rows_out(index.contiguous(), v, out)
+    return out
+
+
 class Graph:
     def __init__(self, src_index: torch.Tensor, dst_index: torch.Tensor, num_src: Optional[int] = None, num_dst: Optional[int] = None,
                  clone: bool = True, slab_mode: str = "auto"):
@@ -101,6 +118,7 @@ class Graph:
         self._plans = {}                # (which, rowbytes, R, units) -> SlabPlan | None
         self._verdict = {}              # (plan id, kind) -> use the plan?
         self._inv = {}                  # plan id -> inverse of e_perm (edge id -> plan position)
+        self._p64 = {}                  # plan id -> e_perm as int64
         self._ends = {}                 # plan id -> (dst per plan position, src per plan position)
         self._to_bwd = {}               # (fwd plan id | None, bwd plan id | None) -> gather index into the forward-side values
         self._deg = None
@@ -172,6 +190,13 @@ class Graph:
             self.stats["trials"] += 1
         return self._verdict[key]
 
+    def _perm64(self, plan) -> torch.Tensor:
+        """The plan's permutation (plan position -> edge id) as the int64 index the row gather takes, made once per plan."""
+        p64 = self._p64.get(id(plan))
+        if p64 is None:
+            p64 = self._p64[id(plan)] = plan.tensors["e_perm"].long()
+        return p64
+
     def _inverse(self, plan) -> torch.Tensor:
         inv = self._inv.get(id(plan))
         if inv is None:
@@ -235,9 +260,7 @@ class Graph:
                     w_edge[0] = weight[3]()
                 elif po:
                     wplan, values = weight
-                    w = torch.empty_like(values)
-                    w[wplan.tensors["e_perm"].long()] = values
-                    w_edge[0] = w
+                    w_edge[0] = _rows_at(values, self._inverse(wplan))
                 else:
                     w_edge[0] = weight.contiguous()
             return w_edge[0]
@@ -304,7 +327,7 @@ class Graph:
             return None, run_plan()
         run_edges()
         if plan_order and plan is not None:                # the caller asked for plan order: give it (one gather)
-            return plan, out[plan.tensors["e_perm"].long()].contiguous()
+            return plan, _rows_at(out, self._perm64(plan))
         return None, out
 
     # ---- public, differentiable -------------------------------------------------------------------------------------------------------
@@ -399,26 +422,22 @@ class _PlanToEdge(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, plan, values):
         ctx.g, ctx.plan = g, plan
-        out = torch.empty_like(values)
-        out[plan.tensors["e_perm"].long()] = values
-        return out
+        return _rows_at(values, g._inverse(plan))
 
     @staticmethod
     def backward(ctx, grad):
-        return None, None, grad[ctx.plan.tensors["e_perm"].long()]
+        return None, None, _rows_at(grad, ctx.g._perm64(ctx.plan))
 
 
 class _EdgeToPlan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, plan, values):
         ctx.g, ctx.plan = g, plan
-        return values[plan.tensors["e_perm"].long()].contiguous()
+        return _rows_at(values, g._perm64(plan))
 
     @staticmethod
     def backward(ctx, grad):
-        out = torch.empty_like(grad)
-        out[ctx.plan.tensors["e_perm"].long()] = grad
-        return None, None, out
+        return None, None, _rows_at(grad, ctx.g._inverse(ctx.plan))
 
 
 class _SpmmFn(torch.autograd.Function):
@@ -475,15 +494,10 @@ def _spmm_backward(g: "Graph", plan, values, x, grad, reduce: str, need_x: bool,
     if has_w and need_w:
         wplan, gw = g._sddmm(grad, x.detach(), plan is not None)      # (plan order asked for when the weight came in plan order)
         if plan is not None and wplan is not plan:       # the scores came back in another order than the weight's: re-order once
-            gw_edge = gw
-            if wplan is not None:
-                gw_edge = torch.empty_like(gw)
-                gw_edge[wplan.tensors["e_perm"].long()] = gw
-            gw = gw_edge[plan.tensors["e_perm"].long()].contiguous()
+            gw_edge = gw if wplan is None else _rows_at(gw, g._inverse(wplan))
+            gw = _rows_at(gw_edge, g._perm64(plan))
         elif plan is None and wplan is not None:
-            gw_edge = torch.empty_like(gw)
-            gw_edge[wplan.tensors["e_perm"].long()] = gw
-            gw = gw_edge
+            gw = _rows_at(gw, g._inverse(wplan))
     return gx, gw
 
 

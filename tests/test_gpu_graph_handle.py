@@ -228,3 +228,24 @@ def test_plan_order_is_always_a_plan_ordered_and_many_heads_fall_back(geot):
     y = g.mh_spmm(w, x)
     want = torch.zeros(nodes, H2, F2, device="cuda", dtype=torch.float64).index_add_(0, di, x[si].double() * w.double()[:, :, None])
     assert float((y.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,cols", [(torch.bfloat16, 8), (torch.float32, 4), (torch.float16, 1), (torch.float32, 0)])
+def test_per_edge_values_are_permuted_by_the_library(geot, dtype, cols):
+    """graph._rows_at: rows of a per-edge value tensor at an int64 index through geot_gather_rows - what PlanOrdered, edge_order() and
+    the handle's backward passes use instead of torch's advanced indexing (which returned garbage for the last 2^26 rows of a
+    [115 M, 8] bfloat16 tensor on this stack: tests/test_gpu_round6.py::test_cfg4_full_size_bf16_properties[plan-8-64] found it).
+    Against torch's indexing at a size where that is right, [nnz] and [nnz, H]; and the scatter form through the inverse permutation."""
+    from geot_amd import graph
+    n = 300_000
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    v = torch.rand((n, cols) if cols else (n,), device="cuda", generator=gen).to(dtype)
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    got = graph._rows_at(v, perm)
+    assert got.shape == v.shape and got.dtype == v.dtype and torch.equal(got, v[perm])
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device="cuda")
+    want = torch.empty_like(v)
+    want[perm] = v                                                      # the scatter ...
+    assert torch.equal(graph._rows_at(v, inv), want)                    # ... is the gather through the inverse

@@ -330,13 +330,14 @@ def _device_powerlaw(nnz, keys, seed):
     return gen(nnz, keys, seed, torch.device("cuda"))
 
 
-@pytest.mark.parametrize("order", ["edge", "plan"])
-def test_cfg4_full_size_bf16_properties(geot, order):
-    """BASELINE.json configs[3] at FULL size in bf16 storage (232 965 nodes, 114 615 892 edges, H=4 x F=64): the matrix-core SpMM and the
-    matrix-core score SDDMM as geot_amd.Graph dispatches them, weights in edge order and in plan order.  Size-independent properties
-    (rows without edges exactly zero, determinism, the checksum of checksums in float64 within bf16's rounding of the OUTPUT) and
-    sampled rows - the hub, the ends, 150 random rows - against the float64 sum at 2^-7 relative."""
-    nodes, nnz, H, F = 232_965, 114_615_892, 4, 64
+@pytest.mark.parametrize("order,H,F", [("edge", 4, 64), ("plan", 4, 64), ("plan", 8, 64)])
+def test_cfg4_full_size_bf16_properties(geot, order, H, F):
+    """BASELINE.json configs[3] at FULL size in bf16 storage (232 965 nodes, 114 615 892 edges, H=4 x F=64 - and eight heads of 64: rows of
+    1 KiB, the two-pass form over 16-row plans with the lockstep at full scale): the matrix-core SpMM and the matrix-core score SDDMM
+    as geot_amd.Graph dispatches them, weights in edge order and in plan order.  Size-independent properties (rows without edges
+    exactly zero, determinism, the checksum of checksums in float64 within bf16's rounding of the OUTPUT) and sampled rows - the hub,
+    the ends, 150 random rows - against the float64 sum at 2^-7 relative."""
+    nodes, nnz = 232_965, 114_615_892
     di = _device_powerlaw(nnz, nodes, 11)
     g = torch.Generator(device="cuda")
     g.manual_seed(12)

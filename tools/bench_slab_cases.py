@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 if any(n in " ".join(sys.argv) for n in ("slab_probe", "slab_pair", "slab_wrow_all", "slab_nt", "slab_tight", "slab_stage", "slab_unroll")):
     os.environ.setdefault("GEOT_HIP_LIB", "dev")
 from bench import device_ms, powerlaw_index  # noqa: E402
-from geot_amd import hip, slab  # noqa: E402
+from geot_amd import graph, hip, slab  # noqa: E402
 
 
 def main():
@@ -87,7 +87,7 @@ def main():
             line(f"mh_spmm H={H} F={Fh} {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, as the ABI serves them", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh),
                  f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} units={plan.meta['units']}")
             line(f"mh_spmm H={H} F={Fh} {tname} rows {H * Fh * esz} B, weights [nnz,H] in edge order, through e_perm", lambda: slab.slab_spmm_out(plan, w, 2, x, out, H, Fh, stage_weights=False))
-            wp = w[plan.tensors["e_perm"].long()].contiguous()
+            wp = graph._rows_at(w, plan.tensors["e_perm"].long())   # (the library's row gather: torch's indexing of [115 M, 8] 16-bit rows is wrong on this stack)
             line(f"mh_spmm H={H} F={Fh} {tname} rows {H * Fh * esz} B, weights in PLAN order (mode 5)", lambda: slab.slab_spmm_out(plan, wp, 5, x, out, H, Fh))
             del wp
             if not only or "sddmm" in only:
@@ -112,7 +112,7 @@ def main():
             line(f"gws F={F} {tname} rows {F * esz} B, weight[e] in edge order, as the ABI serves them", lambda: slab.slab_spmm_out(plan, w, 1, x, out, 1, F),
                  f"R={plan.meta['rows_per_group']} rounds={plan.meta['rounds']} units={plan.meta['units']}")
             line(f"gws F={F} {tname} rows {F * esz} B, weight[e] in edge order, through e_perm", lambda: slab.slab_spmm_out(plan, w, 1, x, out, 1, F, stage_weights=False))
-            wp = w[plan.tensors["e_perm"].long()].contiguous()
+            wp = graph._rows_at(w, plan.tensors["e_perm"].long())   # (the library's row gather: torch's indexing of [115 M, 8] 16-bit rows is wrong on this stack)
             line(f"gws F={F} {tname} rows {F * esz} B, weight in PLAN order (mode 4)", lambda: slab.slab_spmm_out(plan, wp, 4, x, out, 1, F))
             line(f"gs  F={F} {tname} rows {F * esz} B, no weight", lambda: slab.slab_spmm_out(plan, None, 0, x, out, 1, F))
             line(f"gs  F={F} {tname} rows {F * esz} B, mean", lambda: slab.slab_spmm_out(plan, None, 0, x, out, 1, F, reduce="mean"))
