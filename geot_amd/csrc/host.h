@@ -307,6 +307,10 @@ std::shared_ptr<SlabPlanHolder> slab_plan_for(const at::Tensor &si, const at::Te
 // false: the plan's arrays have been released (a trial on another thread rejected it) - the caller runs the per-edge kernels
 bool run_slab(SlabPlanHolder &H, const void *weight, int wmode, const at::Tensor &src, at::Tensor &out, int64_t heads, int64_t feat,
               int red = GEOT_REDUCE_SUM);
+// values[index] along dim 0 (int64 index) for a per-edge tensor ([nnz] or [nnz, heads]): the library's row gather for contiguous
+// floating CUDA tensors (torch's own gathers of such tensors have returned garbage at configs[3]'s size twice: index_select with an
+// int32 index, [nnz, 4], round 5; advanced indexing of [115 M, 8] 16-bit rows, round 6), index_select otherwise
+at::Tensor take_rows(const at::Tensor &values, const at::Tensor &index);
 std::vector<at::Tensor> slab_plan_op(const at::Tensor &si, const at::Tensor &di, int64_t rows, int64_t src_rows, int64_t rowbytes,
                                      int64_t weight_mode, int64_t heads, int64_t slab_bytes, int64_t rows_per_group, int64_t units);
 bool slab_worthwhile_op(int64_t nnz, int64_t rows, int64_t src_rows, int64_t rowbytes);

@@ -3,6 +3,24 @@
 
 namespace geot_host {
 
+at::Tensor take_rows(const at::Tensor &values, const at::Tensor &index) {
+  const auto st = values.scalar_type();
+  const bool lib = values.is_cuda() && values.is_contiguous() && values.dim() >= 1 && values.size(0) > 0 && index.is_cuda() && index.dim() == 1 &&
+                   index.scalar_type() == at::kLong && index.is_contiguous() &&
+                   (st == at::kFloat || st == at::kDouble || st == at::kHalf || st == at::kBFloat16);
+  if (!lib) return values.index_select(0, index);
+  auto shape = values.sizes().vec();
+  shape[0] = index.numel();
+  at::Tensor out = at::empty(shape, values.options());
+  if (index.numel() == 0) return out;
+  const int64_t feat = values.numel() / values.size(0);
+  const int rc = geot_gather_rows(index.data_ptr<int64_t>(), values.data_ptr(), out.data_ptr(), index.numel(), feat, values.size(0),
+                                  dtype_code(values, "take_rows"), stream_of(values));
+  TORCH_CHECK(rc == GEOT_OK, "geot_gather_rows failed (code ", rc, "): ", geot_last_error());
+  return out;
+}
+
+
 // ---- content guard of the remembered products (csrc/seg_guard.hip) -----------------------------------------------------------
 // Everything the caches below keep was derived from the caller's index tensors and is found again by their identity and
 // version counter.  A write behind the version counter (.data, DLPack, a raw pointer) leaves a product that describes bytes
@@ -463,7 +481,7 @@ at::Tensor transposed_weight_op(const at::Tensor &si, const at::Tensor &di, cons
         return e.w_perm;
       }
   }
-  at::Tensor wp = weight.index_select(0, perm);
+  at::Tensor wp = take_rows(weight, perm);
   if (keyed && !tl_capturing) {
     at::Tensor wfp = guard_store({&weight});
     std::lock_guard<std::mutex> lk(g_mu);

@@ -367,7 +367,7 @@ Edges dst_ordered(const at::Tensor &si_in, const at::Tensor &di_in, const c10::o
   if (e.permuted) {
     auto kp = sorted_form(e.di, f.kmin, f.kmax);
     e.si = e.si.index_select(0, kp.second);
-    if (e.w.defined()) e.w = e.w.index_select(w_edge_dim, kp.second).contiguous();
+    if (e.w.defined()) e.w = w_edge_dim == 0 ? take_rows(e.w.contiguous(), kp.second.contiguous()) : e.w.index_select(w_edge_dim, kp.second).contiguous();
     e.di = kp.first;
   }
   return e;
