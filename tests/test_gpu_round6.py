@@ -377,6 +377,50 @@ def test_cfg4_full_size_bf16_properties(geot, order, H, F):
     torch.cuda.empty_cache()
 
 
+def test_cfg4_full_size_eight_heads_through_the_operators_with_autograd(geot):
+    """configs[3]'s graph at full size with EIGHT bf16 heads of 64 (rows of 1 KiB, 16 bytes of weights an edge) through the drop-in
+    operator and its backward pass: the host layer's own permutations of per-edge values at this size (plan order, the transposed
+    list: take_rows / geot_slab_to_plan_order - torch's gathers of such tensors are not to be trusted here, see graph._rows_at), the
+    two-pass matrix-core SpMM over both lists' plans and the matrix-core SDDMM.  Sampled rows / edges against float64."""
+    from geot_amd import ops
+    nodes, nnz, H, F = 232_965, 114_615_892, 8, 64
+    di = _device_powerlaw(nnz, nodes, 11)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    si = torch.randint(0, nodes, (nnz,), device="cuda", generator=g)
+    w = (torch.rand(nnz, H, device="cuda", generator=g) + 0.25).bfloat16().requires_grad_()
+    x = (torch.rand(nodes, H, F, device="cuda", generator=g) + 0.25).bfloat16().requires_grad_()
+    up = (torch.rand(nodes, H, F, device="cuda", generator=g) / 8).bfloat16()
+    old = ops.set_option("slab_mode", "always")
+    try:
+        ops.clear_caches()
+        for _ in range(2):
+            y = geot.mh_spmm(si, di, w.detach(), x.detach())             # (the second sighting builds the plan)
+        y = geot.mh_spmm(si, di, w, x)
+        assert "seg_slab_spmm_mfma_kernel" in geot.hip.last_kernel() and "1024" in geot.hip.last_kernel(), geot.hip.last_kernel()
+        gx, gw = torch.autograd.grad(y, [x, w], up)
+    finally:
+        ops.set_option("slab_mode", old)
+        ops.clear_caches()
+    assert bool(torch.isfinite(y.float()).all()) and bool(torch.isfinite(gx.float()).all()) and bool(torch.isfinite(gw.float()).all())
+    counts = torch.bincount(di, minlength=nodes)
+    offs = torch.cumsum(counts, 0) - counts
+    wd, xd = w.detach(), x.detach()
+    for k in [int(counts.argmax()), 0, nodes - 1] + torch.randint(0, nodes, (40,), generator=torch.Generator().manual_seed(5)).tolist():
+        e = slice(int(offs[k]), int(offs[k] + counts[k]))
+        want = (xd[si[e]].double() * wd[e].double()[:, :, None]).sum(0)
+        assert float((y[k].double() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()) + 1e-30, k
+    eid = torch.randint(0, nnz, (20_000,), device="cuda", generator=g)                 # d/dweight[e, h] = <up[dst], x[src]>
+    ref = (up[di[eid]].double() * xd[si[eid]].double()).sum(-1)
+    assert float((gw[eid].double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    for s_row in torch.randint(0, nodes, (4,), generator=torch.Generator().manual_seed(6)).tolist():   # d/dx[s] = sum over the edges out of s
+        e = torch.nonzero(si == s_row).flatten()
+        want = (up[di[e]].double() * wd[e].double()[:, :, None]).sum(0)
+        assert float((gx[s_row].double() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max()) + 1e-30, s_row
+    del y, gx, gw, w, x, up
+    torch.cuda.empty_cache()
+
+
 def test_cfg3_full_size_bf16_properties(geot):
     """BASELINE.json configs[2] at full size in bf16 storage (gws, 2.45 M nodes, 123.7 M edges, F=128; the per-edge tile kernel with fp32
     accumulation): rows without edges, sampled rows against float64 at 2^-7, the checksum of checksums."""
