@@ -1879,13 +1879,15 @@ __global__ __launch_bounds__(kThreads, 3) void seg_slab_spmm_mfma_kernel(SlabPar
 // - up to 16 rows a group, whose 512 features x 16 rows of fp32 sums seg_slab_kernel's LDS cannot hold (it takes 4-5 rows: 21-26
 // rounds, each a sweep of the table through every L2) - so a source table with an Inf / NaN in it (the gate, see
 // slab_nonfinite_kernel) and the option "slab_spmm_mfma" = 0 are served by THIS kernel: the same plan, the same grid, no lockstep,
-// nothing in flight - kSub rows of accumulators in LDS at a time, the group's edges walked once per kSub rows, one edge at a time.
+// nothing in flight - kSub = 4 rows of accumulators in LDS at a time, the group's edges walked once per kSub rows (their fields loaded 64
+// at a time), one edge's row at a time.
 // Correct and slow by design (the path a diverged model takes); out-of-range sources contribute nothing, as in the matrix-core kernel.
 // WMODE 0 none | 2 weight[e * H + h] | 3 weight[h * nnz + e]; p.w_in_plan_order as everywhere.
+constexpr int kTwin1kRows = 4;
 template <typename T, int WMODE>
 __global__ __launch_bounds__(kThreads) void seg_slab_twin1k_kernel(SlabParams p) {
   static_assert(sizeof(T) == 2 && (WMODE == 0 || WMODE == 2 || WMODE == 3), "16-bit rows of 1 KiB, multi-head weights or none");
-  constexpr int kSub = 4;                                  // rows of fp32 accumulators in LDS at a time: 4 x 2 KB a wave
+  constexpr int kSub = kTwin1kRows;                        // rows of fp32 accumulators in LDS at a time: 4 x 2 KB a wave (8 rows, two workgroups a CU: 43 against 31 ms - fewer waves to hide the loads behind)
   typedef T t8_t __attribute__((ext_vector_type(8)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (p.gate && ((slab_gate_word(p.gate) != 0) != (p.gate_want != 0))) return;
@@ -1907,19 +1909,27 @@ __global__ __launch_bounds__(kThreads) void seg_slab_twin1k_kernel(SlabParams p)
     for (int lo = 0; lo < nv; lo += kSub) {
 #pragma unroll
       for (int q = 0; q < kSub * 8; ++q) acc[q * 64 + lane] = 0.f;
-      for (int i = 0; i < len; ++i) {
-        const int dl = (int)P.e_dl[e0 + i];
-        const uint32_t s_ = (uint32_t)P.e_src[e0 + i];
-        if (dl < lo || dl >= lo + kSub || s_ >= (uint32_t)p.src_rows) continue;      // (wave-uniform)
-        float w = 1.f;
-        if constexpr (WMODE != 0) {
-          const int64_t pe = wpo ? e0 + i : (int64_t)P.e_perm[e0 + i];
-          w = (float)(WMODE == 2 ? weight[pe * p.H + head] : weight[(int64_t)head * P.nnz + pe]);
-        }
-        const t8_t x = *reinterpret_cast<const t8_t *>(src + (int64_t)s_ * 512 + lane * 8);
-        float *a = acc + (size_t)(dl - lo) * 512 + lane * 8;
+      for (int c0 = 0; c0 < len; c0 += 64) {                    // a chunk of 64 edges: every lane loads one edge's fields ...
+        const int mine = c0 + lane;
+        const bool in = mine < len;
+        const int my_dl = in ? (int)P.e_dl[e0 + mine] : 255;
+        const uint32_t my_src = in ? (uint32_t)P.e_src[e0 + mine] : 0u;
+        const uint32_t my_pe = (WMODE != 0 && in && !wpo) ? (uint32_t)P.e_perm[e0 + mine] : 0u;
+        const int n_here = len - c0 < 64 ? len - c0 : 64;
+        for (int j = 0; j < n_here; ++j) {                      // ... and the wave walks them one at a time
+          const int dl = __builtin_amdgcn_readlane(my_dl, j);
+          const uint32_t s_ = (uint32_t)__builtin_amdgcn_readlane((int)my_src, j);
+          if (dl < lo || dl >= lo + kSub || s_ >= (uint32_t)p.src_rows) continue;      // (wave-uniform)
+          float w = 1.f;
+          if constexpr (WMODE != 0) {
+            const int64_t pe = wpo ? e0 + c0 + j : (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_pe, j);
+            w = (float)(WMODE == 2 ? weight[pe * p.H + head] : weight[(int64_t)head * P.nnz + pe]);
+          }
+          const t8_t x = *reinterpret_cast<const t8_t *>(src + (int64_t)s_ * 512 + lane * 8);
+          float *a = acc + (size_t)(dl - lo) * 512 + lane * 8;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] += w * (float)x[q];
+          for (int q = 0; q < 8; ++q) a[q] += w * (float)x[q];
+        }
       }
       for (int l = lo; l < nv && l < lo + kSub; ++l) {
         const int64_t tg = P.v_out[v0 + l];
@@ -2542,7 +2552,7 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
         else { if (el == 4) { GEOT_SLAB_WROW_MODE(bf16_t, 4) } else { GEOT_SLAB_WROW_MODE(bf16_t, 2) } }
       }
       else if (big1k) {
-        const size_t tlds = (size_t)4 * 4 * 512 * sizeof(float);       // four rows of fp32 sums a wave
+        const size_t tlds = (size_t)4 * kTwin1kRows * 512 * sizeof(float);   // four rows of fp32 sums a wave
 #define GEOT_SLAB_TWIN1K(T_)                                                                                  \
         do {                                                                                                  \
           geot_internal_note_kernel((std::string("seg_slab_twin1k_kernel<") + slab_tname<T_>() + ", " + std::to_string(weight_mode) + ">").c_str()); \
