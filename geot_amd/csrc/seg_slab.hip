@@ -2062,8 +2062,7 @@ __global__ __launch_bounds__(kStageThreads) void slab_stage_kernel(const int64_t
                                                                    const T *__restrict__ weight, T *__restrict__ staged, int64_t n_groups) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T *tile = reinterpret_cast<T *>(smem);
-  constexpr int kTileElems = kStageTileBytes / (int)sizeof(T);
-  static_assert(kTileElems >= kStageIters * kStageThreads, "a tile holds what a workgroup loads in one phase");
+  // (a tile of kStageIters x kStageThreads elements: 64 KB of 8-byte weights, two workgroups a CU; 128 KB of 16-byte ones, one)
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const int64_t e0 = g_begin[g];
     const int len = (int)(g_begin[g + 1] - e0);
@@ -2286,7 +2285,7 @@ size_t geot_slab_workspace_bytes_staged(const geot_slab_plan *plan, int64_t feat
   // (one weight per edge, or 8 bytes of heads an edge in edge-major layout: what the pre-passes of geot_slab_spmm serve; "slab_stage"
   //  = 2, development build: every multi-head layout through the plain gather)
   const size_t wb = (size_t)(weight_mode == 1 ? 1 : heads) * (dtype == GEOT_F32 ? 4 : 2);
-  if (weight_mode != 1 && !(weight_mode == 2 && (wb == 8 || g_slab_stage == 2))) return base;
+  if (weight_mode != 1 && !(weight_mode == 2 && (wb == 8 || (wb == 16 && dtype != GEOT_F32) || g_slab_stage == 2))) return base;
   return base + (size_t)plan->nnz * wb;
 }
 
@@ -2375,7 +2374,9 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
   //  F=128 fp32 4.50 -> 3.98 ms, F=64 3.40 -> 2.74, bf16 F=128 3.19 -> 2.79; four heads of weights: the pre-pass moves 4 GB and costs more
   //  than the permuted reads - fp32 7.18 -> 7.51, bf16 5.24 -> 5.61: multi-head weights are staged only on request, "slab_stage" = 2)
   //  Round 6: four 16-bit heads (8 bytes an edge) go through LDS a GROUP at a time instead (slab_stage_kernel) - bf16 4.58 -> 4.21 ms.
-  if (!w_in_plan_order && (weight_mode == 1 || (weight_mode == 2 && (wbytes == 8 || g_slab_stage == 2))) && g_slab_stage && plan->n_groups > 0 &&
+  //  Eight 16-bit heads (16 bytes an edge) likewise, since their consumer went to the matrix cores (bf16 H=8 x F=64 9.16 -> see
+  //  profiles/r06/slab_cases__rows_of_1_kib_16_bit.txt); four fp32 heads - the same 16 bytes - measured no gain and stay as they were.
+  if (!w_in_plan_order && (weight_mode == 1 || (weight_mode == 2 && (wbytes == 8 || (wbytes == 16 && tsize == 2) || g_slab_stage == 2))) && g_slab_stage && plan->n_groups > 0 &&
       (wbytes == 2 || wbytes == 4 || wbytes == 8 || wbytes == 16) && (((uintptr_t)weight) & (wbytes - 1)) == 0 &&
       workspace_bytes >= geot_slab_workspace_bytes_staged(plan, F, weight_mode, heads, dtype))
     wstage = static_cast<char *>(workspace) + need;
@@ -2400,10 +2401,15 @@ int geot_slab_spmm(const geot_slab_plan *plan, const void *weight, int weight_mo
     if (sblocks > (int64_t)slab_device().cus * 16) sblocks = (int64_t)slab_device().cus * 16;
     const dim3 sgrid((unsigned)(sblocks > 0 ? sblocks : 1)), sblk(kThreads);
     const bool x4 = (((uintptr_t)wstage | (uintptr_t)plan->e_perm) & 15) == 0 && plan->nnz >= 4;
+    static const hipError_t big_tile = hipFuncSetAttribute(reinterpret_cast<const void *>(&slab_stage_kernel<f4_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageTileBytes);
     if (weight_mode == 2 && wbytes == 8 && g_slab_stage != 2) {            // a group at a time through LDS, two workgroups per CU
       const unsigned gb = (unsigned)(plan->n_groups < (int64_t)slab_device().cus * 2 ? plan->n_groups : (int64_t)slab_device().cus * 2);
       hipLaunchKernelGGL((slab_stage_kernel<uint64_t>), dim3(gb), dim3(kStageThreads), kStageTileBytes, st, plan->g_begin, plan->e_perm,
                          static_cast<const uint64_t *>(weight), static_cast<uint64_t *>(wstage), plan->n_groups);
+    } else if (weight_mode == 2 && wbytes == 16 && tsize == 2 && g_slab_stage != 2 && big_tile == hipSuccess) {   // ... 128 KB tiles, one per CU
+      const unsigned gb = (unsigned)(plan->n_groups < (int64_t)slab_device().cus ? plan->n_groups : (int64_t)slab_device().cus);
+      hipLaunchKernelGGL((slab_stage_kernel<f4_t>), dim3(gb), dim3(kStageThreads), 2 * kStageTileBytes, st, plan->g_begin, plan->e_perm,
+                         static_cast<const f4_t *>(weight), static_cast<f4_t *>(wstage), plan->n_groups);
     } else
     if (wbytes == 2 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint16_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(wstage), plan->nnz);
     else if (wbytes == 4 && x4) hipLaunchKernelGGL((slab_stage_weights_x4_kernel<uint32_t>), sgrid, sblk, 0, st, plan->e_perm, static_cast<const uint32_t *>(weight), static_cast<uint32_t *>(wstage), plan->nnz);

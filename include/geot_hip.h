@@ -290,8 +290,8 @@ int geot_slab_rows_per_group_dtype(int weight_mode, int64_t heads, int dtype); /
 int geot_slab_units_for(int weight_mode, int64_t rowbytes);
 int geot_slab_rows_per_group_shape(int weight_mode, int64_t heads, int dtype, int64_t rowbytes);
 size_t geot_slab_workspace_bytes(const geot_slab_plan *plan, int64_t feat_total);
-/* ... plus room for the call's weights in plan order (nnz x heads elements: weight mode 1, and weight mode 2 with four 16-bit heads
- * - 8 bytes an edge; otherwise the same number).  Given that much, geot_slab_spmm brings EDGE-order weights into plan order by a
+/* ... plus room for the call's weights in plan order (nnz x heads elements: weight mode 1, and weight mode 2 with four or eight
+ * 16-bit heads - 8 / 16 bytes an edge; otherwise the same number).  Given that much, geot_slab_spmm brings EDGE-order weights into plan order by a
  * pre-pass of its own ahead of the persistent kernel instead of reading each one through the edge permutation in the row loop (gws
  * F=128 fp32 at Reddit scale 4.50 -> 3.98 ms, profiles/r05/slab_cases_*; bf16 H=4 x F=64, a group at a time through LDS, 4.60 ->
  * 4.25 ms, profiles/r06/slab_cases__mh_weights_staged_a_group_at_a_time.txt; four fp32 heads: measured, no gain, not staged). */

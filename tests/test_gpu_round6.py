@@ -90,6 +90,10 @@ def test_matrix_core_spmm_against_float64_and_the_row_per_wave_kernel(geot, dtyp
             outs.append(o)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])          # one order of additions, whatever the layout
         assert torch.equal(run(w, 2, v, 1), outs[0])                                    # fixed by the plan, not by timing
+        if H in (4, 8):                                                                 # 8 / 16 bytes of 16-bit heads an edge: brought into plan order a
+            o_st = torch.full((nodes, H, Fh), float("nan"), device="cuda", dtype=dtype)  # group at a time through LDS first (slab_stage_kernel) - the same bits
+            slab.slab_spmm_out(plan, w, 2, v, o_st, H, Fh)                              # (stage_weights=True: the workspace has room)
+            assert torch.equal(o_st, outs[0])
         ones = ok[:, None].to(dtype).expand(nnz, H)
         ref0, mag0 = _ref(d_si.clamp(max=nodes - 1), d_di, ones, v, nodes), _ref(d_si.clamp(max=nodes - 1), d_di, ones, v.abs(), nodes)
         o0 = run(None, 0, v, 1)
