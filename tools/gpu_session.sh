@@ -60,6 +60,12 @@ PY
                 for sh in 8,64 4,128; do timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --mh-shape $sh --options slab_spmm_mfma=0,slab_sddmm_mfma=0 2>&1 | grep -v amdgpu.ids; done
                 echo "# seg_slab_twin1k_kernel, the stand-in on a 16-row plan (a source table with an Inf / NaN in it; here: forced by the option)"
                 timeout 900 python3 tools/bench_slab_cases.py --only mh --dtypes bf16 --mh-shape 8,64 --rows-per-group 16 --options slab_spmm_mfma=0 --iters 2 2>&1 | grep -v amdgpu.ids; } > $O/slab_cases_rows1k_16bit.txt 2>&1; cat $O/slab_cases_rows1k_16bit.txt ;;
+    hunt1k)   export HUNT_DTYPE=bf16 HUNT_HEADS=8
+              timeout 900 python3 tools/hang_hunt.py --scenario lockstep --runs 10 --slab-turn 1 --T 90 > $O/hunt1k_lockstep.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt1k_lockstep.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario lockstep --runs 6 --slab-turn 0 --T 90 > $O/hunt1k_lockstep_turn0.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt1k_lockstep_turn0.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario procs --runs 8 --T 90 > $O/hunt1k_procs.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt1k_procs.txt
+              timeout 900 python3 tools/hang_hunt.py --scenario graphs --runs 8 --T 90 > $O/hunt1k_graphs.txt 2>&1; echo "rc=$?"; tail -2 $O/hunt1k_graphs.txt
+              unset HUNT_DTYPE HUNT_HEADS ;;
     sddmm16)  timeout 900 python3 -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -m gpu -x -q -k "sddmm or attention or matrix_core" 2>&1 | tail -4
               for o in slab_sddmm_mfma=1 slab_sddmm_mfma=0 slab_sddmm_mfma=1,slab_probe=1; do
                 timeout 600 python3 tools/bench_slab_cases.py --only mh,sddmm --dtypes bf16 --options $o 2>&1 | grep "mh_sddmm\|options"
